@@ -1,0 +1,110 @@
+"""Architecture constants of the captioner forward path.
+
+BLIP-base values follow the HF config defaults the checkpoint's ``config.json``
+overrides at load time (HF:models/blip/configuration_blip.py:52-107; SURVEY.md §8
+"Model constants").  CoCa values follow the reference's
+``experimenting_env/captioner/models/coca/model_configs/coca_ViT-L-14.json:1-30``.
+"""
+from __future__ import annotations
+
+import dataclasses
+import json
+import os
+
+
+@dataclasses.dataclass
+class BlipArch:
+    # vision tower (ViT-B/16)
+    image_size: int = 224
+    patch_size: int = 16
+    v_hidden: int = 768
+    v_layers: int = 12
+    v_heads: int = 12
+    v_mlp: int = 3072
+    v_eps: float = 1e-5
+    # text decoder (BERT-style, post-LN, cross-attention to image tokens)
+    t_hidden: int = 768
+    t_layers: int = 12
+    t_heads: int = 12
+    t_ffn: int = 3072
+    vocab: int = 30524
+    max_pos: int = 512
+    t_eps: float = 1e-12
+    bos: int = 30522
+    eos: int = 102      # sep_token_id: what BlipForConditionalGeneration.generate passes as eos
+    pad: int = 0
+
+    @property
+    def grid(self) -> int:
+        return self.image_size // self.patch_size
+
+    @property
+    def n_patches(self) -> int:
+        return self.grid * self.grid
+
+    @property
+    def n_tokens(self) -> int:
+        return self.n_patches + 1
+
+    @property
+    def v_head_dim(self) -> int:
+        return self.v_hidden // self.v_heads
+
+    @property
+    def t_head_dim(self) -> int:
+        return self.t_hidden // self.t_heads
+
+    def encoder_flops_per_image(self) -> float:
+        """2*MAC of patch-embed + 12x(QKV, QK^T, PV, proj, FC1, FC2); BASELINE.md §4."""
+        n, d, m = self.n_tokens, self.v_hidden, self.v_mlp
+        per_layer = 2.0 * n * d * 3 * d + 2 * 2.0 * n * n * d + 2.0 * n * d * d + 2 * 2.0 * n * d * m
+        patch = 2.0 * self.n_patches * (3 * self.patch_size ** 2) * d
+        return per_layer * self.v_layers + patch
+
+    def cross_kv_flops_per_image(self) -> float:
+        return self.t_layers * 2 * 2.0 * self.n_tokens * self.v_hidden * self.t_hidden
+
+    def decode_flops_per_token(self) -> float:
+        d, f, v = self.t_hidden, self.t_ffn, self.vocab
+        per_layer = 2.0 * d * d * 4 + 2.0 * d * d * 2 + 2 * 2.0 * d * f   # self q,k,v,o + cross q,o + ffn
+        return per_layer * self.t_layers + 2.0 * d * d + 2.0 * d * v
+
+    @staticmethod
+    def tiny() -> "BlipArch":
+        """Fixture-sized config (tests/golden/blip_tiny.npz): hidden 64, 2 layers, vocab 512, 32x32 image."""
+        return BlipArch(image_size=32, patch_size=8, v_hidden=64, v_layers=2, v_heads=2, v_mlp=128,
+                        t_hidden=64, t_layers=2, t_heads=2, t_ffn=128, vocab=512, max_pos=40,
+                        bos=510, eos=102, pad=0)
+
+    @staticmethod
+    def from_hf_config(path_or_dict) -> "BlipArch":
+        """Read a HF ``config.json`` (checkpoint directory or parsed dict)."""
+        if isinstance(path_or_dict, (str, os.PathLike)):
+            p = path_or_dict
+            if os.path.isdir(p):
+                p = os.path.join(p, "config.json")
+            with open(p) as f:
+                cfg = json.load(f)
+        else:
+            cfg = dict(path_or_dict)
+        v = cfg.get("vision_config", {})
+        t = cfg.get("text_config", {})
+        a = BlipArch()
+        a.image_size = v.get("image_size", 384)
+        a.patch_size = v.get("patch_size", 16)
+        a.v_hidden = v.get("hidden_size", 768)
+        a.v_layers = v.get("num_hidden_layers", 12)
+        a.v_heads = v.get("num_attention_heads", 12)
+        a.v_mlp = v.get("intermediate_size", 3072)
+        a.v_eps = v.get("layer_norm_eps", 1e-5)
+        a.t_hidden = t.get("hidden_size", 768)
+        a.t_layers = t.get("num_hidden_layers", 12)
+        a.t_heads = t.get("num_attention_heads", 8)
+        a.t_ffn = t.get("intermediate_size", 3072)
+        a.vocab = t.get("vocab_size", 30524)
+        a.max_pos = t.get("max_position_embeddings", 512)
+        a.t_eps = t.get("layer_norm_eps", 1e-12)
+        a.bos = t.get("bos_token_id", 30522)
+        a.eos = t.get("sep_token_id", 102)
+        a.pad = t.get("pad_token_id", 0)
+        return a

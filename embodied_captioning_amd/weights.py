@@ -1,0 +1,195 @@
+"""Weight sources for the captioner: procedural (seeded) state dicts and checkpoint readers.
+
+The state-dict key set is exactly what ``BlipForConditionalGeneration.state_dict()`` has
+(SURVEY.md §8c lists all 473 tensors) - that key set is the HuggingFace-checkpoint loading
+contract of the boundary (reference precedent: ``captioner/models/blip2/blip2.py:19-22``
+``from_pretrained``; ``utils/predictor_utils.py:182-185`` ``torch.load(path)['model']``).
+
+No checkpoint exists offline, so tests/bench use ``procedural_blip_state_dict``: every tensor is
+drawn from numpy's PCG64 keyed by (seed, crc32(name)), so the values are identical on every
+machine, in any generation order, and for the HF oracle run that produced tests/golden/.
+"""
+from __future__ import annotations
+
+import os
+import zlib
+from typing import Dict, Iterable, List, Tuple
+
+import numpy as np
+import torch
+
+from .config import BlipArch
+
+
+def blip_param_specs(a: BlipArch) -> List[Tuple[str, Tuple[int, ...], str, float]]:
+    """(name, shape, kind, scale) for every learnable tensor, in HF state-dict naming."""
+    D, M, L = a.v_hidden, a.v_mlp, a.v_layers
+    P = a.patch_size
+    s: List[Tuple[str, Tuple[int, ...], str, float]] = []
+    vm = "vision_model."
+    s.append((vm + "embeddings.class_embedding", (1, 1, D), "normal", 0.5))
+    s.append((vm + "embeddings.position_embedding", (1, a.n_tokens, D), "normal", 0.5))
+    s.append((vm + "embeddings.patch_embedding.weight", (D, 3, P, P), "normal", 1.0 / np.sqrt(3 * P * P)))
+    s.append((vm + "embeddings.patch_embedding.bias", (D,), "normal", 0.02))
+    for i in range(L):
+        p = f"{vm}encoder.layers.{i}."
+        s.append((p + "self_attn.qkv.weight", (3 * D, D), "normal", 1.0 / np.sqrt(D)))
+        s.append((p + "self_attn.qkv.bias", (3 * D,), "normal", 0.02))
+        s.append((p + "self_attn.projection.weight", (D, D), "normal", 1.0 / np.sqrt(D)))
+        s.append((p + "self_attn.projection.bias", (D,), "normal", 0.02))
+        s.append((p + "layer_norm1.weight", (D,), "gamma", 0.1))
+        s.append((p + "layer_norm1.bias", (D,), "normal", 0.05))
+        s.append((p + "mlp.fc1.weight", (M, D), "normal", 1.0 / np.sqrt(D)))
+        s.append((p + "mlp.fc1.bias", (M,), "normal", 0.02))
+        s.append((p + "mlp.fc2.weight", (D, M), "normal", 1.0 / np.sqrt(M)))
+        s.append((p + "mlp.fc2.bias", (D,), "normal", 0.02))
+        s.append((p + "layer_norm2.weight", (D,), "gamma", 0.1))
+        s.append((p + "layer_norm2.bias", (D,), "normal", 0.05))
+    s.append((vm + "post_layernorm.weight", (D,), "gamma", 0.1))
+    s.append((vm + "post_layernorm.bias", (D,), "normal", 0.05))
+
+    T, F, V = a.t_hidden, a.t_ffn, a.vocab
+    tb = "text_decoder.bert."
+    s.append((tb + "embeddings.word_embeddings.weight", (V, T), "normal", 0.08))
+    s.append((tb + "embeddings.position_embeddings.weight", (a.max_pos, T), "normal", 0.08))
+    s.append((tb + "embeddings.LayerNorm.weight", (T,), "gamma", 0.1))
+    s.append((tb + "embeddings.LayerNorm.bias", (T,), "normal", 0.05))
+    for i in range(a.t_layers):
+        p = f"{tb}encoder.layer.{i}."
+        for blk, kin in (("attention", T), ("crossattention", D)):
+            for nm, fan in (("query", T), ("key", kin), ("value", kin)):
+                s.append((f"{p}{blk}.self.{nm}.weight", (T, fan), "normal", 1.0 / np.sqrt(fan)))
+                s.append((f"{p}{blk}.self.{nm}.bias", (T,), "normal", 0.02))
+            # small output gains keep the token/position signal alive through 12 post-LN blocks, so greedy
+            # captions vary step to step and with the image (a gain of 1 collapses to one repeated token)
+            gain = 0.5 if blk == "attention" else 0.15
+            s.append((f"{p}{blk}.output.dense.weight", (T, T), "normal", gain / np.sqrt(T)))
+            s.append((f"{p}{blk}.output.dense.bias", (T,), "normal", 0.02))
+            s.append((f"{p}{blk}.output.LayerNorm.weight", (T,), "gamma", 0.1))
+            s.append((f"{p}{blk}.output.LayerNorm.bias", (T,), "normal", 0.05))
+        s.append((p + "intermediate.dense.weight", (F, T), "normal", 1.0 / np.sqrt(T)))
+        s.append((p + "intermediate.dense.bias", (F,), "normal", 0.02))
+        s.append((p + "output.dense.weight", (T, F), "normal", 0.3 / np.sqrt(F)))
+        s.append((p + "output.dense.bias", (T,), "normal", 0.02))
+        s.append((p + "output.LayerNorm.weight", (T,), "gamma", 0.1))
+        s.append((p + "output.LayerNorm.bias", (T,), "normal", 0.05))
+    cp = "text_decoder.cls.predictions."
+    s.append((cp + "transform.dense.weight", (T, T), "normal", 1.0 / np.sqrt(T)))
+    s.append((cp + "transform.dense.bias", (T,), "normal", 0.02))
+    s.append((cp + "transform.LayerNorm.weight", (T,), "gamma", 0.1))
+    s.append((cp + "transform.LayerNorm.bias", (T,), "normal", 0.05))
+    s.append((cp + "bias", (V,), "normal", 0.1))
+    return s
+
+
+# HF ties these at load (HF:modeling_blip_text.py:594-597); a checkpoint may or may not carry them.
+BLIP_TIED = {
+    "text_decoder.cls.predictions.decoder.weight": "text_decoder.bert.embeddings.word_embeddings.weight",
+    "text_decoder.cls.predictions.decoder.bias": "text_decoder.cls.predictions.bias",
+}
+
+
+def _draw(seed: int, name: str, shape, kind: str, scale: float) -> np.ndarray:
+    rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+    x = rng.standard_normal(size=shape, dtype=np.float32)
+    if kind == "gamma":
+        return (1.0 + scale * x).astype(np.float32)
+    return (scale * x).astype(np.float32)
+
+
+def procedural_blip_state_dict(arch: BlipArch, seed: int = 0, eos_boost: float = 0.0) -> Dict[str, torch.Tensor]:
+    """Seeded fp32 state dict with HF key names (tied entries included, sharing storage).
+    `eos_boost` is added to the LM-head bias of the EOS token so that some captions end early."""
+    sd: Dict[str, torch.Tensor] = {}
+    for name, shape, kind, scale in blip_param_specs(arch):
+        sd[name] = torch.from_numpy(_draw(seed, name, shape, kind, scale))
+    if eos_boost:
+        sd["text_decoder.cls.predictions.bias"][arch.eos] += eos_boost
+    for dst, src in BLIP_TIED.items():
+        sd[dst] = sd[src]
+    return sd
+
+
+def synthetic_pixels(batch: int, image_size: int, seed: int = 0, first: int = 0) -> torch.Tensor:
+    """Normalised fp32 NCHW frames, one PCG64 stream per frame index (frame i is the same in any batch).
+
+    Stands in for `BlipImageProcessor` output on 224x224 crops (synthetic
+    frames are generated from seed = frame index so shards need no shared storage).
+    """
+    out = np.empty((batch, 3, image_size, image_size), dtype=np.float32)
+    for i in range(batch):
+        rng = np.random.Generator(np.random.PCG64([seed, 0x1A6E, first + i]))
+        out[i] = rng.standard_normal(size=(3, image_size, image_size), dtype=np.float32)
+    return torch.from_numpy(out)
+
+
+def synthetic_frames_u8(batch: int, height: int, width: int, seed: int = 0, first: int = 0) -> torch.Tensor:
+    """uint8 HWC RGB frames (what the callers crop out of habitat observations)."""
+    out = np.empty((batch, height, width, 3), dtype=np.uint8)
+    for i in range(batch):
+        rng = np.random.Generator(np.random.PCG64([seed, 0xF8A3E, first + i]))
+        out[i] = rng.integers(0, 256, size=(height, width, 3), dtype=np.uint8)
+    return torch.from_numpy(out)
+
+
+# ----------------------------------------------------------------------------------------------
+# checkpoint readers (HF directory / safetensors / torch pickles / {'model': sd} wrappers)
+# ----------------------------------------------------------------------------------------------
+
+def _strip_prefixes(sd: Dict[str, torch.Tensor], prefixes: Iterable[str] = ("module.",)):
+    """DDP-saved checkpoints carry a 'module.' prefix (reference: factory.py:139-142)."""
+    out = {}
+    for k, v in sd.items():
+        for p in prefixes:
+            if k.startswith(p):
+                k = k[len(p):]
+        out[k] = v
+    return out
+
+
+def load_state_dict_file(path: str) -> Dict[str, torch.Tensor]:
+    """Read one weight file. Accepts .safetensors, or a torch pickle that is a state dict or wraps one
+    under 'model' / 'state_dict' (reference: predictor_utils.py:182-185, evaluate_finetuned_model.py:139-146,
+    factory.py:131-143)."""
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        sd = load_file(path)
+    else:
+        obj = torch.load(path, map_location="cpu", weights_only=True)
+        if isinstance(obj, dict) and "model" in obj and isinstance(obj["model"], dict):
+            obj = obj["model"]
+        elif isinstance(obj, dict) and "state_dict" in obj and isinstance(obj["state_dict"], dict):
+            obj = obj["state_dict"]
+        sd = obj
+    return _strip_prefixes(sd, ("module.",))
+
+
+def load_hf_blip_checkpoint(model_dir: str) -> Tuple[BlipArch, Dict[str, torch.Tensor]]:
+    """HF ``from_pretrained`` directory layout: config.json + model.safetensors | pytorch_model.bin."""
+    arch = BlipArch.from_hf_config(model_dir)
+    for fn in ("model.safetensors", "pytorch_model.bin"):
+        p = os.path.join(model_dir, fn)
+        if os.path.exists(p):
+            sd = load_state_dict_file(p)
+            break
+    else:
+        raise RuntimeError(f"no model.safetensors / pytorch_model.bin under {model_dir}")
+    for dst, src in BLIP_TIED.items():
+        if dst not in sd and src in sd:
+            sd[dst] = sd[src]
+    # position table tells the image size the checkpoint was trained at
+    pe = sd["vision_model.embeddings.position_embedding"]
+    g = int(round((pe.shape[1] - 1) ** 0.5))
+    arch.image_size = g * arch.patch_size
+    return arch, sd
+
+
+def resolve_hf_dir(model_name: str) -> str | None:
+    """Map a hub id ('Salesforce/blip-image-captioning-base') or a path to a local directory, offline."""
+    if os.path.isdir(model_name):
+        return model_name
+    try:
+        from huggingface_hub import snapshot_download
+        return snapshot_download(model_name, local_files_only=True)
+    except Exception:
+        return None
