@@ -71,9 +71,10 @@ class BlipArch:
 
     @staticmethod
     def tiny() -> "BlipArch":
-        """Fixture-sized config (tests/golden/blip_tiny.npz): hidden 64, 2 layers, vocab 512, 32x32 image."""
-        return BlipArch(image_size=32, patch_size=8, v_hidden=64, v_layers=2, v_heads=2, v_mlp=128,
-                        t_hidden=64, t_layers=2, t_heads=2, t_ffn=128, vocab=512, max_pos=40,
+        """Fixture-sized config (tests/golden/blip_tiny*.npz): hidden 128 (2 heads of 64), 2 layers, vocab 512,
+        32x32 image with 8x8 patches (17 tokens)."""
+        return BlipArch(image_size=32, patch_size=8, v_hidden=128, v_layers=2, v_heads=2, v_mlp=256,
+                        t_hidden=128, t_layers=2, t_heads=2, t_ffn=256, vocab=512, max_pos=40,
                         bos=510, eos=102, pad=0)
 
     @staticmethod

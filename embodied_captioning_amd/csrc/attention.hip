@@ -1,0 +1,307 @@
+// Attention kernels of the captioner path (head_dim = 64 everywhere on this path).
+//
+//  vit_attention_mfma  bf16, whole K / V^T of one (image, head) resident in LDS (N <= 288 tokens), QK^T and PV on
+//                      v_mfma_f32_32x32x16_bf16.  S^T = K.Q^T is computed so that a lane owns one query column:
+//                      the softmax row-reduction is in-lane (+ one cross-half shuffle), and the S^T accumulator
+//                      registers are fed straight back as the B operand of O^T = V^T.P^T (no LDS round trip).
+//  vit_attention_scalar  any dtype / any N: one thread per query, K/V tiles broadcast from LDS, online softmax in
+//                      fp32.  Strict-fp32 mode uses it; tests use it to cross-check the MFMA kernel.
+//  decode_attention    one new query per (row, head) against cached keys (self-attention cache with per-position
+//                      ancestor indirection for beams, or the beam-shared cross-attention cache). HBM-bound:
+//                      8 lanes x 16 B cover one 128-byte key row, 8 keys per wave-instruction.
+#include "ops.h"
+
+namespace {
+
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+constexpr int VT_LD = 292;   // V^T row stride in bf16: (VT_LD/2) % 64 == 18 -> the 32 d-rows of a ds_read_b64 hit distinct bank pairs
+constexpr float LOG2E = 1.4426950408889634f;
+
+// ------------------------------------------------------------------------------------------------
+template <int KB>
+__global__ __launch_bounds__(256) void vit_attention_mfma(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                          int N, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NP = KB * 32;
+    char* Ks = smem;                                   // [NP] rows of 128 B, chunk-swizzled
+    bf16_t* Vt = (bf16_t*)(smem + NP * 128);           // [64][VT_LD]
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int D = H * 64, ld = 3 * D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, hh = lane >> 5;
+    const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
+
+    for (int c = tid; c < NP * 8; c += 256) {
+        const int row = c >> 3, ch = c & 7;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (row < N) {
+            kv = *(const uint4*)(base + (size_t)row * ld + D + ch * 8);
+            vv = *(const uint4*)(base + (size_t)row * ld + 2 * D + ch * 8);
+        }
+        *(uint4*)(Ks + swz_off(row, ch)) = kv;
+        const bf16_t* ve = (const bf16_t*)&vv;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Vt[(ch * 8 + i) * VT_LD + row] = ve[i];
+    }
+    __syncthreads();
+
+    const int nqt = (N + 31) / 32;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 32 + r32, qc = min(q, N - 1);
+        bf16x8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(base + (size_t)qc * ld + ks * 16 + hh * 8);
+
+        f32x16 s[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 a = *(const bf16x8*)(Ks + swz_off(kb * 32 + r32, ks * 2 + hh));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kb], 0, 0, 0);
+            }
+        }
+        // softmax over keys for query column r32: key(kb, e) = kb*32 + (e&3) + 8*(e>>2) + 4*hh
+        float m = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (key >= N) s[kb][e] = -INFINITY;
+                m = fmaxf(m, s[kb][e]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+        const float c1 = 0.125f * LOG2E;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = exp2f((s[kb][e] - m) * c1);
+                s[kb][e] = p;
+                l += p;
+            }
+        l += __shfl_xor(l, 32, 64);
+
+        f32x16 o[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[j] = (bf16_t)s[kb][8 * s2 + j];
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16_t* vp = Vt + (db * 32 + r32) * VT_LD + kb * 32 + 16 * s2 + 4 * hh;
+                    bf16x4 lo = *(const bf16x4*)vp, hi = *(const bf16x4*)(vp + 8);
+                    bf16x8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
+                }
+            }
+        if (q < N) {
+            const float inv = 1.0f / l;
+            bf16_t* op = ctx + ((size_t)b * N + q) * D + h * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 w;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) w[i] = (bf16_t)(o[db][4 * g + i] * inv);
+                    *(bf16x4*)(op + db * 32 + 8 * g + 4 * hh) = w;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int SC_KT = 128;   // keys per LDS tile
+template <typename T>
+__global__ __launch_bounds__(256) void vit_attention_scalar(const T* __restrict__ qkv, T* __restrict__ ctx, int N, int H) {
+    __shared__ float Ks[SC_KT][65];
+    __shared__ float Vs[SC_KT][65];
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int D = H * 64, ld = 3 * D;
+    const int tid = threadIdx.x;
+    const int q = blockIdx.y * 256 + tid;
+    const T* base = qkv + (size_t)b * N * ld + h * 64;
+    float qv[64], o[64];
+    const int qc = min(q, N - 1);
+#pragma unroll
+    for (int d = 0; d < 64; ++d) { qv[d] = to_f32(base[(size_t)qc * ld + d]) * 0.125f; o[d] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < N; k0 += SC_KT) {
+        const int nk = min(SC_KT, N - k0);
+        __syncthreads();
+        for (int c = tid; c < nk * 64; c += 256) {
+            const int j = c >> 6, d = c & 63;
+            Ks[j][d] = to_f32(base[(size_t)(k0 + j) * ld + D + d]);
+            Vs[j][d] = to_f32(base[(size_t)(k0 + j) * ld + 2 * D + d]);
+        }
+        __syncthreads();
+        for (int j = 0; j < nk; ++j) {
+            float sc = 0.f;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) sc = fmaf(qv[d], Ks[j][d], sc);
+            const float mn = fmaxf(m, sc);
+            const float c = expf(m - mn), p = expf(sc - mn);
+            l = l * c + p;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) o[d] = fmaf(p, Vs[j][d], o[d] * c);
+            m = mn;
+        }
+    }
+    if (q < N) {
+        const float inv = 1.0f / l;
+        T* op = ctx + ((size_t)b * N + q) * D + h * 64;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) op[d] = from_f32<T>(o[d] * inv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restrict__ q, const T* __restrict__ kbase,
+                                                               const T* __restrict__ vbase, const int* __restrict__ anc,
+                                                               int anc_ld, int rows_per_kv, int kv_ld, int n_keys,
+                                                               T* __restrict__ out, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = (float*)smem;                         // [n_keys] scores -> probabilities
+    float* red = sc + ((n_keys + 3) & ~3);            // [8] block reductions
+    float* part = red + 8;                            // [4][64] per-wave partial outputs
+    const int row = blockIdx.x, h = blockIdx.y, Dh = H * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ksub = lane >> 3, dch = lane & 7;
+    float qv[8];
+    load8<T>(q + (size_t)row * Dh + h * 64 + dch * 8, qv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qv[i] *= 0.125f;
+    const int ngroups = (n_keys + 7) / 8;
+    for (int g = wave; g < ngroups; g += 4) {
+        const int key = g * 8 + ksub;
+        float s = 0.f;
+        if (key < n_keys) {
+            const int src = anc ? anc[(size_t)row * anc_ld + key] : row / rows_per_kv;
+            float kv[8];
+            load8<T>(kbase + (((size_t)src * H + h) * kv_ld + key) * 64 + dch * 8, kv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s = fmaf(qv[i], kv[i], s);
+        }
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        if (dch == 0 && key < n_keys) sc[key] = s;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int j = tid; j < n_keys; j += 256) m = fmaxf(m, sc[j]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float l = 0.f;
+    for (int j = tid; j < n_keys; j += 256) { float p = expf(sc[j] - m); sc[j] = p; l += p; }
+    l = wave_sum(l);
+    if (lane == 0) red[4 + wave] = l;
+    __syncthreads();
+    l = red[4] + red[5] + red[6] + red[7];
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = 0.f;
+    for (int g = wave; g < ngroups; g += 4) {
+        const int key = g * 8 + ksub;
+        if (key < n_keys) {
+            const int src = anc ? anc[(size_t)row * anc_ld + key] : row / rows_per_kv;
+            float vv[8];
+            load8<T>(vbase + (((size_t)src * H + h) * kv_ld + key) * 64 + dch * 8, vv);
+            const float p = sc[key];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = fmaf(p, vv[i], o[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        o[i] += __shfl_xor(o[i], 8, 64); o[i] += __shfl_xor(o[i], 16, 64); o[i] += __shfl_xor(o[i], 32, 64);
+    }
+    if (ksub == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) part[wave * 64 + dch * 8 + i] = o[i];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const float v = (part[tid] + part[64 + tid] + part[128 + tid] + part[192 + tid]) / l;
+        out[(size_t)row * Dh + h * 64 + tid] = from_f32<T>(v);
+    }
+}
+
+template <int KB>
+int launch_mfma_kb(const void* qkv, void* ctx, int B, int N, int H, hipStream_t s) {
+    const int lds = KB * 32 * 128 + 64 * VT_LD * 2;
+    static bool attr_done = false;
+    auto kern = vit_attention_mfma<KB>;
+    if (!attr_done && lds > 64 * 1024) {
+        CAP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)ctx, N, H);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s) {
+    const int kb = (N + 31) / 32;
+    const bool mfma_ok = dtype == CAP_DT_BF16 && (kb == 1 || kb == 7 || kb == 9);
+    if (impl == 2 && !mfma_ok) {
+        cap_set_error("vit_attention: MFMA path needs bf16 and 1, 7 or 9 key blocks (N=%d)", N);
+        return -1;
+    }
+    if (impl == 0) impl = mfma_ok ? 2 : 1;
+    if (impl == 2) {
+        if (kb == 1) return launch_mfma_kb<1>(qkv, ctx, B, N, H, s);
+        if (kb == 7) return launch_mfma_kb<7>(qkv, ctx, B, N, H, s);
+        return launch_mfma_kb<9>(qkv, ctx, B, N, H, s);
+    }
+    dim3 grid(B * H, (N + 255) / 256);
+    if (dtype == CAP_DT_BF16)
+        hipLaunchKernelGGL(vit_attention_scalar<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, N, H);
+    else
+        hipLaunchKernelGGL(vit_attention_scalar<float>, grid, dim3(256), 0, s, (const float*)qkv, (float*)ctx, N, H);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int* anc,
+                            int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H,
+                            hipStream_t s) {
+    if (n_keys <= 0 || n_keys > 8192) { cap_set_error("decode_attention: bad key count %d", n_keys); return -1; }
+    const int lds = (((n_keys + 3) & ~3) + 8 + 256) * 4;
+    dim3 grid(R, H);
+    if (dtype == CAP_DT_BF16)
+        hipLaunchKernelGGL(decode_attention_kernel<bf16_t>, grid, dim3(256), lds, s, (const bf16_t*)q,
+                           (const bf16_t*)kbase, (const bf16_t*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys,
+                           (bf16_t*)out, H);
+    else
+        hipLaunchKernelGGL(decode_attention_kernel<float>, grid, dim3(256), lds, s, (const float*)q,
+                           (const float*)kbase, (const float*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys,
+                           (float*)out, H);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}

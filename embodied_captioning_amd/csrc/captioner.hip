@@ -1,0 +1,579 @@
+// Host side of libcaptioner_hip.so: weight registry, arena, the encoder / decoder launch sequences and the C ABI
+// declared in include/captioner_hip.h.  Everything on the data path is a kernel launch on the caller's stream; the
+// launch sequences never allocate or synchronise (so they can be captured into a hipGraph).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/captioner_hip.h"
+#include "gemm.h"
+#include "ops.h"
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[2048] = "";
+void cap_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+struct Slot {            // where one checkpoint tensor (or a row range of a fused tensor) lives
+    void* dst = nullptr;
+    int dtype = CAP_DT_F32;   // storage type at dst: compute dtype or fp32
+    int64_t rows = 0, cols = 0;
+    int dst_ld = 0;
+    bool loaded = false;
+};
+
+struct ProfTag { std::string tag; double flops, bytes; hipEvent_t e0, e1; };
+
+struct VLayer {
+    void *w_qkv, *w_proj, *w_fc1, *w_fc2;
+    float *b_qkv, *b_proj, *b_fc1, *b_fc2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+};
+struct TLayer {
+    void *w_qkv, *w_so, *w_cq, *w_co, *w_f1, *w_f2;
+    float *b_qkv, *b_so, *so_g, *so_b, *b_cq, *b_co, *co_g, *co_b, *b_f1, *b_f2, *f_g, *f_b;
+    void* self_cache;     // [2][R][H][max_len][64] (T)
+};
+
+struct Captioner {
+    CapConfig c;
+    int dt; size_t esz;
+    int NT, P, Kpatch, Kpad;
+    size_t dev_bytes = 0;
+    std::vector<void*> allocs;
+    std::multimap<std::string, Slot> slots;
+    float* stage = nullptr; size_t stage_elems = 0;
+    // vision weights
+    float *cls, *vpos, *b_patch, *post_g, *post_b;
+    void* w_patch;
+    std::vector<VLayer> vl;
+    // text weights
+    float *word_f32, *tpos, *emb_g, *emb_b, *b_ckv, *b_tr, *tr_g, *tr_b, *b_vocab;
+    void *word_t, *w_ckv, *w_tr;
+    std::vector<TLayer> tl;
+    // arena
+    void *patches, *ln, *qkv, *ctx, *mlp, *emb_t, *cross;
+    float *X, *emb_f;
+    int *seq, *finished, *lens, *anc;
+    float *dx, *dy, *logits;
+    void *dx_t, *dq, *dctx, *dh, *beam;
+    int ldl;
+    // profiling
+    bool prof = false;
+    std::vector<ProfTag> prof_recs;
+};
+
+int dev_alloc(Captioner* m, void** p, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    CAP_HIP_CHECK(hipMalloc(p, bytes));
+    m->allocs.push_back(*p);
+    m->dev_bytes += bytes;
+    return 0;
+}
+
+#define TRY(x) do { if ((x) != 0) return -1; } while (0)
+
+int add_slot(Captioner* m, const std::string& name, void* dst, int dtype, int64_t rows, int64_t cols, int dst_ld = 0) {
+    Slot s; s.dst = dst; s.dtype = dtype; s.rows = rows; s.cols = cols; s.dst_ld = dst_ld ? dst_ld : (int)cols;
+    m->slots.insert({name, s});
+    return 0;
+}
+
+// allocate a fp32 vector and register it
+int reg_f32(Captioner* m, const std::string& name, float** p, int64_t n) {
+    TRY(dev_alloc(m, (void**)p, n * 4));
+    return add_slot(m, name, *p, CAP_DT_F32, 1, n);
+}
+// allocate a compute-dtype matrix [rows, ld] and register it
+int reg_mat(Captioner* m, const std::string& name, void** p, int64_t rows, int64_t cols, int ld = 0) {
+    if (!ld) ld = (int)cols;
+    TRY(dev_alloc(m, p, (size_t)rows * ld * m->esz));
+    if (ld != cols) CAP_HIP_CHECK(hipMemset(*p, 0, (size_t)rows * ld * m->esz));
+    return add_slot(m, name, *p, m->dt, rows, cols, ld);
+}
+
+int build_blip(Captioner* m) {
+    const CapConfig& c = m->c;
+    const int D = c.v_hidden, Mv = c.v_mlp, T = c.t_hidden, F = c.t_ffn, V = c.vocab;
+    const std::string vm = "vision_model.";
+    TRY(reg_f32(m, vm + "embeddings.class_embedding", &m->cls, D));
+    TRY(reg_f32(m, vm + "embeddings.position_embedding", &m->vpos, (int64_t)m->NT * D));
+    TRY(reg_mat(m, vm + "embeddings.patch_embedding.weight", &m->w_patch, D, m->Kpatch, m->Kpad));
+    TRY(reg_f32(m, vm + "embeddings.patch_embedding.bias", &m->b_patch, D));
+    m->vl.resize(c.v_layers);
+    for (int i = 0; i < c.v_layers; ++i) {
+        VLayer& L = m->vl[i];
+        const std::string p = vm + "encoder.layers." + std::to_string(i) + ".";
+        TRY(reg_mat(m, p + "self_attn.qkv.weight", &L.w_qkv, 3 * D, D));
+        TRY(reg_f32(m, p + "self_attn.qkv.bias", &L.b_qkv, 3 * D));
+        TRY(reg_mat(m, p + "self_attn.projection.weight", &L.w_proj, D, D));
+        TRY(reg_f32(m, p + "self_attn.projection.bias", &L.b_proj, D));
+        TRY(reg_f32(m, p + "layer_norm1.weight", &L.ln1_g, D));
+        TRY(reg_f32(m, p + "layer_norm1.bias", &L.ln1_b, D));
+        TRY(reg_mat(m, p + "mlp.fc1.weight", &L.w_fc1, Mv, D));
+        TRY(reg_f32(m, p + "mlp.fc1.bias", &L.b_fc1, Mv));
+        TRY(reg_mat(m, p + "mlp.fc2.weight", &L.w_fc2, D, Mv));
+        TRY(reg_f32(m, p + "mlp.fc2.bias", &L.b_fc2, D));
+        TRY(reg_f32(m, p + "layer_norm2.weight", &L.ln2_g, D));
+        TRY(reg_f32(m, p + "layer_norm2.bias", &L.ln2_b, D));
+    }
+    TRY(reg_f32(m, vm + "post_layernorm.weight", &m->post_g, D));
+    TRY(reg_f32(m, vm + "post_layernorm.bias", &m->post_b, D));
+
+    const std::string tb = "text_decoder.bert.";
+    // the embedding table is read twice: fp32 rows for the lookup, compute-dtype [V,T] as the (tied) LM-head weight
+    TRY(dev_alloc(m, (void**)&m->word_f32, (size_t)V * T * 4));
+    add_slot(m, tb + "embeddings.word_embeddings.weight", m->word_f32, CAP_DT_F32, V, T);
+    if (m->dt == CAP_DT_F32) {
+        m->word_t = m->word_f32;
+    } else {
+        TRY(dev_alloc(m, &m->word_t, (size_t)V * T * m->esz));
+        add_slot(m, tb + "embeddings.word_embeddings.weight", m->word_t, m->dt, V, T);
+    }
+    TRY(reg_f32(m, tb + "embeddings.position_embeddings.weight", &m->tpos, (int64_t)c.max_pos * T));
+    TRY(reg_f32(m, tb + "embeddings.LayerNorm.weight", &m->emb_g, T));
+    TRY(reg_f32(m, tb + "embeddings.LayerNorm.bias", &m->emb_b, T));
+    // cross-attention K/V projections of all layers fused into one [L*2*T, D] weight (one GEMM per image batch)
+    TRY(dev_alloc(m, &m->w_ckv, (size_t)c.t_layers * 2 * T * D * m->esz));
+    TRY(dev_alloc(m, (void**)&m->b_ckv, (size_t)c.t_layers * 2 * T * 4));
+    m->tl.resize(c.t_layers);
+    for (int i = 0; i < c.t_layers; ++i) {
+        TLayer& L = m->tl[i];
+        const std::string p = tb + "encoder.layer." + std::to_string(i) + ".";
+        TRY(dev_alloc(m, &L.w_qkv, (size_t)3 * T * T * m->esz));
+        TRY(dev_alloc(m, (void**)&L.b_qkv, (size_t)3 * T * 4));
+        const char* nm[3] = {"query", "key", "value"};
+        for (int j = 0; j < 3; ++j) {
+            add_slot(m, p + "attention.self." + nm[j] + ".weight", (char*)L.w_qkv + (size_t)j * T * T * m->esz, m->dt, T, T);
+            add_slot(m, p + "attention.self." + nm[j] + ".bias", L.b_qkv + (size_t)j * T, CAP_DT_F32, 1, T);
+        }
+        TRY(reg_mat(m, p + "attention.output.dense.weight", &L.w_so, T, T));
+        TRY(reg_f32(m, p + "attention.output.dense.bias", &L.b_so, T));
+        TRY(reg_f32(m, p + "attention.output.LayerNorm.weight", &L.so_g, T));
+        TRY(reg_f32(m, p + "attention.output.LayerNorm.bias", &L.so_b, T));
+        TRY(reg_mat(m, p + "crossattention.self.query.weight", &L.w_cq, T, T));
+        TRY(reg_f32(m, p + "crossattention.self.query.bias", &L.b_cq, T));
+        for (int j = 0; j < 2; ++j) {
+            add_slot(m, p + "crossattention.self." + nm[j + 1] + ".weight",
+                     (char*)m->w_ckv + ((size_t)i * 2 + j) * T * D * m->esz, m->dt, T, D);
+            add_slot(m, p + "crossattention.self." + nm[j + 1] + ".bias", m->b_ckv + ((size_t)i * 2 + j) * T, CAP_DT_F32, 1, T);
+        }
+        TRY(reg_mat(m, p + "crossattention.output.dense.weight", &L.w_co, T, T));
+        TRY(reg_f32(m, p + "crossattention.output.dense.bias", &L.b_co, T));
+        TRY(reg_f32(m, p + "crossattention.output.LayerNorm.weight", &L.co_g, T));
+        TRY(reg_f32(m, p + "crossattention.output.LayerNorm.bias", &L.co_b, T));
+        TRY(reg_mat(m, p + "intermediate.dense.weight", &L.w_f1, F, T));
+        TRY(reg_f32(m, p + "intermediate.dense.bias", &L.b_f1, F));
+        TRY(reg_mat(m, p + "output.dense.weight", &L.w_f2, T, F));
+        TRY(reg_f32(m, p + "output.dense.bias", &L.b_f2, T));
+        TRY(reg_f32(m, p + "output.LayerNorm.weight", &L.f_g, T));
+        TRY(reg_f32(m, p + "output.LayerNorm.bias", &L.f_b, T));
+    }
+    const std::string cp = "text_decoder.cls.predictions.";
+    TRY(reg_mat(m, cp + "transform.dense.weight", &m->w_tr, T, T));
+    TRY(reg_f32(m, cp + "transform.dense.bias", &m->b_tr, T));
+    TRY(reg_f32(m, cp + "transform.LayerNorm.weight", &m->tr_g, T));
+    TRY(reg_f32(m, cp + "transform.LayerNorm.bias", &m->tr_b, T));
+    TRY(reg_f32(m, cp + "bias", &m->b_vocab, V));
+    return 0;
+}
+
+int build_arena(Captioner* m) {
+    const CapConfig& c = m->c;
+    const size_t Bm = c.max_batch, NT = m->NT, D = c.v_hidden, T = c.t_hidden, e = m->esz;
+    const size_t M = Bm * NT, R = Bm * c.max_beams, Lm = c.max_len, H = c.t_heads;
+    TRY(dev_alloc(m, &m->patches, Bm * m->P * m->Kpad * e));
+    CAP_HIP_CHECK(hipMemset(m->patches, 0, Bm * m->P * m->Kpad * e));
+    TRY(dev_alloc(m, (void**)&m->X, M * D * 4));
+    TRY(dev_alloc(m, &m->ln, M * D * e));
+    TRY(dev_alloc(m, &m->qkv, M * 3 * D * e));
+    TRY(dev_alloc(m, &m->ctx, M * D * e));
+    TRY(dev_alloc(m, &m->mlp, M * c.v_mlp * e));
+    TRY(dev_alloc(m, (void**)&m->emb_f, M * D * 4));
+    TRY(dev_alloc(m, &m->emb_t, M * D * e));
+    TRY(dev_alloc(m, &m->cross, (size_t)c.t_layers * 2 * Bm * H * NT * 64 * e));
+    TRY(dev_alloc(m, (void**)&m->seq, R * Lm * 4));
+    TRY(dev_alloc(m, (void**)&m->finished, R * 4));
+    TRY(dev_alloc(m, (void**)&m->lens, R * 4));
+    TRY(dev_alloc(m, (void**)&m->anc, 2 * R * Lm * 4));
+    TRY(dev_alloc(m, (void**)&m->dx, R * T * 4));
+    TRY(dev_alloc(m, (void**)&m->dy, R * T * 4));
+    TRY(dev_alloc(m, &m->dx_t, R * T * e));
+    TRY(dev_alloc(m, &m->dq, R * T * e));
+    TRY(dev_alloc(m, &m->dctx, R * T * e));
+    TRY(dev_alloc(m, &m->dh, R * c.t_ffn * e));
+    m->ldl = (c.vocab + 3) & ~3;
+    TRY(dev_alloc(m, (void**)&m->logits, R * (size_t)m->ldl * 4));
+    for (int i = 0; i < c.t_layers; ++i) TRY(dev_alloc(m, &m->tl[i].self_cache, 2 * R * H * Lm * 64 * e));
+    TRY(dev_alloc(m, &m->beam, beam_state_bytes((int)Bm, c.max_beams, (int)Lm)));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- profiling
+struct ProfScope {
+    Captioner* m; hipStream_t s; int idx = -1;
+    ProfScope(Captioner* m_, hipStream_t s_, const char* tag, double flops, double bytes) : m(m_), s(s_) {
+        if (!m->prof) return;
+        ProfTag t; t.tag = tag; t.flops = flops; t.bytes = bytes;
+        if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess) return;
+        hipEventRecord(t.e0, s);
+        m->prof_recs.push_back(t);
+        idx = (int)m->prof_recs.size() - 1;
+    }
+    ~ProfScope() { if (idx >= 0) hipEventRecord(m->prof_recs[idx].e1, s); }
+};
+
+int gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, int lda, const void* W, int ldw, void* C, int ldc,
+         const float* bias, const float* resid, int M, int N, int K, int gelu, int out_f32, int epi = EPI_STORE,
+         int p0 = 0, int p1 = 0, int p2 = 0, int p3 = 0, const float* aux = nullptr, void* C2 = nullptr) {
+    GemmParams p;
+    p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.bias = bias; p.resid = resid; p.ldr = ldc;
+    p.M = M; p.N = N; p.K = K; p.gelu = gelu; p.out_f32 = out_f32; p.epi = epi;
+    p.p0 = p0; p.p1 = p1; p.p2 = p2; p.p3 = p3; p.aux = aux; p.C2 = C2;
+    const double osz = out_f32 ? 4.0 : (double)m->esz;
+    ProfScope ps(m, s, tag, 2.0 * M * N * K, ((double)M * K + (double)N * K) * m->esz + (double)M * N * osz);
+    return launch_gemm(m->dt, p, 0, s);
+}
+
+// ---------------------------------------------------------------------------------------------- encoder
+int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_embeds, hipStream_t s) {
+    const CapConfig& c = m->c;
+    const int D = c.v_hidden, NT = m->NT, M = B * NT, H = c.v_heads;
+    {
+        ProfScope ps(m, s, "patchify", 0, (double)B * 3 * c.image_size * c.image_size * (fmt ? 1 : 4) + (double)B * m->P * m->Kpad * m->esz);
+        TRY(launch_patchify(m->dt, pixels, fmt, B, c.image_size, c.patch_size, m->Kpad, m->patches, c.pix_mean, c.pix_std, s));
+    }
+    TRY(gemm(m, s, "gemm_patch", m->patches, m->Kpad, m->w_patch, m->Kpad, m->X, D, m->b_patch, nullptr, B * m->P, D,
+             m->Kpad, 0, 1, EPI_PATCH, m->P, 0, 0, 0, m->vpos));
+    TRY(launch_cls_rows(m->cls, m->vpos, m->X, B, NT, D, s));
+    for (int i = 0; i < c.v_layers; ++i) {
+        const VLayer& L = m->vl[i];
+        {
+            ProfScope ps(m, s, "layernorm", 0, (double)M * D * (4 + m->esz));
+            TRY(launch_layernorm(m->dt, m->X, D, L.ln1_g, L.ln1_b, c.v_eps, m->ln, nullptr, M, D, s));
+        }
+        TRY(gemm(m, s, "gemm_qkv", m->ln, D, L.w_qkv, D, m->qkv, 3 * D, L.b_qkv, nullptr, M, 3 * D, D, 0, 0));
+        {
+            ProfScope ps(m, s, "vit_attention", 4.0 * B * H * (double)NT * NT * 64, (double)M * 4 * D * m->esz);
+            TRY(launch_vit_attention(m->dt, m->qkv, m->ctx, B, NT, H, 0, s));
+        }
+        TRY(gemm(m, s, "gemm_proj", m->ctx, D, L.w_proj, D, m->X, D, L.b_proj, m->X, M, D, D, 0, 1));
+        {
+            ProfScope ps(m, s, "layernorm", 0, (double)M * D * (4 + m->esz));
+            TRY(launch_layernorm(m->dt, m->X, D, L.ln2_g, L.ln2_b, c.v_eps, m->ln, nullptr, M, D, s));
+        }
+        TRY(gemm(m, s, "gemm_fc1", m->ln, D, L.w_fc1, D, m->mlp, c.v_mlp, L.b_fc1, nullptr, M, c.v_mlp, D, 1, 0));
+        TRY(gemm(m, s, "gemm_fc2", m->mlp, c.v_mlp, L.w_fc2, c.v_mlp, m->X, D, L.b_fc2, m->X, M, D, c.v_mlp, 0, 1));
+    }
+    {
+        ProfScope ps(m, s, "layernorm", 0, (double)M * D * (8 + m->esz));
+        TRY(launch_layernorm(m->dt, m->X, D, m->post_g, m->post_b, c.v_eps, m->emb_t, out_embeds ? out_embeds : m->emb_f, M, D, s));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- decoder
+int post_ln(Captioner* m, hipStream_t s, const float* g, const float* b, int R) {
+    ProfScope ps(m, s, "dec_layernorm", 0, (double)R * m->c.t_hidden * (8 + m->esz));
+    return launch_layernorm(m->dt, m->dy, m->c.t_hidden, g, b, m->c.t_eps, m->dx_t, m->dx, R, m->c.t_hidden, s);
+}
+
+int run_decoder_step(Captioner* m, const int* tokens, int tok_ld, int t, int B, int K, const int* anc, int Lm,
+                     hipStream_t s) {
+    const CapConfig& c = m->c;
+    const int T = c.t_hidden, F = c.t_ffn, H = c.t_heads, R = B * K, NT = m->NT;
+    const size_t e = m->esz;
+    TRY(launch_embed(m->dt, tokens, tok_ld, t, m->word_f32, m->tpos, m->emb_g, m->emb_b, c.t_eps, m->dx_t, m->dx, R, T, s));
+    for (int i = 0; i < c.t_layers; ++i) {
+        const TLayer& L = m->tl[i];
+        char* kc = (char*)L.self_cache;
+        char* vc = kc + (size_t)R * H * Lm * 64 * e;
+        TRY(gemm(m, s, "dec_gemm_qkv", m->dx_t, T, L.w_qkv, T, m->dq, T, L.b_qkv, nullptr, R, 3 * T, T, 0, 0, EPI_QKVCACHE,
+                 R, H, Lm, t, nullptr, kc));
+        {
+            ProfScope ps(m, s, "dec_self_attn", 4.0 * R * H * (t + 1) * 64, 2.0 * R * H * (t + 1) * 64 * e);
+            TRY(launch_decode_attention(m->dt, m->dq, kc, vc, anc, Lm, 1, Lm, t + 1, m->dctx, R, H, s));
+        }
+        TRY(gemm(m, s, "dec_gemm_so", m->dctx, T, L.w_so, T, m->dy, T, L.b_so, m->dx, R, T, T, 0, 1));
+        TRY(post_ln(m, s, L.so_g, L.so_b, R));
+        TRY(gemm(m, s, "dec_gemm_cq", m->dx_t, T, L.w_cq, T, m->dq, T, L.b_cq, nullptr, R, T, T, 0, 0));
+        {
+            const char* ck = (char*)m->cross + ((size_t)i * 2 + 0) * B * H * NT * 64 * e;
+            const char* cv = (char*)m->cross + ((size_t)i * 2 + 1) * B * H * NT * 64 * e;
+            ProfScope ps(m, s, "dec_cross_attn", 4.0 * R * H * NT * 64, 2.0 * B * H * NT * 64 * e);
+            TRY(launch_decode_attention(m->dt, m->dq, ck, cv, nullptr, 0, K, NT, NT, m->dctx, R, H, s));
+        }
+        TRY(gemm(m, s, "dec_gemm_co", m->dctx, T, L.w_co, T, m->dy, T, L.b_co, m->dx, R, T, T, 0, 1));
+        TRY(post_ln(m, s, L.co_g, L.co_b, R));
+        TRY(gemm(m, s, "dec_gemm_f1", m->dx_t, T, L.w_f1, T, m->dh, F, L.b_f1, nullptr, R, F, T, 1, 0));
+        TRY(gemm(m, s, "dec_gemm_f2", m->dh, F, L.w_f2, F, m->dy, T, L.b_f2, m->dx, R, T, F, 0, 1));
+        TRY(post_ln(m, s, L.f_g, L.f_b, R));
+    }
+    TRY(gemm(m, s, "dec_gemm_tr", m->dx_t, T, m->w_tr, T, m->dy, T, m->b_tr, nullptr, R, T, T, 1, 1));
+    TRY(post_ln(m, s, m->tr_g, m->tr_b, R));
+    TRY(gemm(m, s, "dec_gemm_vocab", m->dx_t, T, m->word_t, T, m->logits, m->ldl, m->b_vocab, nullptr, R, c.vocab, T, 0, 1));
+    return 0;
+}
+
+__global__ void iota_rows_kernel(int* anc, int R, int L) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * R * L; i += gridDim.x * blockDim.x) anc[i] = (i / L) % R;
+}
+__global__ void init_seq_kernel(int* seq, int* fin, int* len, int R, int L, int bos, int pad) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < R * L; i += gridDim.x * blockDim.x) seq[i] = (i % L == 0) ? bos : pad;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < R; i += gridDim.x * blockDim.x) { fin[i] = 0; len[i] = L; }
+}
+__global__ void copy_logits_kernel(const float* src, int ld, float* dst, int R, int V) {
+    const size_t n = (size_t)R * V;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / V, c = i - r * V;
+        dst[i] = src[r * ld + c];
+    }
+}
+__global__ void copy_i32_kernel(const int* s, int* d, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm, float lp, int32_t* out_ids,
+                 int32_t* out_len, float* out_scores, float* out_step_logits, hipStream_t s) {
+    const CapConfig& c = m->c;
+    const int R = B * K, NT = m->NT, D = c.v_hidden, T = c.t_hidden, H = c.t_heads;
+    TRY(run_encoder(m, pixels, fmt, B, nullptr, s));
+    TRY(gemm(m, s, "gemm_crosskv", m->emb_t, D, m->w_ckv, D, m->cross, 0, m->b_ckv, nullptr, B * NT, c.t_layers * 2 * T, D,
+             0, 0, EPI_CROSSKV, NT, H, B));
+    if (K == 1) {
+        hipLaunchKernelGGL(init_seq_kernel, dim3(64), dim3(256), 0, s, m->seq, m->finished, m->lens, R, Lm, c.bos, c.pad);
+    } else {
+        TRY(launch_beam_init(m->beam, B, K, Lm, c.bos, c.pad, c.eos, s));
+        hipLaunchKernelGGL(iota_rows_kernel, dim3(64), dim3(256), 0, s, m->anc, R, Lm);
+    }
+    CAP_HIP_CHECK(hipGetLastError());
+    for (int t = 0; t + 1 < Lm; ++t) {
+        const int cur_len = t + 1;
+        const int* tokens = K == 1 ? m->seq : beam_running_tokens_p(m->beam, B, K, Lm, cur_len & 1);
+        const int* anc = K == 1 ? nullptr : m->anc + (size_t)(cur_len & 1) * R * Lm;
+        TRY(run_decoder_step(m, tokens, Lm, t, B, K, anc, Lm, s));
+        if (out_step_logits) {
+            hipLaunchKernelGGL(copy_logits_kernel, dim3(1024), dim3(256), 0, s, m->logits, m->ldl,
+                               out_step_logits + (size_t)t * R * c.vocab, R, c.vocab);
+            CAP_HIP_CHECK(hipGetLastError());
+        }
+        ProfScope ps(m, s, K == 1 ? "greedy_select" : "beam_step", 0, (double)R * c.vocab * 4);
+        if (K == 1)
+            TRY(launch_greedy_select(m->logits, m->ldl, c.vocab, m->seq, Lm, t, Lm, c.eos, c.pad, m->finished, m->lens, R, s));
+        else
+            TRY(launch_beam_step(m->beam, m->logits, m->ldl, c.vocab, B, K, Lm, cur_len, c.eos, lp, m->anc, Lm, s));
+    }
+    if (K == 1) {
+        hipLaunchKernelGGL(copy_i32_kernel, dim3(64), dim3(256), 0, s, m->seq, out_ids, (size_t)R * Lm);
+        if (out_len) hipLaunchKernelGGL(copy_i32_kernel, dim3(4), dim3(256), 0, s, m->lens, out_len, (size_t)R);
+        CAP_HIP_CHECK(hipGetLastError());
+    } else {
+        TRY(launch_beam_finalize(m->beam, B, K, Lm, out_ids, out_len, out_scores, s));
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+const char* cap_last_error(void) { return g_err; }
+int cap_version(void) { return 1; }
+
+int cap_create(const CapConfig* cfg, CapHandle* out) {
+    if (!cfg || !out) { cap_set_error("cap_create: null argument"); return -1; }
+    if (cfg->struct_size != (int)sizeof(CapConfig)) {
+        cap_set_error("cap_create: CapConfig size mismatch (caller %d, library %d)", cfg->struct_size, (int)sizeof(CapConfig));
+        return -1;
+    }
+    if (cfg->arch != CAP_ARCH_BLIP) { cap_set_error("cap_create: unknown arch %d", cfg->arch); return -1; }
+    if (cfg->compute_dtype != CAP_F32 && cfg->compute_dtype != CAP_BF16) { cap_set_error("cap_create: unknown dtype"); return -1; }
+    if (cfg->v_hidden != cfg->v_heads * 64 || cfg->t_hidden != cfg->t_heads * 64) {
+        cap_set_error("cap_create: head_dim must be 64 (v %d/%d, t %d/%d)", cfg->v_hidden, cfg->v_heads, cfg->t_hidden, cfg->t_heads);
+        return -1;
+    }
+    if (cfg->image_size % cfg->patch_size || cfg->max_batch < 1 || cfg->max_beams < 1 || cfg->max_beams > 8 ||
+        cfg->max_len < 2 || cfg->max_len > cfg->max_pos) {
+        cap_set_error("cap_create: bad geometry/capacity");
+        return -1;
+    }
+    if (cfg->v_hidden % 64 || cfg->v_mlp % 64 || cfg->t_ffn % 64) { cap_set_error("cap_create: widths must be multiples of 64"); return -1; }
+    Captioner* m = new Captioner();
+    m->c = *cfg;
+    m->dt = cfg->compute_dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32;
+    m->esz = m->dt == CAP_DT_BF16 ? 2 : 4;
+    const int g = cfg->image_size / cfg->patch_size;
+    m->P = g * g; m->NT = m->P + 1;
+    m->Kpatch = 3 * cfg->patch_size * cfg->patch_size;
+    m->Kpad = (m->Kpatch + 63) / 64 * 64;
+    if (build_blip(m) != 0 || build_arena(m) != 0) {
+        for (void* p : m->allocs) hipFree(p);
+        delete m;
+        return -1;
+    }
+    *out = (CapHandle)m;
+    return 0;
+}
+
+int cap_destroy(CapHandle h) {
+    if (!h) return 0;
+    Captioner* m = (Captioner*)h;
+    hipDeviceSynchronize();
+    for (auto& r : m->prof_recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (void* p : m->allocs) hipFree(p);
+    if (m->stage) hipFree(m->stage);
+    delete m;
+    return 0;
+}
+
+size_t cap_device_bytes(CapHandle h) { return h ? ((Captioner*)h)->dev_bytes : 0; }
+
+int cap_load_weight(CapHandle h, const char* name, const float* data, int on_device, int ndim, const int64_t* shape,
+                    void* stream) {
+    Captioner* m = (Captioner*)h;
+    if (!m || !name || !data) { cap_set_error("cap_load_weight: null argument"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    auto range = m->slots.equal_range(name);
+    if (range.first == range.second) return 1;   // not a tensor this architecture stores (e.g. tied decoder.weight)
+    const float* src = data;
+    if (!on_device) {
+        if ((size_t)n > m->stage_elems) {
+            if (m->stage) { CAP_HIP_CHECK(hipStreamSynchronize(s)); hipFree(m->stage); }
+            CAP_HIP_CHECK(hipMalloc((void**)&m->stage, (size_t)n * 4));
+            m->stage_elems = n;
+        }
+        CAP_HIP_CHECK(hipMemcpyAsync(m->stage, data, (size_t)n * 4, hipMemcpyHostToDevice, s));
+        src = m->stage;
+    }
+    for (auto it = range.first; it != range.second; ++it) {
+        Slot& sl = it->second;
+        if (sl.rows * sl.cols != n) {
+            cap_set_error("cap_load_weight: %s has %lld elements, expected %lld x %lld", name, (long long)n,
+                          (long long)sl.rows, (long long)sl.cols);
+            return -1;
+        }
+        TRY(launch_convert2d(sl.dtype, src, sl.dst, (int)sl.rows, (int)sl.cols, sl.dst_ld, s));
+        sl.loaded = true;
+    }
+    CAP_HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int cap_finalize_weights(CapHandle h) {
+    Captioner* m = (Captioner*)h;
+    if (!m) { cap_set_error("null handle"); return -1; }
+    int missing = 0;
+    std::string names;
+    for (auto& kv : m->slots)
+        if (!kv.second.loaded) {
+            if (missing < 8) names += (missing ? ", " : "") + kv.first;
+            ++missing;
+        }
+    if (missing) cap_set_error("%d tensors not loaded: %s%s", missing, names.c_str(), missing > 8 ? ", ..." : "");
+    return missing;
+}
+
+static int check_call(Captioner* m, int B, int K, int Lm, int fmt) {
+    if (!m) { cap_set_error("null handle"); return -1; }
+    if (cap_finalize_weights((CapHandle)m) != 0) return -1;
+    if (B < 1 || B > m->c.max_batch || K < 1 || K > m->c.max_beams || Lm < 2 || Lm > m->c.max_len) {
+        cap_set_error("request B=%d beams=%d max_len=%d exceeds the handle's capacity (%d, %d, %d)", B, K, Lm,
+                      m->c.max_batch, m->c.max_beams, m->c.max_len);
+        return -1;
+    }
+    if (fmt != CAP_PIX_F32_NCHW && fmt != CAP_PIX_U8_NHWC) { cap_set_error("unknown pixel format %d", fmt); return -1; }
+    return 0;
+}
+
+int cap_encode(CapHandle h, const void* pixels, int pixel_fmt, int B, float* out_embeds, void* stream) {
+    Captioner* m = (Captioner*)h;
+    TRY(check_call(m, B, 1, 2, pixel_fmt));
+    if (!pixels || !out_embeds) { cap_set_error("cap_encode: null buffer"); return -1; }
+    return run_encoder(m, pixels, pixel_fmt, B, out_embeds, (hipStream_t)stream);
+}
+
+int cap_generate(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_beams, int max_len, float length_penalty,
+                 int32_t* out_ids, int32_t* out_len, float* out_scores, float* out_step_logits, void* stream) {
+    Captioner* m = (Captioner*)h;
+    TRY(check_call(m, B, num_beams, max_len, pixel_fmt));
+    if (!pixels || !out_ids) { cap_set_error("cap_generate: null buffer"); return -1; }
+    return run_generate(m, pixels, pixel_fmt, B, num_beams, max_len, length_penalty, out_ids, out_len, out_scores,
+                        out_step_logits, (hipStream_t)stream);
+}
+
+int cap_profile_enable(CapHandle h, int on) {
+    Captioner* m = (Captioner*)h;
+    if (!m) return -1;
+    for (auto& r : m->prof_recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    m->prof_recs.clear();
+    m->prof = on != 0;
+    return 0;
+}
+
+int cap_profile_report(CapHandle h, char* buf, size_t buf_bytes) {
+    Captioner* m = (Captioner*)h;
+    if (!m || !buf) return -1;
+    CAP_HIP_CHECK(hipDeviceSynchronize());
+    struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::map<std::string, Agg> agg;
+    for (auto& r : m->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        Agg& a = agg[r.tag];
+        a.n++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+    }
+    std::string out = "{";
+    bool first = true;
+    for (auto& kv : agg) {
+        char line[512];
+        snprintf(line, sizeof(line), "%s\"%s\": {\"launches\": %ld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+                 first ? "" : ", ", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops, kv.second.bytes);
+        out += line;
+        first = false;
+    }
+    out += "}";
+    if (out.size() + 1 > buf_bytes) { cap_set_error("cap_profile_report: buffer too small (%zu needed)", out.size() + 1); return -1; }
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return 0;
+}
+
+// ---- single-kernel entry points
+int cap_op_gemm(int dtype, const void* A, const void* W, const float* bias, const float* resid, void* C, int M, int N,
+                int K, int gelu, int out_f32, int tile, void* stream) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = C; p.ldc = N; p.bias = bias; p.resid = resid; p.ldr = N;
+    p.M = M; p.N = N; p.K = K; p.gelu = gelu; p.out_f32 = out_f32; p.epi = EPI_STORE;
+    return launch_gemm(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, p, tile, (hipStream_t)stream);
+}
+int cap_op_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps, void* out_t,
+                     float* out_f, int M, int D, void* stream) {
+    return launch_layernorm(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, in, D, gamma, beta, eps, out_t, out_f, M, D,
+                            (hipStream_t)stream);
+}
+int cap_op_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, void* stream) {
+    return launch_vit_attention(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, qkv, ctx, B, N, H, impl, (hipStream_t)stream);
+}
+int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int32_t* anc,
+                            int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, void* stream) {
+    return launch_decode_attention(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, q, kbase, vbase, anc, anc_ld, rows_per_kv,
+                                   kv_ld, n_keys, out, R, H, (hipStream_t)stream);
+}
+int cap_op_convert(int dtype, const float* src, void* dst, size_t n, void* stream) {
+    return launch_convert(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, src, dst, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,294 @@
+// HBM-bound helper kernels of the captioner path: dtype casts, patch gather, LayerNorm, decoder embeddings,
+// greedy token selection.  One wave (64 lanes) per row for the row-wise ops; 16-byte accesses where the layout allows.
+#include "ops.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void convert_kernel(const float* __restrict__ src, T* __restrict__ dst, size_t n) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        float4 v = *(const float4*)(src + i);
+        dst[i] = from_f32<T>(v.x); dst[i + 1] = from_f32<T>(v.y);
+        dst[i + 2] = from_f32<T>(v.z); dst[i + 3] = from_f32<T>(v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t j = n & ~(size_t)3; j < n; ++j) dst[j] = from_f32<T>(src[j]);
+}
+
+template <typename T>
+__global__ void convert2d_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int cols, int dst_ld) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / cols, c = i - r * cols;
+        dst[r * dst_ld + c] = from_f32<T>(src[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One thread per output element; consecutive threads walk x inside an image row, so the pixel reads are
+// coalesced (fp32 NCHW: 4 B/lane contiguous; u8 NHWC: 3 B stride) and each thread writes one element of the
+// patch matrix.  k = c*ps*ps + dy*ps + dx  (== Conv2d weight [D,3,ps,ps] flattened).
+template <typename T>
+__global__ void patchify_kernel(const void* __restrict__ pixels, int fmt, int B, int img, int ps, int Kpad,
+                                T* __restrict__ out, float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int G = img / ps;
+    const size_t total = (size_t)B * 3 * img * img;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int x = (int)(i % img);
+        size_t r = i / img;
+        int y = (int)(r % img); r /= img;
+        int c = (int)(r % 3);
+        int b = (int)(r / 3);
+        float v;
+        if (fmt == 0) {
+            v = ((const float*)pixels)[i];
+        } else {
+            unsigned char u = ((const unsigned char*)pixels)[(((size_t)b * img + y) * img + x) * 3 + c];
+            float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+            v = ((float)u * (1.0f / 255.0f) - mean) / sd;
+        }
+        int py = y / ps, dy = y - py * ps, px = x / ps, dx = x - px * ps;
+        size_t row = (size_t)b * G * G + (size_t)py * G + px;
+        out[row * Kpad + (size_t)c * ps * ps + dy * ps + dx] = from_f32<T>(v);
+    }
+}
+
+__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ X,
+                                int B, int tokens, int D) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    int b = i / D, d = i - b * D;
+    X[(size_t)b * tokens * D + d] = cls[d] + pos[d];
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm, one wave per row, row held in registers (D <= 64*4*MAXV).  Two-pass mean/variance in fp32,
+// biased variance, eps inside the sqrt (torch.nn.functional.layer_norm).
+constexpr int LN_MAXV = 8;
+
+template <typename T>
+__device__ __forceinline__ void ln_row(const float4 (&v)[LN_MAXV], int nv, int lane, int D, const float* gamma,
+                                       const float* beta, float eps, T* out_t, float* out_f) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+        if (i < nv && lane * 4 + i * 256 < D) s += v[i].x + v[i].y + v[i].z + v[i].w;
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+        if (i < nv && lane * 4 + i * 256 < D) {
+            float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += a * a + b * b + c * c + d * d;
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (i < nv && c < D) {
+            float4 g = *(const float4*)(gamma + c), bb = *(const float4*)(beta + c);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + bb.x; o.y = (v[i].y - mean) * rstd * g.y + bb.y;
+            o.z = (v[i].z - mean) * rstd * g.z + bb.z; o.w = (v[i].w - mean) * rstd * g.w + bb.w;
+            if (out_f) *(float4*)(out_f + c) = o;
+            if (out_t) {
+                out_t[c] = from_f32<T>(o.x); out_t[c + 1] = from_f32<T>(o.y);
+                out_t[c + 2] = from_f32<T>(o.z); out_t[c + 3] = from_f32<T>(o.w);
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, int ld_in,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, T* out_t, float* out_f, int M, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int nv = (D + 255) / 256;
+    float4 v[LN_MAXV];
+    const float* x = in + (size_t)row * ld_in;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+        if (i < nv && lane * 4 + i * 256 < D) v[i] = *(const float4*)(x + lane * 4 + i * 256);
+    ln_row<T>(v, nv, lane, D, gamma, beta, eps, out_t ? out_t + (size_t)row * D : nullptr,
+              out_f ? out_f + (size_t)row * D : nullptr);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ seq, int seq_ld, int t,
+                                                    const float* __restrict__ word, const float* __restrict__ pos,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float eps, T* out_t, float* out_f, int R, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const int tok = seq[(size_t)row * seq_ld + t];
+    const int nv = (D + 255) / 256;
+    float4 v[LN_MAXV];
+    const float* w = word + (size_t)tok * D;
+    const float* p = pos + (size_t)t * D;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (i < nv && c < D) {
+            float4 a = *(const float4*)(w + c), b = *(const float4*)(p + c);
+            v[i].x = a.x + b.x; v[i].y = a.y + b.y; v[i].z = a.z + b.z; v[i].w = a.w + b.w;
+        }
+    }
+    ln_row<T>(v, nv, lane, D, gamma, beta, eps, out_t ? out_t + (size_t)row * D : nullptr,
+              out_f ? out_f + (size_t)row * D : nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Greedy step (HF:generation/utils.py:2925-2937): next = argmax (first maximal index, like torch.argmax);
+// finished rows emit pad; a row finishes when it emits EOS or reaches max_len.
+__global__ __launch_bounds__(256) void greedy_select_kernel(const float* __restrict__ logits, int ld, int V,
+                                                            int* __restrict__ seq, int seq_ld, int t, int max_len,
+                                                            int eos, int pad, int* __restrict__ finished,
+                                                            int* __restrict__ out_len) {
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* x = logits + (size_t)row * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) {
+        float v = x[i];
+        if (v > best) { best = v; bi = i; }
+    }
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    sv[tid] = best; si[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            float v2 = sv[tid + o]; int i2 = si[tid + o];
+            if (v2 > sv[tid] || (v2 == sv[tid] && i2 < si[tid])) { sv[tid] = v2; si[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int fin = finished[row];
+        int tok = fin ? pad : si[0];
+        seq[(size_t)row * seq_ld + t + 1] = tok;
+        if (!fin) {
+            if (tok == eos || t + 2 >= max_len) { finished[row] = 1; out_len[row] = t + 2; }
+        }
+    }
+}
+
+__global__ void fill_i32_kernel(int* p, int v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void fill_f32_kernel(float* p, float v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void copy_f32_kernel(const float* s, float* d, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+inline int grid_for(size_t n, int per_block) {
+    size_t g = (n + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+int launch_convert(int dtype, const float* src, void* dst, size_t n, hipStream_t s) {
+    if (dtype == CAP_DT_BF16)
+        hipLaunchKernelGGL(convert_kernel<bf16_t>, dim3(grid_for(n, 1024)), dim3(256), 0, s, src, (bf16_t*)dst, n);
+    else
+        hipLaunchKernelGGL(convert_kernel<float>, dim3(grid_for(n, 1024)), dim3(256), 0, s, src, (float*)dst, n);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_convert2d(int dtype, const float* src, void* dst, int rows, int cols, int dst_ld, hipStream_t s) {
+    const size_t n = (size_t)rows * cols;
+    if (dtype == CAP_DT_BF16)
+        hipLaunchKernelGGL(convert2d_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, (bf16_t*)dst, rows, cols, dst_ld);
+    else
+        hipLaunchKernelGGL(convert2d_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, (float*)dst, rows, cols, dst_ld);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_patchify(int dtype, const void* pixels, int fmt, int B, int img, int ps, int Kpad, void* out,
+                    const float* mean, const float* stdv, hipStream_t s) {
+    if (img % ps != 0 || 3 * ps * ps > Kpad) {
+        cap_set_error("patchify: image %d not divisible by patch %d or Kpad %d too small", img, ps, Kpad);
+        return -1;
+    }
+    const size_t n = (size_t)B * 3 * img * img;
+    const float m0 = mean ? mean[0] : 0.f, m1 = mean ? mean[1] : 0.f, m2 = mean ? mean[2] : 0.f;
+    const float s0 = stdv ? stdv[0] : 1.f, s1 = stdv ? stdv[1] : 1.f, s2 = stdv ? stdv[2] : 1.f;
+    if (dtype == CAP_DT_BF16)
+        hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, pixels, fmt, B, img, ps,
+                           Kpad, (bf16_t*)out, m0, m1, m2, s0, s1, s2);
+    else
+        hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, pixels, fmt, B, img, ps,
+                           Kpad, (float*)out, m0, m1, m2, s0, s1, s2);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_cls_rows(const float* cls, const float* pos, float* X, int B, int tokens, int D, hipStream_t s) {
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, cls, pos, X, B, tokens, D);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_layernorm(int dtype, const float* in, int ld_in, const float* gamma, const float* beta, float eps,
+                     void* out_t, float* out_f, int M, int D, hipStream_t s) {
+    if (D % 4 != 0 || D > 256 * LN_MAXV || (ld_in % 4) != 0) {
+        cap_set_error("layernorm: unsupported width %d (ld %d)", D, ld_in);
+        return -1;
+    }
+    if (dtype == CAP_DT_BF16)
+        hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3((M + 3) / 4), dim3(256), 0, s, in, ld_in, gamma, beta, eps,
+                           (bf16_t*)out_t, out_f, M, D);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, s, in, ld_in, gamma, beta, eps,
+                           (float*)out_t, out_f, M, D);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_embed(int dtype, const int* seq, int seq_ld, int t, const float* word, const float* pos,
+                 const float* gamma, const float* beta, float eps, void* out_t, float* out_f, int R, int D,
+                 hipStream_t s) {
+    if (D % 4 != 0 || D > 256 * LN_MAXV) { cap_set_error("embed: unsupported width %d", D); return -1; }
+    if (dtype == CAP_DT_BF16)
+        hipLaunchKernelGGL(embed_kernel<bf16_t>, dim3((R + 3) / 4), dim3(256), 0, s, seq, seq_ld, t, word, pos, gamma,
+                           beta, eps, (bf16_t*)out_t, out_f, R, D);
+    else
+        hipLaunchKernelGGL(embed_kernel<float>, dim3((R + 3) / 4), dim3(256), 0, s, seq, seq_ld, t, word, pos, gamma,
+                           beta, eps, (float*)out_t, out_f, R, D);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_greedy_select(const float* logits, int ld, int V, int* seq, int seq_ld, int t, int max_len, int eos,
+                         int pad, int* finished, int* out_len, int R, hipStream_t s) {
+    hipLaunchKernelGGL(greedy_select_kernel, dim3(R), dim3(256), 0, s, logits, ld, V, seq, seq_ld, t, max_len, eos, pad,
+                       finished, out_len);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_fill_i32(int* p, int v, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, v, n);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_fill_f32(float* p, float v, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, v, n);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_copy_f32(const float* src, float* dst, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(copy_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, dst, n);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}

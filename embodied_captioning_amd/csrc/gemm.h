@@ -1,0 +1,31 @@
+// C[M,N] = A[M,K] . W[N,K]^T (+bias, +epilogue) on gfx950 MFMA.  See gemm.hip.
+#pragma once
+#include "common.h"
+
+enum GemmEpi {
+    EPI_STORE = 0,     // C[row*ldc+col] = f(acc + bias) (+ resid)            out: T or f32
+    EPI_PATCH = 1,     // ViT patch-embed: row (b,p) -> token row b*(P+1)+1+p, + pos[(1+p)*N+col]   out: f32
+    EPI_CROSSKV = 2,   // decoder cross-attention K/V for all layers -> [layer][kv][image][head][token][64]  out: T
+    EPI_QKVCACHE = 3,  // decoder self-attention: q -> qbuf, k/v -> cache[kv][row][head][t][64]  out: T
+};
+
+struct GemmParams {
+    const void* A; int lda;        // activations, element type T, row-major [M,K]
+    const void* W; int ldw;        // weights, element type T, row-major [N,K] (torch Linear layout)
+    void* C; int ldc;              // output
+    const float* bias;             // [N] fp32 or nullptr
+    const float* resid; int ldr;   // fp32 [M,N] residual (may alias C) or nullptr
+    int M, N, K;
+    int gelu;                      // exact-erf GELU after bias
+    int out_f32;                   // 1: C is fp32, 0: C is T
+    int epi;
+    // EPI_PATCH: p0 = patches per image, aux = position table [(P+1), N] fp32
+    // EPI_CROSSKV: p0 = tokens per image, p1 = heads, p2 = images   (N = layers*2*heads*64)
+    // EPI_QKVCACHE: p0 = row capacity of the cache, p1 = heads, p2 = max positions, p3 = position t; C2 = cache base
+    int p0, p1, p2, p3;
+    const float* aux;
+    void* C2;
+};
+
+// dtype: CAP_DT_F32 / CAP_DT_BF16.  tile: 0 = auto, 1 = 128x128, 2 = 64x64
+int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream);

@@ -1,0 +1,49 @@
+// Launchers of the non-GEMM kernels (elementwise.hip, attention.hip, beam.hip).  All launch on `stream`,
+// never allocate or synchronise (graph-capturable), and return 0 / -1 (+ cap_set_error).
+#pragma once
+#include "common.h"
+
+// ---- elementwise.hip -------------------------------------------------------------------------
+// fp32 -> T copy (weight upload / activation cast); dst rows may be padded: dst[r*dst_ld + c] = src[r*cols + c]
+int launch_convert(int dtype, const float* src, void* dst, size_t n, hipStream_t s);
+int launch_convert2d(int dtype, const float* src, void* dst, int rows, int cols, int dst_ld, hipStream_t s);
+// im2col-free patch gather: pixels -> A[B*P, Kpad] (T).  fmt 0: fp32 NCHW normalised; fmt 1: u8 NHWC raw RGB,
+// normalised on the fly with (x/255 - mean[c]) / std[c].
+int launch_patchify(int dtype, const void* pixels, int fmt, int B, int img, int ps, int Kpad, void* out,
+                    const float* mean, const float* stdv, hipStream_t s);
+// X[b,0,:] = cls + pos[0]
+int launch_cls_rows(const float* cls, const float* pos, float* X, int B, int tokens, int D, hipStream_t s);
+// row LayerNorm: in fp32 [M,D]; writes out_t (T, optional) and out_f (fp32, optional; may alias in)
+int launch_layernorm(int dtype, const float* in, int ld_in, const float* gamma, const float* beta, float eps,
+                     void* out_t, float* out_f, int M, int D, hipStream_t s);
+// decoder embeddings: x = LN(word[tok] + pos[t]); tok = seq[row*seq_ld + t]
+int launch_embed(int dtype, const int* seq, int seq_ld, int t, const float* word, const float* pos,
+                 const float* gamma, const float* beta, float eps, void* out_t, float* out_f, int R, int D,
+                 hipStream_t s);
+// greedy selection: argmax (lowest index wins ties), pad after EOS, append at seq[row][t+1], track finished/len
+int launch_greedy_select(const float* logits, int ld, int V, int* seq, int seq_ld, int t, int max_len, int eos,
+                         int pad, int* finished, int* out_len, int R, hipStream_t s);
+int launch_fill_i32(int* p, int v, size_t n, hipStream_t s);
+int launch_fill_f32(float* p, float v, size_t n, hipStream_t s);
+int launch_copy_f32(const float* src, float* dst, size_t n, hipStream_t s);
+
+// ---- attention.hip ---------------------------------------------------------------------------
+// ViT self-attention over a fused qkv buffer [B*N, 3*H*64] (T) -> ctx [B*N, H*64] (T); scale = 1/8.
+// impl 0 = auto (MFMA for bf16 when N <= 256, scalar otherwise), 1 = scalar, 2 = MFMA.
+int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s);
+// single-query decode attention. q [R, H*64] (T).  K/V of row r, head h, position j at
+//   kbase + (((size_t)src(r,j) * H + h) * kv_ld + j) * 64   where src(r,j) = anc ? anc[r*anc_ld + j] : r / rows_per_kv
+// n_keys positions; out [R, H*64] (T).
+int launch_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int* anc,
+                            int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H,
+                            hipStream_t s);
+
+// ---- beam.hip --------------------------------------------------------------------------------
+size_t beam_state_bytes(int B, int K, int max_len);
+int launch_beam_init(void* state, int B, int K, int max_len, int bos, int pad, int eos, hipStream_t s);
+int launch_beam_step(void* state, const float* logits, int ld, int V, int B, int K, int max_len, int cur_len,
+                     int eos, float length_penalty, int* anc, int anc_ld, hipStream_t s);
+int launch_beam_finalize(void* state, int B, int K, int max_len, int* out_ids, int* out_len, float* out_scores,
+                         hipStream_t s);
+// device pointer: int32 [B*K, max_len] running sequences of the given parity (= cur_len & 1)
+const int* beam_running_tokens_p(void* state, int B, int K, int max_len, int parity);

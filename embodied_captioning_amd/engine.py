@@ -1,0 +1,151 @@
+"""Host orchestration over the C ABI: builds a handle, streams checkpoint tensors in, exposes encode / generate on
+torch CUDA tensors.  PyTorch here is plumbing only (device buffers, streams); all arithmetic runs in
+libcaptioner_hip.so.  Mirrors what the reference's wrappers call on their torch models:
+`model.generate(...)` (captioner/models/blip2/blip2.py:26, coca/coca.py:29) and `_encode_image` (coca_model.py:152-155).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from typing import Dict, Optional
+
+import torch
+
+from . import _native as N
+from .config import BlipArch
+
+OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+_DTYPES = {"f32": N.CAP_F32, "fp32": N.CAP_F32, "float32": N.CAP_F32, "bf16": N.CAP_BF16, "bfloat16": N.CAP_BF16}
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class CaptionerEngine:
+    """One handle = one model replica on one GPU, bound to torch's current stream of `device` at each call."""
+
+    def __init__(self, arch: BlipArch, dtype: str = "bf16", max_batch: int = 8, max_beams: int = 1,
+                 max_len: int = 20, device: str | torch.device = "cuda:0"):
+        if not torch.cuda.is_available():
+            raise N.CaptionerHipError("CaptionerEngine needs a GPU (torch.cuda.is_available() is False); "
+                                      "there is no CPU fallback in the product path")
+        self.lib = N.load_library()
+        self.arch = arch
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.max_batch, self.max_beams, self.max_len = max_batch, max_beams, max_len
+        cfg = N.CapConfig()
+        cfg.struct_size = C.sizeof(N.CapConfig)
+        cfg.arch = 0
+        cfg.compute_dtype = _DTYPES[dtype]
+        cfg.image_size, cfg.patch_size = arch.image_size, arch.patch_size
+        cfg.v_hidden, cfg.v_layers, cfg.v_heads, cfg.v_mlp, cfg.v_eps = (arch.v_hidden, arch.v_layers, arch.v_heads,
+                                                                         arch.v_mlp, arch.v_eps)
+        cfg.t_hidden, cfg.t_layers, cfg.t_heads, cfg.t_ffn = arch.t_hidden, arch.t_layers, arch.t_heads, arch.t_ffn
+        cfg.vocab, cfg.max_pos, cfg.t_eps = arch.vocab, arch.max_pos, arch.t_eps
+        cfg.bos, cfg.eos, cfg.pad = arch.bos, arch.eos, arch.pad
+        cfg.max_batch, cfg.max_beams, cfg.max_len = max_batch, max_beams, max_len
+        for i in range(3):
+            cfg.pix_mean[i] = OPENAI_CLIP_MEAN[i]
+            cfg.pix_std[i] = OPENAI_CLIP_STD[i]
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            N.check(self.lib.cap_create(C.byref(cfg), C.byref(self._h)), "cap_create")
+
+    # ------------------------------------------------------------------------------------------ lifetime
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.cap_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self.lib.cap_device_bytes(self._h))
+
+    # ------------------------------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        """HF BLIP key names.  Tied / unknown tensors are skipped; missing ones raise."""
+        with torch.cuda.device(self.device):
+            s = _stream_ptr(self.device)
+            for name, t in sd.items():
+                t = t.detach()
+                if t.dtype != torch.float32:
+                    t = t.float()
+                t = t.contiguous()
+                shape = (C.c_int64 * max(t.dim(), 1))(*(t.shape if t.dim() else (1,)))
+                rc = self.lib.cap_load_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), int(t.is_cuda),
+                                              max(t.dim(), 1), shape, C.c_void_p(s))
+                if rc < 0:
+                    raise N.CaptionerHipError(f"cap_load_weight({name}): {N.last_error()}")
+            missing = self.lib.cap_finalize_weights(self._h)
+            if missing and strict:
+                raise N.CaptionerHipError(f"checkpoint incomplete: {N.last_error()}")
+
+    # ------------------------------------------------------------------------------------------ forward
+    def _pixels(self, pixels: torch.Tensor):
+        if pixels.device != self.device:
+            pixels = pixels.to(self.device, non_blocking=True)
+        a = self.arch
+        if pixels.dtype == torch.uint8:
+            if pixels.dim() != 4 or pixels.shape[1:] != (a.image_size, a.image_size, 3):
+                raise ValueError(f"uint8 frames must be [B,{a.image_size},{a.image_size},3], got {tuple(pixels.shape)}")
+            fmt = N.CAP_PIX_U8_NHWC
+        else:
+            if pixels.dim() != 4 or pixels.shape[1:] != (3, a.image_size, a.image_size):
+                raise ValueError(f"float frames must be [B,3,{a.image_size},{a.image_size}], got {tuple(pixels.shape)}")
+            pixels = pixels.float()
+            fmt = N.CAP_PIX_F32_NCHW
+        return pixels.contiguous(), fmt
+
+    def encode(self, pixels: torch.Tensor) -> torch.Tensor:
+        pixels, fmt = self._pixels(pixels)
+        B = pixels.shape[0]
+        out = torch.empty((B, self.arch.n_tokens, self.arch.v_hidden), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.cap_encode(self._h, C.c_void_p(pixels.data_ptr()), fmt, B, C.c_void_p(out.data_ptr()),
+                                        C.c_void_p(_stream_ptr(self.device))), "cap_encode")
+        return out
+
+    def generate(self, pixels: torch.Tensor, num_beams: int = 1, max_length: Optional[int] = None,
+                 length_penalty: float = 1.0, output_logits: bool = False) -> Dict[str, torch.Tensor]:
+        """Returns device tensors: sequences int32 [B, max_length] (incl. BOS), lengths int32 [B],
+        sequences_scores fp32 [B] (beams only), logits fp32 [max_length-1, B*num_beams, vocab] (optional)."""
+        pixels, fmt = self._pixels(pixels)
+        B = pixels.shape[0]
+        L = max_length or self.max_len
+        ids = torch.empty((B, L), dtype=torch.int32, device=self.device)
+        lens = torch.empty((B,), dtype=torch.int32, device=self.device)
+        scores = torch.zeros((B,), dtype=torch.float32, device=self.device)
+        logits = None
+        if output_logits:
+            logits = torch.empty((L - 1, B * num_beams, self.arch.vocab), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.cap_generate(self._h, C.c_void_p(pixels.data_ptr()), fmt, B, num_beams, L,
+                                          C.c_float(length_penalty), C.c_void_p(ids.data_ptr()),
+                                          C.c_void_p(lens.data_ptr()), C.c_void_p(scores.data_ptr()),
+                                          C.c_void_p(logits.data_ptr() if logits is not None else 0),
+                                          C.c_void_p(_stream_ptr(self.device))), "cap_generate")
+        out = {"sequences": ids, "lengths": lens}
+        if num_beams > 1:
+            out["sequences_scores"] = scores
+        if logits is not None:
+            out["logits"] = logits
+        return out
+
+    # ------------------------------------------------------------------------------------------ profiling
+    def profile(self, on: bool) -> None:
+        N.check(self.lib.cap_profile_enable(self._h, int(on)), "cap_profile_enable")
+
+    def profile_report(self) -> dict:
+        buf = C.create_string_buffer(1 << 16)
+        N.check(self.lib.cap_profile_report(self._h, buf, len(buf)), "cap_profile_report")
+        return json.loads(buf.value.decode())

@@ -1,0 +1,110 @@
+/* C ABI of the MI355X-native captioner forward path (libcaptioner_hip.so).
+ *
+ * Nothing like this exists in the reference (it is 100 % Python): every entry point below replaces a
+ * piece of Python/torch that the reference's captioner wrappers run on CPU, and is what a binding for this path
+ * (ctypes here; pybind11/cffi equally) has to call.  Plain pointers and sizes only - no torch types.
+ *
+ *   reference interface replaced                                              entry point
+ *   -------------------------------------------------------------------------------------------------------------
+ *   model construction  captioner/models/blip2/blip2.py:17-22 (from_pretrained),    cap_create, cap_load_weight,
+ *                       captioner/models/coca/factory.py:183-338 (create_model),     cap_finalize_weights
+ *                       utils/predictor_utils.py:182-185 (load_state_dict)
+ *   image tower         coca_model.py:152-155 `_encode_image`;                       cap_encode
+ *                       HF modeling_blip.py:901-906 `vision_model(pixel_values)`
+ *   generate            blip2.py:26 `model.generate(..., output_logits=True)`;       cap_generate
+ *                       coca.py:29 `model.generate(x, generation_type=...)`;
+ *                       coca_model.py:205-333 (greedy/top-k loop), :335-482 (beam)
+ *   device move/free    predictor_utils.py:187 `.to(...)`; object lifetime            cap_destroy
+ *   errors              Python exceptions (utils_captioner.py:6, factory.py:231,309)  int return codes + cap_last_error
+ *
+ * Conventions: every function returns 0 on success, non-zero on failure (message via cap_last_error(), thread-local).
+ * All device buffers are caller-owned; the library owns weights, KV caches and workspace, sized at cap_create from
+ * max_batch / max_beams / max_len.  One handle per stream; a handle is not thread-safe.  Calls enqueue work on the
+ * given hipStream_t (passed as void*) and return without synchronising, except where noted.
+ */
+#ifndef CAPTIONER_HIP_H
+#define CAPTIONER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct CapHandle_s* CapHandle;
+
+enum { CAP_ARCH_BLIP = 0 };
+enum { CAP_F32 = 0, CAP_BF16 = 1 };              /* arithmetic type of the GEMM/attention operands (accumulate: fp32) */
+enum { CAP_PIX_F32_NCHW = 0, CAP_PIX_U8_NHWC = 1 }; /* normalised fp32 [B,3,H,W] | raw RGB uint8 [B,H,W,3] */
+
+typedef struct CapConfig {
+    int32_t struct_size;          /* sizeof(CapConfig), for ABI checking */
+    int32_t arch;                 /* CAP_ARCH_BLIP */
+    int32_t compute_dtype;        /* CAP_F32 (strict parity) | CAP_BF16 (MFMA bf16 in, fp32 accumulate) */
+    /* vision tower */
+    int32_t image_size, patch_size, v_hidden, v_layers, v_heads, v_mlp;
+    float v_eps;
+    /* text decoder */
+    int32_t t_hidden, t_layers, t_heads, t_ffn, vocab, max_pos;
+    float t_eps;
+    int32_t bos, eos, pad;
+    /* capacity of the library-owned arena */
+    int32_t max_batch, max_beams, max_len;
+    /* raw-pixel normalisation for CAP_PIX_U8_NHWC: (x/255 - mean[c]) / std[c] */
+    float pix_mean[3], pix_std[3];
+} CapConfig;
+
+const char* cap_last_error(void);
+int cap_version(void);
+
+int cap_create(const CapConfig* cfg, CapHandle* out);
+int cap_destroy(CapHandle h);
+
+/* Stream one fp32 tensor of the checkpoint into the library (HuggingFace BLIP state-dict key names).  `data` is a
+ * host pointer (on_device = 0) or a device pointer (on_device = 1); the library converts to its compute layout
+ * (bf16 cast, q/k/v and cross-K/V concatenation) on `stream` and synchronises before returning.
+ * Unknown names return 1 (not an error for tied/duplicate heads, see cap_finalize_weights). */
+int cap_load_weight(CapHandle h, const char* name, const float* data, int on_device, int ndim, const int64_t* shape,
+                    void* stream);
+/* Returns 0 when every tensor the architecture needs has been loaded; otherwise the count of missing tensors
+ * (names in cap_last_error()). */
+int cap_finalize_weights(CapHandle h);
+
+/* Image tower.  pixels: B frames in `pixel_fmt`; out_embeds: fp32 [B, tokens, v_hidden] (device). */
+int cap_encode(CapHandle h, const void* pixels, int pixel_fmt, int B, float* out_embeds, void* stream);
+
+/* Encoder + autoregressive decode.
+ *   num_beams == 1: greedy (HF `_sample` with do_sample=False); num_beams > 1: HF v5 beam search.
+ *   out_ids     int32 [B, max_len]   token ids incl. BOS; rows are padded after their end
+ *   out_len     int32 [B]            tokens in each row incl. BOS and EOS (may be NULL)
+ *   out_scores  fp32  [B]            beam `sequences_scores`; untouched for greedy (may be NULL)
+ *   out_step_logits fp32 [max_len-1, B*num_beams, vocab]  raw per-step logits (may be NULL)
+ * max_len <= cfg.max_len, B <= cfg.max_batch, num_beams <= cfg.max_beams. */
+int cap_generate(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_beams, int max_len,
+                 float length_penalty, int32_t* out_ids, int32_t* out_len, float* out_scores,
+                 float* out_step_logits, void* stream);
+
+/* Bytes of device memory held by the handle (weights + arena). */
+size_t cap_device_bytes(CapHandle h);
+
+/* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  While enabled every launch of the
+ * tagged kernels is bracketed by an event pair; cap_profile_report synchronises the stream and writes a JSON object
+ * {"tag": {"launches": n, "ms": total, "flops": f, "bytes": b}, ...} into buf. */
+int cap_profile_enable(CapHandle h, int on);
+int cap_profile_report(CapHandle h, char* buf, size_t buf_bytes);
+
+/* ---- single-kernel entry points (used by tests/ to check each kernel against a plain reference) ---- */
+int cap_op_gemm(int dtype, const void* A, const void* W, const float* bias, const float* resid, void* C, int M, int N,
+                int K, int gelu, int out_f32, int tile, void* stream);
+int cap_op_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps, void* out_t,
+                     float* out_f, int M, int D, void* stream);
+int cap_op_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, void* stream);
+int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int32_t* anc,
+                            int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, void* stream);
+int cap_op_convert(int dtype, const float* src, void* dst, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

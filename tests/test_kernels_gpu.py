@@ -1,0 +1,162 @@
+"""GPU: each hand-written kernel, called through the C ABI, against a plain PyTorch fp32/fp64 reference of the same op."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from embodied_captioning_amd import _native
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _native.load_library()
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check(lib, rc):
+    assert rc == 0, lib.cap_last_error().decode()
+
+
+DT = {"f32": (0, torch.float32), "bf16": (1, torch.bfloat16)}
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("shape", [(256, 256, 128), (197, 768, 768), (300, 200, 192), (33, 30524 // 4, 64), (1, 64, 64)])
+def test_gemm_bias_against_fp64(lib, dtype, tile, shape):
+    M, N, K = shape
+    tag, tdt = DT[dtype]
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    Ad, Wd = A.to(tdt).cuda(), W.to(tdt).cuda()
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    _check(lib, lib.cap_op_gemm(tag, _p(Ad), _p(Wd), _p(bias.cuda()), _p(None), _p(out), M, N, K, 0, 1, tile, _stream()))
+    torch.cuda.synchronize()
+    ref = Ad.double().cpu() @ Wd.double().cpu().T + bias.double()
+    # operands are identical (already rounded to the compute dtype); only the fp32 accumulation order differs
+    assert torch.isfinite(out).all()
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 2e-4 * math.sqrt(K / 64), err
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_gemm_epilogues_gelu_residual_and_typed_output(lib, dtype):
+    M, N, K = 200, 320, 256
+    tag, tdt = DT[dtype]
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(M, K, generator=g).to(tdt)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(tdt)
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    ref = A.double() @ W.double().T + bias.double()
+    # GELU -> compute-dtype output
+    out_t = torch.zeros(M, N, dtype=tdt, device="cuda")
+    _check(lib, lib.cap_op_gemm(tag, _p(A.cuda()), _p(W.cuda()), _p(bias.cuda()), _p(None), _p(out_t), M, N, K, 1, 0, 0, _stream()))
+    want = torch.nn.functional.gelu(ref)
+    tol = 1e-4 if dtype == "f32" else 2e-2
+    assert (out_t.float().cpu().double() - want).abs().max().item() < tol
+    # in-place residual, fp32 output (C aliases resid)
+    x = resid.clone().cuda()
+    _check(lib, lib.cap_op_gemm(tag, _p(A.cuda()), _p(W.cuda()), _p(bias.cuda()), _p(x), _p(x), M, N, K, 0, 1, 0, _stream()))
+    assert (x.cpu().double() - (ref + resid.double())).abs().max().item() < 1e-4
+
+
+def test_gemm_rejects_bad_shapes(lib):
+    a = torch.zeros(64, 48, device="cuda")
+    rc = lib.cap_op_gemm(0, _p(a), _p(a), _p(None), _p(None), _p(a), 64, 64, 48, 0, 1, 0, _stream())
+    assert rc != 0 and b"multiple" in lib.cap_last_error()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("D", [128, 768, 1024])
+def test_layernorm(lib, dtype, D):
+    tag, tdt = DT[dtype]
+    M = 131
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(M, D, generator=g) * 3 + 1
+    gamma, beta = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    for eps in (1e-5, 1e-12):
+        out_t = torch.zeros(M, D, dtype=tdt, device="cuda")
+        out_f = torch.zeros(M, D, dtype=torch.float32, device="cuda")
+        _check(lib, lib.cap_op_layernorm(tag, _p(x.cuda()), _p(gamma.cuda()), _p(beta.cuda()), C.c_float(eps), _p(out_t),
+                                         _p(out_f), M, D, _stream()))
+        ref = torch.nn.functional.layer_norm(x, (D,), gamma, beta, eps)
+        assert (out_f.cpu() - ref).abs().max().item() < 2e-5
+        assert (out_t.float().cpu() - ref).abs().max().item() < (2e-5 if dtype == "f32" else 5e-2)
+
+
+def _attn_ref(qkv, B, N, H):
+    D = H * 64
+    x = qkv.double().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (x[0] @ x[1].transpose(-1, -2)) * 0.125
+    return (torch.softmax(s, -1) @ x[2]).permute(0, 2, 1, 3).reshape(B * N, D)
+
+
+@pytest.mark.parametrize("dtype,impl", [("f32", 1), ("bf16", 1), ("bf16", 2)])
+@pytest.mark.parametrize("N", [17, 197, 257])
+def test_vit_attention(lib, dtype, impl, N):
+    tag, tdt = DT[dtype]
+    B, H = 3, 4
+    g = torch.Generator().manual_seed(N)
+    qkv = (torch.randn(B * N, 3 * H * 64, generator=g) * 1.5).to(tdt)
+    ctx = torch.full((B * N, H * 64), float("nan"), dtype=tdt, device="cuda")
+    _check(lib, lib.cap_op_vit_attention(tag, _p(qkv.cuda()), _p(ctx), B, N, H, impl, _stream()))
+    torch.cuda.synchronize()
+    ref = _attn_ref(qkv, B, N, H)
+    err = (ctx.float().cpu().double() - ref).abs().max().item()
+    assert err < (1e-5 if dtype == "f32" else 3e-2), err
+
+
+def test_vit_attention_mfma_matches_scalar_kernel(lib):
+    """Same bf16 inputs through both kernels: they differ only by the bf16 rounding of P."""
+    B, H, N = 5, 12, 197
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B * N, 3 * H * 64, generator=g).to(torch.bfloat16).cuda()
+    a = torch.zeros(B * N, H * 64, dtype=torch.bfloat16, device="cuda")
+    b = torch.zeros_like(a)
+    _check(lib, lib.cap_op_vit_attention(1, _p(qkv), _p(a), B, N, H, 1, _stream()))
+    _check(lib, lib.cap_op_vit_attention(1, _p(qkv), _p(b), B, N, H, 2, _stream()))
+    assert (a.float() - b.float()).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("n_keys,beams", [(1, 1), (7, 1), (20, 3), (197, 3)])
+def test_decode_attention_with_ancestry_and_shared_kv(lib, dtype, n_keys, beams):
+    tag, tdt = DT[dtype]
+    Bimg, H, kv_ld = 4, 3, max(n_keys, 20)
+    R = Bimg * beams
+    g = torch.Generator().manual_seed(n_keys * 10 + beams)
+    q = torch.randn(R, H * 64, generator=g).to(tdt)
+    shared = n_keys == 197                                 # cross-attention: rows of one image share K/V
+    rows_kv = Bimg if shared else R
+    K = torch.randn(rows_kv, H, kv_ld, 64, generator=g).to(tdt)
+    V = torch.randn(rows_kv, H, kv_ld, 64, generator=g).to(tdt)
+    anc = None
+    if not shared:
+        anc = torch.randint(0, R, (R, kv_ld), generator=g, dtype=torch.int32)
+    out = torch.zeros(R, H * 64, dtype=tdt, device="cuda")
+    _check(lib, lib.cap_op_decode_attention(tag, _p(q.cuda()), _p(K.cuda()), _p(V.cuda()), _p(anc.cuda() if anc is not None else None),
+                                            kv_ld, beams if shared else 1, kv_ld, n_keys, _p(out), R, H, _stream()))
+    ref = torch.zeros(R, H * 64, dtype=torch.float64)
+    for r in range(R):
+        for h in range(H):
+            src = [int(anc[r, j]) if anc is not None else r // beams for j in range(n_keys)]
+            k = torch.stack([K[src[j], h, j] for j in range(n_keys)]).double()
+            v = torch.stack([V[src[j], h, j] for j in range(n_keys)]).double()
+            p = torch.softmax((k @ q[r, h * 64:(h + 1) * 64].double()) * 0.125, 0)
+            ref[r, h * 64:(h + 1) * 64] = p @ v
+    err = (out.float().cpu().double() - ref).abs().max().item()
+    assert err < (1e-5 if dtype == "f32" else 2e-2), err

@@ -1,0 +1,69 @@
+"""CPU: the C-ABI library builds for gfx950 here, loads, and exports every symbol include/captioner_hip.h declares.
+No compute call is made (no GPU in this container)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "captioner_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cap_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_surface():
+    names = _declared()
+    for must in ("cap_create", "cap_destroy", "cap_load_weight", "cap_finalize_weights", "cap_encode", "cap_generate",
+                 "cap_last_error"):
+        assert must in names
+
+
+def test_library_builds_loads_and_exports_all_symbols():
+    from embodied_captioning_amd import _native, build
+    path = build.build(verbose=False)
+    assert os.path.exists(path)
+    lib = _native.load_library()
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} declared in include/captioner_hip.h but not exported"
+    assert set(_native.EXPORTS) == set(_declared())
+    assert lib.cap_version() >= 1
+    assert lib.cap_last_error() is not None
+
+
+def test_config_struct_matches_header_field_order():
+    from embodied_captioning_amd import _native
+    text = open(os.path.join(ROOT, "include", "captioner_hip.h")).read()
+    body = re.search(r"typedef struct CapConfig \{(.*?)\} CapConfig;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        _, names = decl.split(None, 1)
+        for n in names.split(","):
+            fields.append(re.sub(r"\[.*\]", "", n).strip())
+    assert fields == [f[0] for f in _native.CapConfig._fields_]
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from embodied_captioning_amd._native import CaptionerHipError
+    from embodied_captioning_amd.config import BlipArch
+    from embodied_captioning_amd.engine import CaptionerEngine
+    with pytest.raises(CaptionerHipError):
+        CaptionerEngine(BlipArch.tiny())
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "embodied_captioning_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith(".py"):
+                src = open(os.path.join(dp, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, fn)

@@ -93,10 +93,10 @@ def main():
     os.makedirs(gold, exist_ok=True)
     print("blip_tiny")
     np.savez_compressed(os.path.join(gold, "blip_tiny.npz"), **run(BlipArch.tiny(), seed=3, batch=4,
-                                                                     max_length=12, beams=3, full=True, eos_boost=0.9))
+                                                                     max_length=12, beams=3, full=True, eos_boost=2.0))
     print("blip_tiny_eos")
     np.savez_compressed(os.path.join(gold, "blip_tiny_eos.npz"), **run(BlipArch.tiny(), seed=3, batch=4,
-                                                                         max_length=12, beams=3, full=True, eos_boost=1.2))
+                                                                         max_length=12, beams=3, full=True, eos_boost=2.5))
     print("blip_base")
     np.savez_compressed(os.path.join(gold, "blip_base.npz"), **run(BlipArch(), seed=0, batch=8,
                                                                      max_length=20, beams=3, full=False, eos_boost=9.0))
