@@ -48,7 +48,7 @@ _SIGNATURES = {
                                    C.c_int, C.c_int, C.c_void_p]),
     "cap_op_vit_attention": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cap_op_decode_attention": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                          C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+                                          C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cap_op_convert": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 

@@ -250,6 +250,158 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
     }
 }
 
+
+// ---- decode attention, short history (n_keys <= 8*NI): one wave per (row, head), no LDS, no barriers.  All K and V
+// loads of the wave are issued before any arithmetic so the whole history is one memory round trip.
+template <typename T, int NI>
+__global__ __launch_bounds__(256) void decode_attention_wave_kernel(const T* __restrict__ q, const T* __restrict__ kbase,
+                                                                    const T* __restrict__ vbase,
+                                                                    const int* __restrict__ anc, int anc_ld,
+                                                                    int rows_per_kv, int kv_ld, int n_keys,
+                                                                    T* __restrict__ out, int R, int H) {
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= R * H) return;
+    const int row = unit / H, h = unit - row * H, Dh = H * 64;
+    const int lane = threadIdx.x & 63, ksub = lane >> 3, dch = lane & 7;
+    float kk[NI][8], vv[NI][8];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int key = i * 8 + ksub;
+        if (key < n_keys) {
+            const int src = anc ? anc[(size_t)row * anc_ld + key] : row / rows_per_kv;
+            const size_t o = (((size_t)src * H + h) * kv_ld + key) * 64 + dch * 8;
+            load8<T>(kbase + o, kk[i]);
+            load8<T>(vbase + o, vv[i]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kk[i][e] = 0.f; vv[i][e] = 0.f; }
+        }
+    }
+    float qv[8];
+    load8<T>(q + (size_t)row * Dh + h * 64 + dch * 8, qv);
+    float sc[NI], m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(qv[e] * 0.125f, kk[i][e], s);
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        sc[i] = (i * 8 + ksub < n_keys) ? s : -INFINITY;
+        m = fmaxf(m, sc[i]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 8, 64)); m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f, o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const float p = expf(sc[i] - m);
+        l += p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaf(p, vv[i][e], o[e]);
+    }
+    l += __shfl_xor(l, 8, 64); l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o[e] += __shfl_xor(o[e], 8, 64); o[e] += __shfl_xor(o[e], 16, 64); o[e] += __shfl_xor(o[e], 32, 64);
+    }
+    if (ksub == 0) {
+        const float inv = 1.0f / l;
+        T* op = out + (size_t)row * Dh + h * 64 + dch * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) op[e] = from_f32<T>(o[e] * inv);
+    }
+}
+
+// ---- decode attention, long history (cross-attention over the image tokens): one wave per (row, head), the history
+// walked in chunks of 64 keys.  A chunk's 8 K loads and 8 V loads (16 B per lane, one 128-byte key row per 8 lanes)
+// are all issued into raw registers before any arithmetic; with ~4 waves per SIMD that keeps >100 KB in flight per
+// CU, which is what streaming the beam-shared K/V cache at HBM rate needs.  Online softmax across chunks (fp32).
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+    bf16x8 r;
+    __device__ __forceinline__ void load(const bf16_t* p) { r = *(const bf16x8*)p; }
+    __device__ __forceinline__ void zero() { for (int i = 0; i < 8; ++i) r[i] = (bf16_t)0.f; }
+    __device__ __forceinline__ float get(int i) const { return (float)r[i]; }
+};
+template <> struct Raw8<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
+    __device__ __forceinline__ void zero() { a = 0.f; b = 0.f; }
+    __device__ __forceinline__ float get(int i) const { return i < 4 ? a[i] : b[i - 4]; }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void decode_attention_online_kernel(const T* __restrict__ q, const T* __restrict__ kbase,
+                                                                      const T* __restrict__ vbase,
+                                                                      const int* __restrict__ anc, int anc_ld,
+                                                                      int rows_per_kv, int kv_ld, int n_keys,
+                                                                      T* __restrict__ out, int R, int H) {
+    constexpr int G = 8;                               // key groups (of 8 keys) per chunk
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= R * H) return;
+    const int row = unit / H, h = unit - row * H, Dh = H * 64;
+    const int lane = threadIdx.x & 63, ksub = lane >> 3, dch = lane & 7;
+    float qv[8];
+    load8<T>(q + (size_t)row * Dh + h * 64 + dch * 8, qv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] *= 0.125f;
+    const int src0 = row / rows_per_kv;
+    float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    for (int k0 = 0; k0 < n_keys; k0 += 8 * G) {
+        Raw8<T> kr[G], vr[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int key = k0 + g * 8 + ksub;
+            if (key < n_keys) {
+                const int src = anc ? anc[(size_t)row * anc_ld + key] : src0;
+                const size_t off = (((size_t)src * H + h) * kv_ld + key) * 64 + dch * 8;
+                kr[g].load(kbase + off);
+                vr[g].load(vbase + off);
+            } else {
+                kr[g].zero(); vr[g].zero();
+            }
+        }
+        float sc[G], cm = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(qv[e], kr[g].get(e), s);
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            sc[g] = (k0 + g * 8 + ksub < n_keys) ? s : -INFINITY;
+            cm = fmaxf(cm, sc[g]);
+        }
+        cm = fmaxf(cm, __shfl_xor(cm, 8, 64)); cm = fmaxf(cm, __shfl_xor(cm, 16, 64)); cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+        const float mn = fmaxf(m, cm);
+        const float c = expf(m - mn);                   // first chunk: exp(-inf) = 0 and l, o are 0
+        l *= c;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] *= c;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float p = expf(sc[g] - mn);
+            l += p;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(p, vr[g].get(e), o[e]);
+        }
+        m = mn;
+    }
+    l += __shfl_xor(l, 8, 64); l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o[e] += __shfl_xor(o[e], 8, 64); o[e] += __shfl_xor(o[e], 16, 64); o[e] += __shfl_xor(o[e], 32, 64);
+    }
+    if (ksub == 0) {
+        const float inv = 1.0f / l;
+        T* op = out + (size_t)row * Dh + h * 64 + dch * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) op[e] = from_f32<T>(o[e] * inv);
+    }
+}
+
 template <int KB>
 int launch_mfma_kb(const void* qkv, void* ctx, int B, int N, int H, hipStream_t s) {
     const int lds = KB * 32 * 128 + 64 * VT_LD * 2;
@@ -289,9 +441,30 @@ int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
 }
 
 int launch_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int* anc,
-                            int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H,
+                            int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             hipStream_t s) {
     if (n_keys <= 0 || n_keys > 8192) { cap_set_error("decode_attention: bad key count %d", n_keys); return -1; }
+#define CAP_DA_WAVE(TT, NI)                                                                                            \
+    hipLaunchKernelGGL((decode_attention_wave_kernel<TT, NI>), dim3((R * H + 3) / 4), dim3(256), 0, s, (const TT*)q,  \
+                       (const TT*)kbase, (const TT*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, (TT*)out, R, H)
+#define CAP_DA_ONLINE(TT)                                                                                              \
+    hipLaunchKernelGGL((decode_attention_online_kernel<TT>), dim3((R * H + 3) / 4), dim3(256), 0, s, (const TT*)q,    \
+                       (const TT*)kbase, (const TT*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, (TT*)out, R, H)
+    const int ng8 = (n_keys + 7) / 8;            // groups of 8 keys
+    if (impl == 0) {
+        if (dtype == CAP_DT_BF16) {
+            if (ng8 <= 1) CAP_DA_WAVE(bf16_t, 1); else if (ng8 <= 2) CAP_DA_WAVE(bf16_t, 2);
+            else if (ng8 <= 4) CAP_DA_WAVE(bf16_t, 4); else CAP_DA_ONLINE(bf16_t);
+        } else {
+            if (ng8 <= 1) CAP_DA_WAVE(float, 1); else if (ng8 <= 2) CAP_DA_WAVE(float, 2);
+            else if (ng8 <= 4) CAP_DA_WAVE(float, 4); else CAP_DA_ONLINE(float);
+        }
+        CAP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+#undef CAP_DA_WAVE
+#undef CAP_DA_ONLINE
+    // impl 1: the simple two-pass kernel (kept as an independent implementation for the tests)
     const int lds = (((n_keys + 3) & ~3) + 8 + 256) * 4;
     dim3 grid(R, H);
     if (dtype == CAP_DT_BF16)

@@ -62,9 +62,9 @@ struct Captioner {
     std::vector<TLayer> tl;
     // arena
     void *patches, *ln, *qkv, *ctx, *mlp, *emb_t, *cross;
-    float *X, *emb_f;
+    float *X, *emb_f, *delta;
     int *seq, *finished, *lens, *anc;
-    float *dx, *dy, *logits;
+    float *dx, *dy, *logits, *dpart;
     void *dx_t, *dq, *dctx, *dh, *beam;
     int ldl;
     // profiling
@@ -195,6 +195,7 @@ int build_arena(Captioner* m) {
     TRY(dev_alloc(m, &m->patches, Bm * m->P * m->Kpad * e));
     CAP_HIP_CHECK(hipMemset(m->patches, 0, Bm * m->P * m->Kpad * e));
     TRY(dev_alloc(m, (void**)&m->X, M * D * 4));
+    TRY(dev_alloc(m, (void**)&m->delta, M * D * 4));
     TRY(dev_alloc(m, &m->ln, M * D * e));
     TRY(dev_alloc(m, &m->qkv, M * 3 * D * e));
     TRY(dev_alloc(m, &m->ctx, M * D * e));
@@ -208,6 +209,7 @@ int build_arena(Captioner* m) {
     TRY(dev_alloc(m, (void**)&m->anc, 2 * R * Lm * 4));
     TRY(dev_alloc(m, (void**)&m->dx, R * T * 4));
     TRY(dev_alloc(m, (void**)&m->dy, R * T * 4));
+    TRY(dev_alloc(m, (void**)&m->dpart, 8 * R * T * 4));
     TRY(dev_alloc(m, &m->dx_t, R * T * e));
     TRY(dev_alloc(m, &m->dq, R * T * e));
     TRY(dev_alloc(m, &m->dctx, R * T * e));
@@ -226,11 +228,11 @@ struct ProfScope {
         if (!m->prof) return;
         ProfTag t; t.tag = tag; t.flops = flops; t.bytes = bytes;
         if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess) return;
-        hipEventRecord(t.e0, s);
+        (void)hipEventRecord(t.e0, s);
         m->prof_recs.push_back(t);
         idx = (int)m->prof_recs.size() - 1;
     }
-    ~ProfScope() { if (idx >= 0) hipEventRecord(m->prof_recs[idx].e1, s); }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(m->prof_recs[idx].e1, s); }
 };
 
 int gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, int lda, const void* W, int ldw, void* C, int ldc,
@@ -239,10 +241,31 @@ int gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, int lda, c
     GemmParams p;
     p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.bias = bias; p.resid = resid; p.ldr = ldc;
     p.M = M; p.N = N; p.K = K; p.gelu = gelu; p.out_f32 = out_f32; p.epi = epi;
-    p.p0 = p0; p.p1 = p1; p.p2 = p2; p.p3 = p3; p.aux = aux; p.C2 = C2;
+    p.p0 = p0; p.p1 = p1; p.p2 = p2; p.p3 = p3; p.aux = aux; p.C2 = C2; p.splitk = 1;
     const double osz = out_f32 ? 4.0 : (double)m->esz;
     ProfScope ps(m, s, tag, 2.0 * M * N * K, ((double)M * K + (double)N * K) * m->esz + (double)M * N * osz);
-    return launch_gemm(m->dt, p, 0, s);
+    return launch_gemm(m->dt, p, 0, s);   // tile 0 = auto (stream kernel for encoder-sized problems without residual)
+}
+
+// Decode-sized GEMM whose consumer is a post-LayerNorm: split K over S blocks per tile (every block's slabs are all in
+// flight at once -> one memory round trip), partial sums to dpart, then bias + residual + LayerNorm in one kernel.
+int gemm_splitk_ln(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, const float* bias,
+                   const float* g, const float* b, int R, int N, int K) {
+    const int slab = m->dt == CAP_DT_BF16 ? 64 : 32;
+    const int nk = K / slab;
+    int S = 1;
+    for (int cand : {8, 4, 2})
+        if (nk % cand == 0 && nk / cand >= 3) { S = cand; break; }
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = m->dpart; p.ldc = N; p.M = R; p.N = N; p.K = K;
+    p.out_f32 = 1; p.epi = EPI_PARTIAL; p.splitk = S;
+    {
+        ProfScope ps(m, s, tag, 2.0 * R * N * K, ((double)R * K + (double)N * K) * m->esz + (double)S * R * N * 4);
+        TRY(launch_gemm(m->dt, p, 2, s));
+    }
+    ProfScope ps(m, s, "dec_reduce_ln", 0, (double)(S + 2) * R * N * 4 + (double)R * N * m->esz);
+    return launch_reduce_layernorm(m->dt, m->dpart, S, bias, m->dx, g, b, m->c.t_eps, m->dx_t, m->dx, nullptr, R, N, s);
 }
 
 // ---------------------------------------------------------------------------------------------- encoder
@@ -256,29 +279,30 @@ int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_emb
     TRY(gemm(m, s, "gemm_patch", m->patches, m->Kpad, m->w_patch, m->Kpad, m->X, D, m->b_patch, nullptr, B * m->P, D,
              m->Kpad, 0, 1, EPI_PATCH, m->P, 0, 0, 0, m->vpos));
     TRY(launch_cls_rows(m->cls, m->vpos, m->X, B, NT, D, s));
+    // Pre-LN blocks.  The two branch GEMMs (proj, fc2) write their output to `delta`; the next LayerNorm kernel folds it
+    // into the residual stream X (fp32) in the same pass that normalises it, so the GEMM epilogues are store-only.
+    bool pending = false;                                  // delta holds a branch output not yet added to X
+    auto add_ln = [&](const float* g, const float* b, void* out_t, float* out_f) -> int {
+        ProfScope ps(m, s, "layernorm", 0, (double)M * D * ((pending ? 12 : 4) + m->esz + (out_f ? 4 : 0)));
+        if (pending)
+            return launch_reduce_layernorm(m->dt, m->delta, 1, nullptr, m->X, g, b, c.v_eps, out_t, out_f, m->X, M, D, s);
+        return launch_layernorm(m->dt, m->X, D, g, b, c.v_eps, out_t, out_f, M, D, s);
+    };
     for (int i = 0; i < c.v_layers; ++i) {
         const VLayer& L = m->vl[i];
-        {
-            ProfScope ps(m, s, "layernorm", 0, (double)M * D * (4 + m->esz));
-            TRY(launch_layernorm(m->dt, m->X, D, L.ln1_g, L.ln1_b, c.v_eps, m->ln, nullptr, M, D, s));
-        }
+        TRY(add_ln(L.ln1_g, L.ln1_b, m->ln, nullptr));
         TRY(gemm(m, s, "gemm_qkv", m->ln, D, L.w_qkv, D, m->qkv, 3 * D, L.b_qkv, nullptr, M, 3 * D, D, 0, 0));
         {
             ProfScope ps(m, s, "vit_attention", 4.0 * B * H * (double)NT * NT * 64, (double)M * 4 * D * m->esz);
             TRY(launch_vit_attention(m->dt, m->qkv, m->ctx, B, NT, H, 0, s));
         }
-        TRY(gemm(m, s, "gemm_proj", m->ctx, D, L.w_proj, D, m->X, D, L.b_proj, m->X, M, D, D, 0, 1));
-        {
-            ProfScope ps(m, s, "layernorm", 0, (double)M * D * (4 + m->esz));
-            TRY(launch_layernorm(m->dt, m->X, D, L.ln2_g, L.ln2_b, c.v_eps, m->ln, nullptr, M, D, s));
-        }
+        TRY(gemm(m, s, "gemm_proj", m->ctx, D, L.w_proj, D, m->delta, D, L.b_proj, nullptr, M, D, D, 0, 1));
+        pending = true;
+        TRY(add_ln(L.ln2_g, L.ln2_b, m->ln, nullptr));
         TRY(gemm(m, s, "gemm_fc1", m->ln, D, L.w_fc1, D, m->mlp, c.v_mlp, L.b_fc1, nullptr, M, c.v_mlp, D, 1, 0));
-        TRY(gemm(m, s, "gemm_fc2", m->mlp, c.v_mlp, L.w_fc2, c.v_mlp, m->X, D, L.b_fc2, m->X, M, D, c.v_mlp, 0, 1));
+        TRY(gemm(m, s, "gemm_fc2", m->mlp, c.v_mlp, L.w_fc2, c.v_mlp, m->delta, D, L.b_fc2, nullptr, M, D, c.v_mlp, 0, 1));
     }
-    {
-        ProfScope ps(m, s, "layernorm", 0, (double)M * D * (8 + m->esz));
-        TRY(launch_layernorm(m->dt, m->X, D, m->post_g, m->post_b, c.v_eps, m->emb_t, out_embeds ? out_embeds : m->emb_f, M, D, s));
-    }
+    TRY(add_ln(m->post_g, m->post_b, m->emb_t, out_embeds ? out_embeds : m->emb_f));
     return 0;
 }
 
@@ -302,22 +326,19 @@ int run_decoder_step(Captioner* m, const int* tokens, int tok_ld, int t, int B, 
                  R, H, Lm, t, nullptr, kc));
         {
             ProfScope ps(m, s, "dec_self_attn", 4.0 * R * H * (t + 1) * 64, 2.0 * R * H * (t + 1) * 64 * e);
-            TRY(launch_decode_attention(m->dt, m->dq, kc, vc, anc, Lm, 1, Lm, t + 1, m->dctx, R, H, s));
+            TRY(launch_decode_attention(m->dt, m->dq, kc, vc, anc, Lm, 1, Lm, t + 1, m->dctx, R, H, 0, s));
         }
-        TRY(gemm(m, s, "dec_gemm_so", m->dctx, T, L.w_so, T, m->dy, T, L.b_so, m->dx, R, T, T, 0, 1));
-        TRY(post_ln(m, s, L.so_g, L.so_b, R));
+        TRY(gemm_splitk_ln(m, s, "dec_gemm_so", m->dctx, L.w_so, L.b_so, L.so_g, L.so_b, R, T, T));
         TRY(gemm(m, s, "dec_gemm_cq", m->dx_t, T, L.w_cq, T, m->dq, T, L.b_cq, nullptr, R, T, T, 0, 0));
         {
             const char* ck = (char*)m->cross + ((size_t)i * 2 + 0) * B * H * NT * 64 * e;
             const char* cv = (char*)m->cross + ((size_t)i * 2 + 1) * B * H * NT * 64 * e;
             ProfScope ps(m, s, "dec_cross_attn", 4.0 * R * H * NT * 64, 2.0 * B * H * NT * 64 * e);
-            TRY(launch_decode_attention(m->dt, m->dq, ck, cv, nullptr, 0, K, NT, NT, m->dctx, R, H, s));
+            TRY(launch_decode_attention(m->dt, m->dq, ck, cv, nullptr, 0, K, NT, NT, m->dctx, R, H, 0, s));
         }
-        TRY(gemm(m, s, "dec_gemm_co", m->dctx, T, L.w_co, T, m->dy, T, L.b_co, m->dx, R, T, T, 0, 1));
-        TRY(post_ln(m, s, L.co_g, L.co_b, R));
+        TRY(gemm_splitk_ln(m, s, "dec_gemm_co", m->dctx, L.w_co, L.b_co, L.co_g, L.co_b, R, T, T));
         TRY(gemm(m, s, "dec_gemm_f1", m->dx_t, T, L.w_f1, T, m->dh, F, L.b_f1, nullptr, R, F, T, 1, 0));
-        TRY(gemm(m, s, "dec_gemm_f2", m->dh, F, L.w_f2, F, m->dy, T, L.b_f2, m->dx, R, T, F, 0, 1));
-        TRY(post_ln(m, s, L.f_g, L.f_b, R));
+        TRY(gemm_splitk_ln(m, s, "dec_gemm_f2", m->dh, L.w_f2, L.b_f2, L.f_g, L.f_b, R, T, F));
     }
     TRY(gemm(m, s, "dec_gemm_tr", m->dx_t, T, m->w_tr, T, m->dy, T, m->b_tr, nullptr, R, T, T, 1, 1));
     TRY(post_ln(m, s, m->tr_g, m->tr_b, R));
@@ -418,7 +439,7 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
     m->Kpatch = 3 * cfg->patch_size * cfg->patch_size;
     m->Kpad = (m->Kpatch + 63) / 64 * 64;
     if (build_blip(m) != 0 || build_arena(m) != 0) {
-        for (void* p : m->allocs) hipFree(p);
+        for (void* p : m->allocs) (void)hipFree(p);
         delete m;
         return -1;
     }
@@ -429,10 +450,10 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
 int cap_destroy(CapHandle h) {
     if (!h) return 0;
     Captioner* m = (Captioner*)h;
-    hipDeviceSynchronize();
-    for (auto& r : m->prof_recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
-    for (void* p : m->allocs) hipFree(p);
-    if (m->stage) hipFree(m->stage);
+    (void)hipDeviceSynchronize();
+    for (auto& r : m->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (void* p : m->allocs) (void)hipFree(p);
+    if (m->stage) (void)hipFree(m->stage);
     delete m;
     return 0;
 }
@@ -451,7 +472,7 @@ int cap_load_weight(CapHandle h, const char* name, const float* data, int on_dev
     const float* src = data;
     if (!on_device) {
         if ((size_t)n > m->stage_elems) {
-            if (m->stage) { CAP_HIP_CHECK(hipStreamSynchronize(s)); hipFree(m->stage); }
+            if (m->stage) { CAP_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(m->stage); }
             CAP_HIP_CHECK(hipMalloc((void**)&m->stage, (size_t)n * 4));
             m->stage_elems = n;
         }
@@ -517,7 +538,7 @@ int cap_generate(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_
 int cap_profile_enable(CapHandle h, int on) {
     Captioner* m = (Captioner*)h;
     if (!m) return -1;
-    for (auto& r : m->prof_recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (auto& r : m->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     m->prof_recs.clear();
     m->prof = on != 0;
     return 0;
@@ -556,7 +577,7 @@ int cap_op_gemm(int dtype, const void* A, const void* W, const float* bias, cons
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = C; p.ldc = N; p.bias = bias; p.resid = resid; p.ldr = N;
-    p.M = M; p.N = N; p.K = K; p.gelu = gelu; p.out_f32 = out_f32; p.epi = EPI_STORE;
+    p.M = M; p.N = N; p.K = K; p.gelu = gelu; p.out_f32 = out_f32; p.epi = EPI_STORE; p.splitk = 1;
     return launch_gemm(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, p, tile, (hipStream_t)stream);
 }
 int cap_op_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps, void* out_t,
@@ -568,9 +589,10 @@ int cap_op_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
     return launch_vit_attention(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, qkv, ctx, B, N, H, impl, (hipStream_t)stream);
 }
 int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int32_t* anc,
-                            int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, void* stream) {
+                            int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
+                            void* stream) {
     return launch_decode_attention(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, q, kbase, vbase, anc, anc_ld, rows_per_kv,
-                                   kv_ld, n_keys, out, R, H, (hipStream_t)stream);
+                                   kv_ld, n_keys, out, R, H, impl, (hipStream_t)stream);
 }
 int cap_op_convert(int dtype, const float* src, void* dst, size_t n, void* stream) {
     return launch_convert(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, src, dst, n, (hipStream_t)stream);

@@ -118,6 +118,52 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
               out_f ? out_f + (size_t)row * D : nullptr);
 }
 
+// Consumer of a split-K GEMM (EPI_PARTIAL): y = sum_z partial[z] + bias + resid, summed in slice order (deterministic),
+// then LayerNorm -> out_f (fp32 residual stream) and out_t (next GEMM's A operand).
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_layernorm_kernel(const float* __restrict__ part, int S,
+                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ resid,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps, T* out_t,
+                                                                float* out_f, float* y_out, int M, int D) {
+    // one wave per row.  Decode (a few hundred rows) launches one wave per block so every row gets its own CU slot and
+    // all of its S*nv + 2*nv 16-byte loads are issued before the first add; the encoder launches 4 rows per block.
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int nv = (D + 255) / 256;
+    float4 v[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (i < nv && c < D) {
+            float4 a = *(const float4*)(part + (size_t)row * D + c);
+            if (S == 4) {
+                const float4 b1 = *(const float4*)(part + ((size_t)1 * M + row) * D + c);
+                const float4 b2 = *(const float4*)(part + ((size_t)2 * M + row) * D + c);
+                const float4 b3 = *(const float4*)(part + ((size_t)3 * M + row) * D + c);
+                a.x = ((a.x + b1.x) + b2.x) + b3.x; a.y = ((a.y + b1.y) + b2.y) + b3.y;
+                a.z = ((a.z + b1.z) + b2.z) + b3.z; a.w = ((a.w + b1.w) + b2.w) + b3.w;
+            } else {
+#pragma unroll 4
+                for (int z = 1; z < S; ++z) {
+                    const float4 b = *(const float4*)(part + ((size_t)z * M + row) * D + c);
+                    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                }
+            }
+            if (bias) { const float4 b = *(const float4*)(bias + c); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            if (resid) {
+                const float4 b = *(const float4*)(resid + (size_t)row * D + c);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            v[i] = a;
+            if (y_out) *(float4*)(y_out + (size_t)row * D + c) = a;     // pre-LN residual stream (ViT blocks)
+        }
+    }
+    ln_row<T>(v, nv, lane, D, gamma, beta, eps, out_t ? out_t + (size_t)row * D : nullptr,
+              out_f ? out_f + (size_t)row * D : nullptr);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ seq, int seq_ld, int t,
                                                     const float* __restrict__ word, const float* __restrict__ pos,
@@ -251,6 +297,22 @@ int launch_layernorm(int dtype, const float* in, int ld_in, const float* gamma, 
     else
         hipLaunchKernelGGL(layernorm_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, s, in, ld_in, gamma, beta, eps,
                            (float*)out_t, out_f, M, D);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_reduce_layernorm(int dtype, const float* part, int S, const float* bias, const float* resid,
+                            const float* gamma, const float* beta, float eps, void* out_t, float* out_f, float* y_out,
+                            int M, int D, hipStream_t s) {
+    if (D % 4 != 0 || D > 256 * LN_MAXV || S < 1) { cap_set_error("reduce_layernorm: unsupported width %d / slices %d", D, S); return -1; }
+    const int wpb = M >= 2048 ? 4 : 1;
+    const dim3 grid((M + wpb - 1) / wpb), block(64 * wpb);
+    if (dtype == CAP_DT_BF16)
+        hipLaunchKernelGGL(reduce_layernorm_kernel<bf16_t>, grid, block, 0, s, part, S, bias, resid, gamma,
+                           beta, eps, (bf16_t*)out_t, out_f, y_out, M, D);
+    else
+        hipLaunchKernelGGL(reduce_layernorm_kernel<float>, grid, block, 0, s, part, S, bias, resid, gamma,
+                           beta, eps, (float*)out_t, out_f, y_out, M, D);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -7,6 +7,8 @@ enum GemmEpi {
     EPI_PATCH = 1,     // ViT patch-embed: row (b,p) -> token row b*(P+1)+1+p, + pos[(1+p)*N+col]   out: f32
     EPI_CROSSKV = 2,   // decoder cross-attention K/V for all layers -> [layer][kv][image][head][token][64]  out: T
     EPI_QKVCACHE = 3,  // decoder self-attention: q -> qbuf, k/v -> cache[kv][row][head][t][64]  out: T
+    EPI_PARTIAL = 4,   // split-K: slice z writes raw fp32 partial sums to C[z][M][ldc]; bias/residual/LayerNorm are
+                       // applied by the consumer (launch_reduce_layernorm), in a fixed order -> deterministic
 };
 
 struct GemmParams {
@@ -19,6 +21,7 @@ struct GemmParams {
     int gelu;                      // exact-erf GELU after bias
     int out_f32;                   // 1: C is fp32, 0: C is T
     int epi;
+    int splitk;                    // EPI_PARTIAL only: number of K slices (K % (slab*splitk) == 0)
     // EPI_PATCH: p0 = patches per image, aux = position table [(P+1), N] fp32
     // EPI_CROSSKV: p0 = tokens per image, p1 = heads, p2 = images   (N = layers*2*heads*64)
     // EPI_QKVCACHE: p0 = row capacity of the cache, p1 = heads, p2 = max positions, p3 = position t; C2 = cache base
@@ -27,5 +30,6 @@ struct GemmParams {
     void* C2;
 };
 
-// dtype: CAP_DT_F32 / CAP_DT_BF16.  tile: 0 = auto, 1 = 128x128, 2 = 64x64
+// dtype: CAP_DT_F32 / CAP_DT_BF16.  tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 256x256 persistent LDS-DMA kernel,
+// 4 = 256x256 register-staged (kept for A/B comparison), 5 = 256x128 two-workgroups-per-CU LDS-DMA stream kernel
 int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream);

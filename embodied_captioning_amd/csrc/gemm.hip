@@ -10,8 +10,10 @@
 //   fp32:  v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 1/16 the bf16 rate); a 16-byte chunk holds 4 k values,
 //          lane half h takes chunk 2*ks+h and feeds 4 MFMAs - A and W use the same k permutation so the sum is
 //          unchanged.
-// Global->LDS goes through registers (next slab prefetched into VGPRs while the current one is multiplied), LDS is
-// double buffered: one barrier per K-slab.  Edge tiles clamp their load rows and guard their stores.
+// Global->LDS goes through registers: D K-slabs are kept in flight in VGPRs (D = 1 for the 256x256 tile whose slab
+// compute covers the load latency, 2 for 128x128, 4 for the latency-bound 64x64 decode tile); LDS is double
+// buffered with one barrier per K-slab.  Edge tiles clamp their load rows and guard their stores.  The epilogue
+// goes through LDS so global stores are 16-byte (fp32) / 8-byte (bf16) per lane and row-contiguous.
 // Workgroup ids are remapped so each XCD (blockIdx % 8) walks a contiguous run of tiles that share A panels in its L2.
 #include "gemm.h"
 
@@ -36,39 +38,60 @@ template <> struct Mma<float> {
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <typename T, bool OUT_F32, int EPI>
-__device__ __forceinline__ void epi_store(const GemmParams& p, int row, int col, float v) {
-    if (p.bias) v += p.bias[col];
-    if (p.gelu) v = gelu_erf(v);
-    if constexpr (EPI == EPI_STORE) {
-        size_t o = (size_t)row * p.ldc + col;
-        if (p.resid) v += p.resid[(size_t)row * p.ldr + col];
-        if constexpr (OUT_F32) ((float*)p.C)[o] = v; else ((T*)p.C)[o] = from_f32<T>(v);
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // NOT HIP's uint4: its union members defeat SROA and
+                                                                  // the staging registers end up in scratch
+
+// Store 4 consecutive output columns (col % 4 == 0, never straddles a 64-wide head).
+template <typename T, bool OUT_F32, int EPI, bool RESID = true>
+__device__ __forceinline__ void epi_store4(const GemmParams& p, int row, int col, f32x4 v, f32x4 biasv) {
+    // bias is loaded once per lane by the caller (it depends on the column only); residual rows are loaded here
+    if (EPI != EPI_PARTIAL) v += biasv;
+    if (EPI != EPI_PARTIAL && p.gelu) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = gelu_for<T>(v[i]);
+    }
+    size_t o; void* base = p.C;
+    if constexpr (EPI == EPI_PARTIAL) {          // split-K slice z: raw fp32 partial sums, reduced by the consumer
+        *(f32x4*)((float*)p.C + ((size_t)p.p3 * p.M + row) * p.ldc + col) = v;
+        return;
+    } else if constexpr (EPI == EPI_STORE) {
+        o = (size_t)row * p.ldc + col;
+        if (RESID && p.resid) v += *(const f32x4*)(p.resid + (size_t)row * p.ldr + col);
     } else if constexpr (EPI == EPI_PATCH) {
-        int b = row / p.p0, pp = row - b * p.p0;
-        v += p.aux[(size_t)(1 + pp) * p.N + col];
-        size_t o = ((size_t)b * (p.p0 + 1) + 1 + pp) * p.ldc + col;
-        ((float*)p.C)[o] = v;
+        const int b = row / p.p0, pp = row - b * p.p0;
+        v += *(const f32x4*)(p.aux + (size_t)(1 + pp) * p.N + col);
+        o = ((size_t)b * (p.p0 + 1) + 1 + pp) * p.ldc + col;
     } else if constexpr (EPI == EPI_CROSSKV) {
-        int NT = p.p0, H = p.p1, B = p.p2, Dh = H * 64;
-        int b = row / NT, t = row - b * NT;
-        int l = col / (2 * Dh), r = col - l * 2 * Dh, kv = r / Dh, hd = r - kv * Dh, h = hd >> 6, d = hd & 63;
-        size_t o = (((((size_t)l * 2 + kv) * B + b) * H + h) * NT + t) * 64 + d;
-        ((T*)p.C)[o] = from_f32<T>(v);
+        const int NT = p.p0, H = p.p1, B = p.p2, Dh = H * 64;
+        const int b = row / NT, t = row - b * NT;
+        const int l = col / (2 * Dh), r = col - l * 2 * Dh, kv = r / Dh, hd = r - kv * Dh, h = hd >> 6, d = hd & 63;
+        o = (((((size_t)l * 2 + kv) * B + b) * H + h) * NT + t) * 64 + d;
     } else {  // EPI_QKVCACHE
-        int H = p.p1, Dh = H * 64;
+        const int H = p.p1, Dh = H * 64;
         if (col < Dh) {
-            ((T*)p.C)[(size_t)row * Dh + col] = from_f32<T>(v);
+            o = (size_t)row * Dh + col;
         } else {
-            int kv = col / Dh - 1, hd = col % Dh, h = hd >> 6, d = hd & 63;
-            size_t o = ((((size_t)kv * p.p0 + row) * H + h) * p.p2 + p.p3) * 64 + d;
-            ((T*)p.C2)[o] = from_f32<T>(v);
+            const int kv = col / Dh - 1, hd = col % Dh, h = hd >> 6, d = hd & 63;
+            o = ((((size_t)kv * p.p0 + row) * H + h) * p.p2 + p.p3) * 64 + d;
+            base = p.C2;
         }
+    }
+    if constexpr (OUT_F32) {
+        *(f32x4*)((float*)base + o) = v;
+    } else if constexpr (sizeof(T) == 4) {
+        *(f32x4*)((float*)base + o) = v;
+    } else {
+        bf16x4 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (bf16_t)v[i];
+        *(bf16x4*)((bf16_t*)base + o) = w;
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool OUT_F32, int EPI>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmParams p) {
+// D = K-slabs kept in flight in registers (host guarantees nk % D == 0); WPE = min waves per SIMD for the allocator.
+template <typename T, int BM, int BN, int WM, int WN, int D, int WPE, bool OUT_F32, int EPI>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(GemmParams p) {
+    // p.splitk > 1: consecutive block ids are the K-slices of one tile; slice index travels in p.p3 (EPI_PARTIAL)
     constexpr int NWM = BM / WM, NWN = BN / WN, NT = NWM * NWN * 64;
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT;      // 16-byte chunks per thread per slab
@@ -81,12 +104,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmPa
     constexpr int BUF = (BM + BN) * 128;                   // bytes per LDS buffer: A tile then W tile
 
     // XCD-aware, bijective remap of the linear block id (guide T1): blocks b, b+8, ... share an XCD.
-    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nwg = ntm * ntn;
+    const int S = EPI == EPI_PARTIAL ? p.splitk : 1;
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nwg = ntm * ntn * S;
     int bid = blockIdx.x;
     {
         int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int kz = bid % S;
+    bid /= S;
+    if constexpr (EPI == EPI_PARTIAL) p.p3 = kz;
+    const int Ks = p.K / S;                                  // K extent of this block
     const int tm = bid / ntn, tn = bid - tm * ntn;
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -98,20 +126,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmPa
     const T* W = (const T*)p.W;
 
     // per-thread global source pointers and LDS destinations for the staging copies
-    const uint4* ga[LA]; const uint4* gb[LB]; int da[LA], db[LB];
+    const u32x4* ga[LA]; const u32x4* gb[LB]; int da[LA], db[LB];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         int c = tid + i * NT, row = c >> 3, ch = c & 7;
         int gr = min(m0 + row, p.M - 1);
-        ga[i] = (const uint4*)(A + (size_t)gr * p.lda + ch * EPC);
+        ga[i] = (const u32x4*)(A + (size_t)gr * p.lda + (size_t)kz * Ks + ch * EPC);
         da[i] = swz_off(row, ch);
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
         int c = tid + i * NT, row = c >> 3, ch = c & 7;
         int gr = min(n0 + row, p.N - 1);
-        gb[i] = (const uint4*)(W + (size_t)gr * p.ldw + ch * EPC);
-        db[i] = swz_off(row, ch);
+        gb[i] = (const u32x4*)(W + (size_t)gr * p.ldw + (size_t)kz * Ks + ch * EPC);
+        db[i] = BM * 128 + swz_off(row, ch);
     }
 
     f32x16 acc[MI][NI];
@@ -122,91 +150,467 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmPa
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    uint4 ra[LA], rb[LB];
-    const int nk = p.K / SLAB;
+    u32x4 ra[D][LA], rb[D][LB];
+    const int nk = Ks / SLAB;
 #pragma unroll
-    for (int i = 0; i < LA; ++i) ra[i] = ga[i][0];
+    for (int s = 0; s < D; ++s) {
 #pragma unroll
-    for (int i = 0; i < LB; ++i) rb[i] = gb[i][0];
+        for (int i = 0; i < LA; ++i) ra[s][i] = ga[i][s * 8];
 #pragma unroll
-    for (int i = 0; i < LA; ++i) *(uint4*)(smem + da[i]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < LB; ++i) *(uint4*)(smem + BM * 128 + db[i]) = rb[i];
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {   // prefetch the next slab into registers; it lands while the MFMAs run
-            const int ko = (kt + 1) * (SLAB * (int)sizeof(T) / 16);
-#pragma unroll
-            for (int i = 0; i < LA; ++i) ra[i] = ga[i][ko];
-#pragma unroll
-            for (int i = 0; i < LB; ++i) rb[i] = gb[i][ko];
-        }
-        const char* a_s = smem + cur * BUF;
-        const char* b_s = a_s + BM * 128;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            vec af[MI], bf[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz_off(wm0 + i * 32 + r32, ks * 2 + h));
-#pragma unroll
-            for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz_off(wn0 + j * 32 + r32, ks * 2 + h));
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], af[i], bf[j]);
-        }
-        if (kt + 1 < nk) {
-#pragma unroll
-            for (int i = 0; i < LA; ++i) *(uint4*)(smem + (cur ^ 1) * BUF + da[i]) = ra[i];
-#pragma unroll
-            for (int i = 0; i < LB; ++i) *(uint4*)(smem + (cur ^ 1) * BUF + BM * 128 + db[i]) = rb[i];
-        }
-        __syncthreads();
+        for (int i = 0; i < LB; ++i) rb[s][i] = gb[i][s * 8];
     }
 
-    // epilogue: acc[i][j][e] is C[row = (e&3) + 8*(e>>2) + 4*h][col = lane&31] of its 32x32 tile
+    for (int k0 = 0; k0 < nk; k0 += D) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+        for (int s = 0; s < D; ++s) {
+            const int kt = k0 + s;
+            char* buf = smem + (kt & 1) * BUF;
+            // slab kt: registers -> LDS (waits only for this slab's loads; younger slabs stay in flight)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int col = n0 + wn0 + j * 32 + r32;
-            if (col >= p.N) continue;
+            for (int i = 0; i < LA; ++i) *(u32x4*)(buf + da[i]) = ra[s][i];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < p.M) epi_store<T, OUT_F32, EPI>(p, row, col, acc[i][j][e]);
+            for (int i = 0; i < LB; ++i) *(u32x4*)(buf + db[i]) = rb[s][i];
+            if (kt + D < nk) {           // refill this register stage with slab kt + D
+                const int ko = (kt + D) * 8;
+#pragma unroll
+                for (int i = 0; i < LA; ++i) ra[s][i] = ga[i][ko];
+#pragma unroll
+                for (int i = 0; i < LB; ++i) rb[s][i] = gb[i][ko];
+            }
+            __syncthreads();
+            const char* a_s = buf;
+            const char* b_s = buf + BM * 128;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                vec af[MI], bf[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz_off(wm0 + i * 32 + r32, ks * 2 + h));
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz_off(wn0 + j * 32 + r32, ks * 2 + h));
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], af[i], bf[j]);
             }
         }
+    }
+    __syncthreads();   // every wave is done with the staging buffers: reuse them for the epilogue
+
+    // Epilogue through LDS: a wave parks one 32 x WN fp32 strip of its accumulators in a private LDS region
+    // (acc[i][j][e] is C[row = (e&3) + 8*(e>>2) + 4*h][col = lane&31] of its 32x32 tile), then reads it back
+    // row-wise so each lane owns 4 consecutive columns: 16-byte (fp32) / 8-byte (bf16) coalesced global stores.
+    float* strip = (float*)(smem + wave * (32 * WN * 4));
+    constexpr int LPR = WN / 4;          // lanes per row
+    constexpr int RPP = 64 / LPR;        // rows per pass
+    const int rl = lane / LPR, cl = (lane % LPR) * 4;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                strip[((e & 3) + 8 * (e >> 2) + 4 * h) * WN + j * 32 + r32] = acc[i][j][e];
+        // same-wave LDS accesses complete in order; the compiler's lgkmcnt wait orders the read-back
+        const int col = n0 + wn0 + cl;
+        f32x4 biasv = 0.f;
+        if (EPI != EPI_PARTIAL && p.bias && col < p.N) biasv = *(const f32x4*)(p.bias + col);
+#pragma unroll
+        for (int ps = 0; ps < 32 / RPP; ++ps) {
+            const int rr = ps * RPP + rl;
+            const int row = m0 + wm0 + i * 32 + rr;
+            const f32x4 v = *(const f32x4*)(strip + rr * WN + cl);
+            if (row < p.M && col < p.N) epi_store4<T, OUT_F32, EPI>(p, row, col, v, biasv);
+        }
+    }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool OUT_F32, int EPI>
+// ------------------------------------------------------------------------------------------------------------------
+// 256x256 persistent kernel for the encoder-sized GEMMs.  One 8-wave workgroup per CU walks a run of output tiles.
+//   * global -> LDS by LDS-DMA (`global_load_lds_dwordx4`, 1 KiB = 8 tile rows per wave-instruction, no VGPR staging,
+//     no ds_write); the XOR chunk swizzle is applied on the per-lane SOURCE address because the DMA destination is
+//     lane-linear, and undone by the same XOR on the fragment reads;
+//   * two 64 KiB stage buffers, the DMA of slab k+1 is issued right after the barrier that retires slab k and lands
+//     under slab k's 32 MFMAs per wave;
+//   * the next tile's first slab is issued BEFORE this tile's epilogue, so the C write-back (through wave-private LDS
+//     strips that alias the stage buffer just drained) overlaps the DMA instead of leaving the CU idle.
+#define CAP_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define CAP_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <typename T, bool OUT_F32, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
+    constexpr int BM = 256, BN = 256, WM = 128, WN = 64, MI = 4, NI = 2;
+    constexpr int EPC = Mma<T>::EPC, SLAB = 8 * EPC;
+    constexpr int STAGE = (BM + BN) * 128;               // 64 KiB
+    using vec = typename Mma<T>::vec;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 2) * WM, wn0 = (wave & 3) * WN;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
+    const int nk = p.K / SLAB;
+
+    // XCD-aware tile schedule: XCD x (= blockIdx % 8) owns a contiguous run of tiles; its blocks stride through it,
+    // so the tiles in flight on one XCD are consecutive (n fastest -> shared A panel and neighbouring W panels in L2).
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int nl = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
+    const int tq = ntiles >> 3, tr = ntiles & 7;
+    const int c0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int c1 = c0 + tq + (xcd < tr ? 1 : 0);
+
+    // DMA addressing: wave w issues 4 A pieces and 4 W pieces per slab; piece j covers tile rows (w*4+j)*8 .. +7.
+    const int prow = lane >> 3, ppos = lane & 7;
+    const T* A = (const T*)p.A;
+    const T* W = (const T*)p.W;
+
+    auto issue = [&](int tile, int kt, char* stage) {
+        const int tm = tile / ntn, tn = tile - tm * ntn;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rowbase = (wave * 4 + j) * 8, row = rowbase + prow;
+            const int gch = ppos ^ ((row >> 1) & 7);
+            const int ga = min(tm * BM + row, p.M - 1), gb = min(tn * BN + row, p.N - 1);
+            const T* sa = A + (size_t)ga * p.lda + (size_t)kt * SLAB + gch * EPC;
+            const T* sb = W + (size_t)gb * p.ldw + (size_t)kt * SLAB + gch * EPC;
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(sa), CAP_LPTR(stage + rowbase * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(sb), CAP_LPTR(stage + BM * 128 + rowbase * 128), 16, 0, 0);
+        }
+    };
+
+    int cnt = 0;                                          // running slab counter: slab uses stage buffer cnt & 1
+    int tile = c0 + li;
+    if (tile < c1) issue(tile, 0, smem);
+    for (; tile < c1; tile += nl) {
+        const int tm = tile / ntn, tn = tile - tm * ntn;
+        const int m0 = tm * BM, n0 = tn * BN;
+        f32x16 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        for (int kt = 0; kt < nk; ++kt, ++cnt) {
+            __syncthreads();      // vmcnt(0): this wave's pieces of slab kt landed; barrier: everybody's did, and
+                                  // every wave is done reading the other stage buffer
+            if (kt + 1 < nk) issue(tile, kt + 1, smem + ((cnt + 1) & 1) * STAGE);
+            const char* a_s = smem + (cnt & 1) * STAGE;
+            const char* b_s = a_s + BM * 128;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                vec af[MI], bf[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz_off(wm0 + i * 32 + r32, ks * 2 + h));
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz_off(wn0 + j * 32 + r32, ks * 2 + h));
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], af[i], bf[j]);
+            }
+        }
+        constexpr int LPR = WN / 4, RPP = 64 / LPR, NPS = 32 / RPP;
+        const int rl = lane / LPR, cl = (lane % LPR) * 4;
+        const int col = n0 + wn0 + cl;
+        // bias is a register-destination load: take it before the DMA below is in flight (hipcc waits vmcnt(0) for
+        // any ordinary load while an LDS-DMA is outstanding)
+        f32x4 biasv = 0.f;
+        if (EPI != EPI_PARTIAL && p.bias && col < p.N) biasv = *(const f32x4*)(p.bias + col);
+        // stage buffer cnt & 1 was last read one slab ago and everyone has passed a barrier since: prefetch the next
+        // tile's first slab into it, then drain the other buffer (raw barrier: must not wait for the DMA just issued)
+        if (tile + nl < c1) issue(tile + nl, 0, smem + (cnt & 1) * STAGE);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        float* strip = (float*)(smem + ((cnt + 1) & 1) * STAGE + wave * (32 * WN * 4));
+        const bool has_resid = EPI == EPI_STORE && p.resid != nullptr;
+        GemmParams q = p;
+        q.resid = nullptr;                                  // residual is added here, from registers
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            // all residual rows of this 32-row block in one batch of loads -> one wait instead of one per store
+            f32x4 rv[NPS];
+            if (has_resid) {
+#pragma unroll
+                for (int ps = 0; ps < NPS; ++ps) {
+                    const int row = min(m0 + wm0 + i * 32 + ps * RPP + rl, p.M - 1);
+                    rv[ps] = *(const f32x4*)(p.resid + (size_t)row * p.ldr + min(col, p.N - 4));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    strip[((e & 3) + 8 * (e >> 2) + 4 * h) * WN + j * 32 + r32] = acc[i][j][e];
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) {
+                const int rr = ps * RPP + rl;
+                const int row = m0 + wm0 + i * 32 + rr;
+                f32x4 v = *(const f32x4*)(strip + rr * WN + cl);
+                if (has_resid) { v += biasv; v += rv[ps]; }
+                if (row < p.M && col < p.N) epi_store4<T, OUT_F32, EPI, false>(q, row, col, v, has_resid ? f32x4(0.f) : biasv);
+            }
+        }
+    }
+}
+
+template <typename T, bool OUT_F32, int EPI>
+int launch_big(const GemmParams& p, hipStream_t stream) {
+    constexpr int LDS = 2 * 512 * 128;
+    auto kern = gemm_big_kernel<T, OUT_F32, EPI>;
+    static bool attr_done = false;
+    static int n_cu = 0;
+    if (!attr_done) {
+        CAP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        int dev = 0;
+        CAP_HIP_CHECK(hipGetDevice(&dev));
+        CAP_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        attr_done = true;
+    }
+    const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const int grid = ntiles < n_cu ? ntiles : n_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, p);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 256x128 persistent "stream" kernel: TWO independent 4-wave workgroups per CU, each walking its own run of tiles with
+// a continuous LDS-DMA stream of 64-byte-row K-slabs (32 bf16 / 16 fp32 per row):
+//   * 3-stage ring (3 x 24 KiB), two slabs always in flight behind counted `s_waitcnt vmcnt(N)` + raw `s_barrier`
+//     (a `__syncthreads()` would drain the DMA queue); the stream runs across tile boundaries, so the next tile's
+//     first slabs load under this tile's last MFMAs and its epilogue;
+//   * the two workgroups on a CU are independent, so one's epilogue (bias/GELU VALU work + C stores) runs under the
+//     other's MFMAs - one wave of each workgroup per SIMD;
+//   * no register-destination loads at all in the loop or the epilogue (bias arrives by LDS-DMA too): hipcc cannot
+//     count ordinary loads next to LDS-DMA and would drain the queue with vmcnt(0).
+// 64-byte rows: chunk c of row r sits at r*64 + ((c ^ ((r>>2)&3)) << 4) - conflict-free for the 16-lane ds_read_b128
+// groups of a 32-row MFMA operand.  The residual add of the ViT blocks is not done here: the kernel writes the branch
+// output and the following add+LayerNorm kernel folds it into the residual stream.
+__device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, bool OUT_F32, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmParams p) {
+    constexpr int BM = 256, BN = 128, WM = 128, WN = 64, MI = 4, NI = 2;
+    constexpr int EPC = Mma<T>::EPC, SLAB = 4 * EPC;      // K elements per 64-byte slab row
+    constexpr int STAGE = (BM + BN) * 64;                 // 24 KiB
+    constexpr int NSTG = 3;
+    constexpr int GPS = 6;                                // DMA pieces per wave per slab: 4 of A, 2 of W
+    constexpr int NST = 32;                               // C stores per wave per tile
+    using vec = typename Mma<T>::vec;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* bias_lds = smem + NSTG * STAGE;                 // 2 x 512 B (128 columns of fp32), ping-pong per tile
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
+    const int nk = p.K / SLAB;
+
+    // XCD-aware schedule: XCD x (= blockIdx % 8) owns a contiguous run of tiles, its workgroups stride through it
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int nl = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
+    const int tq = ntiles >> 3, tr = ntiles & 7;
+    const int c0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int c1 = c0 + tq + (xcd < tr ? 1 : 0);
+
+    const int prow = lane >> 2, ppos = lane & 3;          // a 1 KiB piece = 16 rows x 64 B
+    const T* A = (const T*)p.A;
+    const T* W = (const T*)p.W;
+
+    auto issue = [&](int tile, int kt, char* stage) {
+        const int tm = tile / ntn, tn = tile - tm * ntn;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rowbase = (wave * 4 + j) * 16, row = rowbase + prow;
+            const int gch = ppos ^ ((row >> 2) & 3);
+            const int ga = min(tm * BM + row, p.M - 1);
+            const T* sa = A + (size_t)ga * p.lda + (size_t)kt * SLAB + gch * EPC;
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(sa), CAP_LPTR(stage + rowbase * 64), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rowbase = (wave * 2 + j) * 16, row = rowbase + prow;
+            const int gch = ppos ^ ((row >> 2) & 3);
+            const int gb = min(tn * BN + row, p.N - 1);
+            const T* sb = W + (size_t)gb * p.ldw + (size_t)kt * SLAB + gch * EPC;
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(sb), CAP_LPTR(stage + BM * 64 + rowbase * 64), 16, 0, 0);
+        }
+    };
+    // one extra piece per tile and wave: this wave's 32-column quarter of the bias row (each wave fills its own part)
+    auto issue_bias = [&](int tile, int slot) {
+        const int tn = tile % ntn;
+        const int c = min(tn * BN + wave * 32 + (lane & 7) * 4, p.N - 4);
+        // lanes 8..63 re-read the same 128 bytes into a scratch tail so the piece stays a full wave-instruction
+        const float* sb = p.bias + c;
+        __builtin_amdgcn_global_load_lds(CAP_GPTR(sb), CAP_LPTR(bias_lds + slot * 4096 + wave * 1024), 16, 0, 0);
+    };
+    const bool has_bias = EPI != EPI_PARTIAL && p.bias != nullptr;
+
+    // stream position s = (tile index in this block's run) * nk + kt; slab s lives in stage s % 3
+    const int my_tiles = c0 + li < c1 ? (c1 - (c0 + li) + nl - 1) / nl : 0;
+    const int total = my_tiles * nk;
+    auto issue_stream = [&](int s) {
+        const int tj = s / nk, kt = s - tj * nk;
+        if (kt == 0 && has_bias) issue_bias(c0 + li + tj * nl, tj & 1);
+        issue(c0 + li + tj * nl, kt, smem + (s % NSTG) * STAGE);
+    };
+    // vmcnt bookkeeping: every stream slab is GPS pieces (+1 bias piece on a tile's first slab, which is OLDER than
+    // that slab's pieces and therefore only ever makes a wait stricter, never too loose)
+    if (total > 0) issue_stream(0);
+    if (total > 1) issue_stream(1);
+
+    int s = 0;
+    bool prev_full = false;
+    for (int tj = 0; tj < my_tiles; ++tj) {
+        const int tile = c0 + li + tj * nl;
+        const int tm = tile / ntn, tn = tile - tm * ntn;
+        const int m0 = tm * BM, n0 = tn * BN;
+        f32x16 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        for (int kt = 0; kt < nk; ++kt, ++s) {
+            // wait for slab s: younger ops = slab s+1 (if any) and, for the two slabs that straddle the previous
+            // tile's epilogue, its NST stores
+            const bool nxt = s + 1 < total;
+            // an edge tile may skip fully masked store instructions, so its store count is unknown: wait for all of
+            // them (in-order queue: a stricter count is always safe, a looser one never)
+            const bool st = tj > 0 && kt < 2 && prev_full;
+            if (nxt && st) wait_vm<GPS + NST>();
+            else if (st) wait_vm<NST>();
+            else if (nxt) wait_vm<GPS>();
+            else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            if (s + 2 < total) issue_stream(s + 2);
+            const char* a_s = smem + (s % NSTG) * STAGE;
+            const char* b_s = a_s + BM * 64;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                vec af[MI], bf[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz64(wm0 + i * 32 + r32, ks * 2 + h));
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz64(wn0 + j * 32 + r32, ks * 2 + h));
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], af[i], bf[j]);
+            }
+        }
+        // Stage (s-1) % 3 (the slab just multiplied) is the only one not targeted by the two slabs in flight; once
+        // every wave has finished reading it, it holds the epilogue strips (4 KiB per wave).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float* strip = (float*)(smem + ((s - 1) % NSTG) * STAGE + wave * 4096);
+        const int rl = lane >> 4, cl = (lane & 15) * 4;       // 16 lanes x 16 B per 64-column row, 4 rows per pass
+        const int col = n0 + wn0 + cl;
+        f32x4 biasv = 0.f;
+        if (has_bias) biasv = *(const f32x4*)(bias_lds + (tj & 1) * 4096 + (wn0 >> 5) * 1024 + ((cl >> 5) * 1024) + (cl & 31) * 4);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {               // 16-row halves of the 32-row accumulator block
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        strip[((e & 3) + 8 * (e >> 2) + 4 * h) * WN + j * 32 + r32] = acc[i][j][hf * 8 + e];
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int rr = ps * 4 + rl;
+                    const int row = m0 + wm0 + i * 32 + hf * 16 + rr;
+                    const f32x4 v = *(const f32x4*)(strip + rr * WN + cl);
+                    // one store instruction per call; on a full tile every call has active lanes, so exactly NST
+                    // stores are issued per wave (what the vmcnt bookkeeping above relies on)
+                    if (row < p.M && col < p.N) epi_store4<T, OUT_F32, EPI, false>(p, row, col, v, biasv);
+                }
+            }
+        prev_full = m0 + BM <= p.M && n0 + BN <= p.N;
+    }
+    wait_vm<0>();
+}
+
+template <typename T, bool OUT_F32, int EPI>
+int launch_stream(const GemmParams& p, hipStream_t stream) {
+    constexpr int LDS = 3 * (256 + 128) * 64 + 2 * 4096;
+    auto kern = gemm_stream_kernel<T, OUT_F32, EPI>;
+    static bool attr_done = false;
+    static int n_cu = 0;
+    if (!attr_done) {
+        CAP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        int dev = 0;
+        CAP_HIP_CHECK(hipGetDevice(&dev));
+        CAP_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        attr_done = true;
+    }
+    const int ntiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
+    const int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, p);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int D, int WPE, bool OUT_F32, int EPI>
 int launch_cfg(const GemmParams& p, hipStream_t stream) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     constexpr int LDS = 2 * (BM + BN) * 128;
+    static_assert((BM / WM) * (BN / WN) * 32 * WN * 4 <= LDS, "epilogue strips must fit in the staging buffers");
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-    auto kern = gemm_kernel<T, BM, BN, WM, WN, OUT_F32, EPI>;
-    hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(NT), LDS, stream, p);
+    auto kern = gemm_kernel<T, BM, BN, WM, WN, D, WPE, OUT_F32, EPI>;
+    if (LDS > 64 * 1024) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            CAP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            attr_done = true;
+        }
+    }
+    const int S = EPI == EPI_PARTIAL ? p.splitk : 1;
+    hipLaunchKernelGGL(kern, dim3(ntm * ntn * S), dim3(NT), LDS, stream, p);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 template <typename T, bool OUT_F32, int EPI>
-int launch_tile(const GemmParams& p, int tile, hipStream_t stream) {
-    if (tile == 1) return launch_cfg<T, 128, 128, 64, 64, OUT_F32, EPI>(p, stream);
-    return launch_cfg<T, 64, 64, 32, 32, OUT_F32, EPI>(p, stream);
+int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
+    if (tile == 5) {
+        if constexpr (EPI == EPI_STORE || EPI == EPI_CROSSKV) { if (!p.resid && nk >= 2) return launch_stream<T, OUT_F32, EPI>(p, stream); }
+        tile = 3;
+    }
+    if (tile == 3) return launch_big<T, OUT_F32, EPI>(p, stream);
+    if (tile == 4) return launch_cfg<T, 256, 256, 128, 64, 1, 2, OUT_F32, EPI>(p, stream);
+    if (tile == 1) {
+        if (nk % 2 == 0) return launch_cfg<T, 128, 128, 64, 64, 2, 2, OUT_F32, EPI>(p, stream);
+        return launch_cfg<T, 128, 128, 64, 64, 1, 2, OUT_F32, EPI>(p, stream);
+    }
+    // decode-sized GEMMs are bound by the global-load round trip: keep as many slabs in flight as divide nk
+    if (nk % 6 == 0) return launch_cfg<T, 64, 64, 32, 32, 6, 3, OUT_F32, EPI>(p, stream);
+    if (nk % 4 == 0) return launch_cfg<T, 64, 64, 32, 32, 4, 4, OUT_F32, EPI>(p, stream);
+    if (nk % 3 == 0) return launch_cfg<T, 64, 64, 32, 32, 3, 4, OUT_F32, EPI>(p, stream);
+    if (nk % 2 == 0) return launch_cfg<T, 64, 64, 32, 32, 2, 4, OUT_F32, EPI>(p, stream);
+    return launch_cfg<T, 64, 64, 32, 32, 1, 4, OUT_F32, EPI>(p, stream);
 }
 
 template <typename T>
 int launch_t(const GemmParams& p, int tile, hipStream_t stream) {
+    const int nk = p.K / (8 * Mma<T>::EPC) / (p.epi == EPI_PARTIAL ? p.splitk : 1);
     switch (p.epi) {
+        case EPI_PARTIAL: return launch_tile<T, true, EPI_PARTIAL>(p, tile, nk, stream);
         case EPI_STORE:
-            return p.out_f32 ? launch_tile<T, true, EPI_STORE>(p, tile, stream)
-                             : launch_tile<T, false, EPI_STORE>(p, tile, stream);
-        case EPI_PATCH: return launch_tile<T, true, EPI_PATCH>(p, tile, stream);
-        case EPI_CROSSKV: return launch_tile<T, false, EPI_CROSSKV>(p, tile, stream);
-        case EPI_QKVCACHE: return launch_tile<T, false, EPI_QKVCACHE>(p, tile, stream);
+            return p.out_f32 ? launch_tile<T, true, EPI_STORE>(p, tile, nk, stream)
+                             : launch_tile<T, false, EPI_STORE>(p, tile, nk, stream);
+        case EPI_PATCH: return launch_tile<T, true, EPI_PATCH>(p, tile, nk, stream);
+        case EPI_CROSSKV: return launch_tile<T, false, EPI_CROSSKV>(p, tile, nk, stream);
+        case EPI_QKVCACHE: return launch_tile<T, false, EPI_QKVCACHE>(p, tile, nk, stream);
     }
     cap_set_error("launch_gemm: unknown epilogue %d", p.epi);
     return -1;
@@ -217,6 +621,10 @@ int launch_t(const GemmParams& p, int tile, hipStream_t stream) {
 int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream) {
     const int slab = dtype == CAP_DT_BF16 ? 64 : 32;
     const int esz = dtype == CAP_DT_BF16 ? 2 : 4;
+    if (p.epi == EPI_PARTIAL && (p.splitk < 1 || p.K % (slab * p.splitk) != 0)) {
+        cap_set_error("launch_gemm: split-K %d does not divide K=%d into whole %d-element slabs", p.splitk, p.K, slab);
+        return -1;
+    }
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.K % slab != 0) {
         cap_set_error("launch_gemm: bad shape M=%d N=%d K=%d (K must be a multiple of %d)", p.M, p.N, p.K, slab);
         return -1;
@@ -225,10 +633,16 @@ int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream) {
         cap_set_error("launch_gemm: operands must be 16-byte aligned (lda=%d ldw=%d)", p.lda, p.ldw);
         return -1;
     }
+    if (p.N % 4 != 0 || (p.epi == EPI_STORE && p.ldc % 4 != 0) || (p.resid && p.ldr % 4 != 0)) {
+        cap_set_error("launch_gemm: N / ldc / ldr must be multiples of 4 (N=%d ldc=%d ldr=%d)", p.N, p.ldc, p.ldr);
+        return -1;
+    }
     if (tile == 0) {
-        // big tile once it still fills the chip (>= 2 tiles per CU), small tile for the decode-sized GEMMs
-        long big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-        tile = big >= 512 ? 1 : 2;
+        // 256x256 (one 8-wave block per CU) once every CU gets at least one tile; 128x128 while that still gives
+        // every CU work; 64x64 with a deep register prefetch ring for the decode-sized (M <= a few hundred) GEMMs
+        const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+        const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+        tile = t256 >= 256 ? 5 : (t128 >= 256 ? 1 : 2);     // 5 = stream kernel (falls back to 3 when it cannot apply)
     }
     if (dtype == CAP_DT_BF16) return launch_t<bf16_t>(p, tile, stream);
     if (dtype == CAP_DT_F32) return launch_t<float>(p, tile, stream);

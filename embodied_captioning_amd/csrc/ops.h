@@ -16,6 +16,11 @@ int launch_cls_rows(const float* cls, const float* pos, float* X, int B, int tok
 // row LayerNorm: in fp32 [M,D]; writes out_t (T, optional) and out_f (fp32, optional; may alias in)
 int launch_layernorm(int dtype, const float* in, int ld_in, const float* gamma, const float* beta, float eps,
                      void* out_t, float* out_f, int M, int D, hipStream_t s);
+// split-K / residual consumer: y = sum_z part[z][M][D] + bias + resid (fixed order); y_out (optional, may alias resid)
+// receives y, then LayerNorm(y) goes to out_t / out_f as above (out_f may alias resid when y_out is null)
+int launch_reduce_layernorm(int dtype, const float* part, int S, const float* bias, const float* resid,
+                            const float* gamma, const float* beta, float eps, void* out_t, float* out_f, float* y_out,
+                            int M, int D, hipStream_t s);
 // decoder embeddings: x = LN(word[tok] + pos[t]); tok = seq[row*seq_ld + t]
 int launch_embed(int dtype, const int* seq, int seq_ld, int t, const float* word, const float* pos,
                  const float* gamma, const float* beta, float eps, void* out_t, float* out_f, int R, int D,
@@ -33,9 +38,10 @@ int launch_copy_f32(const float* src, float* dst, size_t n, hipStream_t s);
 int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s);
 // single-query decode attention. q [R, H*64] (T).  K/V of row r, head h, position j at
 //   kbase + (((size_t)src(r,j) * H + h) * kv_ld + j) * 64   where src(r,j) = anc ? anc[r*anc_ld + j] : r / rows_per_kv
-// n_keys positions; out [R, H*64] (T).
+// n_keys positions; out [R, H*64] (T).  impl 0 = fast kernels (wave-per-head, chunked online softmax),
+// impl 1 = simple two-pass block kernel (independent implementation kept for cross-checks).
 int launch_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int* anc,
-                            int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H,
+                            int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             hipStream_t s);
 
 // ---- beam.hip --------------------------------------------------------------------------------

@@ -101,7 +101,8 @@ int cap_op_layernorm(int dtype, const float* in, const float* gamma, const float
                      float* out_f, int M, int D, void* stream);
 int cap_op_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, void* stream);
 int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int32_t* anc,
-                            int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, void* stream);
+                            int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
+                            void* stream);
 int cap_op_convert(int dtype, const float* src, void* dst, size_t n, void* stream);
 
 #ifdef __cplusplus

@@ -32,8 +32,8 @@ DT = {"f32": (0, torch.float32), "bf16": (1, torch.bfloat16)}
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("tile", [1, 2])
-@pytest.mark.parametrize("shape", [(256, 256, 128), (197, 768, 768), (300, 200, 192), (33, 30524 // 4, 64), (1, 64, 64)])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("shape", [(256, 256, 128), (197, 768, 768), (300, 200, 192), (33, 7632, 64), (1, 64, 64), (520, 516, 3072)])
 def test_gemm_bias_against_fp64(lib, dtype, tile, shape):
     M, N, K = shape
     tag, tdt = DT[dtype]
@@ -42,8 +42,9 @@ def test_gemm_bias_against_fp64(lib, dtype, tile, shape):
     W = torch.randn(N, K, generator=g) / math.sqrt(K)
     bias = torch.randn(N, generator=g)
     Ad, Wd = A.to(tdt).cuda(), W.to(tdt).cuda()
+    bd = bias.cuda()
     out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
-    _check(lib, lib.cap_op_gemm(tag, _p(Ad), _p(Wd), _p(bias.cuda()), _p(None), _p(out), M, N, K, 0, 1, tile, _stream()))
+    _check(lib, lib.cap_op_gemm(tag, _p(Ad), _p(Wd), _p(bd), _p(None), _p(out), M, N, K, 0, 1, tile, _stream()))
     torch.cuda.synchronize()
     ref = Ad.double().cpu() @ Wd.double().cpu().T + bias.double()
     # operands are identical (already rounded to the compute dtype); only the fp32 accumulation order differs
@@ -63,14 +64,15 @@ def test_gemm_epilogues_gelu_residual_and_typed_output(lib, dtype):
     resid = torch.randn(M, N, generator=g)
     ref = A.double() @ W.double().T + bias.double()
     # GELU -> compute-dtype output
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()      # keep the device tensors alive across the async launches
     out_t = torch.zeros(M, N, dtype=tdt, device="cuda")
-    _check(lib, lib.cap_op_gemm(tag, _p(A.cuda()), _p(W.cuda()), _p(bias.cuda()), _p(None), _p(out_t), M, N, K, 1, 0, 0, _stream()))
+    _check(lib, lib.cap_op_gemm(tag, _p(Ad), _p(Wd), _p(bd), _p(None), _p(out_t), M, N, K, 1, 0, 0, _stream()))
     want = torch.nn.functional.gelu(ref)
     tol = 1e-4 if dtype == "f32" else 2e-2
     assert (out_t.float().cpu().double() - want).abs().max().item() < tol
     # in-place residual, fp32 output (C aliases resid)
     x = resid.clone().cuda()
-    _check(lib, lib.cap_op_gemm(tag, _p(A.cuda()), _p(W.cuda()), _p(bias.cuda()), _p(x), _p(x), M, N, K, 0, 1, 0, _stream()))
+    _check(lib, lib.cap_op_gemm(tag, _p(Ad), _p(Wd), _p(bd), _p(x), _p(x), M, N, K, 0, 1, 0, _stream()))
     assert (x.cpu().double() - (ref + resid.double())).abs().max().item() < 1e-4
 
 
@@ -89,9 +91,10 @@ def test_layernorm(lib, dtype, D):
     x = torch.randn(M, D, generator=g) * 3 + 1
     gamma, beta = torch.randn(D, generator=g), torch.randn(D, generator=g)
     for eps in (1e-5, 1e-12):
+        xd, gd, bd = x.cuda(), gamma.cuda(), beta.cuda()
         out_t = torch.zeros(M, D, dtype=tdt, device="cuda")
         out_f = torch.zeros(M, D, dtype=torch.float32, device="cuda")
-        _check(lib, lib.cap_op_layernorm(tag, _p(x.cuda()), _p(gamma.cuda()), _p(beta.cuda()), C.c_float(eps), _p(out_t),
+        _check(lib, lib.cap_op_layernorm(tag, _p(xd), _p(gd), _p(bd), C.c_float(eps), _p(out_t),
                                          _p(out_f), M, D, _stream()))
         ref = torch.nn.functional.layer_norm(x, (D,), gamma, beta, eps)
         assert (out_f.cpu() - ref).abs().max().item() < 2e-5
@@ -112,8 +115,9 @@ def test_vit_attention(lib, dtype, impl, N):
     B, H = 3, 4
     g = torch.Generator().manual_seed(N)
     qkv = (torch.randn(B * N, 3 * H * 64, generator=g) * 1.5).to(tdt)
+    qd = qkv.cuda()
     ctx = torch.full((B * N, H * 64), float("nan"), dtype=tdt, device="cuda")
-    _check(lib, lib.cap_op_vit_attention(tag, _p(qkv.cuda()), _p(ctx), B, N, H, impl, _stream()))
+    _check(lib, lib.cap_op_vit_attention(tag, _p(qd), _p(ctx), B, N, H, impl, _stream()))
     torch.cuda.synchronize()
     ref = _attn_ref(qkv, B, N, H)
     err = (ctx.float().cpu().double() - ref).abs().max().item()
@@ -133,23 +137,26 @@ def test_vit_attention_mfma_matches_scalar_kernel(lib):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("n_keys,beams", [(1, 1), (7, 1), (20, 3), (197, 3)])
-def test_decode_attention_with_ancestry_and_shared_kv(lib, dtype, n_keys, beams):
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("n_keys,beams", [(1, 1), (7, 1), (20, 3), (33, 2), (197, 3), (255, 1)])
+def test_decode_attention_with_ancestry_and_shared_kv(lib, dtype, n_keys, beams, impl):
     tag, tdt = DT[dtype]
     Bimg, H, kv_ld = 4, 3, max(n_keys, 20)
     R = Bimg * beams
     g = torch.Generator().manual_seed(n_keys * 10 + beams)
     q = torch.randn(R, H * 64, generator=g).to(tdt)
-    shared = n_keys == 197                                 # cross-attention: rows of one image share K/V
+    shared = n_keys >= 197                                 # cross-attention: rows of one image share K/V
     rows_kv = Bimg if shared else R
     K = torch.randn(rows_kv, H, kv_ld, 64, generator=g).to(tdt)
     V = torch.randn(rows_kv, H, kv_ld, 64, generator=g).to(tdt)
     anc = None
     if not shared:
         anc = torch.randint(0, R, (R, kv_ld), generator=g, dtype=torch.int32)
+    qd, Kd, Vd = q.cuda(), K.cuda(), V.cuda()
+    ad = anc.cuda() if anc is not None else None
     out = torch.zeros(R, H * 64, dtype=tdt, device="cuda")
-    _check(lib, lib.cap_op_decode_attention(tag, _p(q.cuda()), _p(K.cuda()), _p(V.cuda()), _p(anc.cuda() if anc is not None else None),
-                                            kv_ld, beams if shared else 1, kv_ld, n_keys, _p(out), R, H, _stream()))
+    _check(lib, lib.cap_op_decode_attention(tag, _p(qd), _p(Kd), _p(Vd), _p(ad),
+                                            kv_ld, beams if shared else 1, kv_ld, n_keys, _p(out), R, H, impl, _stream()))
     ref = torch.zeros(R, H * 64, dtype=torch.float64)
     for r in range(R):
         for h in range(H):
