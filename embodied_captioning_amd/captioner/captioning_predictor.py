@@ -1,0 +1,59 @@
+"""Base class of every captioner - mirror of the reference's
+``experimenting_env/captioner/captioning_predictor.py:8-53`` (same attribute names, same `compute_perplexity`
+arithmetic, same `print_caption`).  The reference derives from ``pl.LightningModule``; Lightning is used when it is
+installed, otherwise ``torch.nn.Module`` provides the surface the callers rely on (`.to`, `.eval`, `__call__`)."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+try:  # pragma: no cover - not installed in the build container
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # noqa: BLE001
+    _Base = torch.nn.Module
+
+
+class CaptioningPredictor(_Base):
+    def __init__(self, cfg=None):
+        super().__init__()
+        self.perplexity = 0.0
+        self.outputs = {}
+        if cfg is not None:
+            self.input_height, self.input_width = cfg.height, cfg.width
+
+    def pre_process_input(self, inputs):
+        pass
+
+    def forward(self, inputs):
+        pass
+
+    def training_step(self, batch, batch_idx):
+        pass
+
+    def backward(self):
+        pass
+
+    def configure_optimizers(self):
+        pass
+
+    def return_probabilities(self):
+        pass
+
+    def compute_perplexity(self, logits=None):
+        """exp(-sum(log max softmax) / T) as float64 (reference :34-47).  `logits` [n, T, V]; default: the per-step
+        logits of the last `forward` (`self.outputs["logits"]`, a sequence of T tensors [n, V])."""
+        if logits is None:
+            logits = torch.stack([l.float().cpu() for l in self.outputs["logits"]], dim=1)
+        probs = F.softmax(logits, dim=-1)
+        probs = torch.max(probs, dim=-1).values
+        sum_log_probs = -probs.log().sum()
+        num_tokens = probs.shape[1]
+        self.perplexity = torch.exp(sum_log_probs / num_tokens).double()
+        return self.perplexity
+
+    def post_process_output(self, outputs):
+        pass
+
+    def print_caption(self):
+        print(self.outputs["text"])

@@ -31,5 +31,5 @@ struct GemmParams {
 };
 
 // dtype: CAP_DT_F32 / CAP_DT_BF16.  tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 256x256 persistent LDS-DMA kernel,
-// 4 = 256x256 register-staged (kept for A/B comparison), 5 = 256x128 two-workgroups-per-CU LDS-DMA stream kernel
+// 4 = 256x256 register-staged (kept for A/B comparison)
 int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream);

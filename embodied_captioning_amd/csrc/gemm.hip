@@ -284,6 +284,13 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     for (; tile < c1; tile += nl) {
         const int tm = tile / ntn, tn = tile - tm * ntn;
         const int m0 = tm * BM, n0 = tn * BN;
+        constexpr int LPR = WN / 4, RPP = 64 / LPR, NPS = 32 / RPP;
+        const int rl = lane / LPR, cl = (lane % LPR) * 4;
+        const int col = n0 + wn0 + cl;
+        // bias is the only register-destination load of the tile: take it here, where the first __syncthreads() of the
+        // K loop waits for it anyway (hipcc drains the whole queue for an ordinary load while LDS-DMA is in flight)
+        f32x4 biasv = 0.f;
+        if (EPI != EPI_PARTIAL && p.bias && col < p.N) biasv = *(const f32x4*)(p.bias + col);
         f32x16 acc[MI][NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -311,13 +318,6 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
                     for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], af[i], bf[j]);
             }
         }
-        constexpr int LPR = WN / 4, RPP = 64 / LPR, NPS = 32 / RPP;
-        const int rl = lane / LPR, cl = (lane % LPR) * 4;
-        const int col = n0 + wn0 + cl;
-        // bias is a register-destination load: take it before the DMA below is in flight (hipcc waits vmcnt(0) for
-        // any ordinary load while an LDS-DMA is outstanding)
-        f32x4 biasv = 0.f;
-        if (EPI != EPI_PARTIAL && p.bias && col < p.N) biasv = *(const f32x4*)(p.bias + col);
         // stage buffer cnt & 1 was last read one slab ago and everyone has passed a barrier since: prefetch the next
         // tile's first slab into it, then drain the other buffer (raw barrier: must not wait for the DMA just issued)
         if (tile + nl < c1) issue(tile + nl, 0, smem + (cnt & 1) * STAGE);
@@ -376,190 +376,6 @@ int launch_big(const GemmParams& p, hipStream_t stream) {
     return 0;
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// 256x128 persistent "stream" kernel: TWO independent 4-wave workgroups per CU, each walking its own run of tiles with
-// a continuous LDS-DMA stream of 64-byte-row K-slabs (32 bf16 / 16 fp32 per row):
-//   * 3-stage ring (3 x 24 KiB), two slabs always in flight behind counted `s_waitcnt vmcnt(N)` + raw `s_barrier`
-//     (a `__syncthreads()` would drain the DMA queue); the stream runs across tile boundaries, so the next tile's
-//     first slabs load under this tile's last MFMAs and its epilogue;
-//   * the two workgroups on a CU are independent, so one's epilogue (bias/GELU VALU work + C stores) runs under the
-//     other's MFMAs - one wave of each workgroup per SIMD;
-//   * no register-destination loads at all in the loop or the epilogue (bias arrives by LDS-DMA too): hipcc cannot
-//     count ordinary loads next to LDS-DMA and would drain the queue with vmcnt(0).
-// 64-byte rows: chunk c of row r sits at r*64 + ((c ^ ((r>>2)&3)) << 4) - conflict-free for the 16-lane ds_read_b128
-// groups of a 32-row MFMA operand.  The residual add of the ViT blocks is not done here: the kernel writes the branch
-// output and the following add+LayerNorm kernel folds it into the residual stream.
-__device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
-
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <typename T, bool OUT_F32, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmParams p) {
-    constexpr int BM = 256, BN = 128, WM = 128, WN = 64, MI = 4, NI = 2;
-    constexpr int EPC = Mma<T>::EPC, SLAB = 4 * EPC;      // K elements per 64-byte slab row
-    constexpr int STAGE = (BM + BN) * 64;                 // 24 KiB
-    constexpr int NSTG = 3;
-    constexpr int GPS = 6;                                // DMA pieces per wave per slab: 4 of A, 2 of W
-    constexpr int NST = 32;                               // C stores per wave per tile
-    using vec = typename Mma<T>::vec;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* bias_lds = smem + NSTG * STAGE;                 // 2 x 512 B (128 columns of fp32), ping-pong per tile
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-    const int r32 = lane & 31, h = lane >> 5;
-    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
-    const int nk = p.K / SLAB;
-
-    // XCD-aware schedule: XCD x (= blockIdx % 8) owns a contiguous run of tiles, its workgroups stride through it
-    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
-    const int nl = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
-    const int tq = ntiles >> 3, tr = ntiles & 7;
-    const int c0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
-    const int c1 = c0 + tq + (xcd < tr ? 1 : 0);
-
-    const int prow = lane >> 2, ppos = lane & 3;          // a 1 KiB piece = 16 rows x 64 B
-    const T* A = (const T*)p.A;
-    const T* W = (const T*)p.W;
-
-    auto issue = [&](int tile, int kt, char* stage) {
-        const int tm = tile / ntn, tn = tile - tm * ntn;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rowbase = (wave * 4 + j) * 16, row = rowbase + prow;
-            const int gch = ppos ^ ((row >> 2) & 3);
-            const int ga = min(tm * BM + row, p.M - 1);
-            const T* sa = A + (size_t)ga * p.lda + (size_t)kt * SLAB + gch * EPC;
-            __builtin_amdgcn_global_load_lds(CAP_GPTR(sa), CAP_LPTR(stage + rowbase * 64), 16, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int rowbase = (wave * 2 + j) * 16, row = rowbase + prow;
-            const int gch = ppos ^ ((row >> 2) & 3);
-            const int gb = min(tn * BN + row, p.N - 1);
-            const T* sb = W + (size_t)gb * p.ldw + (size_t)kt * SLAB + gch * EPC;
-            __builtin_amdgcn_global_load_lds(CAP_GPTR(sb), CAP_LPTR(stage + BM * 64 + rowbase * 64), 16, 0, 0);
-        }
-    };
-    // one extra piece per tile and wave: this wave's 32-column quarter of the bias row (each wave fills its own part)
-    auto issue_bias = [&](int tile, int slot) {
-        const int tn = tile % ntn;
-        const int c = min(tn * BN + wave * 32 + (lane & 7) * 4, p.N - 4);
-        // lanes 8..63 re-read the same 128 bytes into a scratch tail so the piece stays a full wave-instruction
-        const float* sb = p.bias + c;
-        __builtin_amdgcn_global_load_lds(CAP_GPTR(sb), CAP_LPTR(bias_lds + slot * 4096 + wave * 1024), 16, 0, 0);
-    };
-    const bool has_bias = EPI != EPI_PARTIAL && p.bias != nullptr;
-
-    // stream position s = (tile index in this block's run) * nk + kt; slab s lives in stage s % 3
-    const int my_tiles = c0 + li < c1 ? (c1 - (c0 + li) + nl - 1) / nl : 0;
-    const int total = my_tiles * nk;
-    auto issue_stream = [&](int s) {
-        const int tj = s / nk, kt = s - tj * nk;
-        if (kt == 0 && has_bias) issue_bias(c0 + li + tj * nl, tj & 1);
-        issue(c0 + li + tj * nl, kt, smem + (s % NSTG) * STAGE);
-    };
-    // vmcnt bookkeeping: every stream slab is GPS pieces (+1 bias piece on a tile's first slab, which is OLDER than
-    // that slab's pieces and therefore only ever makes a wait stricter, never too loose)
-    if (total > 0) issue_stream(0);
-    if (total > 1) issue_stream(1);
-
-    int s = 0;
-    bool prev_full = false;
-    for (int tj = 0; tj < my_tiles; ++tj) {
-        const int tile = c0 + li + tj * nl;
-        const int tm = tile / ntn, tn = tile - tm * ntn;
-        const int m0 = tm * BM, n0 = tn * BN;
-        f32x16 acc[MI][NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-        for (int kt = 0; kt < nk; ++kt, ++s) {
-            // wait for slab s: younger ops = slab s+1 (if any) and, for the two slabs that straddle the previous
-            // tile's epilogue, its NST stores
-            const bool nxt = s + 1 < total;
-            // an edge tile may skip fully masked store instructions, so its store count is unknown: wait for all of
-            // them (in-order queue: a stricter count is always safe, a looser one never)
-            const bool st = tj > 0 && kt < 2 && prev_full;
-            if (nxt && st) wait_vm<GPS + NST>();
-            else if (st) wait_vm<NST>();
-            else if (nxt) wait_vm<GPS>();
-            else wait_vm<0>();
-            __builtin_amdgcn_s_barrier();
-            if (s + 2 < total) issue_stream(s + 2);
-            const char* a_s = smem + (s % NSTG) * STAGE;
-            const char* b_s = a_s + BM * 64;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                vec af[MI], bf[NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz64(wm0 + i * 32 + r32, ks * 2 + h));
-#pragma unroll
-                for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz64(wn0 + j * 32 + r32, ks * 2 + h));
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], af[i], bf[j]);
-            }
-        }
-        // Stage (s-1) % 3 (the slab just multiplied) is the only one not targeted by the two slabs in flight; once
-        // every wave has finished reading it, it holds the epilogue strips (4 KiB per wave).
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        float* strip = (float*)(smem + ((s - 1) % NSTG) * STAGE + wave * 4096);
-        const int rl = lane >> 4, cl = (lane & 15) * 4;       // 16 lanes x 16 B per 64-column row, 4 rows per pass
-        const int col = n0 + wn0 + cl;
-        f32x4 biasv = 0.f;
-        if (has_bias) biasv = *(const f32x4*)(bias_lds + (tj & 1) * 4096 + (wn0 >> 5) * 1024 + ((cl >> 5) * 1024) + (cl & 31) * 4);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {               // 16-row halves of the 32-row accumulator block
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        strip[((e & 3) + 8 * (e >> 2) + 4 * h) * WN + j * 32 + r32] = acc[i][j][hf * 8 + e];
-#pragma unroll
-                for (int ps = 0; ps < 4; ++ps) {
-                    const int rr = ps * 4 + rl;
-                    const int row = m0 + wm0 + i * 32 + hf * 16 + rr;
-                    const f32x4 v = *(const f32x4*)(strip + rr * WN + cl);
-                    // one store instruction per call; on a full tile every call has active lanes, so exactly NST
-                    // stores are issued per wave (what the vmcnt bookkeeping above relies on)
-                    if (row < p.M && col < p.N) epi_store4<T, OUT_F32, EPI, false>(p, row, col, v, biasv);
-                }
-            }
-        prev_full = m0 + BM <= p.M && n0 + BN <= p.N;
-    }
-    wait_vm<0>();
-}
-
-template <typename T, bool OUT_F32, int EPI>
-int launch_stream(const GemmParams& p, hipStream_t stream) {
-    constexpr int LDS = 3 * (256 + 128) * 64 + 2 * 4096;
-    auto kern = gemm_stream_kernel<T, OUT_F32, EPI>;
-    static bool attr_done = false;
-    static int n_cu = 0;
-    if (!attr_done) {
-        CAP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        int dev = 0;
-        CAP_HIP_CHECK(hipGetDevice(&dev));
-        CAP_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        attr_done = true;
-    }
-    const int ntiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
-    const int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, p);
-    CAP_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
 template <typename T, int BM, int BN, int WM, int WN, int D, int WPE, bool OUT_F32, int EPI>
 int launch_cfg(const GemmParams& p, hipStream_t stream) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
@@ -582,10 +398,6 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
 
 template <typename T, bool OUT_F32, int EPI>
 int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
-    if (tile == 5) {
-        if constexpr (EPI == EPI_STORE || EPI == EPI_CROSSKV) { if (!p.resid && nk >= 2) return launch_stream<T, OUT_F32, EPI>(p, stream); }
-        tile = 3;
-    }
     if (tile == 3) return launch_big<T, OUT_F32, EPI>(p, stream);
     if (tile == 4) return launch_cfg<T, 256, 256, 128, 64, 1, 2, OUT_F32, EPI>(p, stream);
     if (tile == 1) {
@@ -642,7 +454,7 @@ int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream) {
         // every CU work; 64x64 with a deep register prefetch ring for the decode-sized (M <= a few hundred) GEMMs
         const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-        tile = t256 >= 256 ? 5 : (t128 >= 256 ? 1 : 2);     // 5 = stream kernel (falls back to 3 when it cannot apply)
+        tile = t256 >= 256 ? 3 : (t128 >= 256 ? 1 : 2);
     }
     if (dtype == CAP_DT_BF16) return launch_t<bf16_t>(p, tile, stream);
     if (dtype == CAP_DT_F32) return launch_t<float>(p, tile, stream);

@@ -1,0 +1,154 @@
+"""Multi-GPU data path of the captioner: frames shard across ranks, each rank runs a full replica, and ONE collective
+(RCCL all-gather over xGMI; gloo in CPU tests) collects fixed-shape caption records for the consensus step.
+
+Reference analogue: ``experimenting_env/utils/train_helpers.py:218-246`` (`collect_results_gpu`: two all-gathers of
+pickled, zero-padded bytes; never called in the reference, which therefore never merges per-rank captions -
+SURVEY.md F8).  Here a record is plain integers, so no size exchange and no pickle are needed:
+
+    ids  int32 [n_pad, max_len]   token ids incl. BOS (rows past the shard's end: all `pad`, length 0)
+    lens int32 [n_pad]            tokens per row (0 = padding row)
+
+Consensus grouping mirrors ``experimenting_env/captioner/pseudocaptioner.py:125-177`` (`group_captions`,
+`compute_captions_frequency`, banned-word filter :96-123) on the gathered table.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Dict, Iterable, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int, int]:
+    """Contiguous, equal-size shards: returns (first, last_exclusive, padded_shard_size).  Every rank gets
+    ceil(n/world) slots; the tail shard is padded with sentinel rows so the gather has a fixed shape."""
+    per = (n_items + world - 1) // world
+    first = min(rank * per, n_items)
+    last = min(first + per, n_items)
+    return first, last, per
+
+
+def init_distributed(backend: str | None = None) -> Tuple[int, int, int]:
+    """(rank, local_rank, world) from the torchrun environment; one process per GPU, backend "nccl" (= RCCL on ROCm)."""
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return rank, local, world
+
+
+def gather_caption_records(ids: torch.Tensor, lens: torch.Tensor, n_pad: int, pad_id: int = 0):
+    """All-gather one shard's records.  ids int32 [n_local, L], lens int32 [n_local] with n_local <= n_pad.
+    Returns (ids_all [world*n_pad, L], lens_all [world*n_pad]) on every rank, rank-major (= global frame order
+    for contiguous shards)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    n_local, L = ids.shape
+    if n_local < n_pad:
+        ids = torch.cat([ids, torch.full((n_pad - n_local, L), pad_id, dtype=ids.dtype, device=ids.device)])
+        lens = torch.cat([lens, torch.zeros(n_pad - n_local, dtype=lens.dtype, device=lens.device)])
+    if world == 1:
+        return ids, lens
+    ids = ids.contiguous()
+    lens = lens.contiguous()
+    ids_all = torch.empty((world * n_pad, L), dtype=ids.dtype, device=ids.device)
+    lens_all = torch.empty((world * n_pad,), dtype=lens.dtype, device=lens.device)
+    dist.all_gather_into_tensor(ids_all, ids)
+    dist.all_gather_into_tensor(lens_all, lens)
+    return ids_all, lens_all
+
+
+def caption_shard(generate: Callable[[torch.Tensor], Dict[str, torch.Tensor]], frames_of: Callable[[int, int], torch.Tensor],
+                  n_frames: int, micro_batch: int, max_len: int, pad_id: int = 0):
+    """Caption frames [first, last) of this rank in micro-batches and gather everything.
+    `frames_of(first, count)` returns the device tensor of frames; `generate(frames)` returns {"sequences","lengths"}.
+    Returns (ids_all, lens_all) trimmed to n_frames rows, in global frame order."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    first, last, per = shard_range(n_frames, rank, world)
+    ids_parts, len_parts = [], []
+    for i in range(first, last, micro_batch):
+        n = min(micro_batch, last - i)
+        out = generate(frames_of(i, n))
+        ids_parts.append(out["sequences"][:, :max_len])
+        len_parts.append(out["lengths"])
+    if ids_parts:
+        ids = torch.cat(ids_parts)
+        lens = torch.cat(len_parts)
+    else:   # a rank beyond the end of a short job still takes part in the collective
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        ids = torch.full((0, max_len), pad_id, dtype=torch.int32, device=dev)
+        lens = torch.zeros((0,), dtype=torch.int32, device=dev)
+    ids_all, lens_all = gather_caption_records(ids, lens, per, pad_id)
+    keep = torch.cat([torch.arange(r * per, r * per + (shard_range(n_frames, r, world)[1] - shard_range(n_frames, r, world)[0]))
+                      for r in range(world)]).to(ids_all.device)
+    return ids_all[keep], lens_all[keep]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# consensus grouping on the gathered table (host side)
+# ------------------------------------------------------------------------------------------------------------------
+
+BANNED_WORDS = [
+    # Living beings
+    "person", "man", "woman", "boy", "girl", "child", "children", "adult", "kid", "baby", "human", "people", "group",
+    "crowd", "dog", "cat", "bird", "fish", "horse", "animal", "pet", "elephant", "lion", "tiger", "monkey", "mouse",
+    "rabbit", "cow", "pig", "sheep", "deer", "bear", "chicken", "duck", "goat", "camel", "snake", "frog", "turtle",
+    "whale", "dolphin", "insect", "bug", "spider",
+    # Image quality or context
+    "blurry", "picture", "image", "photo", "portrait", "painting", "drawing", "sketch", "screenshot", "artwork",
+    "filter", "3d", "rendering",
+    # Generic / non-descriptive terms
+    "thing", "stuff", "object", "item", "something", "stuff", "device", "equipment", "material", "machine", "gadget",
+    "unknown", "unidentified", "indistinguishable", "living room", "kitchen", "bedroom", "bathroom", "dining room",
+    "living room", "room",
+    # Non-indoor terms
+    "car", "vehicle", "bike", "truck", "street", "road", "tree", "forest", "mountain", "park", "outdoor", "sky",
+    "landscape", "scenery",
+    # Action words
+    "running", "jumping", "walking", "talking", "playing", "sitting", "standing", "moving", "holding", "eating",
+    "drinking", "flying", "swimming", "driving",
+]
+
+
+def filter_caption(caption: str) -> bool:
+    """True when the caption contains none of the banned substrings (pseudocaptioner.py:96-123)."""
+    low = caption.lower()
+    return not any(w.lower() in low for w in BANNED_WORDS)
+
+
+def group_captions(keys: Sequence[Tuple[int, int]], captions: Sequence[str], apply_filter: bool = True):
+    """(episode_id, object_id) -> list of captions, in input order (pseudocaptioner.py:125-154)."""
+    grouped: Dict[Tuple[int, int], List[str]] = {}
+    for key, cap in zip(keys, captions):
+        if apply_filter and not filter_caption(cap):
+            continue
+        grouped.setdefault(tuple(key), []).append(cap)
+    return grouped
+
+
+def captions_frequency(grouped: Dict[Tuple[int, int], Iterable[str]]):
+    """(episode_id, object_id) -> [[freq, caption], ...] in first-seen order (pseudocaptioner.py:156-177)."""
+    out = {}
+    for key, caps in grouped.items():
+        freq: Dict[str, int] = {}
+        for c in caps:
+            freq[c] = freq.get(c, 0) + 1
+        out[key] = [[n, c] for c, n in freq.items()]
+    return out
+
+
+def consensus_caption(freq_list):
+    """Most frequent caption of an object; ties go to the first seen (a deterministic stand-in for the reference's LLM
+    merge step, pseudocaptioner.py:364-447, which stays out of scope)."""
+    best = max(freq_list, key=lambda fc: fc[0])
+    return best[1]

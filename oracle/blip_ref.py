@@ -276,6 +276,24 @@ def beam_search_generate(sd, arch, pixels: Tensor, num_beams: int = 3, max_lengt
             "image_embeds": image_embeds}
 
 
+@torch.no_grad()
+def score_sequences(sd, arch, image_embeds: Tensor, sequences: Tensor, lengths: Tensor, length_penalty: float = 1.0):
+    """Teacher-forced HF beam score of given hypotheses: sum of log-probs of the generated tokens (after BOS, up to
+    and including EOS or the last token) divided by n_generated ** length_penalty.  Lets a reduced-precision beam
+    search be judged on the sequence it actually returned, even when a near-tie made it leave the oracle's path."""
+    B, L = sequences.shape
+    state = DecoderState(arch.t_layers)
+    cross_kv(sd, arch, image_embeds, state)
+    total = torch.zeros(B, dtype=torch.float64)
+    for t in range(int(lengths.max()) - 1):
+        logits = decoder_step(sd, arch, sequences[:, t].long(), state)
+        lp = F.log_softmax(logits.float(), dim=-1)
+        nxt = sequences[:, t + 1].long().clamp(min=0)
+        live = (t + 1) < lengths
+        total += torch.where(live, lp.gather(1, nxt[:, None])[:, 0].double(), torch.zeros(B, dtype=torch.float64))
+    return (total / (lengths - 1).double() ** length_penalty).float()
+
+
 # ----------------------------------------------------------------------------------------------
 # perplexity (reference experimenting_env/captioner/captioning_predictor.py:34-47)
 # ----------------------------------------------------------------------------------------------

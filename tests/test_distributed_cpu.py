@@ -1,0 +1,54 @@
+"""CPU, world_size 2 over gloo: the fixed-shape caption-record all-gather and the sharded caption driver."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_frames, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from embodied_captioning_amd import distributed as D
+    L = 6
+
+    def frames_of(first, n):                      # a "frame" is just its global index here
+        return torch.arange(first, first + n, dtype=torch.int32)
+
+    def generate(frames):                         # fake captioner: ids depend only on the frame index
+        ids = torch.stack([(frames * 7 + j) % 1000 for j in range(L)], dim=1).int()
+        return {"sequences": ids, "lengths": (frames % L + 1).int()}
+
+    ids, lens = D.caption_shard(generate, frames_of, n_frames, micro_batch=4, max_len=L)
+    q.put((rank, ids.clone(), lens.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [10, 13, 1])
+def test_sharded_caption_gather_world2(n_frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    frames = torch.arange(n_frames, dtype=torch.int32)
+    want_ids = torch.stack([(frames * 7 + j) % 1000 for j in range(6)], dim=1).int()
+    want_len = (frames % 6 + 1).int()
+    for _, ids, lens in res:                      # every rank holds the full table in global frame order
+        assert torch.equal(ids, want_ids) and torch.equal(lens, want_len)

@@ -1,0 +1,82 @@
+"""CPU: host-side logic of the boundary - plugin API mirror, import shim, shard math, consensus grouping."""
+import json
+import os
+
+import pytest
+import torch
+
+from embodied_captioning_amd import distributed as D
+
+
+def test_perplexity_kats_through_product_class(golden_dir):
+    from embodied_captioning_amd.captioner.captioning_predictor import CaptioningPredictor
+    m = CaptioningPredictor()
+    for k in json.load(open(os.path.join(golden_dir, "perplexity_kat.json"))):
+        x = torch.tensor(k["input"])
+        ppl = m.compute_perplexity(x.permute(1, 0, 2))             # exactly how the reference's KATs call it
+        assert ppl.dtype == torch.float64
+        assert torch.isclose(ppl, torch.tensor(k["expected"], dtype=torch.float64), rtol=1e-3)
+        m.outputs["logits"] = [x[i] for i in range(x.shape[0])]    # list-of-steps form stored by forward()
+        assert torch.isclose(m.compute_perplexity(), ppl, rtol=1e-6)
+
+
+def test_shim_resolves_reference_import_paths():
+    import embodied_captioning_amd.shim as shim
+    shim.install()
+    from experimenting_env.captioner.utils.utils import Configuration
+    from experimenting_env.captioner.utils.utils_captioner import select_captioner
+    from experimenting_env.utils.predictor_utils import Captioner
+    cfg = Configuration(arch_name="blip", model_name="procedural-tiny:1", height=224, width=224)
+    assert cfg.captioner.arch_name == "blip" and cfg.captioner.checkpoint_name is None
+    assert callable(select_captioner) and Captioner is not None
+
+
+def test_select_captioner_rejects_unknown_arch():
+    from embodied_captioning_amd.captioner.utils.utils import Configuration
+    from embodied_captioning_amd.captioner.utils.utils_captioner import select_captioner
+    with pytest.raises(AssertionError):
+        select_captioner(Configuration(arch_name="florence", model_name="x").captioner)
+
+
+def test_missing_checkpoint_raises_runtime_error_like_the_reference_factory():
+    # reference factory.py:309-314 raises RuntimeError for an unknown pretrained tag
+    from embodied_captioning_amd.captioner.utils.utils import Configuration
+    from embodied_captioning_amd.captioner.utils.utils_captioner import select_captioner
+    with pytest.raises(RuntimeError):
+        select_captioner(Configuration(arch_name="blip", model_name="/nonexistent/blip").captioner)
+
+
+def test_shard_range_covers_every_frame_once():
+    for n, w in ((50000, 8), (17, 4), (3, 8), (0, 2), (256, 1)):
+        seen = []
+        per0 = None
+        for r in range(w):
+            first, last, per = D.shard_range(n, r, w)
+            per0 = per if per0 is None else per0
+            assert per == per0 and last - first <= per
+            seen += list(range(first, last))
+        assert seen == list(range(n))
+
+
+def test_consensus_grouping_matches_reference_semantics():
+    keys = [(0, 1), (0, 1), (0, 2), (0, 1), (1, 1), (0, 2)]
+    caps = ["a wooden chair", "a wooden chair", "a man on a sofa", "a brown chair", "a lamp", "a red sofa"]
+    g = D.group_captions(keys, caps)
+    assert g == {(0, 1): ["a wooden chair", "a wooden chair", "a brown chair"], (1, 1): ["a lamp"], (0, 2): ["a red sofa"]}
+    f = D.captions_frequency(g)
+    assert f[(0, 1)] == [[2, "a wooden chair"], [1, "a brown chair"]]
+    assert D.consensus_caption(f[(0, 1)]) == "a wooden chair"
+    assert not D.filter_caption("A Person standing") and D.filter_caption("a white table")
+
+
+def test_state_dict_file_readers(tmp_path):
+    from embodied_captioning_amd.weights import load_state_dict_file
+    sd = {"module.a.weight": torch.randn(3, 2), "b": torch.arange(4.0)}
+    p1 = tmp_path / "w.pt"
+    torch.save({"model": sd}, p1)
+    got = load_state_dict_file(str(p1))
+    assert set(got) == {"a.weight", "b"} and torch.equal(got["b"], sd["b"])
+    from safetensors.torch import save_file
+    p2 = tmp_path / "w.safetensors"
+    save_file({"a.weight": sd["module.a.weight"].contiguous()}, str(p2))
+    assert torch.equal(load_state_dict_file(str(p2))["a.weight"], sd["module.a.weight"])

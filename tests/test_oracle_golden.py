@@ -69,3 +69,16 @@ def test_beam1_equals_greedy_when_no_eos():
     b = R.beam_search_generate(sd, arch, px, 1, 10, image_embeds=g["image_embeds"])
     if not (g["sequences"] == arch.eos).any():
         assert torch.equal(g["sequences"], b["sequences"])
+
+
+def test_score_sequences_reproduces_beam_scores():
+    arch = BlipArch.tiny()
+    sd = procedural_blip_state_dict(arch, 9, eos_boost=2.0)
+    px = synthetic_pixels(4, arch.image_size, seed=9)
+    emb = R.encode_image(sd, arch, px)
+    b = R.beam_search_generate(sd, arch, px, 3, 12, image_embeds=emb)
+    seq = b["sequences"]
+    L = seq.shape[1]
+    lens = torch.tensor([L if arch.eos not in r[1:].tolist() else 2 + r[1:].tolist().index(arch.eos) for r in seq])
+    sc = R.score_sequences(sd, arch, emb, seq, lens)
+    assert torch.allclose(sc, b["sequences_scores"], atol=1e-4)

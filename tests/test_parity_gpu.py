@@ -73,9 +73,25 @@ def test_bf16_matches_golden_within_tolerance(name):
     exact, diverged, bad = token_parity(seq, ref, g["greedy_margin"], BF16_TAU)
     assert bad is None, f"token differs at a confident step (row, step, ours, ref, margin) = {bad}"
     assert exact >= B // 2, (exact, diverged)
-    b = eng.generate(px.cuda(), num_beams=K, max_length=L)
-    np.testing.assert_allclose(b["sequences_scores"].cpu().numpy(), g["beam_scores"], rtol=0, atol=0.05)
+    _check_bf16_beams(eng, arch, sd, px, K, L, g["beam_scores"])
     eng.close()
+
+
+def _check_bf16_beams(eng, arch, sd, px, K, L, ref_scores):
+    """A bf16 beam search may leave the oracle's path at a near-tie and return a different hypothesis.  Judge it on what
+    it returned: (1) its reported score equals the oracle's teacher-forced score of that very sequence (bf16 tolerance),
+    (2) that sequence is about as good as the oracle's own best beam."""
+    from oracle import blip_ref as R
+    b = eng.generate(px.cuda(), num_beams=K, max_length=L)
+    seq = b["sequences"].cpu().long()
+    lens = b["lengths"].cpu().long()
+    emb = R.encode_image(sd, arch, px)
+    true_score = R.score_sequences(sd, arch, emb, seq, lens).numpy()
+    ours = b["sequences_scores"].cpu().numpy()
+    np.testing.assert_allclose(ours, true_score, rtol=0, atol=0.03)
+    assert (true_score >= np.asarray(ref_scores) - 0.1).all(), (true_score, ref_scores)
+    close = np.abs(ours - np.asarray(ref_scores)) < 0.03
+    assert close.sum() >= len(ours) // 2, (ours, ref_scores)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -108,7 +124,7 @@ def test_against_live_oracle_on_fresh_inputs(dtype):
         assert np.array_equal(b["sequences"].cpu().numpy(), pad_to(refb["sequences"].numpy(), L, arch.pad or arch.eos))
         np.testing.assert_allclose(b["sequences_scores"].cpu().numpy(), refb["sequences_scores"].numpy(), atol=1e-3)
     else:
-        np.testing.assert_allclose(b["sequences_scores"].cpu().numpy(), refb["sequences_scores"].numpy(), atol=0.05)
+        _check_bf16_beams(eng, arch, sd, px, 4, L, refb["sequences_scores"].numpy())
     eng.close()
 
 
