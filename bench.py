@@ -82,9 +82,10 @@ def roofline_pass(eng, px, L, dtype, arch, batch):
     n = sum(rep[t]["launches"] for t in ENC_GEMM_TAGS if t in rep)
     achieved = fl / (ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype]
-    roof = {"bound": "mfma", "kernel": "gemm_kernel<128x128> (ViT qkv/proj/fc1/fc2)", "achieved": round(achieved, 2),
+    roof = {"bound": "mfma", "kernel": "gemm_big_kernel 256x256 LDS-DMA (ViT qkv/proj/fc1/fc2 launches)", "achieved": round(achieved, 2),
             "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
             "flops_per_launch": fl / n, "avg_launch_us": round(1e3 * ms / n, 2), "launches_per_step": n // reps}
+    roof["traffic"] = pmc_traffic()
     total_ms = sum(r["ms"] for r in rep.values()) / reps
     return roof, kernels, total_ms
 
@@ -103,6 +104,21 @@ def host_cores() -> int:
 
 def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the encoder GEMM kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r01_bench_pmc.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc.json")))
+        n = b = 0.0
+        for k, v in d.items():
+            if "gemm_big_kernel" in k and ("ELi0E" in k or "E, 0>" in k) and "hbm_read_bytes_corrected" in v:
+                n += v["launches_per_pass"]
+                b += v["launches_per_pass"] * (v["hbm_read_bytes_corrected"] + v.get("hbm_write_bytes", 0.0))
+        return round(b / n) if n else None
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def cpu_baseline(sd, arch, L, sample):
