@@ -15,42 +15,58 @@ namespace {
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-constexpr int VT_LD = 292;   // V^T row stride in bf16: (VT_LD/2) % 64 == 18 -> the 32 d-rows of a ds_read_b64 hit distinct bank pairs
 constexpr float LOG2E = 1.4426950408889634f;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+#define CAP_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define CAP_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 // ------------------------------------------------------------------------------------------------
+// K and V of one (image, head) sit in LDS as [key][64] bf16 rows of 128 B with the same 16-byte-chunk XOR swizzle as the
+// GEMM tiles, filled by LDS-DMA (swizzle on the source address).  Q.K^T reads K rows with ds_read_b128; P.V needs V
+// "by column" (4 consecutive keys for one d per lane): ds_read_b64_tr_b16 delivers exactly that from the row-major
+// image, so V is never transposed in memory.
 template <int KB>
-__global__ __launch_bounds__(256) void vit_attention_mfma(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                          int N, int H) {
+__global__ __launch_bounds__(256, 2) void vit_attention_mfma(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                             int N, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP = KB * 32;
-    char* Ks = smem;                                   // [NP] rows of 128 B, chunk-swizzled
-    bf16_t* Vt = (bf16_t*)(smem + NP * 128);           // [64][VT_LD]
+    char* Ks = smem;                                   // [NP] rows of 128 B
+    char* Vs = smem + NP * 128;                        // [NP] rows of 128 B
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int D = H * 64, ld = 3 * D;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r32 = lane & 31, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, r32 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
 
-    for (int c = tid; c < NP * 8; c += 256) {
-        const int row = c >> 3, ch = c & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (row < N) {
-            kv = *(const uint4*)(base + (size_t)row * ld + D + ch * 8);
-            vv = *(const uint4*)(base + (size_t)row * ld + 2 * D + ch * 8);
-        }
-        *(uint4*)(Ks + swz_off(row, ch)) = kv;
-        const bf16_t* ve = (const bf16_t*)&vv;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) Vt[(ch * 8 + i) * VT_LD + row] = ve[i];
+    // 1 KiB pieces of 8 rows; piece p of K and of V go to wave p % 4
+    for (int p = wave; p < NP / 8; p += 4) {
+        const int row = p * 8 + (lane >> 3);
+        const int gch = (lane & 7) ^ ((row >> 1) & 7);
+        const bf16_t* src = base + (size_t)min(row, N - 1) * ld + gch * 8;
+        __builtin_amdgcn_global_load_lds(CAP_GPTR(src + D), CAP_LPTR(Ks + p * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(CAP_GPTR(src + 2 * D), CAP_LPTR(Vs + p * 1024), 16, 0, 0);
     }
-    __syncthreads();
-
-    const int nqt = (N + 31) / 32;
-    for (int qt = wave; qt < nqt; qt += 4) {
-        const int q = qt * 32 + r32, qc = min(q, N - 1);
-        bf16x8 qf[4];
+    // this wave's query tiles (qt = wave, wave+4, ...): take their Q fragments now, so the loads fly with the K/V DMA
+    constexpr int QT = (KB + 3) / 4;
+    bf16x8 qfa[QT][4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(base + (size_t)qc * ld + ks * 16 + hh * 8);
+    for (int t = 0; t < QT; ++t) {
+        const int qc = min((wave + 4 * t) * 32 + r32, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qfa[t][ks] = *(const bf16x8*)(base + (size_t)qc * ld + ks * 16 + hh * 8);
+    }
+    __syncthreads();   // vmcnt(0) + barrier: every piece has landed
+
+    // transposed-read addressing for the P.V A operand: 16-lane group g = lane>>4 handles d columns (g&1)*16 .. +15 and
+    // key sub-block 4*(g>>1); inside a group lane 4q+p supplies row (key) q, columns 4p..4p+3
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
+    const int nqt = (N + 31) / 32;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qt = wave + 4 * t;
+        if (qt >= nqt) break;
+        const int q = qt * 32 + r32;
+        const bf16x8 (&qf)[4] = qfa[t];
 
         f32x16 s[KB];
 #pragma unroll
@@ -69,8 +85,10 @@ __global__ __launch_bounds__(256) void vit_attention_mfma(const bf16_t* __restri
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int key = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                if (key >= N) s[kb][e] = -INFINITY;
+                if (kb == KB - 1) {      // only the last key block can hold padding keys
+                    const int key = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (key >= N) s[kb][e] = -INFINITY;
+                }
                 m = fmaxf(m, s[kb][e]);
             }
         m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -80,7 +98,7 @@ __global__ __launch_bounds__(256) void vit_attention_mfma(const bf16_t* __restri
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float p = exp2f((s[kb][e] - m) * c1);
+                const float p = __builtin_amdgcn_exp2f((s[kb][e] - m) * c1);   // raw v_exp_f32: inputs are <= 0
                 s[kb][e] = p;
                 l += p;
             }
@@ -95,14 +113,22 @@ __global__ __launch_bounds__(256) void vit_attention_mfma(const bf16_t* __restri
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
+                // B operand: element j of lane half hh is P^T[key = kb*32 + 16*s2 + 8*(j>>2) + 4*hh + (j&3)][q]
                 bf16x8 pb;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pb[j] = (bf16_t)s[kb][8 * s2 + j];
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const bf16_t* vp = Vt + (db * 32 + r32) * VT_LD + kb * 32 + 16 * s2 + 4 * hh;
-                    bf16x4 lo = *(const bf16x4*)vp, hi = *(const bf16x4*)(vp + 8);
-                    bf16x8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    // A operand: lane (d = db*32 + r32, hh) needs V[key0 .. key0+3][d] and V[key0+8 .. +11][d],
+                    // key0 = kb*32 + 16*s2 + 4*hh.  In its 16-lane group this lane ADDRESSES row key0+tq,
+                    // columns dcol..dcol+3 and RECEIVES column (lane&15) of the 4 rows.
+                    const int dcol = db * 32 + (tg & 1) * 16 + tp * 4;
+                    const int key0 = kb * 32 + 16 * s2 + 4 * (tg >> 1) + tq;
+                    const char* a0 = Vs + swz_off(key0, dcol >> 3) + (dcol & 7) * 2;
+                    const char* a1 = Vs + swz_off(key0 + 8, dcol >> 3) + (dcol & 7) * 2;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
                 }
             }
@@ -253,21 +279,46 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
 
 // ---- decode attention, short history (n_keys <= 8*NI): one wave per (row, head), no LDS, no barriers.  All K and V
 // loads of the wave are issued before any arithmetic so the whole history is one memory round trip.
+// Optional fused producer: the q (and, for self-attention, the new k/v) projection arrives as split-K partial sums
+// `part` fp32 [S][R][part_ld] (+ bias); this kernel finishes the reduction, appends k/v of position n_keys-1 to the
+// cache of its own row and attends - saving the GEMM's second round trip and its scatter epilogue.
+struct QSource {
+    const float* part;    // nullptr: q comes from the `q` tensor
+    const float* bias;
+    int S, part_ld, col0;  // q columns start at col0; k at col0 + Dh, v at col0 + 2*Dh when append_kv
+    int append_kv;
+};
+
+template <typename T>
+__device__ __forceinline__ void reduce8(const QSource& qs, int R, int row, int col, float (&v)[8]) {
+    const float* p = qs.part + (size_t)row * qs.part_ld + col;
+    f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    for (int z = 1; z < qs.S; ++z) {
+        const float* pz = p + (size_t)z * R * qs.part_ld;
+        a += *(const f32x4*)pz; b += *(const f32x4*)(pz + 4);
+    }
+    a += *(const f32x4*)(qs.bias + col); b += *(const f32x4*)(qs.bias + col + 4);
+    // round through the compute dtype exactly like the unfused GEMM epilogue would have
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = to_f32(from_f32<T>(a[i])); v[4 + i] = to_f32(from_f32<T>(b[i])); }
+}
+
 template <typename T, int NI>
-__global__ __launch_bounds__(256) void decode_attention_wave_kernel(const T* __restrict__ q, const T* __restrict__ kbase,
-                                                                    const T* __restrict__ vbase,
+__global__ __launch_bounds__(256) void decode_attention_wave_kernel(const T* __restrict__ q, T* __restrict__ kbase,
+                                                                    T* __restrict__ vbase,
                                                                     const int* __restrict__ anc, int anc_ld,
                                                                     int rows_per_kv, int kv_ld, int n_keys,
-                                                                    T* __restrict__ out, int R, int H) {
+                                                                    T* __restrict__ out, int R, int H, QSource qs) {
     const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (unit >= R * H) return;
     const int row = unit / H, h = unit - row * H, Dh = H * 64;
     const int lane = threadIdx.x & 63, ksub = lane >> 3, dch = lane & 7;
+    const bool fused_kv = qs.part != nullptr && qs.append_kv;
     float kk[NI][8], vv[NI][8];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int key = i * 8 + ksub;
-        if (key < n_keys) {
+        if (key < n_keys && !(fused_kv && key == n_keys - 1)) {
             const int src = anc ? anc[(size_t)row * anc_ld + key] : row / rows_per_kv;
             const size_t o = (((size_t)src * H + h) * kv_ld + key) * 64 + dch * 8;
             load8<T>(kbase + o, kk[i]);
@@ -278,7 +329,22 @@ __global__ __launch_bounds__(256) void decode_attention_wave_kernel(const T* __r
         }
     }
     float qv[8];
-    load8<T>(q + (size_t)row * Dh + h * 64 + dch * 8, qv);
+    if (qs.part) reduce8<T>(qs, R, row, qs.col0 + h * 64 + dch * 8, qv);
+    else load8<T>(q + (size_t)row * Dh + h * 64 + dch * 8, qv);
+    if (fused_kv) {
+        // the 8 lanes that own the newest position finish its k/v, append them to this row's cache and use them
+        const int t = n_keys - 1;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (i * 8 + ksub == t) {
+                reduce8<T>(qs, R, row, qs.col0 + Dh + h * 64 + dch * 8, kk[i]);
+                reduce8<T>(qs, R, row, qs.col0 + 2 * Dh + h * 64 + dch * 8, vv[i]);
+                const size_t o = (((size_t)row * H + h) * kv_ld + t) * 64 + dch * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { kbase[o + e] = from_f32<T>(kk[i][e]); vbase[o + e] = from_f32<T>(vv[i][e]); }
+            }
+        }
+    }
     float sc[NI], m = -INFINITY;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -336,14 +402,15 @@ __global__ __launch_bounds__(256) void decode_attention_online_kernel(const T* _
                                                                       const T* __restrict__ vbase,
                                                                       const int* __restrict__ anc, int anc_ld,
                                                                       int rows_per_kv, int kv_ld, int n_keys,
-                                                                      T* __restrict__ out, int R, int H) {
+                                                                      T* __restrict__ out, int R, int H, QSource qs) {
     constexpr int G = 8;                               // key groups (of 8 keys) per chunk
     const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (unit >= R * H) return;
     const int row = unit / H, h = unit - row * H, Dh = H * 64;
     const int lane = threadIdx.x & 63, ksub = lane >> 3, dch = lane & 7;
     float qv[8];
-    load8<T>(q + (size_t)row * Dh + h * 64 + dch * 8, qv);
+    if (qs.part) reduce8<T>(qs, R, row, qs.col0 + h * 64 + dch * 8, qv);
+    else load8<T>(q + (size_t)row * Dh + h * 64 + dch * 8, qv);
 #pragma unroll
     for (int e = 0; e < 8; ++e) qv[e] *= 0.125f;
     const int src0 = row / rows_per_kv;
@@ -404,7 +471,7 @@ __global__ __launch_bounds__(256) void decode_attention_online_kernel(const T* _
 
 template <int KB>
 int launch_mfma_kb(const void* qkv, void* ctx, int B, int N, int H, hipStream_t s) {
-    const int lds = KB * 32 * 128 + 64 * VT_LD * 2;
+    const int lds = 2 * KB * 32 * 128;
     static bool attr_done = false;
     auto kern = vit_attention_mfma<KB>;
     if (!attr_done && lds > 64 * 1024) {
@@ -442,15 +509,26 @@ int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
 
 int launch_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
-                            hipStream_t s) {
+                            hipStream_t s, const float* q_part, int q_S, const float* q_bias, int q_ld, int q_col0,
+                            int append_kv) {
+    QSource qs;
+    qs.part = q_part; qs.bias = q_bias; qs.S = q_S; qs.part_ld = q_ld; qs.col0 = q_col0; qs.append_kv = append_kv;
+    if (q_part && (impl != 0 || q_S < 1 || !q_bias || (q_ld & 3) || (q_col0 & 3))) {
+        cap_set_error("decode_attention: fused split-K query needs impl 0, bias and 16-byte aligned columns");
+        return -1;
+    }
     if (n_keys <= 0 || n_keys > 8192) { cap_set_error("decode_attention: bad key count %d", n_keys); return -1; }
 #define CAP_DA_WAVE(TT, NI)                                                                                            \
     hipLaunchKernelGGL((decode_attention_wave_kernel<TT, NI>), dim3((R * H + 3) / 4), dim3(256), 0, s, (const TT*)q,  \
-                       (const TT*)kbase, (const TT*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, (TT*)out, R, H)
+                       (TT*)kbase, (TT*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, (TT*)out, R, H, qs)
 #define CAP_DA_ONLINE(TT)                                                                                              \
     hipLaunchKernelGGL((decode_attention_online_kernel<TT>), dim3((R * H + 3) / 4), dim3(256), 0, s, (const TT*)q,    \
-                       (const TT*)kbase, (const TT*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, (TT*)out, R, H)
+                       (const TT*)kbase, (const TT*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, (TT*)out, R, H, qs)
     const int ng8 = (n_keys + 7) / 8;            // groups of 8 keys
+    if (append_kv && ng8 > 4 && q_part) {
+        cap_set_error("decode_attention: fused k/v append supports up to 32 positions (got %d)", n_keys);
+        return -1;
+    }
     if (impl == 0) {
         if (dtype == CAP_DT_BF16) {
             if (ng8 <= 1) CAP_DA_WAVE(bf16_t, 1); else if (ng8 <= 2) CAP_DA_WAVE(bf16_t, 2);

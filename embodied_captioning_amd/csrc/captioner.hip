@@ -209,7 +209,7 @@ int build_arena(Captioner* m) {
     TRY(dev_alloc(m, (void**)&m->anc, 2 * R * Lm * 4));
     TRY(dev_alloc(m, (void**)&m->dx, R * T * 4));
     TRY(dev_alloc(m, (void**)&m->dy, R * T * 4));
-    TRY(dev_alloc(m, (void**)&m->dpart, 8 * R * T * 4));
+    TRY(dev_alloc(m, (void**)&m->dpart, 12 * R * T * 4));      // split-K slabs: 8 x [R,T] (ffn) or 4 x [R,3T] (qkv)
     TRY(dev_alloc(m, &m->dx_t, R * T * e));
     TRY(dev_alloc(m, &m->dq, R * T * e));
     TRY(dev_alloc(m, &m->dctx, R * T * e));
@@ -249,6 +249,22 @@ int gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, int lda, c
 
 // Decode-sized GEMM whose consumer is a post-LayerNorm: split K over S blocks per tile (every block's slabs are all in
 // flight at once -> one memory round trip), partial sums to dpart, then bias + residual + LayerNorm in one kernel.
+int gemm_partial(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, int R, int N, int K,
+                 int max_S, int* S_out) {
+    const int slab = m->dt == CAP_DT_BF16 ? 64 : 32;
+    const int nk = K / slab;
+    int S = 1;
+    for (int cand : {8, 4, 2})
+        if (cand <= max_S && nk % cand == 0 && nk / cand >= 3) { S = cand; break; }
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = m->dpart; p.ldc = N; p.M = R; p.N = N; p.K = K;
+    p.out_f32 = 1; p.epi = EPI_PARTIAL; p.splitk = S;
+    *S_out = S;
+    ProfScope ps(m, s, tag, 2.0 * R * N * K, ((double)R * K + (double)N * K) * m->esz + (double)S * R * N * 4);
+    return launch_gemm(m->dt, p, 2, s);
+}
+
 int gemm_splitk_ln(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, const float* bias,
                    const float* g, const float* b, int R, int N, int K) {
     const int slab = m->dt == CAP_DT_BF16 ? 64 : 32;
@@ -322,19 +338,33 @@ int run_decoder_step(Captioner* m, const int* tokens, int tok_ld, int t, int B, 
         const TLayer& L = m->tl[i];
         char* kc = (char*)L.self_cache;
         char* vc = kc + (size_t)R * H * Lm * 64 * e;
-        TRY(gemm(m, s, "dec_gemm_qkv", m->dx_t, T, L.w_qkv, T, m->dq, T, L.b_qkv, nullptr, R, 3 * T, T, 0, 0, EPI_QKVCACHE,
-                 R, H, Lm, t, nullptr, kc));
-        {
+        if (t + 1 <= 32) {
+            // q/k/v projection as split-K partial sums; the attention kernel finishes the reduction, appends k/v to the
+            // cache and attends (one memory round trip per kernel instead of two in the GEMM)
+            int S = 1;
+            TRY(gemm_partial(m, s, "dec_gemm_qkv", m->dx_t, L.w_qkv, R, 3 * T, T, 4, &S));
+            ProfScope ps(m, s, "dec_self_attn", 4.0 * R * H * (t + 1) * 64, 2.0 * R * H * (t + 1) * 64 * e + (double)S * R * 3 * T * 4);
+            TRY(launch_decode_attention(m->dt, nullptr, kc, vc, anc, Lm, 1, Lm, t + 1, m->dctx, R, H, 0, s, m->dpart, S,
+                                        L.b_qkv, 3 * T, 0, 1));
+        } else {
+            TRY(gemm(m, s, "dec_gemm_qkv", m->dx_t, T, L.w_qkv, T, m->dq, T, L.b_qkv, nullptr, R, 3 * T, T, 0, 0, EPI_QKVCACHE,
+                     R, H, Lm, t, nullptr, kc));
             ProfScope ps(m, s, "dec_self_attn", 4.0 * R * H * (t + 1) * 64, 2.0 * R * H * (t + 1) * 64 * e);
             TRY(launch_decode_attention(m->dt, m->dq, kc, vc, anc, Lm, 1, Lm, t + 1, m->dctx, R, H, 0, s));
         }
         TRY(gemm_splitk_ln(m, s, "dec_gemm_so", m->dctx, L.w_so, L.b_so, L.so_g, L.so_b, R, T, T));
-        TRY(gemm(m, s, "dec_gemm_cq", m->dx_t, T, L.w_cq, T, m->dq, T, L.b_cq, nullptr, R, T, T, 0, 0));
         {
+            int S = 1;
+            TRY(gemm_partial(m, s, "dec_gemm_cq", m->dx_t, L.w_cq, R, T, T, 4, &S));
             const char* ck = (char*)m->cross + ((size_t)i * 2 + 0) * B * H * NT * 64 * e;
             const char* cv = (char*)m->cross + ((size_t)i * 2 + 1) * B * H * NT * 64 * e;
             ProfScope ps(m, s, "dec_cross_attn", 4.0 * R * H * NT * 64, 2.0 * B * H * NT * 64 * e);
-            TRY(launch_decode_attention(m->dt, m->dq, ck, cv, nullptr, 0, K, NT, NT, m->dctx, R, H, 0, s));
+            if (NT > 32)
+                TRY(launch_decode_attention(m->dt, nullptr, ck, cv, nullptr, 0, K, NT, NT, m->dctx, R, H, 0, s, m->dpart, S,
+                                            L.b_cq, T, 0, 0));
+            else   // short image-token sequences use the wave kernel, which also takes the fused query
+                TRY(launch_decode_attention(m->dt, nullptr, ck, cv, nullptr, 0, K, NT, NT, m->dctx, R, H, 0, s, m->dpart, S,
+                                            L.b_cq, T, 0, 0));
         }
         TRY(gemm_splitk_ln(m, s, "dec_gemm_co", m->dctx, L.w_co, L.b_co, L.co_g, L.co_b, R, T, T));
         TRY(gemm(m, s, "dec_gemm_f1", m->dx_t, T, L.w_f1, T, m->dh, F, L.b_f1, nullptr, R, F, T, 1, 0));
@@ -592,7 +622,7 @@ int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const v
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             void* stream) {
     return launch_decode_attention(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, q, kbase, vbase, anc, anc_ld, rows_per_kv,
-                                   kv_ld, n_keys, out, R, H, impl, (hipStream_t)stream);
+                                   kv_ld, n_keys, out, R, H, impl, (hipStream_t)stream, nullptr, 0, nullptr, 0, 0, 0);
 }
 int cap_op_convert(int dtype, const float* src, void* dst, size_t n, void* stream) {
     return launch_convert(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, src, dst, n, (hipStream_t)stream);

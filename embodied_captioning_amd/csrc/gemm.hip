@@ -236,7 +236,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(G
 #define CAP_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define CAP_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <typename T, bool OUT_F32, int EPI>
+// VAR selects the scheduling of the inner k-step loop (A/B-tested on the GPU, see tools/bench_gemm_sq.py):
+//   0 plain (compiler scheduled)   1 register double-buffered fragments + sched_group_barrier interleave
+//   2 plain + iglp_opt(0)          3 plain + iglp_opt(1)
+template <typename T, bool OUT_F32, int EPI, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     constexpr int BM = 256, BN = 256, WM = 128, WN = 64, MI = 4, NI = 2;
     constexpr int EPC = Mma<T>::EPC, SLAB = 8 * EPC;
@@ -278,19 +281,28 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
         }
     };
 
+    // bias rides the same LDS-DMA path (a register-destination load would make hipcc drain the DMA queue at every use):
+    // wave 0 fetches the tile's 256 bias values (1 KiB) into a ping-pong slot behind the stage buffers
+    char* bias_lds = smem + 2 * STAGE;
+    const bool has_bias = EPI != EPI_PARTIAL && p.bias != nullptr;
+    auto issue_bias = [&](int tile, int slot) {
+        if (has_bias && wave == 0) {
+            const int tn = tile % ntn;
+            const float* sb = p.bias + min(tn * BN + lane * 4, p.N - 4);
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(sb), CAP_LPTR(bias_lds + slot * 1024), 16, 0, 0);
+        }
+    };
+
     int cnt = 0;                                          // running slab counter: slab uses stage buffer cnt & 1
     int tile = c0 + li;
-    if (tile < c1) issue(tile, 0, smem);
-    for (; tile < c1; tile += nl) {
+    int tcount = 0;                                       // tiles done by this block: bias slot = tcount & 1
+    if (tile < c1) { issue_bias(tile, 0); issue(tile, 0, smem); }
+    for (; tile < c1; tile += nl, ++tcount) {
         const int tm = tile / ntn, tn = tile - tm * ntn;
         const int m0 = tm * BM, n0 = tn * BN;
         constexpr int LPR = WN / 4, RPP = 64 / LPR, NPS = 32 / RPP;
         const int rl = lane / LPR, cl = (lane % LPR) * 4;
         const int col = n0 + wn0 + cl;
-        // bias is the only register-destination load of the tile: take it here, where the first __syncthreads() of the
-        // K loop waits for it anyway (hipcc drains the whole queue for an ordinary load while LDS-DMA is in flight)
-        f32x4 biasv = 0.f;
-        if (EPI != EPI_PARTIAL && p.bias && col < p.N) biasv = *(const f32x4*)(p.bias + col);
         f32x16 acc[MI][NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -305,61 +317,93 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
             if (kt + 1 < nk) issue(tile, kt + 1, smem + ((cnt + 1) & 1) * STAGE);
             const char* a_s = smem + (cnt & 1) * STAGE;
             const char* b_s = a_s + BM * 128;
+            if constexpr (VAR == 1) {
+                // fragments double-buffered in registers: the ds_reads of k-step ks+1 are issued before the MFMAs of ks
+                vec af[2][MI], bf[2][NI];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                vec af[MI], bf[NI];
+                for (int i = 0; i < MI; ++i) af[0][i] = *(const vec*)(a_s + swz_off(wm0 + i * 32 + r32, h));
 #pragma unroll
-                for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz_off(wm0 + i * 32 + r32, ks * 2 + h));
+                for (int j = 0; j < NI; ++j) bf[0][j] = *(const vec*)(b_s + swz_off(wn0 + j * 32 + r32, h));
 #pragma unroll
-                for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz_off(wn0 + j * 32 + r32, ks * 2 + h));
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks < 3) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                        for (int i = 0; i < MI; ++i)
+                            af[(ks + 1) & 1][i] = *(const vec*)(a_s + swz_off(wm0 + i * 32 + r32, (ks + 1) * 2 + h));
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], af[i], bf[j]);
-            }
-        }
-        // stage buffer cnt & 1 was last read one slab ago and everyone has passed a barrier since: prefetch the next
-        // tile's first slab into it, then drain the other buffer (raw barrier: must not wait for the DMA just issued)
-        if (tile + nl < c1) issue(tile + nl, 0, smem + (cnt & 1) * STAGE);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-
-        float* strip = (float*)(smem + ((cnt + 1) & 1) * STAGE + wave * (32 * WN * 4));
-        const bool has_resid = EPI == EPI_STORE && p.resid != nullptr;
-        GemmParams q = p;
-        q.resid = nullptr;                                  // residual is added here, from registers
+                        for (int j = 0; j < NI; ++j)
+                            bf[(ks + 1) & 1][j] = *(const vec*)(b_s + swz_off(wn0 + j * 32 + r32, (ks + 1) * 2 + h));
+                    }
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            // all residual rows of this 32-row block in one batch of loads -> one wait instead of one per store
-            f32x4 rv[NPS];
-            if (has_resid) {
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int ps = 0; ps < NPS; ++ps) {
-                    const int row = min(m0 + wm0 + i * 32 + ps * RPP + rl, p.M - 1);
-                    rv[ps] = *(const f32x4*)(p.resid + (size_t)row * p.ldr + min(col, p.N - 4));
+                        for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], af[ks & 1][i], bf[ks & 1][j]);
+                    if (sizeof(T) == 2 && ks < 3) {
+#pragma unroll
+                        for (int r = 0; r < MI + NI; ++r) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - (MI + NI), 0);
+                    }
+                }
+            } else {
+                if constexpr (VAR == 2) __builtin_amdgcn_iglp_opt(0);
+                if constexpr (VAR == 3) __builtin_amdgcn_iglp_opt(1);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    vec af[MI], bf[NI];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz_off(wm0 + i * 32 + r32, ks * 2 + h));
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz_off(wn0 + j * 32 + r32, ks * 2 + h));
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], af[i], bf[j]);
                 }
             }
+        }
+        // Epilogue.  Phase 1: transpose the accumulators through wave-private LDS strips (in the stage buffer that was
+        // just multiplied) back into registers, row-major: each lane ends up with 4 consecutive columns of 32 rows.
+        // Phase 2 (after the next tile's first slab DMA has been issued - no LDS access from here on, so hipcc has no
+        // reason to drain the DMA queue): bias / GELU / residual, convert, 16-byte (fp32) or 8-byte (bf16) stores.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // every wave is done reading stage (cnt-1) & 1
+        float* strip = (float*)(smem + ((cnt + 1) & 1) * STAGE + wave * (32 * WN * 4));
+        f32x4 tr[MI][NPS];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     strip[((e & 3) + 8 * (e >> 2) + 4 * h) * WN + j * 32 + r32] = acc[i][j][e];
 #pragma unroll
-            for (int ps = 0; ps < NPS; ++ps) {
-                const int rr = ps * RPP + rl;
-                const int row = m0 + wm0 + i * 32 + rr;
-                f32x4 v = *(const f32x4*)(strip + rr * WN + cl);
-                if (has_resid) { v += biasv; v += rv[ps]; }
-                if (row < p.M && col < p.N) epi_store4<T, OUT_F32, EPI, false>(q, row, col, v, has_resid ? f32x4(0.f) : biasv);
-            }
+            for (int ps = 0; ps < NPS; ++ps) tr[i][ps] = *(const f32x4*)(strip + (ps * RPP + rl) * WN + cl);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // stage buffer cnt & 1 was last read one slab ago and everyone has passed a barrier since: prefetch the next
+        // tile's first slab into it now; it lands under phase 2
+        if (tile + nl < c1) { issue_bias(tile + nl, (tcount + 1) & 1); issue(tile + nl, 0, smem + (cnt & 1) * STAGE); }
+        f32x4 biasv = 0.f;
+        if (has_bias) biasv = *(const f32x4*)(bias_lds + (tcount & 1) * 1024 + (wn0 + cl) * 4);
+        // (no residual operand in this kernel: the ViT branch outputs go to `delta` and the add+LayerNorm kernel folds
+        //  them into the residual stream - a register-destination load here would make hipcc drain the DMA queue)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) {
+                const int row = m0 + wm0 + i * 32 + ps * RPP + rl;
+                if (row < p.M && col < p.N) epi_store4<T, OUT_F32, EPI, false>(p, row, col, tr[i][ps], biasv);
+            }
     }
 }
 
-template <typename T, bool OUT_F32, int EPI>
+template <typename T, bool OUT_F32, int EPI, int VAR = 0>
 int launch_big(const GemmParams& p, hipStream_t stream) {
-    constexpr int LDS = 2 * 512 * 128;
-    auto kern = gemm_big_kernel<T, OUT_F32, EPI>;
+    constexpr int LDS = 2 * 512 * 128 + 2 * 1024;       // two stages + bias ping-pong
+    auto kern = gemm_big_kernel<T, OUT_F32, EPI, VAR>;
     static bool attr_done = false;
     static int n_cu = 0;
     if (!attr_done) {
@@ -398,7 +442,20 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
 
 template <typename T, bool OUT_F32, int EPI>
 int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
-    if (tile == 3) return launch_big<T, OUT_F32, EPI>(p, stream);
+    if (tile >= 6 && tile <= 8) {                       // scheduling experiments (bf16 plain store only)
+        if constexpr (sizeof(T) == 2 && !OUT_F32 && EPI == EPI_STORE) {
+            if (tile == 6) return launch_big<T, OUT_F32, EPI, 1>(p, stream);
+            if (tile == 7) return launch_big<T, OUT_F32, EPI, 2>(p, stream);
+            return launch_big<T, OUT_F32, EPI, 0>(p, stream);
+        }
+        tile = 3;
+    }
+    if (tile == 3 && p.resid) tile = 4;                 // the LDS-DMA kernel has no residual operand
+    if (tile == 3) {
+        // iglp_opt(1) interleaves the ds_reads with the bf16 MFMAs: +5..14 % over the plain schedule (A/B, profiles/)
+        if constexpr (sizeof(T) == 2) return launch_big<T, OUT_F32, EPI, 3>(p, stream);
+        else return launch_big<T, OUT_F32, EPI, 0>(p, stream);
+    }
     if (tile == 4) return launch_cfg<T, 256, 256, 128, 64, 1, 2, OUT_F32, EPI>(p, stream);
     if (tile == 1) {
         if (nk % 2 == 0) return launch_cfg<T, 128, 128, 64, 64, 2, 2, OUT_F32, EPI>(p, stream);

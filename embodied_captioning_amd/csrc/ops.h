@@ -40,9 +40,13 @@ int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
 //   kbase + (((size_t)src(r,j) * H + h) * kv_ld + j) * 64   where src(r,j) = anc ? anc[r*anc_ld + j] : r / rows_per_kv
 // n_keys positions; out [R, H*64] (T).  impl 0 = fast kernels (wave-per-head, chunked online softmax),
 // impl 1 = simple two-pass block kernel (independent implementation kept for cross-checks).
+// Fused producer (optional, impl 0 only): q_part != nullptr -> q = sum_z q_part[z][R][q_ld][q_col0 + ...] + q_bias;
+// append_kv -> the new position's k/v are finished the same way (columns q_col0 + H*64, + 2*H*64), written to the
+// cache of the row itself and attended (self-attention with n_keys <= 32).
 int launch_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
-                            hipStream_t s);
+                            hipStream_t s, const float* q_part = nullptr, int q_S = 0, const float* q_bias = nullptr,
+                            int q_ld = 0, int q_col0 = 0, int append_kv = 0);
 
 // ---- beam.hip --------------------------------------------------------------------------------
 size_t beam_state_bytes(int B, int K, int max_len);
