@@ -3,6 +3,7 @@
 // launch sequences never allocate or synchronise (so they can be captured into a hipGraph).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -65,7 +66,13 @@ struct Captioner {
     float *X, *emb_f, *delta;
     int *seq, *finished, *lens, *anc;
     float *dx, *dy, *logits, *dpart;
-    void *dx_t, *dq, *dctx, *dh, *beam;
+    void *dx_t, *dq, *dctx, *dh;
+    // decode runs as up to 4 independent row slices on separate HIP streams (latency-bound kernels overlap)
+    int nslices = 1;
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    void* beam[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t cache_layer_bytes = 0;
     int ldl;
     // profiling
     bool prof = false;
@@ -217,7 +224,7 @@ int build_arena(Captioner* m) {
     m->ldl = (c.vocab + 3) & ~3;
     TRY(dev_alloc(m, (void**)&m->logits, R * (size_t)m->ldl * 4));
     for (int i = 0; i < c.t_layers; ++i) TRY(dev_alloc(m, &m->tl[i].self_cache, 2 * R * H * Lm * 64 * e));
-    TRY(dev_alloc(m, &m->beam, beam_state_bytes((int)Bm, c.max_beams, (int)Lm)));
+    for (int i = 0; i < 4; ++i) TRY(dev_alloc(m, &m->beam[i], beam_state_bytes((int)Bm, c.max_beams, (int)Lm)));
     return 0;
 }
 
@@ -245,43 +252,6 @@ int gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, int lda, c
     const double osz = out_f32 ? 4.0 : (double)m->esz;
     ProfScope ps(m, s, tag, 2.0 * M * N * K, ((double)M * K + (double)N * K) * m->esz + (double)M * N * osz);
     return launch_gemm(m->dt, p, 0, s);   // tile 0 = auto (stream kernel for encoder-sized problems without residual)
-}
-
-// Decode-sized GEMM whose consumer is a post-LayerNorm: split K over S blocks per tile (every block's slabs are all in
-// flight at once -> one memory round trip), partial sums to dpart, then bias + residual + LayerNorm in one kernel.
-int gemm_partial(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, int R, int N, int K,
-                 int max_S, int* S_out) {
-    const int slab = m->dt == CAP_DT_BF16 ? 64 : 32;
-    const int nk = K / slab;
-    int S = 1;
-    for (int cand : {8, 4, 2})
-        if (cand <= max_S && nk % cand == 0 && nk / cand >= 3) { S = cand; break; }
-    GemmParams p;
-    memset(&p, 0, sizeof(p));
-    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = m->dpart; p.ldc = N; p.M = R; p.N = N; p.K = K;
-    p.out_f32 = 1; p.epi = EPI_PARTIAL; p.splitk = S;
-    *S_out = S;
-    ProfScope ps(m, s, tag, 2.0 * R * N * K, ((double)R * K + (double)N * K) * m->esz + (double)S * R * N * 4);
-    return launch_gemm(m->dt, p, 2, s);
-}
-
-int gemm_splitk_ln(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, const float* bias,
-                   const float* g, const float* b, int R, int N, int K) {
-    const int slab = m->dt == CAP_DT_BF16 ? 64 : 32;
-    const int nk = K / slab;
-    int S = 1;
-    for (int cand : {8, 4, 2})
-        if (nk % cand == 0 && nk / cand >= 3) { S = cand; break; }
-    GemmParams p;
-    memset(&p, 0, sizeof(p));
-    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = m->dpart; p.ldc = N; p.M = R; p.N = N; p.K = K;
-    p.out_f32 = 1; p.epi = EPI_PARTIAL; p.splitk = S;
-    {
-        ProfScope ps(m, s, tag, 2.0 * R * N * K, ((double)R * K + (double)N * K) * m->esz + (double)S * R * N * 4);
-        TRY(launch_gemm(m->dt, p, 2, s));
-    }
-    ProfScope ps(m, s, "dec_reduce_ln", 0, (double)(S + 2) * R * N * 4 + (double)R * N * m->esz);
-    return launch_reduce_layernorm(m->dt, m->dpart, S, bias, m->dx, g, b, m->c.t_eps, m->dx_t, m->dx, nullptr, R, N, s);
 }
 
 // ---------------------------------------------------------------------------------------------- encoder
@@ -323,56 +293,104 @@ int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_emb
 }
 
 // ---------------------------------------------------------------------------------------------- decoder
-int post_ln(Captioner* m, hipStream_t s, const float* g, const float* b, int R) {
-    ProfScope ps(m, s, "dec_layernorm", 0, (double)R * m->c.t_hidden * (8 + m->esz));
-    return launch_layernorm(m->dt, m->dy, m->c.t_hidden, g, b, m->c.t_eps, m->dx_t, m->dx, R, m->c.t_hidden, s);
+// One decode slice = a contiguous range of images [b0, b0+B) with R = B*K rows; all pointers are pre-offset, row
+// indices inside the kernels are slice-local.  Slices are independent (no shared mutable state), so they can run on
+// different streams.
+struct Dec {
+    int b0, B, R, Btot;
+    float *dx, *dy, *logits, *dpart;
+    char *dx_t, *dq, *dctx, *dh;
+    int *seq, *finished, *lens, *anc;
+    void* beam;
+    size_t cache_off;     // byte offset of this slice's [k|v][R][H][Lm][64] block inside every layer's self cache
+};
+
+Dec make_slice(Captioner* m, int b0, int B, int Btot, int K, int Lm, int idx) {
+    const CapConfig& c = m->c;
+    const size_t T = c.t_hidden, F = c.t_ffn, H = c.t_heads, e = m->esz;
+    const size_t r0 = (size_t)b0 * K;
+    Dec d;
+    d.b0 = b0; d.B = B; d.R = B * K; d.Btot = Btot;
+    d.dx = m->dx + r0 * T; d.dy = m->dy + r0 * T; d.logits = m->logits + r0 * m->ldl; d.dpart = m->dpart + 12 * r0 * T;
+    d.dx_t = (char*)m->dx_t + r0 * T * e; d.dq = (char*)m->dq + r0 * T * e; d.dctx = (char*)m->dctx + r0 * T * e;
+    d.dh = (char*)m->dh + r0 * F * e;
+    d.seq = m->seq + r0 * Lm; d.finished = m->finished + r0; d.lens = m->lens + r0; d.anc = m->anc + 2 * r0 * Lm;
+    d.beam = m->beam[idx];
+    d.cache_off = 2 * r0 * H * Lm * 64 * e;
+    return d;
 }
 
-int run_decoder_step(Captioner* m, const int* tokens, int tok_ld, int t, int B, int K, const int* anc, int Lm,
+int gemm_partial(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, float* part, int R, int N,
+                 int K, int max_S, int* S_out) {
+    const int slab = m->dt == CAP_DT_BF16 ? 64 : 32;
+    const int nk = K / slab;
+    int S = 1;
+    for (int cand : {8, 4, 2})
+        if (cand <= max_S && nk % cand == 0 && nk / cand >= 3) { S = cand; break; }
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = part; p.ldc = N; p.M = R; p.N = N; p.K = K;
+    p.out_f32 = 1; p.epi = EPI_PARTIAL; p.splitk = S;
+    *S_out = S;
+    ProfScope ps(m, s, tag, 2.0 * R * N * K, ((double)R * K + (double)N * K) * m->esz + (double)S * R * N * 4);
+    return launch_gemm(m->dt, p, 2, s);
+}
+
+// Decode-sized GEMM whose consumer is a post-LayerNorm: split K over S blocks per tile (every block's slabs are all in
+// flight at once -> one memory round trip), partial sums to dpart, then bias + residual + LayerNorm in one kernel.
+int gemm_splitk_ln(Captioner* m, hipStream_t s, const Dec& d, const char* tag, const void* A, const void* W,
+                   const float* bias, const float* g, const float* b, int N, int K) {
+    int S = 1;
+    TRY(gemm_partial(m, s, tag, A, W, d.dpart, d.R, N, K, 8, &S));
+    ProfScope ps(m, s, "dec_reduce_ln", 0, (double)(S + 2) * d.R * N * 4 + (double)d.R * N * m->esz);
+    return launch_reduce_layernorm(m->dt, d.dpart, S, bias, d.dx, g, b, m->c.t_eps, d.dx_t, d.dx, nullptr, d.R, N, s);
+}
+
+int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, int t, int K, const int* anc, int Lm,
                      hipStream_t s) {
     const CapConfig& c = m->c;
-    const int T = c.t_hidden, F = c.t_ffn, H = c.t_heads, R = B * K, NT = m->NT;
+    const int T = c.t_hidden, F = c.t_ffn, H = c.t_heads, R = d.R, NT = m->NT;
     const size_t e = m->esz;
-    TRY(launch_embed(m->dt, tokens, tok_ld, t, m->word_f32, m->tpos, m->emb_g, m->emb_b, c.t_eps, m->dx_t, m->dx, R, T, s));
+    TRY(launch_embed(m->dt, tokens, tok_ld, t, m->word_f32, m->tpos, m->emb_g, m->emb_b, c.t_eps, d.dx_t, d.dx, R, T, s));
     for (int i = 0; i < c.t_layers; ++i) {
         const TLayer& L = m->tl[i];
-        char* kc = (char*)L.self_cache;
+        char* kc = (char*)L.self_cache + d.cache_off;
         char* vc = kc + (size_t)R * H * Lm * 64 * e;
         if (t + 1 <= 32) {
             // q/k/v projection as split-K partial sums; the attention kernel finishes the reduction, appends k/v to the
             // cache and attends (one memory round trip per kernel instead of two in the GEMM)
             int S = 1;
-            TRY(gemm_partial(m, s, "dec_gemm_qkv", m->dx_t, L.w_qkv, R, 3 * T, T, 4, &S));
+            TRY(gemm_partial(m, s, "dec_gemm_qkv", d.dx_t, L.w_qkv, d.dpart, R, 3 * T, T, 4, &S));
             ProfScope ps(m, s, "dec_self_attn", 4.0 * R * H * (t + 1) * 64, 2.0 * R * H * (t + 1) * 64 * e + (double)S * R * 3 * T * 4);
-            TRY(launch_decode_attention(m->dt, nullptr, kc, vc, anc, Lm, 1, Lm, t + 1, m->dctx, R, H, 0, s, m->dpart, S,
+            TRY(launch_decode_attention(m->dt, nullptr, kc, vc, anc, Lm, 1, Lm, t + 1, d.dctx, R, H, 0, s, d.dpart, S,
                                         L.b_qkv, 3 * T, 0, 1));
         } else {
-            TRY(gemm(m, s, "dec_gemm_qkv", m->dx_t, T, L.w_qkv, T, m->dq, T, L.b_qkv, nullptr, R, 3 * T, T, 0, 0, EPI_QKVCACHE,
+            TRY(gemm(m, s, "dec_gemm_qkv", d.dx_t, T, L.w_qkv, T, d.dq, T, L.b_qkv, nullptr, R, 3 * T, T, 0, 0, EPI_QKVCACHE,
                      R, H, Lm, t, nullptr, kc));
             ProfScope ps(m, s, "dec_self_attn", 4.0 * R * H * (t + 1) * 64, 2.0 * R * H * (t + 1) * 64 * e);
-            TRY(launch_decode_attention(m->dt, m->dq, kc, vc, anc, Lm, 1, Lm, t + 1, m->dctx, R, H, 0, s));
+            TRY(launch_decode_attention(m->dt, d.dq, kc, vc, anc, Lm, 1, Lm, t + 1, d.dctx, R, H, 0, s));
         }
-        TRY(gemm_splitk_ln(m, s, "dec_gemm_so", m->dctx, L.w_so, L.b_so, L.so_g, L.so_b, R, T, T));
+        TRY(gemm_splitk_ln(m, s, d, "dec_gemm_so", d.dctx, L.w_so, L.b_so, L.so_g, L.so_b, T, T));
         {
             int S = 1;
-            TRY(gemm_partial(m, s, "dec_gemm_cq", m->dx_t, L.w_cq, R, T, T, 4, &S));
-            const char* ck = (char*)m->cross + ((size_t)i * 2 + 0) * B * H * NT * 64 * e;
-            const char* cv = (char*)m->cross + ((size_t)i * 2 + 1) * B * H * NT * 64 * e;
-            ProfScope ps(m, s, "dec_cross_attn", 4.0 * R * H * NT * 64, 2.0 * B * H * NT * 64 * e);
-            if (NT > 32)
-                TRY(launch_decode_attention(m->dt, nullptr, ck, cv, nullptr, 0, K, NT, NT, m->dctx, R, H, 0, s, m->dpart, S,
-                                            L.b_cq, T, 0, 0));
-            else   // short image-token sequences use the wave kernel, which also takes the fused query
-                TRY(launch_decode_attention(m->dt, nullptr, ck, cv, nullptr, 0, K, NT, NT, m->dctx, R, H, 0, s, m->dpart, S,
-                                            L.b_cq, T, 0, 0));
+            TRY(gemm_partial(m, s, "dec_gemm_cq", d.dx_t, L.w_cq, d.dpart, R, T, T, 4, &S));
+            // beam-shared cross K/V of layer i: [k|v][image (whole batch)][head][token][64]; this slice starts at image b0
+            const char* ck = (char*)m->cross + (((size_t)i * 2 + 0) * d.Btot + d.b0) * H * NT * 64 * e;
+            const char* cv = (char*)m->cross + (((size_t)i * 2 + 1) * d.Btot + d.b0) * H * NT * 64 * e;
+            ProfScope ps(m, s, "dec_cross_attn", 4.0 * R * H * NT * 64, 2.0 * d.B * H * NT * 64 * e);
+            TRY(launch_decode_attention(m->dt, nullptr, ck, cv, nullptr, 0, K, NT, NT, d.dctx, R, H, 0, s, d.dpart, S, L.b_cq,
+                                        T, 0, 0));
         }
-        TRY(gemm_splitk_ln(m, s, "dec_gemm_co", m->dctx, L.w_co, L.b_co, L.co_g, L.co_b, R, T, T));
-        TRY(gemm(m, s, "dec_gemm_f1", m->dx_t, T, L.w_f1, T, m->dh, F, L.b_f1, nullptr, R, F, T, 1, 0));
-        TRY(gemm_splitk_ln(m, s, "dec_gemm_f2", m->dh, L.w_f2, L.b_f2, L.f_g, L.f_b, R, T, F));
+        TRY(gemm_splitk_ln(m, s, d, "dec_gemm_co", d.dctx, L.w_co, L.b_co, L.co_g, L.co_b, T, T));
+        TRY(gemm(m, s, "dec_gemm_f1", d.dx_t, T, L.w_f1, T, d.dh, F, L.b_f1, nullptr, R, F, T, 1, 0));
+        TRY(gemm_splitk_ln(m, s, d, "dec_gemm_f2", d.dh, L.w_f2, L.b_f2, L.f_g, L.f_b, T, F));
     }
-    TRY(gemm(m, s, "dec_gemm_tr", m->dx_t, T, m->w_tr, T, m->dy, T, m->b_tr, nullptr, R, T, T, 1, 1));
-    TRY(post_ln(m, s, m->tr_g, m->tr_b, R));
-    TRY(gemm(m, s, "dec_gemm_vocab", m->dx_t, T, m->word_t, T, m->logits, m->ldl, m->b_vocab, nullptr, R, c.vocab, T, 0, 1));
+    TRY(gemm(m, s, "dec_gemm_tr", d.dx_t, T, m->w_tr, T, d.dy, T, m->b_tr, nullptr, R, T, T, 1, 1));
+    {
+        ProfScope ps(m, s, "dec_layernorm", 0, (double)R * T * (8 + e));
+        TRY(launch_layernorm(m->dt, d.dy, T, m->tr_g, m->tr_b, c.t_eps, d.dx_t, d.dx, R, T, s));
+    }
+    TRY(gemm(m, s, "dec_gemm_vocab", d.dx_t, T, m->word_t, T, d.logits, m->ldl, m->b_vocab, nullptr, R, c.vocab, T, 0, 1));
     return 0;
 }
 
@@ -401,35 +419,53 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
     TRY(run_encoder(m, pixels, fmt, B, nullptr, s));
     TRY(gemm(m, s, "gemm_crosskv", m->emb_t, D, m->w_ckv, D, m->cross, 0, m->b_ckv, nullptr, B * NT, c.t_layers * 2 * T, D,
              0, 0, EPI_CROSSKV, NT, H, B));
-    if (K == 1) {
-        hipLaunchKernelGGL(init_seq_kernel, dim3(64), dim3(256), 0, s, m->seq, m->finished, m->lens, R, Lm, c.bos, c.pad);
-    } else {
-        TRY(launch_beam_init(m->beam, B, K, Lm, c.bos, c.pad, c.eos, s));
-        hipLaunchKernelGGL(iota_rows_kernel, dim3(64), dim3(256), 0, s, m->anc, R, Lm);
-    }
-    CAP_HIP_CHECK(hipGetLastError());
-    for (int t = 0; t + 1 < Lm; ++t) {
-        const int cur_len = t + 1;
-        const int* tokens = K == 1 ? m->seq : beam_running_tokens_p(m->beam, B, K, Lm, cur_len & 1);
-        const int* anc = K == 1 ? nullptr : m->anc + (size_t)(cur_len & 1) * R * Lm;
-        TRY(run_decoder_step(m, tokens, Lm, t, B, K, anc, Lm, s));
-        if (out_step_logits) {
-            hipLaunchKernelGGL(copy_logits_kernel, dim3(1024), dim3(256), 0, s, m->logits, m->ldl,
-                               out_step_logits + (size_t)t * R * c.vocab, R, c.vocab);
-            CAP_HIP_CHECK(hipGetLastError());
+    // decode: independent row slices, one per stream (slice 0 stays on the caller's stream)
+    int ns = m->nslices;
+    if (ns > B) ns = B;
+    if (ns > 1) CAP_HIP_CHECK(hipEventRecord(m->ev_fork, s));
+    const int per = (B + ns - 1) / ns;
+    for (int si = 0; si < ns; ++si) {
+        const int b0 = si * per, Bs = (b0 + per <= B ? per : B - b0);
+        if (Bs <= 0) continue;
+        hipStream_t st = si == 0 ? s : m->aux[si - 1];
+        if (si > 0) CAP_HIP_CHECK(hipStreamWaitEvent(st, m->ev_fork, 0));
+        const Dec d = make_slice(m, b0, Bs, B, K, Lm, si);
+        const int Rs = d.R;
+        if (K == 1) {
+            hipLaunchKernelGGL(init_seq_kernel, dim3(64), dim3(256), 0, st, d.seq, d.finished, d.lens, Rs, Lm, c.bos, c.pad);
+        } else {
+            TRY(launch_beam_init(d.beam, Bs, K, Lm, c.bos, c.pad, c.eos, st));
+            hipLaunchKernelGGL(iota_rows_kernel, dim3(64), dim3(256), 0, st, d.anc, Rs, Lm);
         }
-        ProfScope ps(m, s, K == 1 ? "greedy_select" : "beam_step", 0, (double)R * c.vocab * 4);
-        if (K == 1)
-            TRY(launch_greedy_select(m->logits, m->ldl, c.vocab, m->seq, Lm, t, Lm, c.eos, c.pad, m->finished, m->lens, R, s));
-        else
-            TRY(launch_beam_step(m->beam, m->logits, m->ldl, c.vocab, B, K, Lm, cur_len, c.eos, lp, m->anc, Lm, s));
-    }
-    if (K == 1) {
-        hipLaunchKernelGGL(copy_i32_kernel, dim3(64), dim3(256), 0, s, m->seq, out_ids, (size_t)R * Lm);
-        if (out_len) hipLaunchKernelGGL(copy_i32_kernel, dim3(4), dim3(256), 0, s, m->lens, out_len, (size_t)R);
         CAP_HIP_CHECK(hipGetLastError());
-    } else {
-        TRY(launch_beam_finalize(m->beam, B, K, Lm, out_ids, out_len, out_scores, s));
+        for (int t = 0; t + 1 < Lm; ++t) {
+            const int cur_len = t + 1;
+            const int* tokens = K == 1 ? d.seq : beam_running_tokens_p(d.beam, Bs, K, Lm, cur_len & 1);
+            const int* anc = K == 1 ? nullptr : d.anc + (size_t)(cur_len & 1) * Rs * Lm;
+            TRY(run_decoder_step(m, d, tokens, Lm, t, K, anc, Lm, st));
+            if (out_step_logits) {
+                hipLaunchKernelGGL(copy_logits_kernel, dim3(1024), dim3(256), 0, st, d.logits, m->ldl,
+                                   out_step_logits + ((size_t)t * R + (size_t)b0 * K) * c.vocab, Rs, c.vocab);
+                CAP_HIP_CHECK(hipGetLastError());
+            }
+            ProfScope ps(m, st, K == 1 ? "greedy_select" : "beam_step", 0, (double)Rs * c.vocab * 4);
+            if (K == 1)
+                TRY(launch_greedy_select(d.logits, m->ldl, c.vocab, d.seq, Lm, t, Lm, c.eos, c.pad, d.finished, d.lens, Rs, st));
+            else
+                TRY(launch_beam_step(d.beam, d.logits, m->ldl, c.vocab, Bs, K, Lm, cur_len, c.eos, lp, d.anc, Lm, st));
+        }
+        if (K == 1) {
+            hipLaunchKernelGGL(copy_i32_kernel, dim3(64), dim3(256), 0, st, d.seq, out_ids + (size_t)b0 * Lm, (size_t)Rs * Lm);
+            if (out_len) hipLaunchKernelGGL(copy_i32_kernel, dim3(4), dim3(256), 0, st, d.lens, out_len + b0, (size_t)Rs);
+            CAP_HIP_CHECK(hipGetLastError());
+        } else {
+            TRY(launch_beam_finalize(d.beam, Bs, K, Lm, out_ids + (size_t)b0 * Lm, out_len ? out_len + b0 : nullptr,
+                                     out_scores ? out_scores + b0 : nullptr, st));
+        }
+        if (si > 0) {
+            CAP_HIP_CHECK(hipEventRecord(m->ev_join[si - 1], st));
+            CAP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_join[si - 1], 0));
+        }
     }
     return 0;
 }
@@ -468,6 +504,19 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
     m->P = g * g; m->NT = m->P + 1;
     m->Kpatch = 3 * cfg->patch_size * cfg->patch_size;
     m->Kpad = (m->Kpatch + 63) / 64 * 64;
+    {
+        // decode slices: 1 by default. Measured on MI355X (eager and captured into a hipGraph): kernels of different
+        // streams / graph branches do not overlap for this workload, so 2 slices tie and 4 lose to launch overhead;
+        // CAP_DECODE_SLICES=1..4 keeps the knob for A/B runs.
+        const char* env = getenv("CAP_DECODE_SLICES");
+        int ns = env ? atoi(env) : 1;
+        m->nslices = ns < 1 ? 1 : (ns > 4 ? 4 : ns);
+        bool ok = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i + 1 < m->nslices; ++i)
+            ok = hipStreamCreateWithFlags(&m->aux[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { cap_set_error("cap_create: cannot create decode streams/events"); delete m; return -1; }
+    }
     if (build_blip(m) != 0 || build_arena(m) != 0) {
         for (void* p : m->allocs) (void)hipFree(p);
         delete m;
@@ -484,6 +533,11 @@ int cap_destroy(CapHandle h) {
     for (auto& r : m->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->stage) (void)hipFree(m->stage);
+    for (int i = 0; i < 3; ++i) {
+        if (m->aux[i]) (void)hipStreamDestroy(m->aux[i]);
+        if (m->ev_join[i]) (void)hipEventDestroy(m->ev_join[i]);
+    }
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     delete m;
     return 0;
 }

@@ -199,8 +199,27 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const float* __restr
     const float* x = logits + (size_t)row * ld;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid; i < V; i += 256) {
-        float v = x[i];
+    // 16-byte loads, 4 independent chunks in flight per thread; ascending index order inside a thread keeps "first
+    // maximal index" with a strict > compare
+    const int V4 = V >> 2;
+    for (int c0 = tid; c0 < V4; c0 += 1024) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * 256;
+            v[u] = c < V4 ? *(const float4*)(x + 4 * c) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = 4 * (c0 + u * 256);
+            if (v[u].x > best) { best = v[u].x; bi = i; }
+            if (v[u].y > best) { best = v[u].y; bi = i + 1; }
+            if (v[u].z > best) { best = v[u].z; bi = i + 2; }
+            if (v[u].w > best) { best = v[u].w; bi = i + 3; }
+        }
+    }
+    for (int i = (V4 << 2) + tid; i < V; i += 256) {
+        const float v = x[i];
         if (v > best) { best = v; bi = i; }
     }
     __shared__ float sv[256];

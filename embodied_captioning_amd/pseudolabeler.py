@@ -1,0 +1,79 @@
+"""Batched counterpart of the reference's per-box captioning loop
+(``experimenting_env/detector/pseudolabeler.py:629-711``: `expand_box`, `predict_captions`, `predict_caption`).
+
+The reference crops one box at a time and calls the captioner with batch 1; here every box of a dataloader batch is
+expanded (+20 %), cropped, and captioned in ONE `caption_batch` call (micro-batched inside the engine), then the
+captions are handed back per frame in box order - same crop arithmetic, same BGR->RGB swap, same caption order.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+def expand_box(box, expand_factor: float, image_size) -> np.ndarray:
+    """Reference `expand_box` (:629-643), including its naming quirk: `image_size` is `image.shape` = (H, W, C), and
+    the reference clamps x to image_size[0] and y to image_size[1].  fp32 arithmetic like the torch scalars it uses;
+    `int()` truncates toward zero."""
+    x1, y1, x2, y2 = (torch.as_tensor(v, dtype=torch.float32) for v in box)
+    width, height = image_size[0], image_size[1]
+    box_width = x2 - x1
+    box_height = y2 - y1
+    new_x1 = int(max(x1 - expand_factor * box_width, 0))
+    new_y1 = int(max(y1 - expand_factor * box_height, 0))
+    new_x2 = int(min(x2 + expand_factor * box_width, width))
+    new_y2 = int(min(y2 + expand_factor * box_height, height))
+    return np.array([new_x1, new_y1, new_x2, new_y2])
+
+
+def crop_boxes(image_bgr: np.ndarray, boxes: Sequence, expand_factor: float = 0.2) -> list:
+    """BGR uint8 HWC frame + boxes (x1,y1,x2,y2) -> list of RGB PIL crops (reference :670-675, :694-697)."""
+    from PIL import Image
+    rgb = np.ascontiguousarray(image_bgr[..., ::-1])                     # cv2.COLOR_BGR2RGB
+    pil = Image.fromarray(rgb)
+    return [pil.crop(tuple(int(v) for v in expand_box(b, expand_factor, rgb.shape))) for b in boxes]
+
+
+def record_name(episode: int, step: int) -> str:
+    """File name of a pseudo-label record (reference :835-843)."""
+    return f"episode_{episode}_step_{step}.npz"
+
+
+class BatchedBoxCaptioner:
+    """`captioner` is the plugin (`Captioner` with `caption_batch`) or any callable list[PIL] -> list[str];
+    `encoder` (optional) maps a caption to its sentence embedding (the reference uses MiniLM `encode`)."""
+
+    def __init__(self, captioner, encoder: Optional[Callable[[str], torch.Tensor]] = None, expand_factor: float = 0.2):
+        self.captioner = captioner
+        self.encoder = encoder
+        self.expand_factor = expand_factor
+
+    def _caption(self, crops: list) -> List[str]:
+        if not crops:
+            return []
+        fn = getattr(self.captioner, "caption_batch", None)
+        return list(fn(crops)) if fn is not None else list(self.captioner(crops))
+
+    def predict_captions(self, boxes_per_frame: Sequence[Sequence], frames_bgr: Sequence[np.ndarray]):
+        """One captioner call for the whole dataloader batch.  Returns per frame
+        {"captions": [str], "embeddings": tensor [n, d] | tensor([])} in box order (reference :664-688)."""
+        crops, owner = [], []
+        for fi, (boxes, img) in enumerate(zip(boxes_per_frame, frames_bgr)):
+            cs = crop_boxes(img, boxes, self.expand_factor)
+            crops += cs
+            owner += [fi] * len(cs)
+        captions = self._caption(crops)
+        out = [{"captions": [], "embeddings": torch.tensor([])} for _ in frames_bgr]
+        for fi, cap in zip(owner, captions):
+            out[fi]["captions"].append(cap)
+        if self.encoder is not None:
+            for o in out:
+                if o["captions"]:
+                    o["embeddings"] = torch.stack([torch.as_tensor(self.encoder(c)) for c in o["captions"]])
+        return out
+
+    def predict_caption(self, boxes: Sequence, image_bgr: np.ndarray):
+        """Single-frame form (reference :690-711)."""
+        return self.predict_captions([boxes], [image_bgr])[0]

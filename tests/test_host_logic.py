@@ -80,3 +80,35 @@ def test_state_dict_file_readers(tmp_path):
     p2 = tmp_path / "w.safetensors"
     save_file({"a.weight": sd["module.a.weight"].contiguous()}, str(p2))
     assert torch.equal(load_state_dict_file(str(p2))["a.weight"], sd["module.a.weight"])
+
+
+def test_expand_box_known_answers_from_the_reference_arithmetic():
+    # cases worked out by hand from pseudolabeler.py:629-643
+    from embodied_captioning_amd.pseudolabeler import expand_box, record_name
+    assert expand_box((100, 200, 300, 400), 0.2, (1280, 1280, 3)).tolist() == [60, 160, 340, 440]
+    assert expand_box((0, 0, 1280, 1280), 0.2, (1280, 1280, 3)).tolist() == [0, 0, 1280, 1280]
+    assert expand_box((10.7, 5.2, 20.9, 15.5), 0.2, (480, 640, 3)).tolist() == [8, 3, 22, 17]     # int() truncation
+    assert expand_box((600, 10, 700, 400), 0.2, (480, 640, 3)).tolist() == [580, 0, 480, 478]      # clamp quirk: x <- shape[0]
+    assert record_name(3, 17) == "episode_3_step_17.npz"
+
+
+def test_batched_box_captioner_keeps_frame_and_box_order():
+    import numpy as np
+    from embodied_captioning_amd.pseudolabeler import BatchedBoxCaptioner, crop_boxes
+    rng = np.random.default_rng(0)
+    frames = [rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8) for _ in range(3)]
+    boxes = [[(4, 4, 20, 20), (30, 30, 60, 60)], [], [(0, 0, 64, 64)]]
+    calls = []
+
+    def fake(crops):                                   # caption = crop size + mean red value (after the BGR->RGB swap)
+        calls.append(len(crops))
+        return [f"{c.size[0]}x{c.size[1]}:{int(np.asarray(c)[..., 0].mean())}" for c in crops]
+
+    out = BatchedBoxCaptioner(fake, encoder=lambda s: torch.full((4,), float(len(s)))).predict_captions(boxes, frames)
+    assert calls == [3]                                # one call for the whole batch
+    assert [len(o["captions"]) for o in out] == [2, 0, 1]
+    c0 = crop_boxes(frames[0], boxes[0])
+    assert out[0]["captions"][0].startswith(f"{c0[0].size[0]}x{c0[0].size[1]}")
+    red = int(frames[2][..., 2].mean())                # channel 2 of BGR is red
+    assert out[2]["captions"][0] == f"64x64:{red}"
+    assert out[1]["embeddings"].numel() == 0 and out[0]["embeddings"].shape == (2, 4)
