@@ -85,7 +85,7 @@ def roofline_pass(eng, px, L, dtype, arch, batch):
     roof = {"bound": "mfma", "kernel": "gemm_big_kernel 256x256 LDS-DMA (ViT qkv/proj/fc1/fc2 launches)", "achieved": round(achieved, 2),
             "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
             "flops_per_launch": fl / n, "avg_launch_us": round(1e3 * ms / n, 2), "launches_per_step": n // reps}
-    roof["traffic"] = pmc_traffic()
+    roof["traffic"] = pmc_traffic() if dtype == "bf16" else None   # the committed PMC passes are of the bf16 run
     total_ms = sum(r["ms"] for r in rep.values()) / reps
     return roof, kernels, total_ms
 
@@ -113,7 +113,8 @@ def pmc_traffic():
         d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc.json")))
         n = b = 0.0
         for k, v in d.items():
-            if "gemm_big_kernel" in k and ("ELi0E" in k or "E, 0>" in k) and "hbm_read_bytes_corrected" in v:
+            plain_store = "ELi0ELi" in k or ", 0, " in k          # EPI_STORE instantiations (bf16-out and fp32-out)
+            if "gemm_big_kernel" in k and plain_store and "hbm_read_bytes_corrected" in v:
                 n += v["launches_per_pass"]
                 b += v["launches_per_pass"] * (v["hbm_read_bytes_corrected"] + v.get("hbm_write_bytes", 0.0))
         return round(b / n) if n else None
