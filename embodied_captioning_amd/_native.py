@@ -26,6 +26,8 @@ class CapConfig(C.Structure):
         ("bos", C.c_int32), ("eos", C.c_int32), ("pad", C.c_int32),
         ("max_batch", C.c_int32), ("max_beams", C.c_int32), ("max_len", C.c_int32),
         ("pix_mean", C.c_float * 3), ("pix_std", C.c_float * 3),
+        ("embed_dim", C.c_int32), ("pool_queries", C.c_int32), ("pool_heads", C.c_int32), ("mm_layers", C.c_int32),
+        ("min_len", C.c_int32),
     ]
 
 

@@ -1,13 +1,119 @@
-"""`CoCa(cfg)` entry of the plugin factory (reference ``captioner/models/coca/coca.py:19-33``).
+"""CoCa captioner wrapper with the reference's wrapper shape (``captioner/models/coca/coca.py:19-33``):
+``CoCa(cfg)`` with ``cfg.model_name`` / ``cfg.checkpoint_name``; ``forward(PIL.Image) -> {"text", "logits"}`` where
+``logits`` is the list of per-step MinLength-processed logits of the still-active rows (``coca_model.py:312-313``).
 
-CoCa ViT-L/14 (attentional pooler + unimodal/multimodal text towers) reuses the GEMM / attention / LayerNorm kernels
-of this package; its tower wiring is not built yet (no importable oracle for open_clip in the build
-container), so construction raises instead of silently running something else."""
+Arithmetic runs in libcaptioner_hip.so (`CaptionerEngine` with a `CocaArch`); the decode loop is the reference's
+``generate(generation_type='top_k')`` with top_k = 1 (coca.py:29), KV-cached instead of re-running the prefix.
+
+model_name: ``coca_ViT-L-14`` (the reference's model_configs json) with ``checkpoint_name`` = path of an open_clip
+state-dict file (``.pt`` / ``.bin`` / ``.safetensors``; pretrained *tags* need the network and raise like
+``factory.py:309-314``), or ``procedural-coca:<seed>[:<eos_boost>]`` / ``procedural-coca-tiny:...`` (seeded weights).
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
 from ...captioning_predictor import CaptioningPredictor
+from ....config import CocaArch
+from ....engine import CaptionerEngine
+from ....weights import load_state_dict_file, procedural_coca_state_dict
+
+logger = logging.getLogger(__name__)
 
 
 class CoCa(CaptioningPredictor):
     def __init__(self, cfg=None):
         super().__init__(cfg)
-        raise NotImplementedError("CoCa is not wired to the HIP path yet (open_clip is not available to pin an oracle); "
-                                  "use arch_name 'blip'")
+        name = cfg.model_name or "coca_ViT-L-14"
+        self.batch_size = int(getattr(cfg, "batch_size", 8) or 8)
+        dtype = getattr(cfg, "dtype", "bf16") or "bf16"
+        self._device = torch.device(getattr(cfg, "device", "cuda:0") or "cuda:0")
+        self.tokenizer = None
+        if name.startswith("procedural-coca"):
+            parts = name.split(":")
+            seed = int(parts[1]) if len(parts) > 1 else 0
+            boost = float(parts[2]) if len(parts) > 2 else 0.0
+            self.arch = CocaArch.tiny() if parts[0] == "procedural-coca-tiny" else CocaArch()
+            sd = procedural_coca_state_dict(self.arch, seed, eos_boost=boost)
+        else:
+            if name != "coca_ViT-L-14":
+                raise RuntimeError(f"Model config for {name} not found.")               # factory.py:231-233
+            ck = getattr(cfg, "checkpoint_name", None)
+            if not ck or not os.path.exists(ck):
+                raise RuntimeError(f"Pretrained weights ({ck}) not found for model {name}.")   # factory.py:309-314
+            self.arch = CocaArch()
+            sd = load_state_dict_file(ck)
+            try:
+                import open_clip
+                self.tokenizer = open_clip
+            except Exception:  # noqa: BLE001
+                logger.warning("open_clip is not installed: captions are returned as space-separated token ids")
+        self.engine = CaptionerEngine(self.arch, dtype=dtype, max_batch=self.batch_size, max_beams=1,
+                                      max_len=self.arch.seq_len, device=self._device)
+        self.engine.load_state_dict(sd)
+
+    @property
+    def device(self):
+        return self._device
+
+    def to(self, *args, **kwargs):
+        return self
+
+    def preprocess(self, images) -> torch.Tensor:
+        """open_clip `image_transform(is_train=False)`: bicubic resize of the shorter side to the model size, centre
+        crop, RGB; rescale + OPENAI mean/std are fused into the patch-gather kernel (uint8 in)."""
+        from PIL import Image
+        S = self.arch.image_size
+        if isinstance(images, torch.Tensor):
+            return images if images.dim() == 4 else images[None]
+        if isinstance(images, Image.Image):
+            images = [images]
+        frames = []
+        for im in images:
+            im = im.convert("RGB")
+            w, h = im.size
+            scale = S / min(w, h)
+            nw, nh = max(S, round(w * scale)), max(S, round(h * scale))
+            im = im.resize((nw, nh), resample=Image.BICUBIC)
+            left, top = (nw - S) // 2, (nh - S) // 2
+            frames.append(np.asarray(im.crop((left, top, left + S, top + S))))
+        return torch.from_numpy(np.stack(frames))
+
+    def decode(self, ids: Sequence[int]) -> str:
+        ids = [int(i) for i in ids]
+        if self.tokenizer is not None:
+            text = self.tokenizer.decode(torch.tensor(ids))
+            return text.split("<end_of_text>")[0].replace("<start_of_text>", "")       # coca.py:30
+        a = self.arch
+        return " ".join(str(i) for i in ids if i not in (a.sot, a.eos, a.pad))
+
+    @torch.no_grad()
+    def generate_batch(self, images) -> dict:
+        px = self.preprocess(images)
+        seqs, lens = [], []
+        for i in range(0, px.shape[0], self.batch_size):
+            out = self.engine.generate(px[i:i + self.batch_size].to(self._device), max_length=self.arch.seq_len)
+            seqs.append(out["sequences"]); lens.append(out["lengths"])
+        seq, ln = torch.cat(seqs).cpu(), torch.cat(lens).cpu()
+        return {"texts": [self.decode(r[:n]) for r, n in zip(seq.tolist(), ln.tolist())], "sequences": seq, "lengths": ln}
+
+    @torch.no_grad()
+    def forward(self, inputs):
+        a = self.arch
+        px = self.preprocess(inputs)[:1]
+        out = self.engine.generate(px.to(self._device), max_length=a.seq_len, output_logits=True)
+        n = int(out["lengths"][0])
+        ids = out["sequences"][0, :n].tolist()
+        steps: List[torch.Tensor] = []
+        for t in range(n - 1):                       # one entry per generated token, like the reference's loop
+            lg = out["logits"][t].clone()
+            if t + 1 < a.min_seq_len:
+                lg[:, a.eos] = float("-inf")         # MinLengthLogitsProcessor applied before the logits are recorded
+            steps.append(lg)
+        self.outputs = {"text": self.decode(ids), "logits": steps}
+        return self.outputs

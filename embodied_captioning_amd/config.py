@@ -109,3 +109,49 @@ class BlipArch:
         a.eos = t.get("sep_token_id", 102)
         a.pad = t.get("pad_token_id", 0)
         return a
+
+
+@dataclasses.dataclass
+class CocaArch:
+    """CoCa ViT-L/14 - reference ``experimenting_env/captioner/models/coca/model_configs/coca_ViT-L-14.json:1-30``
+    (+ open_clip defaults: 256 pooler queries, mlp_ratio 4, LayerNorm eps 1e-5, exact GELU)."""
+    image_size: int = 224
+    patch_size: int = 14
+    v_hidden: int = 1024
+    v_layers: int = 24
+    v_heads: int = 16
+    v_mlp: int = 4096
+    embed_dim: int = 768          # pooler output width = text width
+    pool_queries: int = 256
+    pool_heads: int = 8
+    t_hidden: int = 768
+    t_layers: int = 12            # unimodal text tower
+    mm_layers: int = 12           # multimodal decoder (each layer = causal self-attn block + cross-attn block)
+    t_heads: int = 12
+    t_ffn: int = 3072
+    vocab: int = 49408
+    context_length: int = 76
+    eps: float = 1e-5
+    sot: int = 49406
+    eos: int = 49407
+    pad: int = 0
+    seq_len: int = 30             # coca_model.py:209 generate defaults
+    min_seq_len: int = 5
+
+    @property
+    def grid(self) -> int:
+        return self.image_size // self.patch_size
+
+    @property
+    def n_tokens(self) -> int:
+        return self.grid * self.grid + 1
+
+    @property
+    def n_image_embs(self) -> int:
+        return self.pool_queries - 1
+
+    @staticmethod
+    def tiny() -> "CocaArch":
+        return CocaArch(image_size=28, patch_size=14, v_hidden=128, v_layers=2, v_heads=2, v_mlp=256, embed_dim=128,
+                        pool_queries=8, pool_heads=2, t_hidden=128, t_layers=2, mm_layers=2, t_heads=2, t_ffn=256,
+                        vocab=512, context_length=20, sot=510, eos=511, pad=0, seq_len=12, min_seq_len=3)

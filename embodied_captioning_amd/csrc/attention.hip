@@ -469,6 +469,52 @@ __global__ __launch_bounds__(256) void decode_attention_online_kernel(const T* _
     }
 }
 
+// ---- attentional pooler: Q learned queries (already layer-normed and projected on the host, identical for every
+// image) attend over the N image tokens.  One thread per query, K/V tiles broadcast from LDS, online softmax; head_dim is
+// a template parameter (CoCa ViT-L/14: 768 / 8 heads = 96).  ~1 % of the CoCa encoder's flops.
+template <typename T, int HD>
+__global__ __launch_bounds__(64) void pool_attention_kernel(const float* __restrict__ qp, const T* __restrict__ kv,
+                                                            T* __restrict__ out, int N, int Q, int E, int heads) {
+    constexpr int KT = 32;
+    __shared__ float Ks[KT][HD + 1];
+    __shared__ float Vs[KT][HD + 1];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int tid = threadIdx.x, q = blockIdx.y * 64 + tid, qc = min(q, Q - 1);
+    const float scale = rsqrtf((float)HD);
+    float qv[HD], o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { qv[d] = qp[(size_t)qc * E + h * HD + d] * scale; o[d] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    const T* base = kv + (size_t)b * N * 2 * E + h * HD;
+    for (int k0 = 0; k0 < N; k0 += KT) {
+        const int nk = min(KT, N - k0);
+        __syncthreads();
+        for (int c = tid; c < nk * HD; c += 64) {
+            const int j = c / HD, d = c - j * HD;
+            Ks[j][d] = to_f32(base[(size_t)(k0 + j) * 2 * E + d]);
+            Vs[j][d] = to_f32(base[(size_t)(k0 + j) * 2 * E + E + d]);
+        }
+        __syncthreads();
+        for (int j = 0; j < nk; ++j) {
+            float sc = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) sc = fmaf(qv[d], Ks[j][d], sc);
+            const float mn = fmaxf(m, sc);
+            const float c = expf(m - mn), pj = expf(sc - mn);
+            l = l * c + pj;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) o[d] = fmaf(pj, Vs[j][d], o[d] * c);
+            m = mn;
+        }
+    }
+    if (q < Q) {
+        const float inv = 1.0f / l;
+        T* op = out + ((size_t)b * Q + q) * E + h * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) op[d] = from_f32<T>(o[d] * inv);
+    }
+}
+
 template <int KB>
 int launch_mfma_kb(const void* qkv, void* ctx, int B, int N, int H, hipStream_t s) {
     const int lds = 2 * KB * 32 * 128;
@@ -553,6 +599,23 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
         hipLaunchKernelGGL(decode_attention_kernel<float>, grid, dim3(256), lds, s, (const float*)q,
                            (const float*)kbase, (const float*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys,
                            (float*)out, H);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_pool_attention(int dtype, const float* qp, const void* kv, void* out, int B, int N, int Q, int E, int heads,
+                          hipStream_t s) {
+    const int hd = E / heads;
+    if (hd * heads != E || (hd != 64 && hd != 96)) {
+        cap_set_error("pool_attention: head_dim %d not supported (64 or 96)", hd);
+        return -1;
+    }
+    dim3 grid(B * heads, (Q + 63) / 64);
+#define CAP_POOL(TT, HDV)                                                                                     \
+    hipLaunchKernelGGL((pool_attention_kernel<TT, HDV>), grid, dim3(64), 0, s, qp, (const TT*)kv, (TT*)out, N, Q, E, heads)
+    if (dtype == CAP_DT_BF16) { if (hd == 64) CAP_POOL(bf16_t, 64); else CAP_POOL(bf16_t, 96); }
+    else { if (hd == 64) CAP_POOL(float, 64); else CAP_POOL(float, 96); }
+#undef CAP_POOL
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }

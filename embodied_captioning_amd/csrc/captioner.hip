@@ -45,6 +45,15 @@ struct TLayer {
     void* self_cache;     // [2][R][H][max_len][64] (T)
 };
 
+struct CBlock {            // one CoCa text block: causal self-attention (unimodal / multimodal) or cross-attention
+    bool cross = false;
+    int cache = -1;        // self blocks: index of their K/V cache
+    int cross_idx = -1;    // cross blocks: multimodal layer index (cross K/V cache slot)
+    void *w_in = nullptr, *w_o = nullptr, *w_fc = nullptr, *w_pr = nullptr;   // w_in: [3E,E] self, [E,E] cross query
+    float *b_in = nullptr, *b_o = nullptr, *b_fc = nullptr, *b_pr = nullptr;
+    float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+};
+
 struct Captioner {
     CapConfig c;
     int dt; size_t esz;
@@ -73,6 +82,16 @@ struct Captioner {
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     void* beam[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t cache_layer_bytes = 0;
+    // ---- CoCa (CAP_ARCH_COCA)
+    int Q = 0, E = 0;
+    float *ln_pre_g = nullptr, *ln_pre_b = nullptr, *lnk_g = nullptr, *lnk_b = nullptr, *lnpost_g = nullptr,
+          *lnpost_b = nullptr, *pool_q = nullptr, *b_pool_kv = nullptr, *b_pool_o = nullptr, *ones = nullptr,
+          *zeros = nullptr, *tok_emb = nullptr, *lnf_g = nullptr, *lnf_b = nullptr, *pool_o = nullptr,
+          *img_tokens = nullptr;
+    void *w_pool_kv = nullptr, *w_pool_o = nullptr, *w_cvocab = nullptr, *pool_kvbuf = nullptr, *pool_ctx = nullptr,
+         *xhat = nullptr;
+    std::vector<CBlock> cb;
+    std::vector<void*> ccache;
     int ldl;
     // profiling
     bool prof = false;
@@ -195,6 +214,136 @@ int build_blip(Captioner* m) {
     return 0;
 }
 
+int reg_block(Captioner* m, const std::string& p, CBlock& b, int E, int F, bool cross, int idx) {
+    b.cross = cross;
+    TRY(reg_f32(m, p + ".ln_1.weight", &b.ln1_g, E));
+    TRY(reg_f32(m, p + ".ln_1.bias", &b.ln1_b, E));
+    if (!cross) {
+        TRY(reg_mat(m, p + ".attn.in_proj_weight", &b.w_in, 3 * E, E));
+        TRY(reg_f32(m, p + ".attn.in_proj_bias", &b.b_in, 3 * E));
+    } else {
+        const std::string d = "derived.cross_q." + std::to_string(idx);
+        TRY(reg_mat(m, d + ".weight", &b.w_in, E, E));
+        TRY(reg_f32(m, d + ".bias", &b.b_in, E));
+    }
+    TRY(reg_mat(m, p + ".attn.out_proj.weight", &b.w_o, E, E));
+    TRY(reg_f32(m, p + ".attn.out_proj.bias", &b.b_o, E));
+    TRY(reg_f32(m, p + ".ln_2.weight", &b.ln2_g, E));
+    TRY(reg_f32(m, p + ".ln_2.bias", &b.ln2_b, E));
+    TRY(reg_mat(m, p + ".mlp.c_fc.weight", &b.w_fc, F, E));
+    TRY(reg_f32(m, p + ".mlp.c_fc.bias", &b.b_fc, F));
+    TRY(reg_mat(m, p + ".mlp.c_proj.weight", &b.w_pr, E, F));
+    TRY(reg_f32(m, p + ".mlp.c_proj.bias", &b.b_pr, E));
+    return 0;
+}
+
+// open_clip CoCa state-dict names (SURVEY.md section 5 "Checkpoint / resume"); `derived.*` tensors are computed once by
+// the host loader (embodied_captioning_amd/coca_weights.py) from the checkpoint.
+int build_coca(Captioner* m) {
+    const CapConfig& c = m->c;
+    const int D = c.v_hidden, Mv = c.v_mlp, E = c.embed_dim, F = c.t_ffn, V = c.vocab, Q = c.pool_queries;
+    m->Q = Q; m->E = E;
+    TRY(reg_f32(m, "visual.class_embedding", &m->cls, D));
+    TRY(reg_f32(m, "visual.positional_embedding", &m->vpos, (int64_t)m->NT * D));
+    TRY(reg_mat(m, "visual.conv1.weight", &m->w_patch, D, m->Kpatch, m->Kpad));
+    m->b_patch = nullptr;                                  // conv1 has no bias in open_clip's ViT
+    TRY(reg_f32(m, "visual.ln_pre.weight", &m->ln_pre_g, D));
+    TRY(reg_f32(m, "visual.ln_pre.bias", &m->ln_pre_b, D));
+    m->vl.resize(c.v_layers);
+    for (int i = 0; i < c.v_layers; ++i) {
+        VLayer& L = m->vl[i];
+        const std::string p = "visual.transformer.resblocks." + std::to_string(i) + ".";
+        TRY(reg_mat(m, p + "attn.in_proj_weight", &L.w_qkv, 3 * D, D));
+        TRY(reg_f32(m, p + "attn.in_proj_bias", &L.b_qkv, 3 * D));
+        TRY(reg_mat(m, p + "attn.out_proj.weight", &L.w_proj, D, D));
+        TRY(reg_f32(m, p + "attn.out_proj.bias", &L.b_proj, D));
+        TRY(reg_f32(m, p + "ln_1.weight", &L.ln1_g, D));
+        TRY(reg_f32(m, p + "ln_1.bias", &L.ln1_b, D));
+        TRY(reg_mat(m, p + "mlp.c_fc.weight", &L.w_fc1, Mv, D));
+        TRY(reg_f32(m, p + "mlp.c_fc.bias", &L.b_fc1, Mv));
+        TRY(reg_mat(m, p + "mlp.c_proj.weight", &L.w_fc2, D, Mv));
+        TRY(reg_f32(m, p + "mlp.c_proj.bias", &L.b_fc2, D));
+        TRY(reg_f32(m, p + "ln_2.weight", &L.ln2_g, D));
+        TRY(reg_f32(m, p + "ln_2.bias", &L.ln2_b, D));
+    }
+    TRY(reg_f32(m, "visual.attn_pool.ln_k.weight", &m->lnk_g, D));
+    TRY(reg_f32(m, "visual.attn_pool.ln_k.bias", &m->lnk_b, D));
+    TRY(reg_f32(m, "derived.pool_q", &m->pool_q, (int64_t)Q * E));
+    TRY(reg_mat(m, "derived.pool_kv.weight", &m->w_pool_kv, 2 * E, D));
+    TRY(reg_f32(m, "derived.pool_kv.bias", &m->b_pool_kv, 2 * E));
+    TRY(reg_mat(m, "visual.attn_pool.attn.out_proj.weight", &m->w_pool_o, E, E));
+    TRY(reg_f32(m, "visual.attn_pool.attn.out_proj.bias", &m->b_pool_o, E));
+    TRY(reg_f32(m, "visual.ln_post.weight", &m->lnpost_g, E));
+    TRY(reg_f32(m, "visual.ln_post.bias", &m->lnpost_b, E));
+    TRY(reg_f32(m, "text.token_embedding.weight", &m->tok_emb, (int64_t)V * E));
+    TRY(reg_f32(m, "text.positional_embedding", &m->tpos, (int64_t)c.max_pos * E));
+    m->cb.resize(c.t_layers + 2 * c.mm_layers);
+    int nb = 0, ncache = 0;
+    for (int i = 0; i < c.t_layers; ++i) {
+        m->cb[nb].cache = ncache++;
+        TRY(reg_block(m, "text.transformer.resblocks." + std::to_string(i), m->cb[nb], E, F, false, i));
+        ++nb;
+    }
+    for (int i = 0; i < c.mm_layers; ++i) {
+        m->cb[nb].cache = ncache++;
+        TRY(reg_block(m, "text_decoder.resblocks." + std::to_string(i), m->cb[nb], E, F, false, i));
+        ++nb;
+        m->cb[nb].cross_idx = i;
+        TRY(reg_block(m, "text_decoder.cross_attn." + std::to_string(i), m->cb[nb], E, F, true, i));
+        ++nb;
+    }
+    TRY(reg_mat(m, "derived.cross_kv.weight", &m->w_ckv, (int64_t)c.mm_layers * 2 * E, E));
+    TRY(reg_f32(m, "derived.cross_kv.bias", &m->b_ckv, (int64_t)c.mm_layers * 2 * E));
+    TRY(reg_f32(m, "text_decoder.ln_final.weight", &m->lnf_g, E));
+    TRY(reg_f32(m, "text_decoder.ln_final.bias", &m->lnf_b, E));
+    TRY(reg_mat(m, "derived.vocab.weight", &m->w_cvocab, V, E));
+    // constant vectors for the affine-free LayerNorm that feeds the folded cross-K/V projection
+    TRY(dev_alloc(m, (void**)&m->ones, (size_t)E * 4));
+    TRY(dev_alloc(m, (void**)&m->zeros, (size_t)E * 4));
+    TRY(launch_fill_f32(m->ones, 1.0f, E, nullptr));
+    TRY(launch_fill_f32(m->zeros, 0.0f, E, nullptr));
+    CAP_HIP_CHECK(hipDeviceSynchronize());
+    return 0;
+}
+
+int build_arena_coca(Captioner* m) {
+    const CapConfig& c = m->c;
+    const size_t Bm = c.max_batch, NT = m->NT, D = c.v_hidden, E = c.embed_dim, e = m->esz, Q = c.pool_queries;
+    const size_t M = Bm * NT, R = Bm, Lm = c.max_len, H = c.t_heads;
+    TRY(dev_alloc(m, &m->patches, Bm * m->P * m->Kpad * e));
+    CAP_HIP_CHECK(hipMemset(m->patches, 0, Bm * m->P * m->Kpad * e));
+    TRY(dev_alloc(m, (void**)&m->X, M * D * 4));
+    TRY(dev_alloc(m, (void**)&m->delta, M * D * 4));
+    TRY(dev_alloc(m, &m->ln, M * D * e));
+    TRY(dev_alloc(m, &m->qkv, M * 3 * D * e));
+    TRY(dev_alloc(m, &m->ctx, M * D * e));
+    TRY(dev_alloc(m, &m->mlp, M * c.v_mlp * e));
+    TRY(dev_alloc(m, (void**)&m->emb_f, 256));
+    TRY(dev_alloc(m, &m->emb_t, M * D * e));
+    TRY(dev_alloc(m, &m->pool_kvbuf, M * 2 * E * e));
+    TRY(dev_alloc(m, &m->pool_ctx, Bm * Q * E * e));
+    TRY(dev_alloc(m, (void**)&m->pool_o, Bm * Q * E * 4));
+    TRY(dev_alloc(m, (void**)&m->img_tokens, Bm * Q * E * 4));
+    TRY(dev_alloc(m, &m->xhat, Bm * Q * E * e));
+    TRY(dev_alloc(m, &m->cross, (size_t)c.mm_layers * 2 * Bm * H * Q * 64 * e));
+    TRY(dev_alloc(m, (void**)&m->seq, R * Lm * 4));
+    TRY(dev_alloc(m, (void**)&m->finished, R * 4));
+    TRY(dev_alloc(m, (void**)&m->lens, R * 4));
+    TRY(dev_alloc(m, (void**)&m->anc, 256));
+    TRY(dev_alloc(m, (void**)&m->dx, R * E * 4));
+    TRY(dev_alloc(m, (void**)&m->dy, R * E * 4));
+    TRY(dev_alloc(m, (void**)&m->dpart, 12 * R * E * 4));
+    TRY(dev_alloc(m, &m->dx_t, R * E * e));
+    TRY(dev_alloc(m, &m->dq, R * E * e));
+    TRY(dev_alloc(m, &m->dctx, R * E * e));
+    TRY(dev_alloc(m, &m->dh, R * c.t_ffn * e));
+    m->ldl = (c.vocab + 3) & ~3;
+    TRY(dev_alloc(m, (void**)&m->logits, R * (size_t)m->ldl * 4));
+    m->ccache.resize(c.t_layers + c.mm_layers);
+    for (auto& p : m->ccache) TRY(dev_alloc(m, &p, 2 * R * H * Lm * 64 * e));
+    return 0;
+}
+
 int build_arena(Captioner* m) {
     const CapConfig& c = m->c;
     const size_t Bm = c.max_batch, NT = m->NT, D = c.v_hidden, T = c.t_hidden, e = m->esz;
@@ -256,6 +405,9 @@ int gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, int lda, c
 
 // ---------------------------------------------------------------------------------------------- encoder
 int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_embeds, hipStream_t s) {
+    // BLIP: final LayerNorm = post_layernorm -> image_embeds (fp32 to the caller + T for the cross-K/V GEMM).
+    // CoCa: ln_pre after the embeddings; final LayerNorm = the pooler's ln_k -> T only (run_coca_pool continues).
+    const bool coca = m->c.arch == CAP_ARCH_COCA;
     const CapConfig& c = m->c;
     const int D = c.v_hidden, NT = m->NT, M = B * NT, H = c.v_heads;
     {
@@ -265,6 +417,7 @@ int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_emb
     TRY(gemm(m, s, "gemm_patch", m->patches, m->Kpad, m->w_patch, m->Kpad, m->X, D, m->b_patch, nullptr, B * m->P, D,
              m->Kpad, 0, 1, EPI_PATCH, m->P, 0, 0, 0, m->vpos));
     TRY(launch_cls_rows(m->cls, m->vpos, m->X, B, NT, D, s));
+    if (coca) TRY(launch_layernorm(m->dt, m->X, D, m->ln_pre_g, m->ln_pre_b, c.v_eps, nullptr, m->X, M, D, s));
     // Pre-LN blocks.  The two branch GEMMs (proj, fc2) write their output to `delta`; the next LayerNorm kernel folds it
     // into the residual stream X (fp32) in the same pass that normalises it, so the GEMM epilogues are store-only.
     bool pending = false;                                  // delta holds a branch output not yet added to X
@@ -288,7 +441,26 @@ int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_emb
         TRY(gemm(m, s, "gemm_fc1", m->ln, D, L.w_fc1, D, m->mlp, c.v_mlp, L.b_fc1, nullptr, M, c.v_mlp, D, 1, 0));
         TRY(gemm(m, s, "gemm_fc2", m->mlp, c.v_mlp, L.w_fc2, c.v_mlp, m->delta, D, L.b_fc2, nullptr, M, D, c.v_mlp, 0, 1));
     }
-    TRY(add_ln(m->post_g, m->post_b, m->emb_t, out_embeds ? out_embeds : m->emb_f));
+    if (coca) TRY(add_ln(m->lnk_g, m->lnk_b, m->emb_t, nullptr));
+    else TRY(add_ln(m->post_g, m->post_b, m->emb_t, out_embeds ? out_embeds : m->emb_f));
+    return 0;
+}
+
+// CoCa attentional pooler + ln_post, then the affine-free normalisation that feeds the folded cross-K/V projection.
+// tokens_out (optional): fp32 [B, Q, E] = ln_post(pooler output); row 0 of each image is the pooled token, rows 1..Q-1
+// are the image_embs the decoder cross-attends (reference coca_model.py:152-155).
+int run_coca_pool(Captioner* m, int B, float* tokens_out, hipStream_t s) {
+    const CapConfig& c = m->c;
+    const int D = c.v_hidden, E = m->E, Q = m->Q, NT = m->NT;
+    TRY(gemm(m, s, "gemm_pool_kv", m->emb_t, D, m->w_pool_kv, D, m->pool_kvbuf, 2 * E, m->b_pool_kv, nullptr, B * NT, 2 * E, D, 0, 0));
+    {
+        ProfScope ps(m, s, "pool_attention", 4.0 * B * Q * (double)NT * E, (double)B * NT * 2 * E * m->esz);
+        TRY(launch_pool_attention(m->dt, m->pool_q, m->pool_kvbuf, m->pool_ctx, B, NT, Q, E, c.pool_heads, s));
+    }
+    TRY(gemm(m, s, "gemm_pool_o", m->pool_ctx, E, m->w_pool_o, E, m->pool_o, E, m->b_pool_o, nullptr, B * Q, E, E, 0, 1));
+    float* tok = tokens_out ? tokens_out : m->img_tokens;
+    TRY(launch_layernorm(m->dt, m->pool_o, E, m->lnpost_g, m->lnpost_b, c.v_eps, nullptr, tok, B * Q, E, s));
+    TRY(launch_layernorm(m->dt, tok, E, m->ones, m->zeros, c.v_eps, m->xhat, nullptr, B * Q, E, s));
     return 0;
 }
 
@@ -394,6 +566,52 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------- CoCa decoder
+// One KV-cached step through the unimodal text tower (t_layers causal blocks) and the multimodal decoder (mm_layers x
+// [causal self-attention block, cross-attention block]).  Every block is pre-LN: the residual stream x stays fp32 in
+// d.dx and each split-K consumer kernel both adds the branch to x and emits LayerNorm_next(x) as the next GEMM operand.
+// The reference recomputes the whole prefix through both towers every step (coca_model.py:294-303).
+int run_coca_step(Captioner* m, const Dec& d, int t, int Lm, hipStream_t s) {
+    const CapConfig& c = m->c;
+    const int E = m->E, F = c.t_ffn, H = c.t_heads, R = d.R, Q = m->Q;
+    const size_t e = m->esz;
+    const int nb = (int)m->cb.size();
+    // x = tok_emb[token] + pos[t]  (raw sum to d.dx), ln = LayerNorm_{block0.ln_1}(x)
+    TRY(launch_embed(m->dt, d.seq, Lm, t, m->tok_emb, m->tpos, m->cb[0].ln1_g, m->cb[0].ln1_b, c.t_eps, d.dx_t, nullptr, R, E, s,
+                     d.dx));
+    for (int bi = 0; bi < nb; ++bi) {
+        const CBlock& b = m->cb[bi];
+        const float* next_g = bi + 1 < nb ? m->cb[bi + 1].ln1_g : m->lnf_g;
+        const float* next_b = bi + 1 < nb ? m->cb[bi + 1].ln1_b : m->lnf_b;
+        int S = 1;
+        if (!b.cross) {
+            char* kc = (char*)m->ccache[b.cache] + d.cache_off;
+            char* vc = kc + (size_t)R * H * Lm * 64 * e;
+            TRY(gemm_partial(m, s, "coca_gemm_qkv", d.dx_t, b.w_in, d.dpart, R, 3 * E, E, 4, &S));
+            ProfScope ps(m, s, "coca_self_attn", 4.0 * R * H * (t + 1) * 64, 2.0 * R * H * (t + 1) * 64 * e);
+            TRY(launch_decode_attention(m->dt, nullptr, kc, vc, nullptr, 0, 1, Lm, t + 1, d.dctx, R, H, 0, s, d.dpart, S, b.b_in,
+                                        3 * E, 0, 1));
+        } else {
+            TRY(gemm_partial(m, s, "coca_gemm_cq", d.dx_t, b.w_in, d.dpart, R, E, E, 4, &S));
+            // cross K/V of multimodal layer i: [k|v][image][head][Q tokens][64]; token 0 (the pooled token) is skipped
+            const char* ck = (char*)m->cross + ((((size_t)b.cross_idx * 2 + 0) * d.Btot + d.b0) * H * Q + 1) * 64 * e;
+            const char* cv = (char*)m->cross + ((((size_t)b.cross_idx * 2 + 1) * d.Btot + d.b0) * H * Q + 1) * 64 * e;
+            ProfScope ps(m, s, "coca_cross_attn", 4.0 * R * H * (Q - 1) * 64, 2.0 * d.B * H * (Q - 1) * 64 * e);
+            TRY(launch_decode_attention(m->dt, nullptr, ck, cv, nullptr, 0, 1, Q, Q - 1, d.dctx, R, H, 0, s, d.dpart, S, b.b_in, E,
+                                        0, 0));
+        }
+        // x += out_proj(ctx) ; ln = LayerNorm_2(x)
+        TRY(gemm_partial(m, s, "coca_gemm_o", d.dctx, b.w_o, d.dpart, R, E, E, 8, &S));
+        TRY(launch_reduce_layernorm(m->dt, d.dpart, S, b.b_o, d.dx, b.ln2_g, b.ln2_b, c.t_eps, d.dx_t, nullptr, d.dx, R, E, s));
+        // x += c_proj(gelu(c_fc(ln))) ; ln = LayerNorm of the next block (or ln_final)
+        TRY(gemm(m, s, "coca_gemm_fc", d.dx_t, E, b.w_fc, E, d.dh, F, b.b_fc, nullptr, R, F, E, 1, 0));
+        TRY(gemm_partial(m, s, "coca_gemm_pr", d.dh, b.w_pr, d.dpart, R, E, F, 8, &S));
+        TRY(launch_reduce_layernorm(m->dt, d.dpart, S, b.b_pr, d.dx, next_g, next_b, c.t_eps, d.dx_t, nullptr, d.dx, R, E, s));
+    }
+    TRY(gemm(m, s, "coca_gemm_vocab", d.dx_t, E, m->w_cvocab, E, d.logits, m->ldl, nullptr, nullptr, R, c.vocab, E, 0, 1));
+    return 0;
+}
+
 __global__ void iota_rows_kernel(int* anc, int R, int L) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * R * L; i += gridDim.x * blockDim.x) anc[i] = (i / L) % R;
 }
@@ -416,9 +634,16 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
                  int32_t* out_len, float* out_scores, float* out_step_logits, hipStream_t s) {
     const CapConfig& c = m->c;
     const int R = B * K, NT = m->NT, D = c.v_hidden, T = c.t_hidden, H = c.t_heads;
+    const bool coca = c.arch == CAP_ARCH_COCA;
     TRY(run_encoder(m, pixels, fmt, B, nullptr, s));
-    TRY(gemm(m, s, "gemm_crosskv", m->emb_t, D, m->w_ckv, D, m->cross, 0, m->b_ckv, nullptr, B * NT, c.t_layers * 2 * T, D,
-             0, 0, EPI_CROSSKV, NT, H, B));
+    if (coca) {
+        TRY(run_coca_pool(m, B, nullptr, s));
+        TRY(gemm(m, s, "gemm_crosskv", m->xhat, m->E, m->w_ckv, m->E, m->cross, 0, m->b_ckv, nullptr, B * m->Q,
+                 c.mm_layers * 2 * m->E, m->E, 0, 0, EPI_CROSSKV, m->Q, H, B));
+    } else {
+        TRY(gemm(m, s, "gemm_crosskv", m->emb_t, D, m->w_ckv, D, m->cross, 0, m->b_ckv, nullptr, B * NT, c.t_layers * 2 * T, D,
+                 0, 0, EPI_CROSSKV, NT, H, B));
+    }
     // decode: independent row slices, one per stream (slice 0 stays on the caller's stream)
     int ns = m->nslices;
     if (ns > B) ns = B;
@@ -442,7 +667,8 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
             const int cur_len = t + 1;
             const int* tokens = K == 1 ? d.seq : beam_running_tokens_p(d.beam, Bs, K, Lm, cur_len & 1);
             const int* anc = K == 1 ? nullptr : d.anc + (size_t)(cur_len & 1) * Rs * Lm;
-            TRY(run_decoder_step(m, d, tokens, Lm, t, K, anc, Lm, st));
+            if (coca) TRY(run_coca_step(m, d, t, Lm, st));
+            else TRY(run_decoder_step(m, d, tokens, Lm, t, K, anc, Lm, st));
             if (out_step_logits) {
                 hipLaunchKernelGGL(copy_logits_kernel, dim3(1024), dim3(256), 0, st, d.logits, m->ldl,
                                    out_step_logits + ((size_t)t * R + (size_t)b0 * K) * c.vocab, Rs, c.vocab);
@@ -450,7 +676,8 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
             }
             ProfScope ps(m, st, K == 1 ? "greedy_select" : "beam_step", 0, (double)Rs * c.vocab * 4);
             if (K == 1)
-                TRY(launch_greedy_select(d.logits, m->ldl, c.vocab, d.seq, Lm, t, Lm, c.eos, c.pad, d.finished, d.lens, Rs, st));
+                TRY(launch_greedy_select(d.logits, m->ldl, c.vocab, d.seq, Lm, t, Lm, c.eos, c.pad, d.finished, d.lens, Rs, st,
+                                         coca ? c.min_len : 0, coca ? 1 : 0));
             else
                 TRY(launch_beam_step(d.beam, d.logits, m->ldl, c.vocab, Bs, K, Lm, cur_len, c.eos, lp, d.anc, Lm, st));
         }
@@ -484,7 +711,15 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
         cap_set_error("cap_create: CapConfig size mismatch (caller %d, library %d)", cfg->struct_size, (int)sizeof(CapConfig));
         return -1;
     }
-    if (cfg->arch != CAP_ARCH_BLIP) { cap_set_error("cap_create: unknown arch %d", cfg->arch); return -1; }
+    if (cfg->arch != CAP_ARCH_BLIP && cfg->arch != CAP_ARCH_COCA) { cap_set_error("cap_create: unknown arch %d", cfg->arch); return -1; }
+    if (cfg->arch == CAP_ARCH_COCA) {
+        const int hd = cfg->pool_heads > 0 ? cfg->embed_dim / cfg->pool_heads : 0;
+        if (cfg->embed_dim != cfg->t_hidden || cfg->pool_queries < 2 || cfg->mm_layers < 1 || (hd != 64 && hd != 96) ||
+            hd * cfg->pool_heads != cfg->embed_dim || cfg->max_beams != 1) {
+            cap_set_error("cap_create: CoCa needs embed_dim == t_hidden, pooler head_dim 64 or 96, mm_layers >= 1, max_beams 1");
+            return -1;
+        }
+    }
     if (cfg->compute_dtype != CAP_F32 && cfg->compute_dtype != CAP_BF16) { cap_set_error("cap_create: unknown dtype"); return -1; }
     if (cfg->v_hidden != cfg->v_heads * 64 || cfg->t_hidden != cfg->t_heads * 64) {
         cap_set_error("cap_create: head_dim must be 64 (v %d/%d, t %d/%d)", cfg->v_hidden, cfg->v_heads, cfg->t_hidden, cfg->t_heads);
@@ -517,7 +752,9 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
                  hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) { cap_set_error("cap_create: cannot create decode streams/events"); delete m; return -1; }
     }
-    if (build_blip(m) != 0 || build_arena(m) != 0) {
+    const int built = cfg->arch == CAP_ARCH_COCA ? (build_coca(m) != 0 || build_arena_coca(m) != 0)
+                                                 : (build_blip(m) != 0 || build_arena(m) != 0);
+    if (built) {
         for (void* p : m->allocs) (void)hipFree(p);
         delete m;
         return -1;
@@ -607,6 +844,10 @@ int cap_encode(CapHandle h, const void* pixels, int pixel_fmt, int B, float* out
     Captioner* m = (Captioner*)h;
     TRY(check_call(m, B, 1, 2, pixel_fmt));
     if (!pixels || !out_embeds) { cap_set_error("cap_encode: null buffer"); return -1; }
+    if (m->c.arch == CAP_ARCH_COCA) {    // out_embeds: fp32 [B, pool_queries, embed_dim] (row 0 pooled token, rows 1.. image_embs)
+        TRY(run_encoder(m, pixels, pixel_fmt, B, nullptr, (hipStream_t)stream));
+        return run_coca_pool(m, B, out_embeds, (hipStream_t)stream);
+    }
     return run_encoder(m, pixels, pixel_fmt, B, out_embeds, (hipStream_t)stream);
 }
 
@@ -615,6 +856,10 @@ int cap_generate(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_
     Captioner* m = (Captioner*)h;
     TRY(check_call(m, B, num_beams, max_len, pixel_fmt));
     if (!pixels || !out_ids) { cap_set_error("cap_generate: null buffer"); return -1; }
+    if (m->c.arch == CAP_ARCH_COCA && num_beams != 1) {
+        cap_set_error("cap_generate: CoCa supports the reference's top-k(1) loop only (num_beams = 1)");
+        return -1;
+    }
     return run_generate(m, pixels, pixel_fmt, B, num_beams, max_len, length_penalty, out_ids, out_len, out_scores,
                         out_step_logits, (hipStream_t)stream);
 }

@@ -27,6 +27,16 @@ __global__ void convert2d_kernel(const float* __restrict__ src, T* __restrict__ 
     }
 }
 
+template <typename T>
+__global__ void convert2d_t_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int cols) {
+    // dst[c][r] = src[r][c]  (one-off weight transposition, e.g. CoCa's text_projection [width, vocab])
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t c = i / rows, r = i - c * rows;
+        dst[i] = from_f32<T>(src[r * cols + c]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // One thread per output element; consecutive threads walk x inside an image row, so the pixel reads are
 // coalesced (fp32 NCHW: 4 B/lane contiguous; u8 NHWC: 3 B stride) and each thread writes one element of the
@@ -168,7 +178,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ seq, int seq_ld, int t,
                                                     const float* __restrict__ word, const float* __restrict__ pos,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    float eps, T* out_t, float* out_f, int R, int D) {
+                                                    float eps, T* out_t, float* out_f, float* y_out, int R, int D) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= R) return;
     const int tok = seq[(size_t)row * seq_ld + t];
@@ -182,6 +192,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ seq,
         if (i < nv && c < D) {
             float4 a = *(const float4*)(w + c), b = *(const float4*)(p + c);
             v[i].x = a.x + b.x; v[i].y = a.y + b.y; v[i].z = a.z + b.z; v[i].w = a.w + b.w;
+            if (y_out) *(float4*)(y_out + (size_t)row * D + c) = v[i];      // raw sum = pre-LN residual stream (CoCa)
         }
     }
     ln_row<T>(v, nv, lane, D, gamma, beta, eps, out_t ? out_t + (size_t)row * D : nullptr,
@@ -194,8 +205,11 @@ __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ seq,
 __global__ __launch_bounds__(256) void greedy_select_kernel(const float* __restrict__ logits, int ld, int V,
                                                             int* __restrict__ seq, int seq_ld, int t, int max_len,
                                                             int eos, int pad, int* __restrict__ finished,
-                                                            int* __restrict__ out_len) {
+                                                            int* __restrict__ out_len, int min_len, int force_eos) {
+    // min_len > 0: EOS cannot win while the row has fewer than min_len tokens (HF MinLengthLogitsProcessor, used by the
+    // reference's CoCa loop coca_model.py:235-240); force_eos: the last position is EOS (coca_model.py:317-318)
     const int row = blockIdx.x, tid = threadIdx.x;
+    const bool mask_eos = min_len > 0 && t + 1 < min_len;
     const float* x = logits + (size_t)row * ld;
     float best = -INFINITY;
     int bi = 0x7fffffff;
@@ -212,6 +226,7 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const float* __restr
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = 4 * (c0 + u * 256);
+            if (mask_eos && eos >= i && eos < i + 4) ((float*)&v[u])[eos - i] = -INFINITY;
             if (v[u].x > best) { best = v[u].x; bi = i; }
             if (v[u].y > best) { best = v[u].y; bi = i + 1; }
             if (v[u].z > best) { best = v[u].z; bi = i + 2; }
@@ -219,7 +234,7 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const float* __restr
         }
     }
     for (int i = (V4 << 2) + tid; i < V; i += 256) {
-        const float v = x[i];
+        const float v = (mask_eos && i == eos) ? -INFINITY : x[i];
         if (v > best) { best = v; bi = i; }
     }
     __shared__ float sv[256];
@@ -236,6 +251,7 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const float* __restr
     if (tid == 0) {
         int fin = finished[row];
         int tok = fin ? pad : si[0];
+        if (!fin && force_eos && t + 2 >= max_len) tok = eos;
         seq[(size_t)row * seq_ld + t + 1] = tok;
         if (!fin) {
             if (tok == eos || t + 2 >= max_len) { finished[row] = 1; out_len[row] = t + 2; }
@@ -275,6 +291,16 @@ int launch_convert2d(int dtype, const float* src, void* dst, int rows, int cols,
         hipLaunchKernelGGL(convert2d_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, (bf16_t*)dst, rows, cols, dst_ld);
     else
         hipLaunchKernelGGL(convert2d_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, (float*)dst, rows, cols, dst_ld);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_convert2d_t(int dtype, const float* src, void* dst, int rows, int cols, hipStream_t s) {
+    const size_t n = (size_t)rows * cols;
+    if (dtype == CAP_DT_BF16)
+        hipLaunchKernelGGL(convert2d_t_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, (bf16_t*)dst, rows, cols);
+    else
+        hipLaunchKernelGGL(convert2d_t_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, (float*)dst, rows, cols);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -338,22 +364,22 @@ int launch_reduce_layernorm(int dtype, const float* part, int S, const float* bi
 
 int launch_embed(int dtype, const int* seq, int seq_ld, int t, const float* word, const float* pos,
                  const float* gamma, const float* beta, float eps, void* out_t, float* out_f, int R, int D,
-                 hipStream_t s) {
+                 hipStream_t s, float* y_out) {
     if (D % 4 != 0 || D > 256 * LN_MAXV) { cap_set_error("embed: unsupported width %d", D); return -1; }
     if (dtype == CAP_DT_BF16)
         hipLaunchKernelGGL(embed_kernel<bf16_t>, dim3((R + 3) / 4), dim3(256), 0, s, seq, seq_ld, t, word, pos, gamma,
-                           beta, eps, (bf16_t*)out_t, out_f, R, D);
+                           beta, eps, (bf16_t*)out_t, out_f, y_out, R, D);
     else
         hipLaunchKernelGGL(embed_kernel<float>, dim3((R + 3) / 4), dim3(256), 0, s, seq, seq_ld, t, word, pos, gamma,
-                           beta, eps, (float*)out_t, out_f, R, D);
+                           beta, eps, (float*)out_t, out_f, y_out, R, D);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 int launch_greedy_select(const float* logits, int ld, int V, int* seq, int seq_ld, int t, int max_len, int eos,
-                         int pad, int* finished, int* out_len, int R, hipStream_t s) {
+                         int pad, int* finished, int* out_len, int R, hipStream_t s, int min_len, int force_eos) {
     hipLaunchKernelGGL(greedy_select_kernel, dim3(R), dim3(256), 0, s, logits, ld, V, seq, seq_ld, t, max_len, eos, pad,
-                       finished, out_len);
+                       finished, out_len, min_len, force_eos);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }

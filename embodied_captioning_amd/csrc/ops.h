@@ -7,6 +7,8 @@
 // fp32 -> T copy (weight upload / activation cast); dst rows may be padded: dst[r*dst_ld + c] = src[r*cols + c]
 int launch_convert(int dtype, const float* src, void* dst, size_t n, hipStream_t s);
 int launch_convert2d(int dtype, const float* src, void* dst, int rows, int cols, int dst_ld, hipStream_t s);
+// dst[cols][rows] = src[rows][cols]^T
+int launch_convert2d_t(int dtype, const float* src, void* dst, int rows, int cols, hipStream_t s);
 // im2col-free patch gather: pixels -> A[B*P, Kpad] (T).  fmt 0: fp32 NCHW normalised; fmt 1: u8 NHWC raw RGB,
 // normalised on the fly with (x/255 - mean[c]) / std[c].
 int launch_patchify(int dtype, const void* pixels, int fmt, int B, int img, int ps, int Kpad, void* out,
@@ -24,10 +26,10 @@ int launch_reduce_layernorm(int dtype, const float* part, int S, const float* bi
 // decoder embeddings: x = LN(word[tok] + pos[t]); tok = seq[row*seq_ld + t]
 int launch_embed(int dtype, const int* seq, int seq_ld, int t, const float* word, const float* pos,
                  const float* gamma, const float* beta, float eps, void* out_t, float* out_f, int R, int D,
-                 hipStream_t s);
+                 hipStream_t s, float* y_out = nullptr);   // y_out: the un-normalised sum (pre-LN residual stream)
 // greedy selection: argmax (lowest index wins ties), pad after EOS, append at seq[row][t+1], track finished/len
 int launch_greedy_select(const float* logits, int ld, int V, int* seq, int seq_ld, int t, int max_len, int eos,
-                         int pad, int* finished, int* out_len, int R, hipStream_t s);
+                         int pad, int* finished, int* out_len, int R, hipStream_t s, int min_len = 0, int force_eos = 0);
 int launch_fill_i32(int* p, int v, size_t n, hipStream_t s);
 int launch_fill_f32(float* p, float v, size_t n, hipStream_t s);
 int launch_copy_f32(const float* src, float* dst, size_t n, hipStream_t s);
@@ -47,6 +49,11 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             hipStream_t s, const float* q_part = nullptr, int q_S = 0, const float* q_bias = nullptr,
                             int q_ld = 0, int q_col0 = 0, int append_kv = 0);
+
+// attentional pooler (CoCa): fixed projected queries qp fp32 [Q, E] shared by every image; kv (T) [B*N, 2E] with K in
+// columns [0,E) and V in [E,2E); heads of E/heads dims (64 or 96); out (T) [B*Q, E].  scale = 1/sqrt(head_dim).
+int launch_pool_attention(int dtype, const float* qp, const void* kv, void* out, int B, int N, int Q, int E, int heads,
+                          hipStream_t s);
 
 // ---- beam.hip --------------------------------------------------------------------------------
 size_t beam_state_bytes(int B, int K, int max_len);

@@ -12,7 +12,7 @@ from typing import Dict, Optional
 import torch
 
 from . import _native as N
-from .config import BlipArch
+from .config import BlipArch, CocaArch
 
 OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -39,14 +39,25 @@ class CaptionerEngine:
         self.max_batch, self.max_beams, self.max_len = max_batch, max_beams, max_len
         cfg = N.CapConfig()
         cfg.struct_size = C.sizeof(N.CapConfig)
-        cfg.arch = 0
         cfg.compute_dtype = _DTYPES[dtype]
         cfg.image_size, cfg.patch_size = arch.image_size, arch.patch_size
-        cfg.v_hidden, cfg.v_layers, cfg.v_heads, cfg.v_mlp, cfg.v_eps = (arch.v_hidden, arch.v_layers, arch.v_heads,
-                                                                         arch.v_mlp, arch.v_eps)
-        cfg.t_hidden, cfg.t_layers, cfg.t_heads, cfg.t_ffn = arch.t_hidden, arch.t_layers, arch.t_heads, arch.t_ffn
-        cfg.vocab, cfg.max_pos, cfg.t_eps = arch.vocab, arch.max_pos, arch.t_eps
-        cfg.bos, cfg.eos, cfg.pad = arch.bos, arch.eos, arch.pad
+        self.is_coca = isinstance(arch, CocaArch)
+        if self.is_coca:
+            cfg.arch = 1
+            cfg.v_hidden, cfg.v_layers, cfg.v_heads, cfg.v_mlp, cfg.v_eps = (arch.v_hidden, arch.v_layers, arch.v_heads,
+                                                                             arch.v_mlp, arch.eps)
+            cfg.t_hidden, cfg.t_layers, cfg.t_heads, cfg.t_ffn = arch.t_hidden, arch.t_layers, arch.t_heads, arch.t_ffn
+            cfg.vocab, cfg.max_pos, cfg.t_eps = arch.vocab, arch.context_length + 1, arch.eps
+            cfg.bos, cfg.eos, cfg.pad = arch.sot, arch.eos, arch.pad
+            cfg.embed_dim, cfg.pool_queries, cfg.pool_heads = arch.embed_dim, arch.pool_queries, arch.pool_heads
+            cfg.mm_layers, cfg.min_len = arch.mm_layers, arch.min_seq_len
+        else:
+            cfg.arch = 0
+            cfg.v_hidden, cfg.v_layers, cfg.v_heads, cfg.v_mlp, cfg.v_eps = (arch.v_hidden, arch.v_layers, arch.v_heads,
+                                                                             arch.v_mlp, arch.v_eps)
+            cfg.t_hidden, cfg.t_layers, cfg.t_heads, cfg.t_ffn = arch.t_hidden, arch.t_layers, arch.t_heads, arch.t_ffn
+            cfg.vocab, cfg.max_pos, cfg.t_eps = arch.vocab, arch.max_pos, arch.t_eps
+            cfg.bos, cfg.eos, cfg.pad = arch.bos, arch.eos, arch.pad
         cfg.max_batch, cfg.max_beams, cfg.max_len = max_batch, max_beams, max_len
         for i in range(3):
             cfg.pix_mean[i] = OPENAI_CLIP_MEAN[i]
@@ -73,7 +84,11 @@ class CaptionerEngine:
 
     # ------------------------------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
-        """HF BLIP key names.  Tied / unknown tensors are skipped; missing ones raise."""
+        """HF BLIP key names or an open_clip CoCa state dict (derived tensors are added here).
+        Tied / unknown tensors are skipped; missing ones raise."""
+        if self.is_coca and "derived.pool_q" not in sd:
+            from .coca_weights import coca_library_state_dict
+            sd = coca_library_state_dict(sd, self.arch)
         with torch.cuda.device(self.device):
             s = _stream_ptr(self.device)
             for name, t in sd.items():
@@ -109,7 +124,8 @@ class CaptionerEngine:
     def encode(self, pixels: torch.Tensor) -> torch.Tensor:
         pixels, fmt = self._pixels(pixels)
         B = pixels.shape[0]
-        out = torch.empty((B, self.arch.n_tokens, self.arch.v_hidden), dtype=torch.float32, device=self.device)
+        shape = (B, self.arch.pool_queries, self.arch.embed_dim) if self.is_coca else (B, self.arch.n_tokens, self.arch.v_hidden)
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             N.check(self.lib.cap_encode(self._h, C.c_void_p(pixels.data_ptr()), fmt, B, C.c_void_p(out.data_ptr()),
                                         C.c_void_p(_stream_ptr(self.device))), "cap_encode")

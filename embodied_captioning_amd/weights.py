@@ -18,7 +18,7 @@ from typing import Dict, Iterable, List, Tuple
 import numpy as np
 import torch
 
-from .config import BlipArch
+from .config import BlipArch, CocaArch
 
 
 def blip_param_specs(a: BlipArch) -> List[Tuple[str, Tuple[int, ...], str, float]]:
@@ -107,6 +107,71 @@ def procedural_blip_state_dict(arch: BlipArch, seed: int = 0, eos_boost: float =
         sd["text_decoder.cls.predictions.bias"][arch.eos] += eos_boost
     for dst, src in BLIP_TIED.items():
         sd[dst] = sd[src]
+    return sd
+
+
+def coca_param_specs(a: CocaArch) -> List[Tuple[str, Tuple[int, ...], str, float]]:
+    """open_clip CoCa state-dict names/shapes (`visual.*`, `text.*`, `text_decoder.*`; SURVEY.md §5 checkpoint contract)."""
+    s: List[Tuple[str, Tuple[int, ...], str, float]] = []
+
+    def block(p, W, F, out_gain=1.0, cross=False):
+        s.append((p + ".ln_1.weight", (W,), "gamma", 0.1)); s.append((p + ".ln_1.bias", (W,), "normal", 0.05))
+        if cross:
+            s.append((p + ".ln_1_kv.weight", (W,), "gamma", 0.1)); s.append((p + ".ln_1_kv.bias", (W,), "normal", 0.05))
+        s.append((p + ".attn.in_proj_weight", (3 * W, W), "normal", 1.0 / np.sqrt(W)))
+        s.append((p + ".attn.in_proj_bias", (3 * W,), "normal", 0.02))
+        s.append((p + ".attn.out_proj.weight", (W, W), "normal", out_gain / np.sqrt(W)))
+        s.append((p + ".attn.out_proj.bias", (W,), "normal", 0.02))
+        s.append((p + ".ln_2.weight", (W,), "gamma", 0.1)); s.append((p + ".ln_2.bias", (W,), "normal", 0.05))
+        s.append((p + ".mlp.c_fc.weight", (F, W), "normal", 1.0 / np.sqrt(W)))
+        s.append((p + ".mlp.c_fc.bias", (F,), "normal", 0.02))
+        s.append((p + ".mlp.c_proj.weight", (W, F), "normal", out_gain / np.sqrt(F)))
+        s.append((p + ".mlp.c_proj.bias", (W,), "normal", 0.02))
+
+    D, E, T = a.v_hidden, a.embed_dim, a.t_hidden
+    P = a.patch_size
+    s.append(("visual.class_embedding", (D,), "normal", 0.5))
+    s.append(("visual.positional_embedding", (a.n_tokens, D), "normal", 0.5))
+    s.append(("visual.conv1.weight", (D, 3, P, P), "normal", 1.0 / np.sqrt(3 * P * P)))
+    s.append(("visual.ln_pre.weight", (D,), "gamma", 0.1)); s.append(("visual.ln_pre.bias", (D,), "normal", 0.05))
+    for i in range(a.v_layers):
+        block(f"visual.transformer.resblocks.{i}", D, a.v_mlp)
+    s.append(("visual.attn_pool.query", (a.pool_queries, E), "normal", 0.5))
+    s.append(("visual.attn_pool.attn.q_proj_weight", (E, E), "normal", 1.0 / np.sqrt(E)))
+    s.append(("visual.attn_pool.attn.k_proj_weight", (E, D), "normal", 1.0 / np.sqrt(D)))
+    s.append(("visual.attn_pool.attn.v_proj_weight", (E, D), "normal", 1.0 / np.sqrt(D)))
+    s.append(("visual.attn_pool.attn.in_proj_bias", (3 * E,), "normal", 0.02))
+    s.append(("visual.attn_pool.attn.out_proj.weight", (E, E), "normal", 1.0 / np.sqrt(E)))
+    s.append(("visual.attn_pool.attn.out_proj.bias", (E,), "normal", 0.02))
+    for n, w in (("ln_q", E), ("ln_k", D)):
+        s.append((f"visual.attn_pool.{n}.weight", (w,), "gamma", 0.1)); s.append((f"visual.attn_pool.{n}.bias", (w,), "normal", 0.05))
+    s.append(("visual.ln_post.weight", (E,), "gamma", 0.1)); s.append(("visual.ln_post.bias", (E,), "normal", 0.05))
+    s.append(("visual.proj", (E, E), "normal", 1.0 / np.sqrt(E)))
+    s.append(("text.token_embedding.weight", (a.vocab, T), "normal", 0.5))
+    s.append(("text.positional_embedding", (a.context_length + 1, T), "normal", 0.5))
+    s.append(("text.cls_emb", (T,), "normal", 0.5))
+    for i in range(a.t_layers):
+        block(f"text.transformer.resblocks.{i}", T, a.t_ffn, out_gain=0.4)
+    s.append(("text.ln_final.weight", (T,), "gamma", 0.1)); s.append(("text.ln_final.bias", (T,), "normal", 0.05))
+    s.append(("text.text_projection", (T, E), "normal", 1.0 / np.sqrt(T)))
+    for i in range(a.mm_layers):
+        block(f"text_decoder.resblocks.{i}", T, a.t_ffn, out_gain=0.4)
+        block(f"text_decoder.cross_attn.{i}", T, a.t_ffn, out_gain=0.4, cross=True)
+    s.append(("text_decoder.ln_final.weight", (T,), "gamma", 0.1)); s.append(("text_decoder.ln_final.bias", (T,), "normal", 0.05))
+    s.append(("text_decoder.text_projection", (T, a.vocab), "normal", 0.08))
+    return s
+
+
+def procedural_coca_state_dict(arch: CocaArch, seed: int = 0, eos_boost: float = 0.0) -> Dict[str, torch.Tensor]:
+    """Seeded fp32 CoCa state dict (open_clip key names).  `eos_boost` shifts the EOS logit through ln_final's bias
+    direction (the head has no bias vector of its own)."""
+    sd: Dict[str, torch.Tensor] = {}
+    for name, shape, kind, scale in coca_param_specs(arch):
+        sd[name] = torch.from_numpy(_draw(seed, name, shape, kind, scale))
+    if eos_boost:
+        beta = sd["text_decoder.ln_final.bias"]
+        sd["text_decoder.text_projection"][:, arch.eos] += eos_boost * beta / float(beta @ beta)
+    sd["logit_scale"] = torch.tensor(float(np.log(1 / 0.07)))
     return sd
 
 

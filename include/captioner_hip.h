@@ -34,7 +34,7 @@ extern "C" {
 
 typedef struct CapHandle_s* CapHandle;
 
-enum { CAP_ARCH_BLIP = 0 };
+enum { CAP_ARCH_BLIP = 0, CAP_ARCH_COCA = 1 };
 enum { CAP_F32 = 0, CAP_BF16 = 1 };              /* arithmetic type of the GEMM/attention operands (accumulate: fp32) */
 enum { CAP_PIX_F32_NCHW = 0, CAP_PIX_U8_NHWC = 1 }; /* normalised fp32 [B,3,H,W] | raw RGB uint8 [B,H,W,3] */
 
@@ -53,6 +53,10 @@ typedef struct CapConfig {
     int32_t max_batch, max_beams, max_len;
     /* raw-pixel normalisation for CAP_PIX_U8_NHWC: (x/255 - mean[c]) / std[c] */
     float pix_mean[3], pix_std[3];
+    /* CAP_ARCH_COCA only (open_clip coca_ViT-L-14.json): attentional pooler output width / queries / heads, number of
+     * multimodal decoder layers (t_layers = unimodal text layers), MinLength of the decode loop.  For CoCa
+     * bos = start-of-text id, max_pos = context_length + 1, max_len = generate()'s seq_len. */
+    int32_t embed_dim, pool_queries, pool_heads, mm_layers, min_len;
 } CapConfig;
 
 const char* cap_last_error(void);
@@ -61,7 +65,11 @@ int cap_version(void);
 int cap_create(const CapConfig* cfg, CapHandle* out);
 int cap_destroy(CapHandle h);
 
-/* Stream one fp32 tensor of the checkpoint into the library (HuggingFace BLIP state-dict key names).  `data` is a
+/* Stream one fp32 tensor of the checkpoint into the library.  Names: HuggingFace BLIP state-dict keys for CAP_ARCH_BLIP;
+ * open_clip CoCa keys (`visual.*`, `text.*`, `text_decoder.*`) for CAP_ARCH_COCA plus a few tensors the host derives
+ * once at load (embodied_captioning_amd/coca_weights.py): `derived.pool_q` (ln_q(query) projected), `derived.pool_kv.*`
+ * (k|v projection of the pooler fused), `derived.cross_q.{i}.*`, `derived.cross_kv.*` (all layers' cross k|v projections
+ * with ln_1_kv folded in), `derived.vocab.weight` (text_projection transposed).  `data` is a
  * host pointer (on_device = 0) or a device pointer (on_device = 1); the library converts to its compute layout
  * (bf16 cast, q/k/v and cross-K/V concatenation) on `stream` and synchronises before returning.
  * Unknown names return 1 (not an error for tied/duplicate heads, see cap_finalize_weights). */

@@ -1,0 +1,56 @@
+"""CPU: CoCa oracle restatement (parity UNPINNED - open_clip is not available) - self-consistency only."""
+import torch
+
+from embodied_captioning_amd.config import CocaArch
+from embodied_captioning_amd.coca_weights import derive_coca_tensors
+from embodied_captioning_amd.weights import procedural_coca_state_dict, synthetic_pixels
+from oracle import coca_ref as R
+
+
+def test_kv_cached_step_equals_full_prefix_recompute():
+    """The reference re-runs both towers on the whole prefix every step (coca_model.py:294-303); the cached step must
+    give the same tokens and the same processed logits."""
+    a = CocaArch.tiny()
+    for boost in (0.0, 4.0):
+        sd = procedural_coca_state_dict(a, 1, eos_boost=boost)
+        px = synthetic_pixels(4, a.image_size, seed=1)
+        g = R.generate_top1(sd, a, px)
+        f = R.generate_top1(sd, a, px, use_cache=False)
+        assert torch.equal(g["text"], f["text"])
+        for x, y in zip(g["logits"], f["logits"]):
+            fin = torch.isfinite(x)
+            assert torch.equal(fin, torch.isfinite(y)) and (x[fin] - y[fin]).abs().max() < 1e-4
+
+
+def test_decode_loop_semantics():
+    a = CocaArch.tiny()
+    sd = procedural_coca_state_dict(a, 1, eos_boost=4.0)
+    px = synthetic_pixels(4, a.image_size, seed=1)
+    g = R.generate_top1(sd, a, px)
+    text = g["text"]
+    assert (text[:, 0] == a.sot).all() and text.shape[1] <= a.seq_len
+    for row in text.tolist():
+        if a.eos in row:
+            i = row.index(a.eos)
+            assert i >= a.min_seq_len                      # MinLength: EOS cannot be emitted before min_seq_len tokens
+            assert all(t == a.pad for t in row[i + 1:])    # rows whose last token is EOS/pad emit pad
+    full = R.generate_top1(procedural_coca_state_dict(a, 1), a, px)["text"]
+    assert full.shape[1] == a.seq_len and (full[:, -1] == a.eos).all()   # forced EOS at cur_len + 1 == seq_len
+    assert torch.isinf(g["logits"][0][:, a.eos]).all() and torch.isfinite(g["logits"][a.min_seq_len][:, a.eos]).all()
+
+
+def test_folded_cross_kv_equals_ln_then_projection():
+    import torch.nn.functional as F
+    a = CocaArch.tiny()
+    sd = procedural_coca_state_dict(a, 2)
+    d = derive_coca_tensors(sd, a)
+    E = a.embed_dim
+    x = torch.randn(7, E)
+    xh = F.layer_norm(x, (E,), None, None, a.eps)
+    for i in range(a.mm_layers):
+        c = f"text_decoder.cross_attn.{i}."
+        ref = F.linear(F.layer_norm(x, (E,), sd[c + "ln_1_kv.weight"], sd[c + "ln_1_kv.bias"], a.eps),
+                       sd[c + "attn.in_proj_weight"][E:], sd[c + "attn.in_proj_bias"][E:])
+        got = F.linear(xh, d["derived.cross_kv.weight"][2 * E * i:2 * E * (i + 1)], d["derived.cross_kv.bias"][2 * E * i:2 * E * (i + 1)])
+        assert (ref - got).abs().max() < 1e-5
+    assert d["derived.vocab.weight"].shape == (a.vocab, E) and d["derived.pool_q"].shape == (a.pool_queries, E)

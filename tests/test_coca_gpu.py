@@ -1,0 +1,108 @@
+"""GPU: CoCa through the C ABI against the CPU restatement (oracle/coca_ref.py - unpinned, see its header)."""
+import numpy as np
+import pytest
+import torch
+
+from _util import token_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(arch, seed, boost, batch, dtype):
+    from embodied_captioning_amd.engine import CaptionerEngine
+    from embodied_captioning_amd.weights import procedural_coca_state_dict, synthetic_pixels
+    sd = procedural_coca_state_dict(arch, seed, eos_boost=boost)
+    px = synthetic_pixels(batch, arch.image_size, seed=seed)
+    eng = CaptionerEngine(arch, dtype=dtype, max_batch=batch, max_beams=1, max_len=arch.seq_len)
+    eng.load_state_dict(sd)
+    return sd, px, eng
+
+
+def _padded(text, L, pad):
+    out = np.full((text.shape[0], L), pad, dtype=np.int64)
+    out[:, : text.shape[1]] = text.numpy()
+    return out
+
+
+@pytest.mark.parametrize("boost", [0.0, 4.0])
+def test_coca_tiny_fp32_matches_restatement(boost):
+    from embodied_captioning_amd.config import CocaArch
+    from oracle import coca_ref as R
+    a = CocaArch.tiny()
+    sd, px, eng = _setup(a, 1, boost, 4, "f32")
+    pooled, embs = R.encode_image(sd, a, px)
+    tok = eng.encode(px.cuda()).cpu()                       # [B, Q, E]: row 0 pooled token (before visual.proj), rows 1.. image_embs
+    assert (tok[:, 1:] - embs).abs().max().item() < 2e-4
+    assert (tok[:, 0] @ sd["visual.proj"] - pooled).abs().max().item() < 2e-4
+    ref = R.generate_top1(sd, a, px, image_embs=embs)
+    out = eng.generate(px.cuda(), max_length=a.seq_len, output_logits=True)
+    want = _padded(ref["text"], a.seq_len, a.pad)
+    assert np.array_equal(out["sequences"].cpu().numpy(), want)
+    # step-0 logits (every row active): raw logits except the MinLength-masked EOS column
+    l0 = out["logits"][0].cpu()
+    r0 = ref["logits"][0]
+    fin = torch.isfinite(r0)
+    assert (l0[fin] - r0[fin]).abs().max().item() < 1e-3
+    eng.close()
+
+
+def test_coca_tiny_bf16_within_tolerance():
+    from embodied_captioning_amd.config import CocaArch
+    from oracle import coca_ref as R
+    a = CocaArch.tiny()
+    sd, px, eng = _setup(a, 1, 4.0, 4, "bf16")
+    _, embs = R.encode_image(sd, a, px)
+    tok = eng.encode(px.cuda()).cpu()
+    assert (tok[:, 1:] - embs).abs().max().item() < 0.15
+    ref = R.generate_top1(sd, a, px, image_embs=embs)
+    out = eng.generate(px.cuda(), max_length=a.seq_len)
+    # margins of the active rows, scattered back to [steps, B]
+    B = 4
+    margins = np.full((a.seq_len - 1, B), 1e9, dtype=np.float32)
+    active = np.ones(B, dtype=bool)
+    text = ref["text"]
+    for t, lg in enumerate(ref["logits"]):
+        t2 = torch.topk(lg, 2, dim=-1).values
+        margins[t, active] = (t2[:, 0] - t2[:, 1]).numpy()
+        if t + 1 < text.shape[1]:
+            active = active & ~np.isin(text[:, t + 1].numpy(), [a.eos, a.pad])
+    exact, diverged, bad = token_parity(out["sequences"].cpu().numpy(), _padded(text, a.seq_len, a.pad), margins, 0.3)
+    assert bad is None, bad
+    eng.close()
+
+
+def test_coca_vit_l14_full_size_bf16_encoder_and_first_tokens():
+    """Real coca_ViT-L-14 shapes (24x1024 ViT, 257 tokens, 96-wide pooler heads, 49408 vocab), batch 2."""
+    from embodied_captioning_amd.config import CocaArch
+    from oracle import coca_ref as R
+    a = CocaArch()
+    sd, px, eng = _setup(a, 0, 0.0, 2, "bf16")
+    _, embs = R.encode_image(sd, a, px)
+    tok = eng.encode(px.cuda()).cpu()
+    err = (tok[:, 1:] - embs).abs().max().item()
+    assert err < 0.25, err
+    out = eng.generate(px.cuda(), max_length=a.seq_len, output_logits=True)
+    st = R.CocaState(a.t_layers + a.mm_layers)
+    r0 = R.step(sd, a, torch.full((2,), a.sot, dtype=torch.int64), embs, st)
+    top = torch.topk(r0, 8, dim=-1)
+    ours = torch.gather(out["logits"][0].cpu(), 1, top.indices)
+    assert (ours - top.values).abs().max().item() < 0.35
+    seq = out["sequences"].cpu()
+    assert (seq[:, 0] == a.sot).all() and (seq[:, -1] == a.eos).all()
+    eng.close()
+
+
+def test_coca_wrapper_dict_api():
+    from PIL import Image
+    from embodied_captioning_amd.captioner.utils.utils import Configuration
+    from embodied_captioning_amd.captioner.utils.utils_captioner import select_captioner
+    rng = np.random.default_rng(0)
+    im = Image.fromarray(rng.integers(0, 256, size=(40, 52, 3), dtype=np.uint8), "RGB")
+    cfg = Configuration(arch_name="coca", model_name="procedural-coca-tiny:1:4.0", height=224, width=224, dtype="f32").captioner
+    model = select_captioner(cfg).eval()
+    out = model(im)
+    assert isinstance(out["text"], str) and len(out["logits"]) >= 1
+    assert out["logits"][0].shape == (1, model.arch.vocab)
+    assert torch.isinf(out["logits"][0][0, model.arch.eos])        # MinLength mask visible in the recorded logits
+    ppl = model.compute_perplexity()
+    assert torch.isfinite(ppl)
