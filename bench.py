@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the extra strict-fp32 measurement")
     ap.add_argument("--cpu-sample", type=int, default=64, help="captions timed on the host CPU oracle")
+    ap.add_argument("--model", default="blip", choices=["blip", "coca"],
+                    help="blip = BASELINE.json metric workload (default); coca = extra line for config 5's model "
+                         "(CoCa ViT-L/14 @224, reference top-k(1) loop, seq_len 30)")
     return ap.parse_args()
 
 
@@ -137,8 +140,39 @@ def cpu_baseline(sd, arch, L, sample):
                       f"oracle/blip_ref.py on {torch.get_num_threads()} threads"}, out
 
 
+def main_coca(a):
+    """Extra (non-headline) measurement: CoCa ViT-L/14 at 224x224, batch --batch (default 128 here), top-k(1)."""
+    from embodied_captioning_amd.config import CocaArch
+    from embodied_captioning_amd.weights import procedural_coca_state_dict
+    torch.cuda.set_device(0)
+    arch = CocaArch()
+    B = a.batch if a.batch != 256 else 128
+    sd = procedural_coca_state_dict(arch, 0)
+    px = synthetic_pixels(B, arch.image_size, seed=0).cuda()
+    eng = CaptionerEngine(arch, dtype=a.dtype, max_batch=B, max_beams=1, max_len=arch.seq_len)
+    eng.load_state_dict(sd)
+    dt, _ = timed_steps(eng, px, arch.seq_len, a.steps, a.warmup, 1, lambda i, l: (i, l))
+    eng.profile(True)
+    eng.generate(px, max_length=arch.seq_len)
+    rep = eng.profile_report()
+    eng.profile(False)
+    tags = [t for t in ENC_GEMM_TAGS if t in rep]
+    fl = sum(rep[t]["flops"] for t in tags); ms = sum(rep[t]["ms"] for t in tags)
+    line = {"metric": "captions/sec (CoCa ViT-L/14 224x224, top_k=1, seq_len=30)", "value": round(B * a.steps / dt, 2),
+            "unit": "captions/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "higher_is_better": True, "dtype": a.dtype, "data": "synthetic frames, procedural weights",
+            "config": {"workload": f"CoCa ViT-L/14 encoder + attentional pooler + 29 KV-cached decode steps, {B} frames"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_big_kernel (ViT-L qkv/proj/fc1/fc2)",
+                         "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
+                         "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_TFLOPS[a.dtype], 4), "traffic": None},
+            "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:12]}}
+    print(json.dumps(line))
+
+
 def main():
     a = parse()
+    if a.model == "coca":
+        return main_coca(a)
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
