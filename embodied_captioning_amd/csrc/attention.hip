@@ -289,22 +289,57 @@ struct QSource {
     int append_kv;
 };
 
-template <typename T>
-__device__ __forceinline__ void reduce8(const QSource& qs, int R, int row, int col, float (&v)[8]) {
-    const float* p = qs.part + (size_t)row * qs.part_ld + col;
-    f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
-    for (int z = 1; z < qs.S; ++z) {
-        const float* pz = p + (size_t)z * R * qs.part_ld;
-        a += *(const f32x4*)pz; b += *(const f32x4*)(pz + 4);
-    }
-    a += *(const f32x4*)(qs.bias + col); b += *(const f32x4*)(qs.bias + col + 4);
-    // round through the compute dtype exactly like the unfused GEMM epilogue would have
+// Split-K partials of 8 consecutive columns: issue() puts every slice's loads (and the bias) in flight without a
+// dependent add between them; finish() sums them in slice order.  Slices beyond S re-read slice 0 with weight 0, so
+// there is no branch between the loads (up to 4 slices unrolled, which is what the decode GEMMs produce).
+struct Part8 {
+    f32x4 a[4], b[4], ba, bb;
+    const float* p;
+    size_t zs;
+    __device__ __forceinline__ void issue(const QSource& qs, int R, int row, int col) {
+        p = qs.part + (size_t)row * qs.part_ld + col;
+        zs = (size_t)R * qs.part_ld;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { v[i] = to_f32(from_f32<T>(a[i])); v[4 + i] = to_f32(from_f32<T>(b[i])); }
-}
+        for (int z = 0; z < 4; ++z) {
+            const float* pz = p + (z < qs.S ? (size_t)z * zs : 0);
+            a[z] = *(const f32x4*)pz; b[z] = *(const f32x4*)(pz + 4);
+        }
+        ba = *(const f32x4*)(qs.bias + col); bb = *(const f32x4*)(qs.bias + col + 4);
+    }
+    template <typename T>
+    __device__ __forceinline__ void finish(const QSource& qs, float (&v)[8]) {
+        f32x4 sa = a[0], sb = b[0];
+#pragma unroll
+        for (int z = 1; z < 4; ++z) {
+            const float w = z < qs.S ? 1.f : 0.f;
+            sa += a[z] * w; sb += b[z] * w;
+        }
+        for (int z = 4; z < qs.S; ++z) { sa += *(const f32x4*)(p + z * zs); sb += *(const f32x4*)(p + z * zs + 4); }
+        sa += ba; sb += bb;
+        // round through the compute dtype exactly like the unfused GEMM epilogue would have
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = to_f32(from_f32<T>(sa[i])); v[4 + i] = to_f32(from_f32<T>(sb[i])); }
+    }
+};
+
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+    bf16x8 r;
+    __device__ __forceinline__ void load(const bf16_t* p) { r = *(const bf16x8*)p; }
+    __device__ __forceinline__ void zero() { for (int i = 0; i < 8; ++i) r[i] = (bf16_t)0.f; }
+    __device__ __forceinline__ float get(int i) const { return (float)r[i]; }
+    __device__ __forceinline__ void set(int i, float x) { r[i] = (bf16_t)x; }
+};
+template <> struct Raw8<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
+    __device__ __forceinline__ void zero() { a = 0.f; b = 0.f; }
+    __device__ __forceinline__ float get(int i) const { return i < 4 ? a[i] : b[i - 4]; }
+    __device__ __forceinline__ void set(int i, float x) { if (i < 4) a[i] = x; else b[i - 4] = x; }
+};
 
 template <typename T, int NI>
-__global__ __launch_bounds__(256) void decode_attention_wave_kernel(const T* __restrict__ q, T* __restrict__ kbase,
+__global__ __launch_bounds__(256, 3) void decode_attention_wave_kernel(const T* __restrict__ q, T* __restrict__ kbase,
                                                                     T* __restrict__ vbase,
                                                                     const int* __restrict__ anc, int anc_ld,
                                                                     int rows_per_kv, int kv_ld, int n_keys,
@@ -314,34 +349,51 @@ __global__ __launch_bounds__(256) void decode_attention_wave_kernel(const T* __r
     const int row = unit / H, h = unit - row * H, Dh = H * 64;
     const int lane = threadIdx.x & 63, ksub = lane >> 3, dch = lane & 7;
     const bool fused_kv = qs.part != nullptr && qs.append_kv;
-    float kk[NI][8], vv[NI][8];
+    // program order = issue order: ancestry indices, then the split-K partials, then the history (which waits on the
+    // indices only), then arithmetic
+    int srcs[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int key = i * 8 + ksub;
+        srcs[i] = (anc && key < n_keys) ? anc[(size_t)row * anc_ld + key] : row / rows_per_kv;
+    }
+    Part8 pq, pk, pv;
+    if (qs.part) pq.issue(qs, R, row, qs.col0 + h * 64 + dch * 8);
+    if (fused_kv) {
+        pk.issue(qs, R, row, qs.col0 + Dh + h * 64 + dch * 8);
+        pv.issue(qs, R, row, qs.col0 + 2 * Dh + h * 64 + dch * 8);
+    }
+    Raw8<T> kk[NI], vv[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int key = i * 8 + ksub;
         if (key < n_keys && !(fused_kv && key == n_keys - 1)) {
-            const int src = anc ? anc[(size_t)row * anc_ld + key] : row / rows_per_kv;
-            const size_t o = (((size_t)src * H + h) * kv_ld + key) * 64 + dch * 8;
-            load8<T>(kbase + o, kk[i]);
-            load8<T>(vbase + o, vv[i]);
+            const size_t o = (((size_t)srcs[i] * H + h) * kv_ld + key) * 64 + dch * 8;
+            kk[i].load(kbase + o);
+            vv[i].load(vbase + o);
         } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { kk[i][e] = 0.f; vv[i][e] = 0.f; }
+            kk[i].zero(); vv[i].zero();
         }
     }
     float qv[8];
-    if (qs.part) reduce8<T>(qs, R, row, qs.col0 + h * 64 + dch * 8, qv);
+    if (qs.part) pq.finish<T>(qs, qv);
     else load8<T>(q + (size_t)row * Dh + h * 64 + dch * 8, qv);
     if (fused_kv) {
-        // the 8 lanes that own the newest position finish its k/v, append them to this row's cache and use them
+        // every lane finishes the newest position's k/v for its 8 columns (same addresses across the 8 key sub-lanes);
+        // the 8 lanes that own that position append them to this row's cache and use them
+        float kn[8], vn[8];
+        pk.finish<T>(qs, kn);
+        pv.finish<T>(qs, vn);
         const int t = n_keys - 1;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             if (i * 8 + ksub == t) {
-                reduce8<T>(qs, R, row, qs.col0 + Dh + h * 64 + dch * 8, kk[i]);
-                reduce8<T>(qs, R, row, qs.col0 + 2 * Dh + h * 64 + dch * 8, vv[i]);
                 const size_t o = (((size_t)row * H + h) * kv_ld + t) * 64 + dch * 8;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { kbase[o + e] = from_f32<T>(kk[i][e]); vbase[o + e] = from_f32<T>(vv[i][e]); }
+                for (int e = 0; e < 8; ++e) {
+                    kk[i].set(e, kn[e]); vv[i].set(e, vn[e]);
+                    kbase[o + e] = from_f32<T>(kn[e]); vbase[o + e] = from_f32<T>(vn[e]);
+                }
             }
         }
     }
@@ -350,7 +402,7 @@ __global__ __launch_bounds__(256) void decode_attention_wave_kernel(const T* __r
     for (int i = 0; i < NI; ++i) {
         float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s = fmaf(qv[e] * 0.125f, kk[i][e], s);
+        for (int e = 0; e < 8; ++e) s = fmaf(qv[e] * 0.125f, kk[i].get(e), s);
         s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
         sc[i] = (i * 8 + ksub < n_keys) ? s : -INFINITY;
         m = fmaxf(m, sc[i]);
@@ -364,7 +416,7 @@ __global__ __launch_bounds__(256) void decode_attention_wave_kernel(const T* __r
         const float p = expf(sc[i] - m);
         l += p;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = fmaf(p, vv[i][e], o[e]);
+        for (int e = 0; e < 8; ++e) o[e] = fmaf(p, vv[i].get(e), o[e]);
     }
     l += __shfl_xor(l, 8, 64); l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
 #pragma unroll
@@ -383,42 +435,25 @@ __global__ __launch_bounds__(256) void decode_attention_wave_kernel(const T* __r
 // walked in chunks of 64 keys.  A chunk's 8 K loads and 8 V loads (16 B per lane, one 128-byte key row per 8 lanes)
 // are all issued into raw registers before any arithmetic; with ~4 waves per SIMD that keeps >100 KB in flight per
 // CU, which is what streaming the beam-shared K/V cache at HBM rate needs.  Online softmax across chunks (fp32).
-template <typename T> struct Raw8;
-template <> struct Raw8<bf16_t> {
-    bf16x8 r;
-    __device__ __forceinline__ void load(const bf16_t* p) { r = *(const bf16x8*)p; }
-    __device__ __forceinline__ void zero() { for (int i = 0; i < 8; ++i) r[i] = (bf16_t)0.f; }
-    __device__ __forceinline__ float get(int i) const { return (float)r[i]; }
-};
-template <> struct Raw8<float> {
-    f32x4 a, b;
-    __device__ __forceinline__ void load(const float* p) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
-    __device__ __forceinline__ void zero() { a = 0.f; b = 0.f; }
-    __device__ __forceinline__ float get(int i) const { return i < 4 ? a[i] : b[i - 4]; }
-};
-
-template <typename T>
-__global__ __launch_bounds__(256) void decode_attention_online_kernel(const T* __restrict__ q, const T* __restrict__ kbase,
+template <typename T, int G, bool DB>
+__global__ __launch_bounds__(256, 3) void decode_attention_online_kernel(const T* __restrict__ q, const T* __restrict__ kbase,
                                                                       const T* __restrict__ vbase,
                                                                       const int* __restrict__ anc, int anc_ld,
                                                                       int rows_per_kv, int kv_ld, int n_keys,
                                                                       T* __restrict__ out, int R, int H, QSource qs) {
-    constexpr int G = 8;                               // key groups (of 8 keys) per chunk
+    // G = key groups (of 8 keys) per chunk, chosen by the launcher so the chunks are balanced (197 keys -> 4 x 56).
+    // DB: two register buffers, the next chunk's loads are in flight while the current one is consumed.
+    constexpr int CH = 8 * G;
     const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (unit >= R * H) return;
     const int row = unit / H, h = unit - row * H, Dh = H * 64;
     const int lane = threadIdx.x & 63, ksub = lane >> 3, dch = lane & 7;
-    float qv[8];
-    if (qs.part) reduce8<T>(qs, R, row, qs.col0 + h * 64 + dch * 8, qv);
-    else load8<T>(q + (size_t)row * Dh + h * 64 + dch * 8, qv);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) qv[e] *= 0.125f;
     const int src0 = row / rows_per_kv;
-    float m = -INFINITY, l = 0.f, o[8];
+    float m = -INFINITY, l = 0.f, o[8], qv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    for (int k0 = 0; k0 < n_keys; k0 += 8 * G) {
-        Raw8<T> kr[G], vr[G];
+
+    auto issue = [&](Raw8<T>(&kr)[G], Raw8<T>(&vr)[G], int k0) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int key = k0 + g * 8 + ksub;
@@ -431,6 +466,8 @@ __global__ __launch_bounds__(256) void decode_attention_online_kernel(const T* _
                 kr[g].zero(); vr[g].zero();
             }
         }
+    };
+    auto consume = [&](const Raw8<T>(&kr)[G], const Raw8<T>(&vr)[G], int k0) {
         float sc[G], cm = -INFINITY;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -455,6 +492,37 @@ __global__ __launch_bounds__(256) void decode_attention_online_kernel(const T* _
             for (int e = 0; e < 8; ++e) o[e] = fmaf(p, vr[g].get(e), o[e]);
         }
         m = mn;
+    };
+
+    Part8 pq;
+    if (qs.part) pq.issue(qs, R, row, qs.col0 + h * 64 + dch * 8);
+    Raw8<T> ka[G], va[G];
+    issue(ka, va, 0);
+    if constexpr (DB) {
+        Raw8<T> kb[G], vb[G];
+        if (CH < n_keys) issue(kb, vb, CH);
+        if (qs.part) pq.finish<T>(qs, qv); else load8<T>(q + (size_t)row * Dh + h * 64 + dch * 8, qv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] *= 0.125f;
+        for (int k0 = 0;;) {
+            consume(ka, va, k0);
+            if (k0 + 2 * CH < n_keys) issue(ka, va, k0 + 2 * CH);
+            if (k0 + CH >= n_keys) break;
+            consume(kb, vb, k0 + CH);
+            if (k0 + 3 * CH < n_keys) issue(kb, vb, k0 + 3 * CH);
+            k0 += 2 * CH;
+            if (k0 >= n_keys) break;
+        }
+    } else {
+        if (qs.part) pq.finish<T>(qs, qv); else load8<T>(q + (size_t)row * Dh + h * 64 + dch * 8, qv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] *= 0.125f;
+        for (int k0 = 0;;) {
+            consume(ka, va, k0);
+            k0 += CH;
+            if (k0 >= n_keys) break;
+            issue(ka, va, k0);
+        }
     }
     l += __shfl_xor(l, 8, 64); l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
 #pragma unroll
@@ -567,9 +635,13 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
 #define CAP_DA_WAVE(TT, NI)                                                                                            \
     hipLaunchKernelGGL((decode_attention_wave_kernel<TT, NI>), dim3((R * H + 3) / 4), dim3(256), 0, s, (const TT*)q,  \
                        (TT*)kbase, (TT*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, (TT*)out, R, H, qs)
-#define CAP_DA_ONLINE(TT)                                                                                              \
-    hipLaunchKernelGGL((decode_attention_online_kernel<TT>), dim3((R * H + 3) / 4), dim3(256), 0, s, (const TT*)q,    \
-                       (const TT*)kbase, (const TT*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, (TT*)out, R, H, qs)
+#define CAP_DA_ONLINE_G(TT, GG, DBB)                                                                                    \
+    hipLaunchKernelGGL((decode_attention_online_kernel<TT, GG, DBB>), dim3((R * H + 3) / 4), dim3(256), 0, s,         \
+                       (const TT*)q, (const TT*)kbase, (const TT*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys,     \
+                       (TT*)out, R, H, qs)
+    // bf16: chunks of 40 keys, double-buffered (168 VGPRs -> 3 waves/SIMD, all of a 256-row launch resident at once;
+    // 197 image tokens = 5 chunks).  fp32: chunks of 56 keys, single buffer (same register budget).
+#define CAP_DA_ONLINE(TT, DBB) CAP_DA_ONLINE_G(TT, (DBB ? 5 : 7), DBB)
     const int ng8 = (n_keys + 7) / 8;            // groups of 8 keys
     if (append_kv && ng8 > 4 && q_part) {
         cap_set_error("decode_attention: fused k/v append supports up to 32 positions (got %d)", n_keys);
@@ -578,16 +650,17 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
     if (impl == 0) {
         if (dtype == CAP_DT_BF16) {
             if (ng8 <= 1) CAP_DA_WAVE(bf16_t, 1); else if (ng8 <= 2) CAP_DA_WAVE(bf16_t, 2);
-            else if (ng8 <= 4) CAP_DA_WAVE(bf16_t, 4); else CAP_DA_ONLINE(bf16_t);
+            else if (ng8 <= 4) CAP_DA_WAVE(bf16_t, 4); else CAP_DA_ONLINE(bf16_t, true);
         } else {
             if (ng8 <= 1) CAP_DA_WAVE(float, 1); else if (ng8 <= 2) CAP_DA_WAVE(float, 2);
-            else if (ng8 <= 4) CAP_DA_WAVE(float, 4); else CAP_DA_ONLINE(float);
+            else if (ng8 <= 4) CAP_DA_WAVE(float, 4); else CAP_DA_ONLINE(float, false);
         }
         CAP_HIP_CHECK(hipGetLastError());
         return 0;
     }
 #undef CAP_DA_WAVE
 #undef CAP_DA_ONLINE
+#undef CAP_DA_ONLINE_G
     // impl 1: the simple two-pass kernel (kept as an independent implementation for the tests)
     const int lds = (((n_keys + 3) & ~3) + 8 + 256) * 4;
     dim3 grid(R, H);

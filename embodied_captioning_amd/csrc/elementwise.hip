@@ -130,8 +130,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 // Consumer of a split-K GEMM (EPI_PARTIAL): y = sum_z partial[z] + bias + resid, summed in slice order (deterministic),
 // then LayerNorm -> out_f (fp32 residual stream) and out_t (next GEMM's A operand).
-template <typename T>
-__global__ __launch_bounds__(256) void reduce_layernorm_kernel(const float* __restrict__ part, int S,
+template <typename P> __device__ __forceinline__ float4 load4f(const P* p);
+template <> __device__ __forceinline__ float4 load4f<float>(const float* p) { return *(const float4*)p; }
+template <> __device__ __forceinline__ float4 load4f<bf16_t>(const bf16_t* p) {
+    const bf16x4 r = *(const bf16x4*)p;
+    return make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
+}
+
+// P = element type of the partial sums: fp32 (split-K slices) or the compute type (the ViT branch outputs in `delta`).
+template <typename T, typename P>
+__global__ __launch_bounds__(256) void reduce_layernorm_kernel(const P* __restrict__ part, int S,
                                                                 const float* __restrict__ bias,
                                                                 const float* __restrict__ resid,
                                                                 const float* __restrict__ gamma,
@@ -147,17 +155,17 @@ __global__ __launch_bounds__(256) void reduce_layernorm_kernel(const float* __re
     for (int i = 0; i < LN_MAXV; ++i) {
         const int c = lane * 4 + i * 256;
         if (i < nv && c < D) {
-            float4 a = *(const float4*)(part + (size_t)row * D + c);
+            float4 a = load4f<P>(part + (size_t)row * D + c);
             if (S == 4) {
-                const float4 b1 = *(const float4*)(part + ((size_t)1 * M + row) * D + c);
-                const float4 b2 = *(const float4*)(part + ((size_t)2 * M + row) * D + c);
-                const float4 b3 = *(const float4*)(part + ((size_t)3 * M + row) * D + c);
+                const float4 b1 = load4f<P>(part + ((size_t)1 * M + row) * D + c);
+                const float4 b2 = load4f<P>(part + ((size_t)2 * M + row) * D + c);
+                const float4 b3 = load4f<P>(part + ((size_t)3 * M + row) * D + c);
                 a.x = ((a.x + b1.x) + b2.x) + b3.x; a.y = ((a.y + b1.y) + b2.y) + b3.y;
                 a.z = ((a.z + b1.z) + b2.z) + b3.z; a.w = ((a.w + b1.w) + b2.w) + b3.w;
             } else {
 #pragma unroll 4
                 for (int z = 1; z < S; ++z) {
-                    const float4 b = *(const float4*)(part + ((size_t)z * M + row) * D + c);
+                    const float4 b = load4f<P>(part + ((size_t)z * M + row) * D + c);
                     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
                 }
             }
@@ -172,6 +180,62 @@ __global__ __launch_bounds__(256) void reduce_layernorm_kernel(const float* __re
     }
     ln_row<T>(v, nv, lane, D, gamma, beta, eps, out_t ? out_t + (size_t)row * D : nullptr,
               out_f ? out_f + (size_t)row * D : nullptr);
+}
+
+// Decode-sized variant (a few hundred rows): one 256-thread block per row, one float4 per thread, every partial / bias /
+// residual / gamma / beta load issued before the first add -> one memory round trip, then two LDS cross-wave reductions.
+// Same summation order over slices as the wave-per-row kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_layernorm_row_kernel(const float* __restrict__ part, int S,
+                                                                    const float* __restrict__ bias,
+                                                                    const float* __restrict__ resid,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float eps, T* out_t,
+                                                                    float* out_f, float* y_out, int M, int D) {
+    __shared__ float sp[2][256];
+    const int row = blockIdx.x, tid = threadIdx.x, c = tid * 4;
+    const bool act = c < D;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 pz[8], bb = z4, rr = z4, g = z4, be = z4;
+#pragma unroll
+    for (int z = 0; z < 8; ++z) pz[z] = (act && z < S) ? *(const float4*)(part + ((size_t)z * M + row) * D + c) : z4;
+    if (act) {
+        if (bias) bb = *(const float4*)(bias + c);
+        if (resid) rr = *(const float4*)(resid + (size_t)row * D + c);
+        g = *(const float4*)(gamma + c);
+        be = *(const float4*)(beta + c);
+    }
+    float4 a = pz[0];
+#pragma unroll
+    for (int z = 1; z < 8; ++z)
+        if (z < S) { a.x += pz[z].x; a.y += pz[z].y; a.z += pz[z].z; a.w += pz[z].w; }
+    for (int z = 8; z < S; ++z) {
+        const float4 b = act ? *(const float4*)(part + ((size_t)z * M + row) * D + c) : z4;
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (bias) { a.x += bb.x; a.y += bb.y; a.z += bb.z; a.w += bb.w; }
+    if (resid) { a.x += rr.x; a.y += rr.y; a.z += rr.z; a.w += rr.w; }
+    if (act && y_out) *(float4*)(y_out + (size_t)row * D + c) = a;
+    // statistics in exactly the wave-per-row kernel's order (thread j + 64 i holds that kernel's lane j, vector i), so a
+    // row normalises to the same bits whichever kernel the row count selects (batch invariance)
+    const int lane = tid & 63;
+    sp[0][tid] = act ? a.x + a.y + a.z + a.w : 0.f;
+    __syncthreads();
+    const float mean = wave_sum(((sp[0][lane] + sp[0][64 + lane]) + sp[0][128 + lane]) + sp[0][192 + lane]) / (float)D;
+    const float dx = a.x - mean, dy = a.y - mean, dz = a.z - mean, dw = a.w - mean;
+    sp[1][tid] = act ? dx * dx + dy * dy + dz * dz + dw * dw : 0.f;
+    __syncthreads();
+    const float rstd =
+        1.0f / sqrtf(wave_sum(((sp[1][lane] + sp[1][64 + lane]) + sp[1][128 + lane]) + sp[1][192 + lane]) / (float)D + eps);
+    if (act) {
+        float4 o;
+        o.x = dx * rstd * g.x + be.x; o.y = dy * rstd * g.y + be.y; o.z = dz * rstd * g.z + be.z; o.w = dw * rstd * g.w + be.w;
+        if (out_f) *(float4*)(out_f + (size_t)row * D + c) = o;
+        if (out_t) {
+            T* ot = out_t + (size_t)row * D + c;
+            ot[0] = from_f32<T>(o.x); ot[1] = from_f32<T>(o.y); ot[2] = from_f32<T>(o.z); ot[3] = from_f32<T>(o.w);
+        }
+    }
 }
 
 template <typename T>
@@ -226,7 +290,12 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const float* __restr
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = 4 * (c0 + u * 256);
-            if (mask_eos && eos >= i && eos < i + 4) ((float*)&v[u])[eos - i] = -INFINITY;
+            if (mask_eos) {          // component-wise: a dynamic index would push v[] into scratch
+                if (eos == i) v[u].x = -INFINITY;
+                if (eos == i + 1) v[u].y = -INFINITY;
+                if (eos == i + 2) v[u].z = -INFINITY;
+                if (eos == i + 3) v[u].w = -INFINITY;
+            }
             if (v[u].x > best) { best = v[u].x; bi = i; }
             if (v[u].y > best) { best = v[u].y; bi = i + 1; }
             if (v[u].z > best) { best = v[u].z; bi = i + 2; }
@@ -346,18 +415,35 @@ int launch_layernorm(int dtype, const float* in, int ld_in, const float* gamma, 
     return 0;
 }
 
-int launch_reduce_layernorm(int dtype, const float* part, int S, const float* bias, const float* resid,
+int launch_reduce_layernorm(int dtype, const void* part, int S, const float* bias, const float* resid,
                             const float* gamma, const float* beta, float eps, void* out_t, float* out_f, float* y_out,
-                            int M, int D, hipStream_t s) {
+                            int M, int D, hipStream_t s, bool per_row_block, bool part_in_t) {
+    if (per_row_block && part_in_t) { cap_set_error("reduce_layernorm: the per-row-block kernel takes fp32 partial sums"); return -1; }
     if (D % 4 != 0 || D > 256 * LN_MAXV || S < 1) { cap_set_error("reduce_layernorm: unsupported width %d / slices %d", D, S); return -1; }
+    // per_row_block: the decoder's choice (a few hundred rows, latency-bound).  The two kernels round differently in the
+    // last bit, so the choice is the CALLER's (by path), never the row count's: a frame's result must not depend on the
+    // batch it rides in.
+    if (per_row_block && D <= 1024) {
+        if (dtype == CAP_DT_BF16)
+            hipLaunchKernelGGL(reduce_layernorm_row_kernel<bf16_t>, dim3(M), dim3(256), 0, s, (const float*)part, S, bias, resid, gamma,
+                               beta, eps, (bf16_t*)out_t, out_f, y_out, M, D);
+        else
+            hipLaunchKernelGGL(reduce_layernorm_row_kernel<float>, dim3(M), dim3(256), 0, s, (const float*)part, S, bias, resid, gamma,
+                               beta, eps, (float*)out_t, out_f, y_out, M, D);
+        CAP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const int wpb = M >= 2048 ? 4 : 1;
     const dim3 grid((M + wpb - 1) / wpb), block(64 * wpb);
-    if (dtype == CAP_DT_BF16)
-        hipLaunchKernelGGL(reduce_layernorm_kernel<bf16_t>, grid, block, 0, s, part, S, bias, resid, gamma,
-                           beta, eps, (bf16_t*)out_t, out_f, y_out, M, D);
+    if (dtype == CAP_DT_BF16 && part_in_t)
+        hipLaunchKernelGGL((reduce_layernorm_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)part, S, bias, resid,
+                           gamma, beta, eps, (bf16_t*)out_t, out_f, y_out, M, D);
+    else if (dtype == CAP_DT_BF16)
+        hipLaunchKernelGGL((reduce_layernorm_kernel<bf16_t, float>), grid, block, 0, s, (const float*)part, S, bias, resid,
+                           gamma, beta, eps, (bf16_t*)out_t, out_f, y_out, M, D);
     else
-        hipLaunchKernelGGL(reduce_layernorm_kernel<float>, grid, block, 0, s, part, S, bias, resid, gamma,
-                           beta, eps, (float*)out_t, out_f, y_out, M, D);
+        hipLaunchKernelGGL((reduce_layernorm_kernel<float, float>), grid, block, 0, s, (const float*)part, S, bias, resid,
+                           gamma, beta, eps, (float*)out_t, out_f, y_out, M, D);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -26,6 +26,12 @@ template <> struct Mma<bf16_t> {
     __device__ static __forceinline__ void run(f32x16& acc, const vec& a, const vec& b) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     }
+    // 16x16x32: lane (r16 = lane & 15, kg = lane >> 4) supplies row r16, k = 8 kg .. 8 kg + 7 of a 32-wide k-step;
+    // D[4 kg + e][r16].  Every bf16 GEMM kernel of this file accumulates with THIS instruction, k-steps in ascending
+    // order, so a row of C has the same bits whichever tile shape its batch size selects (batch invariance).
+    __device__ static __forceinline__ void run16(f32x4& acc, const vec& a, const vec& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+    }
 };
 template <> struct Mma<float> {
     using vec = f32x4;
@@ -142,13 +148,24 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(G
         db[i] = BM * 128 + swz_off(row, ch);
     }
 
-    f32x16 acc[MI][NI];
+    constexpr bool B16 = sizeof(T) == 2;                  // bf16: 16x16x32 blocks (see Mma<bf16_t>::run16)
+    constexpr int MI16 = WM / 16, NI16 = WN / 16;
+    const int r16 = lane & 15, kg = lane >> 4;
+    f32x16 acc[B16 ? 1 : MI][B16 ? 1 : NI];
+    f32x4 acc16[B16 ? MI16 : 1][B16 ? NI16 : 1];
+    if constexpr (B16) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI16; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+            for (int j = 0; j < NI16; ++j) acc16[i][j] = 0.f;
+    } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    }
 
     u32x4 ra[D][LA], rb[D][LB];
     const int nk = Ks / SLAB;
@@ -180,17 +197,32 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(G
             __syncthreads();
             const char* a_s = buf;
             const char* b_s = buf + BM * 128;
+            if constexpr (B16) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                vec af[MI], bf[NI];
+                for (int ks = 0; ks < 2; ++ks) {
+                    vec af[MI16], bf[NI16];
 #pragma unroll
-                for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz_off(wm0 + i * 32 + r32, ks * 2 + h));
+                    for (int i = 0; i < MI16; ++i) af[i] = *(const vec*)(a_s + swz_off(wm0 + i * 16 + r16, ks * 4 + kg));
 #pragma unroll
-                for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz_off(wn0 + j * 32 + r32, ks * 2 + h));
+                    for (int j = 0; j < NI16; ++j) bf[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, ks * 4 + kg));
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                    for (int i = 0; i < MI16; ++i)
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], af[i], bf[j]);
+                        for (int j = 0; j < NI16; ++j) Mma<bf16_t>::run16(acc16[i][j], af[i], bf[j]);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    vec af[MI], bf[NI];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz_off(wm0 + i * 32 + r32, ks * 2 + h));
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz_off(wn0 + j * 32 + r32, ks * 2 + h));
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], af[i], bf[j]);
+                }
             }
         }
     }
@@ -205,11 +237,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(G
     const int rl = lane / LPR, cl = (lane % LPR) * 4;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+        if constexpr (B16) {
+            // rows i*32 .. i*32+31 of the wave tile = 16-row blocks 2i, 2i+1; acc16[.][j][e] is C[4 kg + e][r16]
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+            for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                strip[((e & 3) + 8 * (e >> 2) + 4 * h) * WN + j * 32 + r32] = acc[i][j][e];
+                for (int j = 0; j < NI16; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        strip[(ii * 16 + 4 * kg + e) * WN + j * 16 + r16] = acc16[i * 2 + ii][j][e];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    strip[((e & 3) + 8 * (e >> 2) + 4 * h) * WN + j * 32 + r32] = acc[i][j][e];
+        }
         // same-wave LDS accesses complete in order; the compiler's lgkmcnt wait orders the read-back
         const int col = n0 + wn0 + cl;
         f32x4 biasv = 0.f;
@@ -293,6 +336,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
         }
     };
 
+    long long prof_dma = 0, prof_bar = 0, prof_epi = 0;
+    const long long prof_c0 = VAR == 4 ? clock64() : 0, prof_w0 = VAR == 4 ? wall_clock64() : 0;
     int cnt = 0;                                          // running slab counter: slab uses stage buffer cnt & 1
     int tile = c0 + li;
     int tcount = 0;                                       // tiles done by this block: bias slot = tcount & 1
@@ -312,6 +357,14 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
         for (int kt = 0; kt < nk; ++kt, ++cnt) {
+            if constexpr (VAR == 4) {   // instrumented: cycles waiting for this wave's DMA vs. for the other waves
+                const long long t0 = clock64();
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const long long t1 = clock64();
+                __builtin_amdgcn_s_barrier();
+                const long long t2 = clock64();
+                prof_dma += t1 - t0; prof_bar += t2 - t1;
+            } else
             __syncthreads();      // vmcnt(0): this wave's pieces of slab kt landed; barrier: everybody's did, and
                                   // every wave is done reading the other stage buffer
             if (kt + 1 < nk) issue(tile, kt + 1, smem + ((cnt + 1) & 1) * STAGE);
@@ -368,6 +421,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
         // just multiplied) back into registers, row-major: each lane ends up with 4 consecutive columns of 32 rows.
         // Phase 2 (after the next tile's first slab DMA has been issued - no LDS access from here on, so hipcc has no
         // reason to drain the DMA queue): bias / GELU / residual, convert, 16-byte (fp32) or 8-byte (bf16) stores.
+        const long long prof_e0 = VAR == 4 ? clock64() : 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // every wave is done reading stage (cnt-1) & 1
         float* strip = (float*)(smem + ((cnt + 1) & 1) * STAGE + wave * (32 * WN * 4));
@@ -397,7 +451,285 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
                 const int row = m0 + wm0 + i * 32 + ps * RPP + rl;
                 if (row < p.M && col < p.N) epi_store4<T, OUT_F32, EPI, false>(p, row, col, tr[i][ps], biasv);
             }
+        if constexpr (VAR == 4) prof_epi += clock64() - prof_e0;
     }
+    if constexpr (VAR == 4) {
+        if (lane == 0 && p.aux) {
+            long long* d = (long long*)p.aux + ((size_t)blockIdx.x * 8 + wave) * 6;
+            d[0] = clock64() - prof_c0; d[1] = wall_clock64() - prof_w0; d[2] = prof_dma; d[3] = prof_bar; d[4] = prof_epi;
+            d[5] = tcount;
+        }
+    }
+}
+
+// Epilogue stores of the second-generation kernel: values are final (bias / GELU applied, converted); these only map
+// (row, col) to the destination of the epilogue in use and store 16 bytes (8 bf16 or 4 fp32 consecutive columns).
+template <int EPI>
+__device__ __forceinline__ size_t epi_offset(const GemmParams& p, int row, int col, void*& base) {
+    base = p.C;
+    if constexpr (EPI == EPI_PARTIAL) {
+        return ((size_t)p.p3 * p.M + row) * p.ldc + col;
+    } else if constexpr (EPI == EPI_STORE) {
+        return (size_t)row * p.ldc + col;
+    } else if constexpr (EPI == EPI_PATCH) {
+        const int b = row / p.p0, pp = row - b * p.p0;
+        return ((size_t)b * (p.p0 + 1) + 1 + pp) * p.ldc + col;
+    } else if constexpr (EPI == EPI_CROSSKV) {
+        const int NT = p.p0, H = p.p1, B = p.p2, Dh = H * 64;
+        const int b = row / NT, t = row - b * NT;
+        const int l = col / (2 * Dh), r = col - l * 2 * Dh, kv = r / Dh, hd = r - kv * Dh, h = hd >> 6, d = hd & 63;
+        return (((((size_t)l * 2 + kv) * B + b) * H + h) * NT + t) * 64 + d;
+    } else {  // EPI_QKVCACHE
+        const int H = p.p1, Dh = H * 64;
+        if (col < Dh) return (size_t)row * Dh + col;
+        const int kv = col / Dh - 1, hd = col % Dh, h = hd >> 6, d = hd & 63;
+        base = p.C2;
+        return ((((size_t)kv * p.p0 + row) * H + h) * p.p2 + p.p3) * 64 + d;
+    }
+}
+template <typename T, int EPI>
+__device__ __forceinline__ void epi_store_raw(const GemmParams& p, int row, int col, u32x4 raw, bool full) {
+    void* base;
+    const size_t o = epi_offset<EPI>(p, row, col, base);
+    if (full) *(u32x4*)((T*)base + o) = raw;
+    else *(unsigned long long*)((T*)base + o) = (unsigned long long)raw[0] | ((unsigned long long)raw[1] << 32);   // N % 8 == 4 tail
+}
+template <int EPI>
+__device__ __forceinline__ void epi_store_f32(const GemmParams& p, int row, int col, f32x4 v) {
+    if constexpr (EPI == EPI_PATCH) {
+        const int pp = row % p.p0;
+        v += *(const f32x4*)(p.aux + (size_t)(1 + pp) * p.N + col);
+    }
+    void* base;
+    const size_t o = epi_offset<EPI>(p, row, col, base);
+    *(f32x4*)((float*)base + o) = v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 256x256 persistent kernel, second generation.  Same LDS-DMA staging, swizzle and XCD-aware tile walk as
+// gemm_big_kernel; what changed follows from in-kernel cycle accounting (tools/gemm_cycles.py: the old epilogue cost
+// ~10 k cycles per tile against ~3.6 k per K-slab, and the chip holds ~1.85 GHz under this loop):
+//   * v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (same LDS bytes, same cycles per flop; the chip sustains a higher
+//     clock on this shape - MI355X_MICROARCH.md, DVFS give-back item 7);
+//   * operands swapped (W fragment as MFMA A, activation fragment as MFMA B), so a lane's 4 accumulator registers of a
+//     16x16 block are 4 CONSECUTIVE OUTPUT COLUMNS of one row: bias/GELU/convert happen in that layout and the transpose
+//     to whole-cache-line stores goes through a small wave-private strip with 8/16-byte LDS writes (the old epilogue
+//     wrote 4 bytes per lane into strips aliasing the stage buffers and needed a barrier on each side; storing straight
+//     from this layout - 16 rows x 32 B per instruction - measured 14-18 k cycles per tile, worse than the old 10 k);
+//   * the slab pipeline runs across tile boundaries: the next tile's first slab is issued during this tile's last slab;
+//     a wave confirms its own pieces landed (vmcnt(0)) BEFORE its epilogue stores, so the barrier after the epilogue
+//     does not wait for those stores.
+// VAR: 0 compiler schedule, 1 iglp_opt(0), 2 iglp_opt(1); PROF: cycle stamps to p.aux (diagnostic build only).
+template <bool OUT_F32, int EPI, int VAR, bool PROF>
+__global__ __launch_bounds__(512, 2) void gemm_big2_kernel(GemmParams p) {
+    using T = bf16_t;
+    using vec = bf16x8;
+    constexpr int BM = 256, BN = 256, WM = 128, WN = 64, MI = WM / 16, NI = WN / 16;
+    constexpr int EPC = 8, STAGE = (BM + BN) * 128;      // 64 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 2) * WM, wn0 = (wave & 3) * WN;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
+    const int nk = p.K >> 6;
+
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int nl = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
+    const int tq = ntiles >> 3, tr = ntiles & 7;
+    const int c0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int c1 = c0 + tq + (xcd < tr ? 1 : 0);
+
+    // issue side of the pipeline: byte pointers (k = 0) of this lane's 4 A and 4 W pieces of the tile being fetched
+    const int prow = lane >> 3, ppos = lane & 7;
+    const char* pa[4];
+    const char* pb[4];
+    auto set_ptrs = [&](int t) {
+        const int tm = t / ntn, tn = t - tm * ntn;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (wave * 4 + j) * 8 + prow;
+            const int gch = ppos ^ ((row >> 1) & 7);
+            const int ga = min(tm * BM + row, p.M - 1), gb = min(tn * BN + row, p.N - 1);
+            pa[j] = (const char*)((const T*)p.A + (size_t)ga * p.lda + gch * EPC);
+            pb[j] = (const char*)((const T*)p.W + (size_t)gb * p.ldw + gch * EPC);
+        }
+    };
+    auto issue = [&](int kt, char* stage) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rowbase = (wave * 4 + j) * 8;
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(pa[j] + (size_t)kt * 128), CAP_LPTR(stage + rowbase * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(pb[j] + (size_t)kt * 128), CAP_LPTR(stage + BM * 128 + rowbase * 128), 16, 0, 0);
+        }
+    };
+    char* bias_lds = smem + 2 * STAGE;
+    const bool has_bias = EPI != EPI_PARTIAL && p.bias != nullptr;
+    auto issue_bias = [&](int t, int slot) {
+        if (has_bias && wave == 0) {
+            const int tn = t % ntn;
+            const float* sb = p.bias + min(tn * BN + lane * 4, p.N - 4);
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(sb), CAP_LPTR(bias_lds + slot * 1024), 16, 0, 0);
+        }
+    };
+
+    long long prof_dma = 0, prof_bar = 0, prof_epi = 0;
+    const long long prof_c0 = PROF ? clock64() : 0, prof_w0 = PROF ? wall_clock64() : 0;
+
+    int cnt = 0, tcount = 0;
+    int tile = c0 + li;
+    int itile = tile, ikt = 0;
+    auto advance = [&]() {
+        if (++ikt == nk) {
+            ikt = 0;
+            itile += nl;
+            if (itile < c1) set_ptrs(itile);
+        }
+    };
+    if (itile < c1) { set_ptrs(itile); issue_bias(itile, 0); issue(0, smem); advance(); }
+
+    for (; tile < c1; tile += nl, ++tcount) {
+        const int tm = tile / ntn, tn = tile - tm * ntn;
+        const int m0 = tm * BM, n0 = tn * BN;
+        f32x4 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = 0.f;
+
+        for (int kt = 0; kt < nk; ++kt, ++cnt) {
+            if (kt > 0 || tcount == 0) {
+                // vmcnt(0): this wave's pieces of the slab landed; barrier: everybody's did and every wave is done
+                // reading the other stage buffer.  (First slab of later tiles: see the end of the tile loop.)
+                if constexpr (PROF) {
+                    const long long t0 = clock64();
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    const long long t1 = clock64();
+                    __builtin_amdgcn_s_barrier();
+                    prof_dma += t1 - t0; prof_bar += clock64() - t1;
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            if (itile < c1) {
+                if (ikt == 0) issue_bias(itile, (tcount + 1) & 1);
+                issue(ikt, smem + ((cnt + 1) & 1) * STAGE);
+                advance();
+            }
+            const char* a_s = smem + (cnt & 1) * STAGE;
+            const char* b_s = a_s + BM * 128;
+            if constexpr (VAR == 1) __builtin_amdgcn_iglp_opt(0);
+            if constexpr (VAR == 2) __builtin_amdgcn_iglp_opt(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                vec af[MI], bf[NI];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, ks * 4 + kg));
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz_off(wm0 + i * 16 + r16, ks * 4 + kg));
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        // This wave's pieces of the next tile's first slab (issued one slab ago) have landed - checked now, before the
+        // epilogue stores enter the same in-order counter.
+        const long long prof_e0 = PROF ? clock64() : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Epilogue.  acc[i][j][e] = C[m0 + wm0 + 16 i + r16][n0 + wn0 + 16 j + 4 kg + e]: bias / GELU / convert in that
+        // layout, then a wave-private LDS strip (16 rows x 128 payload bytes, row pitch 144) turns "4 consecutive columns
+        // per lane" into "16 consecutive bytes per lane, 8 lanes per 128-byte row": every global store instruction
+        // writes 8 whole cache lines.  The strip is outside the stage buffers, so no barrier is involved.
+        char* strip = smem + 2 * STAGE + 2048 + wave * (16 * 144);
+        const bool do_gelu = EPI != EPI_PARTIAL && p.gelu;
+        f32x4 biasv[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            biasv[j] = has_bias ? *(const f32x4*)(bias_lds + (tcount & 1) * 1024 + (wn0 + j * 16 + 4 * kg) * 4) : f32x4(0.f);
+        const int srow = lane >> 3, spiece = lane & 7;
+        constexpr bool F32OUT = OUT_F32 || EPI == EPI_PARTIAL || EPI == EPI_PATCH;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if constexpr (!F32OUT) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    f32x4 v = acc[i][j] + biasv[j];
+                    if (do_gelu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_for<T>(v[e]);
+                    }
+                    bf16x4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = (bf16_t)v[e];
+                    *(bf16x4*)(strip + r16 * 144 + (j * 16 + 4 * kg) * 2) = w;
+                }
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const u32x4 raw = *(const u32x4*)(strip + (rr * 8 + srow) * 144 + spiece * 16);
+                    const int row = m0 + wm0 + i * 16 + rr * 8 + srow, col = n0 + wn0 + spiece * 8;
+                    if (row < p.M && col < p.N) epi_store_raw<T, EPI>(p, row, col, raw, col + 8 <= p.N);
+                }
+            } else {
+#pragma unroll
+                for (int jp = 0; jp < NI / 2; ++jp) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        f32x4 v = acc[i][jp * 2 + jj];
+                        if (EPI != EPI_PARTIAL) v += biasv[jp * 2 + jj];
+                        if (do_gelu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_for<T>(v[e]);
+                        }
+                        *(f32x4*)(strip + r16 * 144 + (jj * 16 + 4 * kg) * 4) = v;
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const f32x4 v = *(const f32x4*)(strip + (rr * 8 + srow) * 144 + spiece * 16);
+                        const int row = m0 + wm0 + i * 16 + rr * 8 + srow, col = n0 + wn0 + jp * 32 + spiece * 4;
+                        if (row < p.M && col < p.N) epi_store_f32<EPI>(p, row, col, v);
+                    }
+                }
+            }
+        }
+        if (tile + nl < c1) {
+            // every wave is done reading the last slab's stage buffer and the bias slot, and has seen its own pieces of
+            // the next tile's first slab land: that slab may be read and the other buffer overwritten
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (PROF) prof_epi += clock64() - prof_e0;
+    }
+    if constexpr (PROF) {
+        if (lane == 0 && p.aux) {
+            long long* d = (long long*)p.aux + ((size_t)blockIdx.x * 8 + wave) * 6;
+            d[0] = clock64() - prof_c0; d[1] = wall_clock64() - prof_w0; d[2] = prof_dma; d[3] = prof_bar; d[4] = prof_epi;
+            d[5] = tcount;
+        }
+    }
+}
+
+template <bool OUT_F32, int EPI, int VAR, bool PROF>
+int launch_big2(const GemmParams& p, hipStream_t stream) {
+    constexpr int LDS = 2 * 512 * 128 + 2 * 1024 + 8 * 16 * 144;   // two stages + bias ping-pong + epilogue strips
+    auto kern = gemm_big2_kernel<OUT_F32, EPI, VAR, PROF>;
+    static bool attr_done = false;
+    static int n_cu = 0;
+    if (!attr_done) {
+        CAP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        int dev = 0;
+        CAP_HIP_CHECK(hipGetDevice(&dev));
+        CAP_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        attr_done = true;
+    }
+    const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const int grid = ntiles < n_cu ? ntiles : n_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, p);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 template <typename T, bool OUT_F32, int EPI, int VAR = 0>
@@ -442,6 +774,21 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
 
 template <typename T, bool OUT_F32, int EPI>
 int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
+    if (tile >= 10 && tile <= 13) {                     // second-generation kernel (bf16): A/B ids, 13 = instrumented
+        if constexpr (sizeof(T) == 2) {
+            if (p.K >= 128 && !p.resid) {
+                if (tile == 10) return launch_big2<OUT_F32, EPI, 0, false>(p, stream);
+                if (tile == 11) return launch_big2<OUT_F32, EPI, 1, false>(p, stream);
+                if (tile == 12) return launch_big2<OUT_F32, EPI, 2, false>(p, stream);
+                if constexpr (!OUT_F32 && EPI == EPI_STORE) return launch_big2<OUT_F32, EPI, 2, true>(p, stream);
+            }
+        }
+        tile = 3;
+    }
+    if (tile == 9) {                                    // instrumented main loop: per-wave cycle counts to p.aux
+        if constexpr (sizeof(T) == 2 && !OUT_F32 && EPI == EPI_STORE) return launch_big<T, OUT_F32, EPI, 4>(p, stream);
+        tile = 3;
+    }
     if (tile >= 6 && tile <= 8) {                       // scheduling experiments (bf16 plain store only)
         if constexpr (sizeof(T) == 2 && !OUT_F32 && EPI == EPI_STORE) {
             if (tile == 6) return launch_big<T, OUT_F32, EPI, 1>(p, stream);
@@ -450,9 +797,18 @@ int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
         }
         tile = 3;
     }
-    if (tile == 3 && p.resid) tile = 4;                 // the LDS-DMA kernel has no residual operand
+    if ((tile == 3 || tile == 5) && p.resid) tile = 4;  // the LDS-DMA kernels have no residual operand
     if (tile == 3) {
-        // iglp_opt(1) interleaves the ds_reads with the bf16 MFMAs: +5..14 % over the plain schedule (A/B, profiles/)
+        // bf16: second-generation kernel (16x16x32 MFMA, register-layout epilogue); iglp_opt(1) interleaves the ds_reads
+        // with the MFMAs (A/B: tools/gemm_cycles.py, profiles/)
+        if constexpr (sizeof(T) == 2) {
+            if (p.K >= 128) return launch_big2<OUT_F32, EPI, 2, false>(p, stream);
+            return launch_big<T, OUT_F32, EPI, 3>(p, stream);
+        } else {
+            return launch_big<T, OUT_F32, EPI, 0>(p, stream);
+        }
+    }
+    if (tile == 5) {                                    // first-generation kernel, kept for A/B
         if constexpr (sizeof(T) == 2) return launch_big<T, OUT_F32, EPI, 3>(p, stream);
         else return launch_big<T, OUT_F32, EPI, 0>(p, stream);
     }

@@ -20,9 +20,9 @@ int launch_layernorm(int dtype, const float* in, int ld_in, const float* gamma, 
                      void* out_t, float* out_f, int M, int D, hipStream_t s);
 // split-K / residual consumer: y = sum_z part[z][M][D] + bias + resid (fixed order); y_out (optional, may alias resid)
 // receives y, then LayerNorm(y) goes to out_t / out_f as above (out_f may alias resid when y_out is null)
-int launch_reduce_layernorm(int dtype, const float* part, int S, const float* bias, const float* resid,
+int launch_reduce_layernorm(int dtype, const void* part, int S, const float* bias, const float* resid,
                             const float* gamma, const float* beta, float eps, void* out_t, float* out_f, float* y_out,
-                            int M, int D, hipStream_t s);
+                            int M, int D, hipStream_t s, bool per_row_block = false, bool part_in_t = false);
 // decoder embeddings: x = LN(word[tok] + pos[t]); tok = seq[row*seq_ld + t]
 int launch_embed(int dtype, const int* seq, int seq_ld, int t, const float* word, const float* pos,
                  const float* gamma, const float* beta, float eps, void* out_t, float* out_f, int R, int D,
