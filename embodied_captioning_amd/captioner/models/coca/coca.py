@@ -11,6 +11,7 @@ state-dict file (``.pt`` / ``.bin`` / ``.safetensors``; pretrained *tags* need t
 """
 from __future__ import annotations
 
+import dataclasses
 import logging
 import os
 from typing import List, Sequence
@@ -34,11 +35,16 @@ class CoCa(CaptioningPredictor):
         dtype = getattr(cfg, "dtype", "bf16") or "bf16"
         self._device = torch.device(getattr(cfg, "device", "cuda:0") or "cuda:0")
         self.tokenizer = None
+        # optional config key `image_size` = open_clip's force_image_size (factory.py:243-245): 224 (pretrained) or e.g. 336;
+        # the checkpoint's position table is resized at load (coca_weights.resize_visual_pos_embed)
+        image_size = int(getattr(cfg, "image_size", 0) or 0)
         if name.startswith("procedural-coca"):
             parts = name.split(":")
             seed = int(parts[1]) if len(parts) > 1 else 0
             boost = float(parts[2]) if len(parts) > 2 else 0.0
             self.arch = CocaArch.tiny() if parts[0] == "procedural-coca-tiny" else CocaArch()
+            if image_size:
+                self.arch = dataclasses.replace(self.arch, image_size=image_size)
             sd = procedural_coca_state_dict(self.arch, seed, eos_boost=boost)
         else:
             if name != "coca_ViT-L-14":
@@ -46,7 +52,7 @@ class CoCa(CaptioningPredictor):
             ck = getattr(cfg, "checkpoint_name", None)
             if not ck or not os.path.exists(ck):
                 raise RuntimeError(f"Pretrained weights ({ck}) not found for model {name}.")   # factory.py:309-314
-            self.arch = CocaArch()
+            self.arch = CocaArch(image_size=image_size) if image_size else CocaArch()
             sd = load_state_dict_file(ck)
             try:
                 import open_clip

@@ -1,5 +1,6 @@
 """Plugin configuration objects - same fields as the reference's ``experimenting_env/captioner/utils/utils.py:2-12``
-plus optional keys (defaults keep existing yamls working): num_beams, max_length, dtype, batch_size."""
+plus optional keys (defaults keep existing yamls working): num_beams, max_length, dtype, batch_size, device,
+image_size (CoCa: open_clip's force_image_size)."""
 
 
 class Configuration:
@@ -10,7 +11,7 @@ class Configuration:
 
 class CaptionerField:
     def __init__(self, arch_name=None, model_name=None, checkpoint_name=None, height=None, width=None,
-                 num_beams=1, max_length=20, dtype="bf16", batch_size=8, device="cuda:0"):
+                 num_beams=1, max_length=20, dtype="bf16", batch_size=8, device="cuda:0", image_size=None):
         self.arch_name = arch_name
         self.model_name = model_name
         self.checkpoint_name = checkpoint_name
@@ -21,3 +22,4 @@ class CaptionerField:
         self.dtype = dtype
         self.batch_size = batch_size
         self.device = device
+        self.image_size = image_size

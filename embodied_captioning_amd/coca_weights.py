@@ -47,8 +47,26 @@ def derive_coca_tensors(sd: Dict[str, torch.Tensor], a: CocaArch) -> Dict[str, t
     return out
 
 
+def resize_visual_pos_embed(pos: torch.Tensor, a: CocaArch) -> torch.Tensor:
+    """Position table of a checkpoint trained at another resolution -> this arch's token count, the way open_clip's
+    `resize_pos_embed` does when `force_image_size` differs from the pretrained size (reference factory.py:243-245,
+    334-337): the class row is kept, the g0 x g0 grid rows are interpolated to g x g (bicubic, antialias,
+    align_corners=False)."""
+    n, d = pos.shape
+    if n == a.n_tokens:
+        return pos
+    g0 = int(round((n - 1) ** 0.5))
+    if g0 * g0 + 1 != n:
+        raise ValueError(f"visual.positional_embedding has {n} rows: not a class row + square grid")
+    grid = pos[1:].float().reshape(1, g0, g0, d).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, size=(a.grid, a.grid), mode="bicubic", antialias=True, align_corners=False)
+    grid = grid.permute(0, 2, 3, 1).reshape(a.grid * a.grid, d)
+    return torch.cat([pos[:1].float(), grid], 0).contiguous()
+
+
 def coca_library_state_dict(sd: Dict[str, torch.Tensor], a: CocaArch) -> Dict[str, torch.Tensor]:
     """Everything `CaptionerEngine.load_state_dict` should stream in: the checkpoint + the derived tensors."""
     full = dict(sd)
+    full["visual.positional_embedding"] = resize_visual_pos_embed(sd["visual.positional_embedding"], a)
     full.update(derive_coca_tensors(sd, a))
     return full

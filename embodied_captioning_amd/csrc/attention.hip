@@ -4,6 +4,8 @@
 //                      v_mfma_f32_32x32x16_bf16.  S^T = K.Q^T is computed so that a lane owns one query column:
 //                      the softmax row-reduction is in-lane (+ one cross-half shuffle), and the S^T accumulator
 //                      registers are fed straight back as the B operand of O^T = V^T.P^T (no LDS round trip).
+//  vit_attention_flash bf16, 289..608 tokens (CoCa at 336x336): same LDS-resident K/V, keys walked in chunks with an
+//                      online softmax because the score tile no longer fits in registers.
 //  vit_attention_scalar  any dtype / any N: one thread per query, K/V tiles broadcast from LDS, online softmax in
 //                      fp32.  Strict-fp32 mode uses it; tests use it to cross-check the MFMA kernel.
 //  decode_attention    one new query per (row, head) against cached keys (self-attention cache with per-position
@@ -145,6 +147,134 @@ __global__ __launch_bounds__(256, 2) void vit_attention_mfma(const bf16_t* __res
                     *(bf16x4*)(op + db * 32 + 8 * g + 4 * hh) = w;
                 }
         }
+    }
+}
+
+// Long-sequence variant (CoCa ViT-L/14 at 336x336: 577 tokens, KB = 19): K and V of the (image, head) still fit in LDS
+// (2 x 608 x 128 B = 152 KiB, one workgroup per CU), but the 32 x 608 score tile of a query block does not fit in
+// registers, so the keys are walked in chunks of KC blocks with an online softmax (running max m, running sum l,
+// O rescaled by exp2((m_old - m_new) c)) - same MFMA dataflow per chunk as vit_attention_mfma.
+template <int KB, int KC>
+__global__ __launch_bounds__(256, 1) void vit_attention_flash(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                              int N, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NP = KB * 32;
+    char* Ks = smem;
+    char* Vs = smem + NP * 128;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int D = H * 64, ld = 3 * D;
+    const int tid = threadIdx.x, lane = tid & 63, r32 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
+
+    for (int p = wave; p < NP / 8; p += 4) {
+        const int row = p * 8 + (lane >> 3);
+        const int gch = (lane & 7) ^ ((row >> 1) & 7);
+        const bf16_t* src = base + (size_t)min(row, N - 1) * ld + gch * 8;
+        __builtin_amdgcn_global_load_lds(CAP_GPTR(src + D), CAP_LPTR(Ks + p * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(CAP_GPTR(src + 2 * D), CAP_LPTR(Vs + p * 1024), 16, 0, 0);
+    }
+    const int nqt = (N + 31) / 32;
+    auto load_q = [&](int qt, bf16x8 (&qf)[4]) {
+        const int qc = min(qt * 32 + r32, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(base + (size_t)qc * ld + ks * 16 + hh * 8);
+    };
+    bf16x8 qf[4], qn[4];
+    load_q(min(wave, nqt - 1), qf);
+    __syncthreads();   // vmcnt(0) + barrier: every piece has landed
+
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
+    const float c1 = 0.125f * LOG2E;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        load_q(min(qt + 4, nqt - 1), qn);                 // next tile's Q flies under this tile's MFMAs
+        const int q = qt * 32 + r32;
+        float m = -INFINITY, l = 0.f;
+        f32x16 o[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
+#pragma unroll
+        for (int c0 = 0; c0 < KB; c0 += KC) {
+            f32x16 s[KC];
+            float cm = -INFINITY;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const int kb = c0 + kc;
+                if (kb < KB) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) s[kc][e] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        bf16x8 a = *(const bf16x8*)(Ks + swz_off(kb * 32 + r32, ks * 2 + hh));
+                        s[kc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kc], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        if (kb == KB - 1) {      // only the last key block can hold padding keys
+                            const int key = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                            if (key >= N) s[kc][e] = -INFINITY;
+                        }
+                        cm = fmaxf(cm, s[kc][e]);
+                    }
+                }
+            }
+            cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+            const float mn = fmaxf(m, cm);
+            const float alpha = __builtin_amdgcn_exp2f((m - mn) * c1);     // first chunk: exp2(-inf) = 0, l and o are 0
+            l *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+            m = mn;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const int kb = c0 + kc;
+                if (kb < KB) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float pv = __builtin_amdgcn_exp2f((s[kc][e] - mn) * c1);
+                        s[kc][e] = pv;
+                        l += pv;
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        bf16x8 pb;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pb[j] = (bf16_t)s[kc][8 * s2 + j];
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) {
+                            const int dcol = db * 32 + (tg & 1) * 16 + tp * 4;
+                            const int key0 = kb * 32 + 16 * s2 + 4 * (tg >> 1) + tq;
+                            const char* a0 = Vs + swz_off(key0, dcol >> 3) + (dcol & 7) * 2;
+                            const char* a1 = Vs + swz_off(key0 + 8, dcol >> 3) + (dcol & 7) * 2;
+                            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+                            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+                            const bf16x8 a = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        l += __shfl_xor(l, 32, 64);
+        if (q < N) {
+            const float inv = 1.0f / l;
+            bf16_t* op = ctx + ((size_t)b * N + q) * D + h * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 w;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) w[i] = (bf16_t)(o[db][4 * g + i] * inv);
+                    *(bf16x4*)(op + db * 32 + 8 * g + 4 * hh) = w;
+                }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
     }
 }
 
@@ -597,19 +727,34 @@ int launch_mfma_kb(const void* qkv, void* ctx, int B, int N, int H, hipStream_t 
     return 0;
 }
 
+template <int KB, int KC>
+int launch_flash_kb(const void* qkv, void* ctx, int B, int N, int H, hipStream_t s) {
+    const int lds = 2 * KB * 32 * 128;
+    static bool attr_done = false;
+    auto kern = vit_attention_flash<KB, KC>;
+    if (!attr_done && lds > 64 * 1024) {
+        CAP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)ctx, N, H);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s) {
     const int kb = (N + 31) / 32;
-    const bool mfma_ok = dtype == CAP_DT_BF16 && (kb == 1 || kb == 7 || kb == 9);
+    const bool mfma_ok = dtype == CAP_DT_BF16 && (kb == 1 || kb == 7 || kb == 9 || kb == 19);
     if (impl == 2 && !mfma_ok) {
-        cap_set_error("vit_attention: MFMA path needs bf16 and 1, 7 or 9 key blocks (N=%d)", N);
+        cap_set_error("vit_attention: MFMA path needs bf16 and 1, 7, 9 or 19 key blocks (N=%d)", N);
         return -1;
     }
     if (impl == 0) impl = mfma_ok ? 2 : 1;
     if (impl == 2) {
         if (kb == 1) return launch_mfma_kb<1>(qkv, ctx, B, N, H, s);
         if (kb == 7) return launch_mfma_kb<7>(qkv, ctx, B, N, H, s);
+        if (kb == 19) return launch_flash_kb<19, 5>(qkv, ctx, B, N, H, s);
         return launch_mfma_kb<9>(qkv, ctx, B, N, H, s);
     }
     dim3 grid(B * H, (N + 255) / 256);

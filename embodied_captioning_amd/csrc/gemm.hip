@@ -520,12 +520,14 @@ __device__ __forceinline__ void epi_store_f32(const GemmParams& p, int row, int 
 //     a wave confirms its own pieces landed (vmcnt(0)) BEFORE its epilogue stores, so the barrier after the epilogue
 //     does not wait for those stores.
 // VAR: 0 compiler schedule, 1 iglp_opt(0), 2 iglp_opt(1); PROF: cycle stamps to p.aux (diagnostic build only).
+// (Cache-policy A/B on MI355X: non-temporal A loads -5..-20 %, non-temporal C stores within noise - neither kept.)
 template <bool OUT_F32, int EPI, int VAR, bool PROF>
 __global__ __launch_bounds__(512, 2) void gemm_big2_kernel(GemmParams p) {
     using T = bf16_t;
     using vec = bf16x8;
     constexpr int BM = 256, BN = 256, WM = 128, WN = 64, MI = WM / 16, NI = WN / 16;
     constexpr int EPC = 8, STAGE = (BM + BN) * 128;      // 64 KiB
+    constexpr int SCHED = VAR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -620,8 +622,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big2_kernel(GemmParams p) {
             }
             const char* a_s = smem + (cnt & 1) * STAGE;
             const char* b_s = a_s + BM * 128;
-            if constexpr (VAR == 1) __builtin_amdgcn_iglp_opt(0);
-            if constexpr (VAR == 2) __builtin_amdgcn_iglp_opt(1);
+            if constexpr (SCHED == 1) __builtin_amdgcn_iglp_opt(0);
+            if constexpr (SCHED == 2) __builtin_amdgcn_iglp_opt(1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 vec af[MI], bf[NI];

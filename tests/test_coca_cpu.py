@@ -1,4 +1,5 @@
 """CPU: CoCa oracle restatement (parity UNPINNED - open_clip is not available) - self-consistency only."""
+import pytest
 import torch
 
 from embodied_captioning_amd.config import CocaArch
@@ -54,3 +55,22 @@ def test_folded_cross_kv_equals_ln_then_projection():
         got = F.linear(xh, d["derived.cross_kv.weight"][2 * E * i:2 * E * (i + 1)], d["derived.cross_kv.bias"][2 * E * i:2 * E * (i + 1)])
         assert (ref - got).abs().max() < 1e-5
     assert d["derived.vocab.weight"].shape == (a.vocab, E) and d["derived.pool_q"].shape == (a.pool_queries, E)
+
+
+def test_pos_embed_resize_matches_open_clip_recipe():
+    """Class row kept, grid rows bicubic-antialias interpolated (open_clip resize_pos_embed); identity at equal size."""
+    import dataclasses
+    import torch.nn.functional as F
+    from embodied_captioning_amd.coca_weights import resize_visual_pos_embed
+    from embodied_captioning_amd.config import CocaArch
+    a = CocaArch.tiny()                                     # 28 px / patch 14 -> 2x2 grid
+    b = dataclasses.replace(a, image_size=56)               # 4x4 grid
+    pos = torch.randn(a.n_tokens, a.v_hidden, generator=torch.Generator().manual_seed(0))
+    assert resize_visual_pos_embed(pos, a) is pos
+    out = resize_visual_pos_embed(pos, b)
+    assert out.shape == (17, a.v_hidden) and torch.equal(out[0], pos[0])
+    want = F.interpolate(pos[1:].reshape(1, 2, 2, -1).permute(0, 3, 1, 2), size=(4, 4), mode="bicubic", antialias=True,
+                         align_corners=False).permute(0, 2, 3, 1).reshape(16, -1)
+    assert torch.allclose(out[1:], want)
+    with pytest.raises(ValueError):
+        resize_visual_pos_embed(torch.zeros(7, a.v_hidden), b)

@@ -92,6 +92,34 @@ def test_coca_vit_l14_full_size_bf16_encoder_and_first_tokens():
     eng.close()
 
 
+def test_coca_vit_l14_336_encoder_bf16():
+    """SURVEY.md 8(d) config 5's input size: 336x336 -> 577 tokens (the online-softmax ViT attention kernel), with the
+    position table of a 224-pixel checkpoint resized at load the way open_clip's force_image_size does."""
+    import dataclasses
+    from embodied_captioning_amd.coca_weights import coca_library_state_dict
+    from embodied_captioning_amd.config import CocaArch
+    from embodied_captioning_amd.engine import CaptionerEngine
+    from embodied_captioning_amd.weights import procedural_coca_state_dict, synthetic_pixels
+    from oracle import coca_ref as R
+    a224 = CocaArch()
+    a = dataclasses.replace(a224, image_size=336)
+    assert a.n_tokens == 577
+    sd224 = procedural_coca_state_dict(a224, 0, eos_boost=0.0)
+    sd = coca_library_state_dict(sd224, a)                 # resizes visual.positional_embedding 257 -> 577 rows
+    assert sd["visual.positional_embedding"].shape == (577, a.v_hidden)
+    assert torch.equal(sd["visual.positional_embedding"][0], sd224["visual.positional_embedding"][0].float())
+    px = synthetic_pixels(2, 336, seed=0)
+    eng = CaptionerEngine(a, dtype="bf16", max_batch=2, max_beams=1, max_len=a.seq_len)
+    eng.load_state_dict(sd)
+    _, embs = R.encode_image(sd, a, px)
+    tok = eng.encode(px.cuda()).cpu()
+    err = (tok[:, 1:] - embs).abs().max().item()
+    assert err < 0.25, err
+    seq = eng.generate(px.cuda(), max_length=a.seq_len)["sequences"].cpu()
+    assert (seq[:, 0] == a.sot).all() and (seq[:, -1] == a.eos).all()
+    eng.close()
+
+
 def test_coca_wrapper_dict_api():
     from PIL import Image
     from embodied_captioning_amd.captioner.utils.utils import Configuration

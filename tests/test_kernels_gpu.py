@@ -109,7 +109,7 @@ def _attn_ref(qkv, B, N, H):
 
 
 @pytest.mark.parametrize("dtype,impl", [("f32", 1), ("bf16", 1), ("bf16", 2)])
-@pytest.mark.parametrize("N", [17, 197, 257])
+@pytest.mark.parametrize("N", [17, 197, 257, 577])
 def test_vit_attention(lib, dtype, impl, N):
     tag, tdt = DT[dtype]
     B, H = 3, 4
