@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the extra strict-fp32 measurement")
     ap.add_argument("--cpu-sample", type=int, default=64, help="captions timed on the host CPU oracle")
-    ap.add_argument("--model", default="blip", choices=["blip", "coca"],
+    ap.add_argument("--model", default="blip", choices=["blip", "coca", "minilm"],
                     help="blip = BASELINE.json metric workload (default); coca = extra line for config 5's model "
                          "(CoCa ViT-L/14, reference top-k(1) loop, seq_len 30)")
     ap.add_argument("--lite", action="store_true", help="timed steps only (profiler counter passes): no roofline / "
@@ -194,10 +194,55 @@ def main_coca(a):
     print(json.dumps(line))
 
 
+def main_minilm(a):
+    """Extra (non-headline) measurement: the caption-embedding step (all-MiniLM-L6-v2 shapes) on one batch of --batch
+    caption-sized token rows (3..24 tokens), with the CPU restatement timed beside it."""
+    from embodied_captioning_amd.config import MiniLMArch
+    from embodied_captioning_amd.engine import TextEncoderEngine
+    from embodied_captioning_amd.weights import procedural_minilm_state_dict, synthetic_token_batch
+    torch.cuda.set_device(0)
+    arch, B, L = MiniLMArch(), a.batch, 24
+    sd = procedural_minilm_state_dict(arch, 0)
+    ids, lens = synthetic_token_batch(arch, B, L, 0)
+    eng = TextEncoderEngine(arch, dtype=a.dtype, max_batch=B, max_len=L)
+    eng.load_state_dict(sd)
+    idd, lnd = ids.cuda(), lens.cuda()
+    for _ in range(a.warmup):
+        eng.embed(idd, lnd)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = eng.embed(idd, lnd)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.profile(True)
+    eng.embed(idd, lnd)
+    rep = eng.profile_report()
+    eng.profile(False)
+    line = {"metric": "caption embeddings/sec (all-MiniLM-L6-v2 shapes, 3..24 tokens)", "value": round(B * a.steps / dt, 1),
+            "unit": "sentences/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "higher_is_better": True, "dtype": a.dtype, "data": "synthetic token rows, procedural weights",
+            "config": {"workload": f"6-layer BERT encoder + mean pool + L2 norm, {B} sentences x {L} padded tokens"},
+            "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}}
+    if not a.no_cpu_baseline:
+        from oracle import minilm_ref as R
+        torch.set_num_threads(host_cores())
+        R.encode_tokens(sd, arch, ids[:32], lens[:32])
+        t0 = time.perf_counter()
+        ref = R.encode_tokens(sd, arch, ids, lens)
+        cdt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": round(B / cdt, 1), "unit": "sentences/s", "cores": host_cores(), "kind": "port",
+                                "sample": f"{B} sentences, oracle/minilm_ref.py fp32, {cdt:.2f}s wall"}
+        line["max_abs_diff_vs_oracle"] = float((out.cpu() - ref).abs().max())
+    print(json.dumps(line))
+
+
 def main():
     a = parse()
     if a.model == "coca":
         return main_coca(a)
+    if a.model == "minilm":
+        return main_minilm(a)
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

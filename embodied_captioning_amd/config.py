@@ -155,3 +155,26 @@ class CocaArch:
         return CocaArch(image_size=28, patch_size=14, v_hidden=128, v_layers=2, v_heads=2, v_mlp=256, embed_dim=128,
                         pool_queries=8, pool_heads=2, t_hidden=128, t_layers=2, mm_layers=2, t_heads=2, t_ffn=256,
                         vocab=512, context_length=20, sot=510, eos=511, pad=0, seq_len=12, min_seq_len=3)
+
+
+@dataclasses.dataclass
+class MiniLMArch:
+    """sentence-transformers/all-MiniLM-L6-v2 (the caption embedder of the reference: goal_exploration.py:57,
+    pseudolabeler.py:568): HF BertModel 6 x 384, 12 heads of 32, FFN 1536, post-LN eps 1e-12, WordPiece vocab 30522,
+    then mean pooling over the attention mask and L2 normalisation -> 384-d."""
+    hidden: int = 384
+    layers: int = 6
+    heads: int = 12
+    ffn: int = 1536
+    vocab: int = 30522
+    max_pos: int = 512
+    eps: float = 1e-12
+    cls: int = 101
+    sep: int = 102
+    pad: int = 0
+    max_seq_length: int = 256      # sentence-transformers truncation for this model
+
+    @staticmethod
+    def tiny() -> "MiniLMArch":
+        return MiniLMArch(hidden=64, layers=2, heads=2, ffn=128, vocab=300, max_pos=40, cls=1, sep=2, pad=0,
+                          max_seq_length=32)

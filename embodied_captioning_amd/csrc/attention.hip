@@ -713,6 +713,51 @@ __global__ __launch_bounds__(64) void pool_attention_kernel(const float* __restr
     }
 }
 
+// ---- sentence-encoder self-attention (bidirectional, key-padding mask from the sentence length): a caption is <= a few
+// dozen tokens, so one wave owns one (sentence, head): K and V rows sit in LDS as fp32, lane = query, online softmax over
+// the valid keys.  <0.5 % of the encoder's flops; head_dim is a template parameter (MiniLM: 384 / 12 = 32).
+template <typename T, int HD>
+__global__ __launch_bounds__(64) void text_attention_kernel(const T* __restrict__ qkv, const int* __restrict__ lens,
+                                                            T* __restrict__ ctx, int L, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ks = (float*)smem;
+    float* Vs = Ks + (size_t)L * HD;
+    const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+    const int D = H * HD, ld = 3 * D;
+    const int n = min(max(lens[b], 1), L);
+    const T* base = qkv + (size_t)b * L * ld + h * HD;
+    for (int i = lane; i < n * HD; i += 64) {
+        const int j = i / HD, d = i - j * HD;
+        Ks[i] = to_f32(base[(size_t)j * ld + D + d]);
+        Vs[i] = to_f32(base[(size_t)j * ld + 2 * D + d]);
+    }
+    __syncthreads();
+    const float scale = HD == 32 ? 0.17677669529663687f : 0.125f;
+    for (int q0 = 0; q0 < L; q0 += 64) {
+        const int q = q0 + lane;
+        if (q >= L) break;
+        float qv[HD], o[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { qv[d] = to_f32(base[(size_t)q * ld + d]) * scale; o[d] = 0.f; }
+        float m = -INFINITY, l = 0.f;
+        for (int j = 0; j < n; ++j) {
+            float sc = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) sc = fmaf(qv[d], Ks[j * HD + d], sc);
+            const float mn = fmaxf(m, sc);
+            const float c = expf(m - mn), pj = expf(sc - mn);
+            l = l * c + pj;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) o[d] = fmaf(pj, Vs[j * HD + d], o[d] * c);
+            m = mn;
+        }
+        const float inv = 1.0f / l;
+        T* op = ctx + ((size_t)b * L + q) * D + h * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) op[d] = from_f32<T>(o[d] * inv);
+    }
+}
+
 template <int KB>
 int launch_mfma_kb(const void* qkv, void* ctx, int B, int N, int H, hipStream_t s) {
     const int lds = 2 * KB * 32 * 128;
@@ -817,6 +862,22 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
         hipLaunchKernelGGL(decode_attention_kernel<float>, grid, dim3(256), lds, s, (const float*)q,
                            (const float*)kbase, (const float*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys,
                            (float*)out, H);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_text_attention(int dtype, const void* qkv, const int* lens, void* ctx, int B, int L, int H, int head_dim,
+                          hipStream_t s) {
+    if ((head_dim != 32 && head_dim != 64) || L < 1 || L > 512) {
+        cap_set_error("text_attention: head_dim %d / length %d unsupported (32 or 64, 1..512)", head_dim, L);
+        return -1;
+    }
+    const int lds = 2 * L * head_dim * 4;
+#define CAP_TA(TT, HDD)                                                                                                \
+    hipLaunchKernelGGL((text_attention_kernel<TT, HDD>), dim3(B * H), dim3(64), lds, s, (const TT*)qkv, lens, (TT*)ctx, L, H)
+    if (dtype == CAP_DT_BF16) { if (head_dim == 32) CAP_TA(bf16_t, 32); else CAP_TA(bf16_t, 64); }
+    else { if (head_dim == 32) CAP_TA(float, 32); else CAP_TA(float, 64); }
+#undef CAP_TA
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }

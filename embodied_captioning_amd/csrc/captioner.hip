@@ -98,6 +98,9 @@ struct Captioner {
     std::vector<CBlock> cb;
     std::vector<void*> ccache;
     int ldl;
+    // ---- sentence encoder (CAP_ARCH_MINILM): token-type row 0, activations [max_batch * max_len, .]
+    float *tok_type = nullptr, *te_x = nullptr, *te_y = nullptr;
+    void *te_xt = nullptr, *te_qkv = nullptr, *te_ctx = nullptr, *te_h = nullptr;
     // profiling
     bool prof = false;
     std::vector<ProfTag> prof_recs;
@@ -408,6 +411,88 @@ int gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, int lda, c
     return launch_gemm(m->dt, p, 0, s);   // tile 0 = auto (stream kernel for encoder-sized problems without residual)
 }
 
+// ---------------------------------------------------------------------------------------------- sentence encoder
+// HF BertModel state-dict names, as sentence-transformers stores all-MiniLM-L6-v2 (6 layers, 384 wide, 12 heads of 32,
+// FFN 1536, post-LN, eps 1e-12).  Replaces `SentenceTransformer("all-MiniLM-L6-v2").encode(caption)` - reference
+// agents/goal_exploration/goal_exploration.py:57,102 and detector/pseudolabeler.py:568,677.
+int build_minilm(Captioner* m) {
+    const CapConfig& c = m->c;
+    const int T = c.t_hidden, F = c.t_ffn, V = c.vocab;
+    TRY(reg_f32(m, "embeddings.word_embeddings.weight", &m->word_f32, (int64_t)V * T));
+    TRY(reg_f32(m, "embeddings.position_embeddings.weight", &m->tpos, (int64_t)c.max_pos * T));
+    TRY(dev_alloc(m, (void**)&m->tok_type, (size_t)2 * T * 4));
+    add_slot(m, "embeddings.token_type_embeddings.weight", m->tok_type, CAP_DT_F32, 2, T);
+    TRY(reg_f32(m, "embeddings.LayerNorm.weight", &m->emb_g, T));
+    TRY(reg_f32(m, "embeddings.LayerNorm.bias", &m->emb_b, T));
+    m->tl.resize(c.t_layers);
+    for (int i = 0; i < c.t_layers; ++i) {
+        TLayer& L = m->tl[i];
+        const std::string p = "encoder.layer." + std::to_string(i) + ".";
+        TRY(dev_alloc(m, &L.w_qkv, (size_t)3 * T * T * m->esz));
+        TRY(dev_alloc(m, (void**)&L.b_qkv, (size_t)3 * T * 4));
+        const char* nm[3] = {"query", "key", "value"};
+        for (int j = 0; j < 3; ++j) {
+            add_slot(m, p + "attention.self." + nm[j] + ".weight", (char*)L.w_qkv + (size_t)j * T * T * m->esz, m->dt, T, T);
+            add_slot(m, p + "attention.self." + nm[j] + ".bias", L.b_qkv + (size_t)j * T, CAP_DT_F32, 1, T);
+        }
+        TRY(reg_mat(m, p + "attention.output.dense.weight", &L.w_so, T, T));
+        TRY(reg_f32(m, p + "attention.output.dense.bias", &L.b_so, T));
+        TRY(reg_f32(m, p + "attention.output.LayerNorm.weight", &L.so_g, T));
+        TRY(reg_f32(m, p + "attention.output.LayerNorm.bias", &L.so_b, T));
+        TRY(reg_mat(m, p + "intermediate.dense.weight", &L.w_f1, F, T));
+        TRY(reg_f32(m, p + "intermediate.dense.bias", &L.b_f1, F));
+        TRY(reg_mat(m, p + "output.dense.weight", &L.w_f2, T, F));
+        TRY(reg_f32(m, p + "output.dense.bias", &L.b_f2, T));
+        TRY(reg_f32(m, p + "output.LayerNorm.weight", &L.f_g, T));
+        TRY(reg_f32(m, p + "output.LayerNorm.bias", &L.f_b, T));
+    }
+    const size_t M = (size_t)c.max_batch * c.max_len, e = m->esz;
+    TRY(dev_alloc(m, (void**)&m->te_x, M * T * 4));
+    TRY(dev_alloc(m, (void**)&m->te_y, M * T * 4));
+    TRY(dev_alloc(m, &m->te_xt, M * T * e));
+    TRY(dev_alloc(m, &m->te_qkv, M * 3 * T * e));
+    TRY(dev_alloc(m, &m->te_ctx, M * T * e));
+    TRY(dev_alloc(m, &m->te_h, M * F * e));
+    return 0;
+}
+
+// ids int32 [B, L] (padded rows: any valid id), lens int32 [B] (tokens incl. [CLS]/[SEP]) -> out fp32 [B, T]: mean of the
+// last hidden states over the valid tokens, L2-normalised.
+int run_text_encoder(Captioner* m, const int* ids, const int* lens, int B, int L, float* out, hipStream_t s) {
+    const CapConfig& c = m->c;
+    const int T = c.t_hidden, F = c.t_ffn, H = c.t_heads, M = B * L;
+    {
+        ProfScope ps(m, s, "te_embed", 0, (double)M * T * (12 + m->esz));
+        TRY(launch_embed_tokens(m->dt, ids, L, m->word_f32, m->tpos, m->tok_type, m->emb_g, m->emb_b, c.t_eps, m->te_xt,
+                                m->te_x, M, T, s));
+    }
+    for (int i = 0; i < c.t_layers; ++i) {
+        const TLayer& Ly = m->tl[i];
+        TRY(gemm(m, s, "te_gemm_qkv", m->te_xt, T, Ly.w_qkv, T, m->te_qkv, 3 * T, Ly.b_qkv, nullptr, M, 3 * T, T, 0, 0,
+                 EPI_STORE, 0, 0, 0, 0, nullptr, nullptr));
+        {
+            ProfScope ps(m, s, "te_attention", 4.0 * B * H * (double)L * L * (T / H), (double)M * 4 * T * m->esz);
+            TRY(launch_text_attention(m->dt, m->te_qkv, lens, m->te_ctx, B, L, H, T / H, s));
+        }
+        TRY(gemm(m, s, "te_gemm_o", m->te_ctx, T, Ly.w_so, T, m->te_y, T, Ly.b_so, m->te_x, M, T, T, 0, 1, EPI_STORE, 0, 0, 0,
+                 0, nullptr, nullptr));
+        {
+            ProfScope ps(m, s, "te_layernorm", 0, (double)M * T * (8 + m->esz));
+            TRY(launch_layernorm(m->dt, m->te_y, T, Ly.so_g, Ly.so_b, c.t_eps, m->te_xt, m->te_x, M, T, s));
+        }
+        TRY(gemm(m, s, "te_gemm_f1", m->te_xt, T, Ly.w_f1, T, m->te_h, F, Ly.b_f1, nullptr, M, F, T, 1, 0, EPI_STORE, 0, 0, 0,
+                 0, nullptr, nullptr));
+        TRY(gemm(m, s, "te_gemm_f2", m->te_h, F, Ly.w_f2, F, m->te_y, T, Ly.b_f2, m->te_x, M, T, F, 0, 1, EPI_STORE, 0, 0, 0,
+                 0, nullptr, nullptr));
+        {
+            ProfScope ps(m, s, "te_layernorm", 0, (double)M * T * (8 + m->esz));
+            TRY(launch_layernorm(m->dt, m->te_y, T, Ly.f_g, Ly.f_b, c.t_eps, m->te_xt, m->te_x, M, T, s));
+        }
+    }
+    ProfScope ps(m, s, "te_pool", 0, (double)M * T * 4);
+    return launch_mean_pool_normalize(m->te_x, lens, B, L, T, out, s);
+}
+
 // ---------------------------------------------------------------------------------------------- encoder
 int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_embeds, hipStream_t s) {
     // BLIP: final LayerNorm = post_layernorm -> image_embeds (fp32 to the caller + T for the cross-K/V GEMM).
@@ -716,33 +801,48 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
         cap_set_error("cap_create: CapConfig size mismatch (caller %d, library %d)", cfg->struct_size, (int)sizeof(CapConfig));
         return -1;
     }
-    if (cfg->arch != CAP_ARCH_BLIP && cfg->arch != CAP_ARCH_COCA) { cap_set_error("cap_create: unknown arch %d", cfg->arch); return -1; }
-    if (cfg->arch == CAP_ARCH_COCA) {
-        const int hd = cfg->pool_heads > 0 ? cfg->embed_dim / cfg->pool_heads : 0;
-        if (cfg->embed_dim != cfg->t_hidden || cfg->pool_queries < 2 || cfg->mm_layers < 1 || (hd != 64 && hd != 96) ||
-            hd * cfg->pool_heads != cfg->embed_dim || cfg->max_beams != 1) {
-            cap_set_error("cap_create: CoCa needs embed_dim == t_hidden, pooler head_dim 64 or 96, mm_layers >= 1, max_beams 1");
-            return -1;
-        }
+    if (cfg->arch != CAP_ARCH_BLIP && cfg->arch != CAP_ARCH_COCA && cfg->arch != CAP_ARCH_MINILM) {
+        cap_set_error("cap_create: unknown arch %d", cfg->arch);
+        return -1;
     }
     if (cfg->compute_dtype != CAP_F32 && cfg->compute_dtype != CAP_BF16) { cap_set_error("cap_create: unknown dtype"); return -1; }
-    if (cfg->v_hidden != cfg->v_heads * 64 || cfg->t_hidden != cfg->t_heads * 64) {
-        cap_set_error("cap_create: head_dim must be 64 (v %d/%d, t %d/%d)", cfg->v_hidden, cfg->v_heads, cfg->t_hidden, cfg->t_heads);
-        return -1;
+    const bool text_only = cfg->arch == CAP_ARCH_MINILM;
+    if (text_only) {
+        const int hd = cfg->t_heads > 0 ? cfg->t_hidden / cfg->t_heads : 0;
+        if ((hd != 32 && hd != 64) || hd * cfg->t_heads != cfg->t_hidden || cfg->t_hidden % 64 || cfg->t_ffn % 64 ||
+            cfg->t_hidden > 1024 || cfg->t_layers < 1 || cfg->max_batch < 1 || cfg->max_len < 1 || cfg->max_len > cfg->max_pos ||
+            cfg->max_len > 512 || cfg->vocab < 1) {
+            cap_set_error("cap_create: sentence encoder needs head_dim 32 or 64, widths multiple of 64 (hidden <= 1024), "
+                          "1 <= max_len <= min(max_pos, 512)");
+            return -1;
+        }
+    } else {
+        if (cfg->arch == CAP_ARCH_COCA) {
+            const int hd = cfg->pool_heads > 0 ? cfg->embed_dim / cfg->pool_heads : 0;
+            if (cfg->embed_dim != cfg->t_hidden || cfg->pool_queries < 2 || cfg->mm_layers < 1 || (hd != 64 && hd != 96) ||
+                hd * cfg->pool_heads != cfg->embed_dim || cfg->max_beams != 1) {
+                cap_set_error("cap_create: CoCa needs embed_dim == t_hidden, pooler head_dim 64 or 96, mm_layers >= 1, max_beams 1");
+                return -1;
+            }
+        }
+        if (cfg->v_hidden != cfg->v_heads * 64 || cfg->t_hidden != cfg->t_heads * 64) {
+            cap_set_error("cap_create: head_dim must be 64 (v %d/%d, t %d/%d)", cfg->v_hidden, cfg->v_heads, cfg->t_hidden, cfg->t_heads);
+            return -1;
+        }
+        if (cfg->image_size % cfg->patch_size || cfg->max_batch < 1 || cfg->max_beams < 1 || cfg->max_beams > 8 ||
+            cfg->max_len < 2 || cfg->max_len > cfg->max_pos) {
+            cap_set_error("cap_create: bad geometry/capacity");
+            return -1;
+        }
+        if (cfg->v_hidden % 64 || cfg->v_mlp % 64 || cfg->t_ffn % 64) { cap_set_error("cap_create: widths must be multiples of 64"); return -1; }
     }
-    if (cfg->image_size % cfg->patch_size || cfg->max_batch < 1 || cfg->max_beams < 1 || cfg->max_beams > 8 ||
-        cfg->max_len < 2 || cfg->max_len > cfg->max_pos) {
-        cap_set_error("cap_create: bad geometry/capacity");
-        return -1;
-    }
-    if (cfg->v_hidden % 64 || cfg->v_mlp % 64 || cfg->t_ffn % 64) { cap_set_error("cap_create: widths must be multiples of 64"); return -1; }
     Captioner* m = new Captioner();
     m->c = *cfg;
     m->dt = cfg->compute_dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32;
     m->esz = m->dt == CAP_DT_BF16 ? 2 : 4;
-    const int g = cfg->image_size / cfg->patch_size;
+    const int g = text_only ? 0 : cfg->image_size / cfg->patch_size;
     m->P = g * g; m->NT = m->P + 1;
-    m->Kpatch = 3 * cfg->patch_size * cfg->patch_size;
+    m->Kpatch = text_only ? 0 : 3 * cfg->patch_size * cfg->patch_size;
     m->Kpad = (m->Kpatch + 63) / 64 * 64;
     {
         // decode slices: 1 by default. Measured on MI355X (eager and captured into a hipGraph): kernels of different
@@ -757,8 +857,9 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
                  hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) { cap_set_error("cap_create: cannot create decode streams/events"); delete m; return -1; }
     }
-    const int built = cfg->arch == CAP_ARCH_COCA ? (build_coca(m) != 0 || build_arena_coca(m) != 0)
-                                                 : (build_blip(m) != 0 || build_arena(m) != 0);
+    const int built = text_only ? (build_minilm(m) != 0)
+                      : cfg->arch == CAP_ARCH_COCA ? (build_coca(m) != 0 || build_arena_coca(m) != 0)
+                                                   : (build_blip(m) != 0 || build_arena(m) != 0);
     if (built) {
         for (void* p : m->allocs) (void)hipFree(p);
         delete m;
@@ -842,7 +943,21 @@ static int check_call(Captioner* m, int B, int K, int Lm, int fmt) {
         return -1;
     }
     if (fmt != CAP_PIX_F32_NCHW && fmt != CAP_PIX_U8_NHWC) { cap_set_error("unknown pixel format %d", fmt); return -1; }
+    if (m->c.arch == CAP_ARCH_MINILM) { cap_set_error("this handle is a sentence encoder: use cap_embed_text"); return -1; }
     return 0;
+}
+
+int cap_embed_text(CapHandle h, const int32_t* ids, const int32_t* lens, int B, int L, float* out, void* stream) {
+    Captioner* m = (Captioner*)h;
+    if (!m) { cap_set_error("null handle"); return -1; }
+    if (m->c.arch != CAP_ARCH_MINILM) { cap_set_error("cap_embed_text: the handle is not a sentence encoder"); return -1; }
+    if (cap_finalize_weights(h) != 0) return -1;
+    if (!ids || !lens || !out) { cap_set_error("cap_embed_text: null buffer"); return -1; }
+    if (B < 1 || B > m->c.max_batch || L < 1 || L > m->c.max_len) {
+        cap_set_error("cap_embed_text: B=%d L=%d exceeds the handle's capacity (%d, %d)", B, L, m->c.max_batch, m->c.max_len);
+        return -1;
+    }
+    return run_text_encoder(m, ids, lens, B, L, out, (hipStream_t)stream);
 }
 
 int cap_encode(CapHandle h, const void* pixels, int pixel_fmt, int B, float* out_embeds, void* stream) {

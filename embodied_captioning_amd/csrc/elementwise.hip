@@ -263,6 +263,57 @@ __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ seq,
               out_f ? out_f + (size_t)row * D : nullptr);
 }
 
+// Sentence-encoder input embeddings (HF BertEmbeddings, HF:models/bert/modeling_bert.py `BertEmbeddings.forward`):
+// (word[id] + token_type[0]) + position[l], then LayerNorm.  One wave per token row; row = b * L + l.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int* __restrict__ ids, int L,
+                                                           const float* __restrict__ word, const float* __restrict__ pos,
+                                                           const float* __restrict__ type0,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float eps, T* out_t, float* out_f, int R, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const int tok = ids[row], l = row % L;
+    const int nv = (D + 255) / 256;
+    float4 v[LN_MAXV];
+    const float* w = word + (size_t)tok * D;
+    const float* p = pos + (size_t)l * D;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (i < nv && c < D) {
+            const float4 a = *(const float4*)(w + c), t = *(const float4*)(type0 + c), b = *(const float4*)(p + c);
+            v[i].x = (a.x + t.x) + b.x; v[i].y = (a.y + t.y) + b.y; v[i].z = (a.z + t.z) + b.z; v[i].w = (a.w + t.w) + b.w;
+        }
+    }
+    ln_row<T>(v, nv, lane, D, gamma, beta, eps, out_t + (size_t)row * D, out_f + (size_t)row * D);
+}
+
+// sentence-transformers Pooling(mean over the attention mask) + Normalize (F.normalize, eps 1e-12): one block per
+// sentence, one thread per 4 columns.
+__global__ __launch_bounds__(256) void mean_pool_normalize_kernel(const float* __restrict__ x, const int* __restrict__ lens,
+                                                                  int L, int D, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, c = tid * 4;
+    const int n = min(max(lens[b], 1), L);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < D)
+        for (int l = 0; l < n; ++l) {
+            const float4 v = *(const float4*)(x + ((size_t)b * L + l) * D + c);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    const float inv = 1.0f / (float)n;
+    a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
+    float q = wave_sum(c < D ? a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w : 0.f);
+    if ((tid & 63) == 0) red[tid >> 6] = q;
+    __syncthreads();
+    const float nrm = fmaxf(sqrtf(((red[0] + red[1]) + red[2]) + red[3]), 1e-12f);
+    if (c < D) {
+        a.x /= nrm; a.y /= nrm; a.z /= nrm; a.w /= nrm;
+        *(float4*)(out + (size_t)b * D + c) = a;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Greedy step (HF:generation/utils.py:2925-2937): next = argmax (first maximal index, like torch.argmax);
 // finished rows emit pad; a row finishes when it emits EOS or reaches max_len.
@@ -444,6 +495,27 @@ int launch_reduce_layernorm(int dtype, const void* part, int S, const float* bia
     else
         hipLaunchKernelGGL((reduce_layernorm_kernel<float, float>), grid, block, 0, s, (const float*)part, S, bias, resid,
                            gamma, beta, eps, (float*)out_t, out_f, y_out, M, D);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_embed_tokens(int dtype, const int* ids, int L, const float* word, const float* pos, const float* type0,
+                        const float* gamma, const float* beta, float eps, void* out_t, float* out_f, int R, int D,
+                        hipStream_t s) {
+    if (D % 4 != 0 || D > 256 * LN_MAXV) { cap_set_error("embed_tokens: unsupported width %d", D); return -1; }
+    if (dtype == CAP_DT_BF16)
+        hipLaunchKernelGGL(embed_tokens_kernel<bf16_t>, dim3((R + 3) / 4), dim3(256), 0, s, ids, L, word, pos, type0, gamma,
+                           beta, eps, (bf16_t*)out_t, out_f, R, D);
+    else
+        hipLaunchKernelGGL(embed_tokens_kernel<float>, dim3((R + 3) / 4), dim3(256), 0, s, ids, L, word, pos, type0, gamma,
+                           beta, eps, (float*)out_t, out_f, R, D);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_mean_pool_normalize(const float* x, const int* lens, int B, int L, int D, float* out, hipStream_t s) {
+    if (D % 4 != 0 || D > 1024) { cap_set_error("mean_pool: unsupported width %d", D); return -1; }
+    hipLaunchKernelGGL(mean_pool_normalize_kernel, dim3(B), dim3(256), 0, s, x, lens, L, D, out);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }

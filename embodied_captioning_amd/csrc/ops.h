@@ -24,6 +24,12 @@ int launch_reduce_layernorm(int dtype, const void* part, int S, const float* bia
                             const float* gamma, const float* beta, float eps, void* out_t, float* out_f, float* y_out,
                             int M, int D, hipStream_t s, bool per_row_block = false, bool part_in_t = false);
 // decoder embeddings: x = LN(word[tok] + pos[t]); tok = seq[row*seq_ld + t]
+int launch_embed_tokens(int dtype, const int* ids, int L, const float* word, const float* pos, const float* type0,
+                        const float* gamma, const float* beta, float eps, void* out_t, float* out_f, int R, int D,
+                        hipStream_t s);
+int launch_mean_pool_normalize(const float* x, const int* lens, int B, int L, int D, float* out, hipStream_t s);
+int launch_text_attention(int dtype, const void* qkv, const int* lens, void* ctx, int B, int L, int H, int head_dim,
+                          hipStream_t s);
 int launch_embed(int dtype, const int* seq, int seq_ld, int t, const float* word, const float* pos,
                  const float* gamma, const float* beta, float eps, void* out_t, float* out_f, int R, int D,
                  hipStream_t s, float* y_out = nullptr);   // y_out: the un-normalised sum (pre-LN residual stream)

@@ -12,7 +12,7 @@ from typing import Dict, Optional
 import torch
 
 from . import _native as N
-from .config import BlipArch, CocaArch
+from .config import BlipArch, CocaArch, MiniLMArch
 
 OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -165,3 +165,61 @@ class CaptionerEngine:
         buf = C.create_string_buffer(1 << 16)
         N.check(self.lib.cap_profile_report(self._h, buf, len(buf)), "cap_profile_report")
         return json.loads(buf.value.decode())
+
+
+class TextEncoderEngine:
+    """Sentence encoder replica (CAP_ARCH_MINILM handle): WordPiece ids + lengths -> L2-normalised mean-pooled embeddings.
+    Replaces `SentenceTransformer("all-MiniLM-L6-v2").encode(...)` (reference goal_exploration.py:57,102;
+    pseudolabeler.py:568,677); tokenisation stays on the host (captioner/sentence_encoder.py)."""
+
+    def __init__(self, arch: MiniLMArch, dtype: str = "bf16", max_batch: int = 64, max_len: int = 32,
+                 device: str | torch.device = "cuda:0"):
+        if not torch.cuda.is_available():
+            raise N.CaptionerHipError("TextEncoderEngine needs a GPU; there is no CPU fallback in the product path")
+        self.lib = N.load_library()
+        self.arch, self.dtype, self.device = arch, dtype, torch.device(device)
+        self.max_batch, self.max_len = max_batch, max_len
+        cfg = N.CapConfig()
+        cfg.struct_size = C.sizeof(N.CapConfig)
+        cfg.arch = 2
+        cfg.compute_dtype = _DTYPES[dtype]
+        cfg.t_hidden, cfg.t_layers, cfg.t_heads, cfg.t_ffn = arch.hidden, arch.layers, arch.heads, arch.ffn
+        cfg.vocab, cfg.max_pos, cfg.t_eps = arch.vocab, arch.max_pos, arch.eps
+        cfg.max_batch, cfg.max_beams, cfg.max_len = max_batch, 1, max_len
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            N.check(self.lib.cap_create(C.byref(cfg), C.byref(self._h)), "cap_create")
+
+    close = CaptionerEngine.close
+    __del__ = CaptionerEngine.__del__
+    device_bytes = CaptionerEngine.device_bytes
+    profile = CaptionerEngine.profile
+    profile_report = CaptionerEngine.profile_report
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        """HF BertModel names; a leading `0.auto_model.` / `bert.` prefix (sentence-transformers / BertFor* saves) is dropped."""
+        clean = {}
+        for k, v in sd.items():
+            for pre in ("0.auto_model.", "auto_model.", "bert."):
+                if k.startswith(pre):
+                    k = k[len(pre):]
+            clean[k] = v
+        self.is_coca = False
+        CaptionerEngine.load_state_dict(self, clean, strict)
+
+    def embed(self, ids: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
+        """ids int [B, L] (pad anywhere after `lens[b]` tokens), lens int [B] -> fp32 [B, hidden] on the device."""
+        if ids.dim() != 2 or lens.shape != (ids.shape[0],):
+            raise ValueError(f"ids must be [B, L] and lens [B], got {tuple(ids.shape)} / {tuple(lens.shape)}")
+        B, L = ids.shape
+        if int(lens.max()) > L or int(lens.min()) < 1:
+            raise ValueError("lens must be within 1..L")
+        if int(ids.max()) >= self.arch.vocab or int(ids.min()) < 0:
+            raise ValueError("token id outside the vocabulary")
+        ids = ids.to(self.device, torch.int32).contiguous()
+        lens = lens.to(self.device, torch.int32).contiguous()
+        out = torch.empty((B, self.arch.hidden), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.cap_embed_text(self._h, C.c_void_p(ids.data_ptr()), C.c_void_p(lens.data_ptr()), B, L,
+                                            C.c_void_p(out.data_ptr()), C.c_void_p(_stream_ptr(self.device))), "cap_embed_text")
+        return out

@@ -18,7 +18,7 @@ from typing import Dict, Iterable, List, Tuple
 import numpy as np
 import torch
 
-from .config import BlipArch, CocaArch
+from .config import BlipArch, CocaArch, MiniLMArch
 
 
 def blip_param_specs(a: BlipArch) -> List[Tuple[str, Tuple[int, ...], str, float]]:
@@ -173,6 +173,52 @@ def procedural_coca_state_dict(arch: CocaArch, seed: int = 0, eos_boost: float =
         sd["text_decoder.text_projection"][:, arch.eos] += eos_boost * beta / float(beta @ beta)
     sd["logit_scale"] = torch.tensor(float(np.log(1 / 0.07)))
     return sd
+
+
+def minilm_param_specs(a: MiniLMArch) -> List[Tuple[str, Tuple[int, ...], str, float]]:
+    """HF BertModel state-dict names (what sentence-transformers saves for all-MiniLM-L6-v2; pooler absent/unused)."""
+    T, F = a.hidden, a.ffn
+    s: List[Tuple[str, Tuple[int, ...], str, float]] = [
+        ("embeddings.word_embeddings.weight", (a.vocab, T), "normal", 0.5),
+        ("embeddings.position_embeddings.weight", (a.max_pos, T), "normal", 0.2),
+        ("embeddings.token_type_embeddings.weight", (2, T), "normal", 0.1),
+        ("embeddings.LayerNorm.weight", (T,), "gamma", 0.1),
+        ("embeddings.LayerNorm.bias", (T,), "normal", 0.05),
+    ]
+    for i in range(a.layers):
+        p = f"encoder.layer.{i}."
+        for nm in ("query", "key", "value"):
+            s.append((p + f"attention.self.{nm}.weight", (T, T), "normal", 1.5 / np.sqrt(T)))
+            s.append((p + f"attention.self.{nm}.bias", (T,), "normal", 0.02))
+        s.append((p + "attention.output.dense.weight", (T, T), "normal", 1.0 / np.sqrt(T)))
+        s.append((p + "attention.output.dense.bias", (T,), "normal", 0.02))
+        s.append((p + "attention.output.LayerNorm.weight", (T,), "gamma", 0.1))
+        s.append((p + "attention.output.LayerNorm.bias", (T,), "normal", 0.05))
+        s.append((p + "intermediate.dense.weight", (F, T), "normal", 1.0 / np.sqrt(T)))
+        s.append((p + "intermediate.dense.bias", (F,), "normal", 0.02))
+        s.append((p + "output.dense.weight", (T, F), "normal", 1.0 / np.sqrt(F)))
+        s.append((p + "output.dense.bias", (T,), "normal", 0.02))
+        s.append((p + "output.LayerNorm.weight", (T,), "gamma", 0.1))
+        s.append((p + "output.LayerNorm.bias", (T,), "normal", 0.05))
+    return s
+
+
+def procedural_minilm_state_dict(arch: MiniLMArch, seed: int = 0) -> Dict[str, torch.Tensor]:
+    return {name: torch.from_numpy(_draw(seed, name, shape, kind, scale)) for name, shape, kind, scale in minilm_param_specs(arch)}
+
+
+def synthetic_token_batch(arch: MiniLMArch, batch: int, max_len: int, seed: int = 0):
+    """Seeded WordPiece-like id rows: [CLS] w.. [SEP] then pad; lengths 3..max_len (ragged).  -> (ids int32 [B, L], lens int32 [B])"""
+    rng = np.random.Generator(np.random.PCG64(seed + 7919))
+    lens = rng.integers(3, max_len + 1, size=batch)
+    lens[0] = max_len
+    ids = np.full((batch, max_len), arch.pad, dtype=np.int32)
+    for b in range(batch):
+        n = int(lens[b])
+        ids[b, 0] = arch.cls
+        ids[b, 1:n - 1] = rng.integers(max(arch.sep, arch.cls) + 1, arch.vocab, size=n - 2)
+        ids[b, n - 1] = arch.sep
+    return torch.from_numpy(ids), torch.from_numpy(lens.astype(np.int32))
 
 
 def synthetic_pixels(batch: int, image_size: int, seed: int = 0, first: int = 0) -> torch.Tensor:

@@ -14,6 +14,8 @@
  *   generate            blip2.py:26 `model.generate(..., output_logits=True)`;       cap_generate
  *                       coca.py:29 `model.generate(x, generation_type=...)`;
  *                       coca_model.py:205-333 (greedy/top-k loop), :335-482 (beam)
+ *   caption embedding   agents/goal_exploration/goal_exploration.py:57,102 and                cap_embed_text
+ *                       detector/pseudolabeler.py:568,677 `SentenceTransformer("all-MiniLM-L6-v2").encode(caption)`  (CAP_ARCH_MINILM handle)
  *   device move/free    predictor_utils.py:187 `.to(...)`; object lifetime            cap_destroy
  *   errors              Python exceptions (utils_captioner.py:6, factory.py:231,309)  int return codes + cap_last_error
  *
@@ -34,13 +36,14 @@ extern "C" {
 
 typedef struct CapHandle_s* CapHandle;
 
-enum { CAP_ARCH_BLIP = 0, CAP_ARCH_COCA = 1 };
+enum { CAP_ARCH_BLIP = 0, CAP_ARCH_COCA = 1, CAP_ARCH_MINILM = 2 };
 enum { CAP_F32 = 0, CAP_BF16 = 1 };              /* arithmetic type of the GEMM/attention operands (accumulate: fp32) */
 enum { CAP_PIX_F32_NCHW = 0, CAP_PIX_U8_NHWC = 1 }; /* normalised fp32 [B,3,H,W] | raw RGB uint8 [B,H,W,3] */
 
 typedef struct CapConfig {
     int32_t struct_size;          /* sizeof(CapConfig), for ABI checking */
-    int32_t arch;                 /* CAP_ARCH_BLIP */
+    int32_t arch;                 /* CAP_ARCH_BLIP | CAP_ARCH_COCA | CAP_ARCH_MINILM (sentence encoder: only the t_* / vocab /
+                                     max_pos / max_batch / max_len fields are read; max_len = tokens per sentence) */
     int32_t compute_dtype;        /* CAP_F32 (strict parity) | CAP_BF16 (MFMA bf16 in, fp32 accumulate) */
     /* vision tower */
     int32_t image_size, patch_size, v_hidden, v_layers, v_heads, v_mlp;
@@ -92,6 +95,12 @@ int cap_encode(CapHandle h, const void* pixels, int pixel_fmt, int B, float* out
 int cap_generate(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_beams, int max_len,
                  float length_penalty, int32_t* out_ids, int32_t* out_len, float* out_scores,
                  float* out_step_logits, void* stream);
+
+/* Sentence encoder (CAP_ARCH_MINILM handle; weights by HF BertModel names as sentence-transformers stores them):
+ * WordPiece ids int32 [B, L] incl. [CLS]/[SEP] (rows padded with any valid id), lens int32 [B] = valid tokens per row
+ * -> out fp32 [B, t_hidden]: mean of the last hidden states over the valid tokens, L2-normalised
+ * (sentence-transformers Pooling(mean) + Normalize).  All pointers are device pointers. */
+int cap_embed_text(CapHandle h, const int32_t* ids, const int32_t* lens, int B, int L, float* out, void* stream);
 
 /* Bytes of device memory held by the handle (weights + arena). */
 size_t cap_device_bytes(CapHandle h);
