@@ -45,15 +45,16 @@ def parse():
     ap.add_argument("--model", default="blip", choices=["blip", "coca", "minilm"],
                     help="blip = BASELINE.json metric workload (default); coca = extra line for config 5's model "
                          "(CoCa ViT-L/14, reference top-k(1) loop, seq_len 30)")
+    ap.add_argument("--beams", type=int, default=1, help="> 1: extra line for SURVEY config 3 (HF beam search; use --batch 64)")
     ap.add_argument("--lite", action="store_true", help="timed steps only (profiler counter passes): no roofline / "
                     "encoder-only / parity / fp32 / CPU legs")
     ap.add_argument("--image-size", type=int, default=224, help="--model coca only: 224 or 336 (SURVEY config 5)")
     return ap.parse_args()
 
 
-def timed_steps(eng, px, L, steps, warmup, world, gather):
+def timed_steps(eng, px, L, steps, warmup, world, gather, beams=1):
     def one():
-        out = eng.generate(px, num_beams=1, max_length=L)
+        out = eng.generate(px, num_beams=beams, max_length=L)
         return gather(out["sequences"], out["lengths"])
     for _ in range(warmup):
         one()
@@ -272,10 +273,10 @@ def main():
             return ids, lens
 
     log(f"rank {rank}/{world}: weights + {B} frames ready, host cores usable: {host_cores()}")
-    eng = CaptionerEngine(arch, dtype=a.dtype, max_batch=B, max_beams=1, max_len=L, device=dev)
+    eng = CaptionerEngine(arch, dtype=a.dtype, max_batch=B, max_beams=a.beams, max_len=L, device=dev)
     eng.load_state_dict(sd)
     log("weights loaded; timing")
-    dt, (ids, lens) = timed_steps(eng, px, L, a.steps, a.warmup, world, gather)
+    dt, (ids, lens) = timed_steps(eng, px, L, a.steps, a.warmup, world, gather, a.beams)
     log(f"timed region: {dt:.3f}s for {a.steps} steps")
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -284,14 +285,20 @@ def main():
 
     if rank == 0:
         value = world * B * a.steps / dt
-        line = {"metric": "captions/sec (224x224, beam=1)", "value": round(value, 2), "unit": "captions/s",
+        line = {"metric": f"captions/sec (224x224, beam={a.beams})", "value": round(value, 2), "unit": "captions/s",
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
                 "data": "synthetic frames (PCG64, seed = frame index), procedural weights (no checkpoint offline)",
-                "config": {"workload": f"BLIP-base ViT-B/16 encoder + greedy decode, {B} frames/GPU 224x224, "
+                "config": {"workload": f"BLIP-base ViT-B/16 encoder + {'greedy' if a.beams == 1 else f'beam-{a.beams}'} decode, {B} frames/GPU 224x224, "
                                        f"max_length={L}, caption all-gather", "global_batch": world * B,
                            "parallelism": f"dp{world}"}}
-        if a.lite:
+        if a.beams > 1:                      # config 3 extra line: per-kernel profile of one beam generate, then stop
+            eng.profile(True)
+            eng.generate(px, num_beams=a.beams, max_length=L)
+            rep = eng.profile_report()
+            eng.profile(False)
+            line["kernels_ms"] = {k: round(v["ms"], 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:14]}
+        if a.lite or a.beams > 1:
             print(json.dumps(line))
             eng.close()
             return

@@ -4,8 +4,8 @@
 // beam reorder: each row carries a table anc[row][pos] = physical row that wrote position `pos` of its history.
 //
 //   beam_rows_kernel   one block per (item, beam) row: log-softmax statistics + the row's top-2K candidates
-//   beam_merge_kernel  one thread per item: merge K*2K candidates, update running beams / finished pool / ancestry;
-//                      then one reduction for the global "loop still running" flag.
+//   beam_merge_kernel  one 64-thread block per item: merge K*2K candidates, update running beams / finished pool /
+//                      ancestry (ranking sorts in LDS); the global "loop still running" flag is an atomic OR.
 #include "ops.h"
 
 namespace {
@@ -56,7 +56,10 @@ __global__ void beam_init_kernel(char* st, BeamLayout lo, int B, int K, int L, i
         }
     }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) ((int*)(st + lo.open))[i] = 1;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *(int*)(st + lo.active) = 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int* flags = (int*)(st + lo.active);
+        flags[0] = 1; flags[1] = 0; flags[2] = 0; flags[3] = 0; flags[4] = 0;
+    }
 }
 
 // (value desc, index asc) strict ordering: is (v,i) after (pv,pi)?
@@ -114,118 +117,221 @@ __global__ __launch_bounds__(256) void beam_rows_kernel(char* st, BeamLayout lo,
     }
 }
 
-__global__ __launch_bounds__(256) void beam_merge_kernel(char* st, BeamLayout lo, int B, int K, int L, int V,
-                                                         int cur_len, int eos, float denom_fin, float denom_run,
-                                                         const int* __restrict__ anc_old, int* __restrict__ anc_new,
-                                                         int anc_ld) {
-    __shared__ int s_any_open, s_all_hits;
-    const int active = *(const int*)(st + lo.active);
-    if (threadIdx.x == 0) { s_any_open = 0; s_all_hits = 1; }
+// Single-pass variant of beam_rows_kernel: the row is read from global memory once (16-byte loads) into LDS; max, sum-exp
+// and the candidate scan run over the LDS copy; each thread keeps the CT best of ITS elements in a register list
+// (unrolled insertion, static indices), and the block then merges the 256 sorted lists by 2K rounds of block arg-max.
+// Same arithmetic and the same (value desc, index asc) order as beam_rows_kernel, which stays as the fallback for rows
+// that do not fit in LDS.
+template <int CT>
+__global__ __launch_bounds__(256) void beam_rows_lds_kernel(char* st, BeamLayout lo, const float* __restrict__ logits,
+                                                            int ld, int V, int K, int par) {
+    if (*(const int*)(st + lo.active) == 0) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int V4 = (V + 3) >> 2, C = 2 * K;
+    float* xs = (float*)smem;                                  // [V4 * 4], tail padded with -inf
+    float* lv = xs + (size_t)V4 * 4;                           // [C][256] candidate values, c-major
+    int* li = (int*)(lv + (size_t)C * 256);                    // [C][256] candidate indices
+    __shared__ float redf[4];
+    __shared__ int redi[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* x = logits + (size_t)row * ld;
+    float m = -INFINITY;
+    for (int j = tid; j < V4; j += 256) {
+        float4 v;
+        if (4 * j + 3 < V) v = *(const float4*)(x + 4 * j);
+        else {
+            v.x = 4 * j < V ? x[4 * j] : -INFINITY; v.y = 4 * j + 1 < V ? x[4 * j + 1] : -INFINITY;
+            v.z = 4 * j + 2 < V ? x[4 * j + 2] : -INFINITY; v.w = -INFINITY;
+        }
+        *(float4*)(xs + 4 * j) = v;
+        m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    m = wave_max(m);
+    if (lane == 0) redf[wave] = m;
     __syncthreads();
-    if (active) {
-        const int par = cur_len & 1, nxt = par ^ 1, C = 2 * K;
-        const int* rs_old = (const int*)(st + lo.run_seq[par]);   int* rs_new = (int*)(st + lo.run_seq[nxt]);
-        const int* ps_old = (const int*)(st + lo.pool_seq[par]);  int* ps_new = (int*)(st + lo.pool_seq[nxt]);
-        const float* rsc_old = (const float*)(st + lo.run_score[par]); float* rsc_new = (float*)(st + lo.run_score[nxt]);
-        const float* psc_old = (const float*)(st + lo.pool_score[par]); float* psc_new = (float*)(st + lo.pool_score[nxt]);
-        const int* pf_old = (const int*)(st + lo.pool_fin[par]);  int* pf_new = (int*)(st + lo.pool_fin[nxt]);
-        const int* pl_old = (const int*)(st + lo.pool_len[par]);  int* pl_new = (int*)(st + lo.pool_len[nxt]);
-        int* open = (int*)(st + lo.open);
-        (void)rsc_old;
-        for (int b = threadIdx.x; b < B; b += blockDim.x) {
-            // ---- c. top-2K continuations over the K rows' candidate lists (each already sorted)
-            const float* cv = (const float*)(st + lo.cand_val) + (size_t)b * K * C;
-            const int* ci = (const int*)(st + lo.cand_idx) + (size_t)b * K * C;
-            int head[MAXK];
-            for (int k = 0; k < K; ++k) head[k] = 0;
-            float val[MAXC]; int src[MAXC], tok[MAXC]; bool hit[MAXC];
-            bool all_hits = true;
-            for (int c = 0; c < C; ++c) {
-                float bv = -INFINITY; int bk = -1, bflat = 0x7fffffff;
-                for (int k = 0; k < K; ++k) {
-                    if (head[k] >= C) continue;
-                    const float v = cv[k * C + head[k]];
-                    const int flat = k * V + ci[k * C + head[k]];
-                    if (bk < 0 || better(v, flat, bv, bflat)) { bv = v; bk = k; bflat = flat; }
-                }
-                val[c] = bv; src[c] = bk; tok[c] = ci[bk * C + head[bk]]; head[bk]++;
-                hit[c] = (tok[c] == eos) || (cur_len + 1 >= L);
-                all_hits = all_hits && hit[c];
+    m = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    __syncthreads();
+    // log-softmax statistics, same association order as torch: (x - max) - log(sum(exp(x - max))).  The per-thread
+    // element order differs from beam_rows_kernel's (4 consecutive elements per step instead of stride 256), so the fp32
+    // sum may differ from it in the last bits - as it does between any two reduction orders; both are tested against
+    // the oracle's beam scores.
+    float sum = 0.f;
+    for (int j = tid; j < V4; j += 256) {
+        const float4 v = *(const float4*)(xs + 4 * j);
+        sum += expf(v.x - m); sum += expf(v.y - m); sum += expf(v.z - m); sum += expf(v.w - m);   // exp(-inf) = 0 on the pad
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) redf[wave] = sum;
+    __syncthreads();
+    const float lsum = logf(redf[0] + redf[1] + redf[2] + redf[3]);
+    const float run = ((const float*)(st + lo.run_score[par]))[row];
+    __syncthreads();
+    float tv[CT]; int ti[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) { tv[c] = -INFINITY; ti[c] = 0x7fffffff; }
+    for (int j = tid; j < V4; j += 256) {
+        const float4 q = *(const float4*)(xs + 4 * j);
+        const float e[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = 4 * j + u;
+            const float v = ((e[u] - m) - lsum) + run;
+            if (i < V && better(v, i, tv[CT - 1], ti[CT - 1])) {
+                tv[CT - 1] = v; ti[CT - 1] = i;
+#pragma unroll
+                for (int c = CT - 1; c > 0; --c)
+                    if (better(tv[c], ti[c], tv[c - 1], ti[c - 1])) {
+                        const float fv = tv[c]; tv[c] = tv[c - 1]; tv[c - 1] = fv;
+                        const int fi = ti[c]; ti[c] = ti[c - 1]; ti[c - 1] = fi;
+                    }
             }
-            // ---- e. running beams for the next iteration
-            float run_lp[MAXC];
-            for (int c = 0; c < C; ++c) run_lp[c] = val[c] + (hit[c] ? 1.0f : 0.0f) * -1.0e9f;
-            bool used[MAXC];
-            for (int c = 0; c < C; ++c) used[c] = false;
-            for (int k = 0; k < K; ++k) {
-                int bc_ = -1;
-                for (int c = 0; c < C; ++c)
-                    if (!used[c] && (bc_ < 0 || run_lp[c] > run_lp[bc_])) bc_ = c;
-                used[bc_] = true;
-                const int r_new = b * K + k, r_src = b * K + src[bc_];
-                for (int j = 0; j < cur_len; ++j) rs_new[(size_t)r_new * L + j] = rs_old[(size_t)r_src * L + j];
-                rs_new[(size_t)r_new * L + cur_len] = tok[bc_];
-                for (int j = cur_len + 1; j < L; ++j) rs_new[(size_t)r_new * L + j] = rs_old[(size_t)r_src * L + j];
-                rsc_new[r_new] = run_lp[bc_];
-                if (anc_new) {
-                    for (int j = 0; j < cur_len; ++j) anc_new[(size_t)r_new * anc_ld + j] = anc_old[(size_t)r_src * anc_ld + j];
-                    if (cur_len < anc_ld) anc_new[(size_t)r_new * anc_ld + cur_len] = r_new;
-                }
-            }
-            // ---- f. finished pool
-            const bool is_open = open[b] != 0;
-            float msc[MAXK + MAXC];
-            for (int k = 0; k < K; ++k) msc[k] = psc_old[b * K + k];
-            for (int c = 0; c < C; ++c) {
-                const bool just = hit[c] && c < K;
-                float f = val[c] / denom_fin;
-                f = f + 0.0f * -1.0e9f;                              // early_stopping is False on this path
-                f = f + (is_open ? 0.0f : 1.0f) * -1.0e9f;
-                f = f + (just ? 0.0f : 1.0f) * -1.0e9f;
-                msc[K + c] = f;
-            }
-            bool mused[MAXK + MAXC];
-            for (int i = 0; i < K + C; ++i) mused[i] = false;
-            float new_sc[MAXK]; int new_fin[MAXK];
-            for (int k = 0; k < K; ++k) {
-                int bi = -1;
-                for (int i = 0; i < K + C; ++i)
-                    if (!mused[i] && (bi < 0 || msc[i] > msc[bi])) bi = i;
-                mused[bi] = true;
-                const int r_new = b * K + k;
-                if (bi < K) {
-                    const int r_old = b * K + bi;
-                    for (int j = 0; j < L; ++j) ps_new[(size_t)r_new * L + j] = ps_old[(size_t)r_old * L + j];
-                    new_fin[k] = pf_old[r_old]; pl_new[r_new] = pl_old[r_old];
-                } else {
-                    const int c = bi - K, r_src = b * K + src[c];
-                    for (int j = 0; j < L; ++j) ps_new[(size_t)r_new * L + j] = rs_old[(size_t)r_src * L + j];
-                    ps_new[(size_t)r_new * L + cur_len] = tok[c];
-                    new_fin[k] = (hit[c] && c < K) ? 1 : 0; pl_new[r_new] = cur_len + 1;
-                }
-                new_sc[k] = msc[bi]; psc_new[r_new] = msc[bi]; pf_new[r_new] = new_fin[k];
-            }
-            // ---- g. early-stop heuristic (cur_len already advanced by one)
-            float mn = new_sc[0];
-            for (int k = 1; k < K; ++k) mn = fminf(mn, new_sc[k]);
-            const float best_run = rsc_new[b * K] / denom_run;
-            bool any = false;
-            for (int k = 0; k < K; ++k) {
-                const float worst = new_fin[k] ? mn : -1.0e9f;
-                any = any || (best_run > worst);
-            }
-            const int o2 = (is_open && any) ? 1 : 0;
-            open[b] = o2;
-            if (o2) atomicOr(&s_any_open, 1);
-            if (!all_hits) atomicAnd(&s_all_hits, 0);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+        if (c < C) { lv[c * 256 + tid] = tv[c]; li[c * 256 + tid] = ti[c]; }
+    float* cv = (float*)(st + lo.cand_val) + (size_t)row * C;
+    int* ci = (int*)(st + lo.cand_idx) + (size_t)row * C;
+    int h = 0;                                                  // head of this thread's list
+    for (int c = 0; c < C; ++c) {
+        float bv = h < C ? lv[h * 256 + tid] : -INFINITY;
+        int bi = h < C ? li[h * 256 + tid] : 0x7fffffff;
+        const int mine = bi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(bv, o, 64); const int i2 = __shfl_xor(bi, o, 64);
+            if (better(v2, i2, bv, bi)) { bv = v2; bi = i2; }
+        }
+        if (lane == 0) { redf[wave] = bv; redi[wave] = bi; }
+        __syncthreads();
+        float fv = redf[0]; int fi = redi[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) if (better(redf[w], redi[w], fv, fi)) { fv = redf[w]; fi = redi[w]; }
+        if (mine == fi && fi != 0x7fffffff) ++h;                // indices are unique within a row
+        if (tid == 0) { cv[c] = fv; ci[c] = fi; }
+        __syncthreads();
+    }
+}
+
+// One 64-thread block per item.  The three selections of a step (top-2K continuations over the K candidate lists,
+// next running beams, finished pool) are RANKING sorts over <= 128 / 16 / 24 entries held in LDS - every lane ranks its
+// entries by counting the entries that beat them under exactly the comparators of the serial formulation (value
+// descending, then flat index / slot ascending, i.e. "first maximal" of a repeated arg-max) - and the sequence / ancestry
+// rows are copied by all lanes.  The loop-still-running flag is an OR over the items: atomics on the state block, the last
+// block to finish publishes it and clears the accumulators.
+__global__ __launch_bounds__(64) void beam_merge_kernel(char* st, BeamLayout lo, int B, int K, int L, int V,
+                                                        int cur_len, int eos, float denom_fin, float denom_run,
+                                                        const int* __restrict__ anc_old, int* __restrict__ anc_new,
+                                                        int anc_ld) {
+    int* flags = (int*)(st + lo.active);          // [0] active, [1] parity of the final state, [2] any_open, [3] some_miss, [4] done
+    if (flags[0] == 0) return;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int par = cur_len & 1, nxt = par ^ 1, C = 2 * K, NC = K * C;
+    const int* rs_old = (const int*)(st + lo.run_seq[par]);   int* rs_new = (int*)(st + lo.run_seq[nxt]);
+    const int* ps_old = (const int*)(st + lo.pool_seq[par]);  int* ps_new = (int*)(st + lo.pool_seq[nxt]);
+    float* rsc_new = (float*)(st + lo.run_score[nxt]);
+    const float* psc_old = (const float*)(st + lo.pool_score[par]); float* psc_new = (float*)(st + lo.pool_score[nxt]);
+    const int* pf_old = (const int*)(st + lo.pool_fin[par]);  int* pf_new = (int*)(st + lo.pool_fin[nxt]);
+    const int* pl_old = (const int*)(st + lo.pool_len[par]);  int* pl_new = (int*)(st + lo.pool_len[nxt]);
+    int* open = (int*)(st + lo.open);
+
+    __shared__ float cvS[MAXK * MAXC];            // candidate lists of the item's K rows
+    __shared__ int cfS[MAXK * MAXC];              // flat index k * V + token
+    __shared__ float val[MAXC], run_lp[MAXC], msc[MAXK + MAXC], new_sc[MAXK];
+    __shared__ int src[MAXC], tok[MAXC], hit[MAXC], run_pick[MAXK], pool_pick[MAXK], new_fin[MAXK];
+
+    // ---- c. top-2K continuations = the C best of the K*C candidates by (value desc, flat index asc)
+    const float* cv = (const float*)(st + lo.cand_val) + (size_t)b * NC;
+    const int* ci = (const int*)(st + lo.cand_idx) + (size_t)b * NC;
+    for (int i = lane; i < NC; i += 64) { cvS[i] = cv[i]; cfS[i] = (i / C) * V + ci[i]; }
+    __syncthreads();
+    for (int i = lane; i < NC; i += 64) {
+        const float v = cvS[i]; const int f = cfS[i];
+        int rank = 0;
+        for (int j = 0; j < NC; ++j) rank += better(cvS[j], cfS[j], v, f) ? 1 : 0;
+        if (rank < C) {
+            const int k = i / C, t = f - k * V;
+            val[rank] = v; src[rank] = k; tok[rank] = t;
+            hit[rank] = (t == eos || cur_len + 1 >= L) ? 1 : 0;
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0 && active) {
-        const int go = (s_any_open != 0) && (s_all_hits == 0);
-        *(int*)(st + lo.active) = go;
-        // a stopped loop leaves its final state in parity `cur_len & 1 ^ 1`; remember it for finalize
-        ((int*)(st + lo.active))[1] = (cur_len & 1) ^ 1;
+    // ---- e / f inputs
+    const bool is_open = open[b] != 0;
+    if (lane < C) {
+        run_lp[lane] = val[lane] + (hit[lane] ? 1.0f : 0.0f) * -1.0e9f;
+        const bool just = hit[lane] && lane < K;
+        float f = val[lane] / denom_fin;
+        f = f + 0.0f * -1.0e9f;                              // early_stopping is False on this path
+        f = f + (is_open ? 0.0f : 1.0f) * -1.0e9f;
+        f = f + (just ? 0.0f : 1.0f) * -1.0e9f;
+        msc[K + lane] = f;
+    }
+    if (lane < K) msc[lane] = psc_old[b * K + lane];
+    __syncthreads();
+    // ---- e. running beams: K best of run_lp, first maximal slot on ties
+    if (lane < C) {
+        int rank = 0;
+        for (int j = 0; j < C; ++j) rank += (run_lp[j] > run_lp[lane] || (run_lp[j] == run_lp[lane] && j < lane)) ? 1 : 0;
+        if (rank < K) run_pick[rank] = lane;
+    }
+    // ---- f. finished pool: K best of the K old entries and the C candidates, first maximal slot on ties
+    if (lane < K + C) {
+        int rank = 0;
+        for (int j = 0; j < K + C; ++j) rank += (msc[j] > msc[lane] || (msc[j] == msc[lane] && j < lane)) ? 1 : 0;
+        if (rank < K) pool_pick[rank] = lane;
+    }
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        const int r_new = b * K + k;
+        {
+            const int c = run_pick[k], r_src = b * K + src[c];
+            for (int j = lane; j < L; j += 64) rs_new[(size_t)r_new * L + j] = j == cur_len ? tok[c] : rs_old[(size_t)r_src * L + j];
+            if (anc_new)
+                for (int j = lane; j <= cur_len && j < anc_ld; j += 64)
+                    anc_new[(size_t)r_new * anc_ld + j] = j == cur_len ? r_new : anc_old[(size_t)r_src * anc_ld + j];
+            if (lane == 0) rsc_new[r_new] = run_lp[c];
+        }
+        {
+            const int bi = pool_pick[k];
+            if (bi < K) {
+                const int r_old = b * K + bi;
+                for (int j = lane; j < L; j += 64) ps_new[(size_t)r_new * L + j] = ps_old[(size_t)r_old * L + j];
+                if (lane == 0) { new_fin[k] = pf_old[r_old]; pl_new[r_new] = pl_old[r_old]; }
+            } else {
+                const int c = bi - K, r_src = b * K + src[c];
+                for (int j = lane; j < L; j += 64) ps_new[(size_t)r_new * L + j] = j == cur_len ? tok[c] : rs_old[(size_t)r_src * L + j];
+                if (lane == 0) { new_fin[k] = (hit[c] && c < K) ? 1 : 0; pl_new[r_new] = cur_len + 1; }
+            }
+            if (lane == 0) { new_sc[k] = msc[bi]; psc_new[r_new] = msc[bi]; }
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        for (int k = 0; k < K; ++k) pf_new[b * K + k] = new_fin[k];
+        // ---- g. early-stop heuristic (cur_len already advanced by one)
+        float mn = new_sc[0];
+        for (int k = 1; k < K; ++k) mn = fminf(mn, new_sc[k]);
+        const float best_run = run_lp[run_pick[0]] / denom_run;
+        bool any = false, all_hits = true;
+        for (int k = 0; k < K; ++k) {
+            const float worst = new_fin[k] ? mn : -1.0e9f;
+            any = any || (best_run > worst);
+        }
+        for (int c = 0; c < C; ++c) all_hits = all_hits && hit[c];
+        const int o2 = (is_open && any) ? 1 : 0;
+        open[b] = o2;
+        if (o2) atomicOr(&flags[2], 1);
+        if (!all_hits) atomicOr(&flags[3], 1);
+        __threadfence();
+        if (atomicAdd(&flags[4], 1) == B - 1) {
+            __threadfence();
+            const int any_open = atomicOr(&flags[2], 0), some_miss = atomicOr(&flags[3], 0);
+            flags[1] = (cur_len & 1) ^ 1;          // a stopped loop leaves its final state in this parity: finalize reads it
+            flags[2] = 0; flags[3] = 0; flags[4] = 0;
+            __threadfence();
+            flags[0] = (any_open != 0 && some_miss != 0) ? 1 : 0;
+        }
     }
 }
 
@@ -263,14 +369,31 @@ int launch_beam_step(void* state, const float* logits, int ld, int V, int B, int
                      int eos, float length_penalty, int* anc, int anc_ld, hipStream_t s) {
     const BeamLayout lo = beam_layout(B, K, max_len);
     const int par = cur_len & 1;
-    hipLaunchKernelGGL(beam_rows_kernel, dim3(B * K), dim3(256), 0, s, (char*)state, lo, logits, ld, V, K, par);
+    const size_t lds = (size_t)((V + 3) / 4) * 16 + (size_t)2 * K * 256 * 8;
+    if (lds <= 150 * 1024 && (ld & 3) == 0 && V > 2 * K) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            CAP_HIP_CHECK(hipFuncSetAttribute((const void*)beam_rows_lds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            CAP_HIP_CHECK(hipFuncSetAttribute((const void*)beam_rows_lds_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            CAP_HIP_CHECK(hipFuncSetAttribute((const void*)beam_rows_lds_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_done = true;
+        }
+        if (2 * K <= 4)
+            hipLaunchKernelGGL(beam_rows_lds_kernel<4>, dim3(B * K), dim3(256), lds, s, (char*)state, lo, logits, ld, V, K, par);
+        else if (2 * K <= 8)
+            hipLaunchKernelGGL(beam_rows_lds_kernel<8>, dim3(B * K), dim3(256), lds, s, (char*)state, lo, logits, ld, V, K, par);
+        else
+            hipLaunchKernelGGL(beam_rows_lds_kernel<16>, dim3(B * K), dim3(256), lds, s, (char*)state, lo, logits, ld, V, K, par);
+    } else {
+        hipLaunchKernelGGL(beam_rows_kernel, dim3(B * K), dim3(256), 0, s, (char*)state, lo, logits, ld, V, K, par);
+    }
     CAP_HIP_CHECK(hipGetLastError());
     // prompt length is 1 ([BOS]); python computes the float power in double, torch divides in fp32
     const float denom_fin = (float)pow((double)(cur_len + 1 - 1), (double)length_penalty);
     const float denom_run = (float)pow((double)(cur_len + 1 - 1), (double)length_penalty);
     const int* anc_old = anc ? anc + (size_t)par * B * K * anc_ld : nullptr;
     int* anc_new = anc ? anc + (size_t)(par ^ 1) * B * K * anc_ld : nullptr;
-    hipLaunchKernelGGL(beam_merge_kernel, dim3(1), dim3(256), 0, s, (char*)state, lo, B, K, max_len, V, cur_len, eos,
+    hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, s, (char*)state, lo, B, K, max_len, V, cur_len, eos,
                        denom_fin, denom_run, anc_old, anc_new, anc_ld);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
