@@ -4,17 +4,21 @@
 //
 // Both operands are K-contiguous (activations row-major, torch Linear weights [out,in]), so A and W tiles
 // have the same shape in LDS: rows of one 128-byte K-slab (64 bf16 / 32 fp32), 16-byte chunks XOR-swizzled
-// by ((row>>1)&7) so that the ds_read_b128 fragment reads of a 32-row MFMA operand are bank-conflict free
+// by ((row>>1)&7) so that the ds_read_b128 fragment reads of a 16- or 32-row MFMA operand are bank-conflict free
 // (MI355X LDS: ds_read_b128 is served in 16-lane groups over 64 banks).
-//   bf16:  v_mfma_f32_32x32x16_bf16, one 16-byte chunk per lane per k-step (lane half h takes chunk 2*ks+h).
+//   bf16:  v_mfma_f32_16x16x32_bf16 in every kernel (lane (r16, kg) supplies row r16, 16-byte chunk 4*ks+kg); the
+//          first-generation 256x256 kernel (A/B id 5) still uses 32x32x16 - measured bit-identical results.
 //   fp32:  v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 1/16 the bf16 rate); a 16-byte chunk holds 4 k values,
 //          lane half h takes chunk 2*ks+h and feeds 4 MFMAs - A and W use the same k permutation so the sum is
 //          unchanged.
-// Global->LDS goes through registers: D K-slabs are kept in flight in VGPRs (D = 1 for the 256x256 tile whose slab
-// compute covers the load latency, 2 for 128x128, 4 for the latency-bound 64x64 decode tile); LDS is double
-// buffered with one barrier per K-slab.  Edge tiles clamp their load rows and guard their stores.  The epilogue
-// goes through LDS so global stores are 16-byte (fp32) / 8-byte (bf16) per lane and row-contiguous.
-// Workgroup ids are remapped so each XCD (blockIdx % 8) walks a contiguous run of tiles that share A panels in its L2.
+// Three kernels:
+//   gemm_kernel       generic register-staged tiles (128x128, 64x64, 256x256): D K-slabs in flight in VGPRs (2 for
+//                     128x128, 3..6 for the latency-bound 64x64 decode tile), LDS double buffered, one barrier per slab,
+//                     epilogue through LDS strips; split-K (EPI_PARTIAL), residual operand, every epilogue kind.
+//   gemm_big_kernel   256x256 persistent, LDS-DMA staging (fp32 mode; bf16 first generation).
+//   gemm_big2_kernel  bf16 256x256 persistent, second generation (the encoder GEMMs): see its header.
+// Edge tiles clamp their load rows and guard their stores.  Workgroup ids are remapped so each XCD (blockIdx % 8) walks
+// a contiguous run of tiles that share A panels in its L2.
 #include "gemm.h"
 
 namespace {
@@ -279,9 +283,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(G
 #define CAP_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define CAP_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-// VAR selects the scheduling of the inner k-step loop (A/B-tested on the GPU, see tools/bench_gemm_sq.py):
-//   0 plain (compiler scheduled)   1 register double-buffered fragments + sched_group_barrier interleave
-//   2 plain + iglp_opt(0)          3 plain + iglp_opt(1)
+// VAR selects the scheduling of the inner k-step loop: 0 compiler scheduled (fp32), 2 iglp_opt(0), 3 iglp_opt(1) (bf16),
+// 4 = 3 + cycle stamps (diagnostic build, tools/gemm_cycles.py).  (A manual register double-buffer + sched_group_barrier
+// variant measured below iglp_opt(1) and was removed.)
 template <typename T, bool OUT_F32, int EPI, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     constexpr int BM = 256, BN = 256, WM = 128, WN = 64, MI = 4, NI = 2;
@@ -370,39 +374,9 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
             if (kt + 1 < nk) issue(tile, kt + 1, smem + ((cnt + 1) & 1) * STAGE);
             const char* a_s = smem + (cnt & 1) * STAGE;
             const char* b_s = a_s + BM * 128;
-            if constexpr (VAR == 1) {
-                // fragments double-buffered in registers: the ds_reads of k-step ks+1 are issued before the MFMAs of ks
-                vec af[2][MI], bf[2][NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) af[0][i] = *(const vec*)(a_s + swz_off(wm0 + i * 32 + r32, h));
-#pragma unroll
-                for (int j = 0; j < NI; ++j) bf[0][j] = *(const vec*)(b_s + swz_off(wn0 + j * 32 + r32, h));
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    if (ks < 3) {
-#pragma unroll
-                        for (int i = 0; i < MI; ++i)
-                            af[(ks + 1) & 1][i] = *(const vec*)(a_s + swz_off(wm0 + i * 32 + r32, (ks + 1) * 2 + h));
-#pragma unroll
-                        for (int j = 0; j < NI; ++j)
-                            bf[(ks + 1) & 1][j] = *(const vec*)(b_s + swz_off(wn0 + j * 32 + r32, (ks + 1) * 2 + h));
-                    }
-#pragma unroll
-                    for (int i = 0; i < MI; ++i)
-#pragma unroll
-                        for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], af[ks & 1][i], bf[ks & 1][j]);
-                    if (sizeof(T) == 2 && ks < 3) {
-#pragma unroll
-                        for (int r = 0; r < MI + NI; ++r) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        }
-                        __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - (MI + NI), 0);
-                    }
-                }
-            } else {
+            {
                 if constexpr (VAR == 2) __builtin_amdgcn_iglp_opt(0);
-                if constexpr (VAR == 3) __builtin_amdgcn_iglp_opt(1);
+                if constexpr (VAR >= 3) __builtin_amdgcn_iglp_opt(1);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     vec af[MI], bf[NI];
@@ -521,18 +495,22 @@ __device__ __forceinline__ void epi_store_f32(const GemmParams& p, int row, int 
 //     does not wait for those stores.
 // VAR: 0 compiler schedule, 1 iglp_opt(0), 2 iglp_opt(1); PROF: cycle stamps to p.aux (diagnostic build only).
 // (Cache-policy A/B on MI355X: non-temporal A loads -5..-20 %, non-temporal C stores within noise - neither kept.)
-template <bool OUT_F32, int EPI, int VAR, bool PROF>
-__global__ __launch_bounds__(512, 2) void gemm_big2_kernel(GemmParams p) {
+template <bool OUT_F32, int EPI, int VAR, bool PROF, int NWM = 2, int NWN = 4>
+__global__ __launch_bounds__(NWM * NWN * 64, NWM * NWN == 8 ? 2 : 1) void gemm_big2_kernel(GemmParams p) {
     using T = bf16_t;
     using vec = bf16x8;
-    constexpr int BM = 256, BN = 256, WM = 128, WN = 64, MI = WM / 16, NI = WN / 16;
+    // wave grid NWM x NWN over the 256x256 tile: 2x4 = two waves per SIMD, 128x64 each (shipped).  2x2 = one wave per
+    // SIMD with 128x128 each (256 accumulator registers, a third less LDS read traffic per flop) measured 7-25 % SLOWER
+    // with the compiler's schedule (212 B/lane of scratch at 512 registers), so it is not instantiated.
+    constexpr int BM = 256, BN = 256, NW = NWM * NWN, WM = BM / NWM, WN = BN / NWN, MI = WM / 16, NI = WN / 16;
+    constexpr int PPW = 32 / NW;                         // 8-row DMA pieces of A (and of W) per wave per slab
     constexpr int EPC = 8, STAGE = (BM + BN) * 128;      // 64 KiB
     constexpr int SCHED = VAR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave >> 2) * WM, wn0 = (wave & 3) * WN;
+    const int wm0 = (wave / NWN) * WM, wn0 = (wave % NWN) * WN;
     const int r16 = lane & 15, kg = lane >> 4;
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
     const int nk = p.K >> 6;
@@ -545,13 +523,13 @@ __global__ __launch_bounds__(512, 2) void gemm_big2_kernel(GemmParams p) {
 
     // issue side of the pipeline: byte pointers (k = 0) of this lane's 4 A and 4 W pieces of the tile being fetched
     const int prow = lane >> 3, ppos = lane & 7;
-    const char* pa[4];
-    const char* pb[4];
+    const char* pa[PPW];
+    const char* pb[PPW];
     auto set_ptrs = [&](int t) {
         const int tm = t / ntn, tn = t - tm * ntn;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = (wave * 4 + j) * 8 + prow;
+        for (int j = 0; j < PPW; ++j) {
+            const int row = (wave * PPW + j) * 8 + prow;
             const int gch = ppos ^ ((row >> 1) & 7);
             const int ga = min(tm * BM + row, p.M - 1), gb = min(tn * BN + row, p.N - 1);
             pa[j] = (const char*)((const T*)p.A + (size_t)ga * p.lda + gch * EPC);
@@ -560,8 +538,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big2_kernel(GemmParams p) {
     };
     auto issue = [&](int kt, char* stage) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rowbase = (wave * 4 + j) * 8;
+        for (int j = 0; j < PPW; ++j) {
+            const int rowbase = (wave * PPW + j) * 8;
             __builtin_amdgcn_global_load_lds(CAP_GPTR(pa[j] + (size_t)kt * 128), CAP_LPTR(stage + rowbase * 128), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(CAP_GPTR(pb[j] + (size_t)kt * 128), CAP_LPTR(stage + BM * 128 + rowbase * 128), 16, 0, 0);
         }
@@ -654,45 +632,40 @@ __global__ __launch_bounds__(512, 2) void gemm_big2_kernel(GemmParams p) {
             biasv[j] = has_bias ? *(const f32x4*)(bias_lds + (tcount & 1) * 1024 + (wn0 + j * 16 + 4 * kg) * 4) : f32x4(0.f);
         const int srow = lane >> 3, spiece = lane & 7;
         constexpr bool F32OUT = OUT_F32 || EPI == EPI_PARTIAL || EPI == EPI_PATCH;
+        constexpr int NPB = F32OUT ? 2 : 4;                 // 16-column blocks per 128-byte strip row
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            if constexpr (!F32OUT) {
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    f32x4 v = acc[i][j] + biasv[j];
+            for (int jp = 0; jp < NI / NPB; ++jp) {
+#pragma unroll
+                for (int jj = 0; jj < NPB; ++jj) {
+                    const int j = jp * NPB + jj;
+                    f32x4 v = acc[i][j];
+                    if (EPI != EPI_PARTIAL) v += biasv[j];
                     if (do_gelu) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gelu_for<T>(v[e]);
                     }
-                    bf16x4 w;
+                    if constexpr (F32OUT) {
+                        *(f32x4*)(strip + r16 * 144 + (jj * 16 + 4 * kg) * 4) = v;
+                    } else {
+                        bf16x4 w;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) w[e] = (bf16_t)v[e];
-                    *(bf16x4*)(strip + r16 * 144 + (j * 16 + 4 * kg) * 2) = w;
+                        for (int e = 0; e < 4; ++e) w[e] = (bf16_t)v[e];
+                        *(bf16x4*)(strip + r16 * 144 + (jj * 16 + 4 * kg) * 2) = w;
+                    }
                 }
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
-                    const u32x4 raw = *(const u32x4*)(strip + (rr * 8 + srow) * 144 + spiece * 16);
-                    const int row = m0 + wm0 + i * 16 + rr * 8 + srow, col = n0 + wn0 + spiece * 8;
-                    if (row < p.M && col < p.N) epi_store_raw<T, EPI>(p, row, col, raw, col + 8 <= p.N);
-                }
-            } else {
-#pragma unroll
-                for (int jp = 0; jp < NI / 2; ++jp) {
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        f32x4 v = acc[i][jp * 2 + jj];
-                        if (EPI != EPI_PARTIAL) v += biasv[jp * 2 + jj];
-                        if (do_gelu) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = gelu_for<T>(v[e]);
-                        }
-                        *(f32x4*)(strip + r16 * 144 + (jj * 16 + 4 * kg) * 4) = v;
-                    }
-#pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {
+                    const int row = m0 + wm0 + i * 16 + rr * 8 + srow;
+                    if constexpr (F32OUT) {
                         const f32x4 v = *(const f32x4*)(strip + (rr * 8 + srow) * 144 + spiece * 16);
-                        const int row = m0 + wm0 + i * 16 + rr * 8 + srow, col = n0 + wn0 + jp * 32 + spiece * 4;
+                        const int col = n0 + wn0 + jp * 32 + spiece * 4;
                         if (row < p.M && col < p.N) epi_store_f32<EPI>(p, row, col, v);
+                    } else {
+                        const u32x4 raw = *(const u32x4*)(strip + (rr * 8 + srow) * 144 + spiece * 16);
+                        const int col = n0 + wn0 + jp * 64 + spiece * 8;
+                        if (row < p.M && col < p.N) epi_store_raw<T, EPI>(p, row, col, raw, col + 8 <= p.N);
                     }
                 }
             }
@@ -714,10 +687,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big2_kernel(GemmParams p) {
     }
 }
 
-template <bool OUT_F32, int EPI, int VAR, bool PROF>
+template <bool OUT_F32, int EPI, int VAR, bool PROF, int NWM = 2, int NWN = 4>
 int launch_big2(const GemmParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 512 * 128 + 2 * 1024 + 8 * 16 * 144;   // two stages + bias ping-pong + epilogue strips
-    auto kern = gemm_big2_kernel<OUT_F32, EPI, VAR, PROF>;
+    auto kern = gemm_big2_kernel<OUT_F32, EPI, VAR, PROF, NWM, NWN>;
     static bool attr_done = false;
     static int n_cu = 0;
     if (!attr_done) {
@@ -729,7 +702,7 @@ int launch_big2(const GemmParams& p, hipStream_t stream) {
     }
     const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int grid = ntiles < n_cu ? ntiles : n_cu;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWM * NWN * 64), LDS, stream, p);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -789,14 +762,6 @@ int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
     }
     if (tile == 9) {                                    // instrumented main loop: per-wave cycle counts to p.aux
         if constexpr (sizeof(T) == 2 && !OUT_F32 && EPI == EPI_STORE) return launch_big<T, OUT_F32, EPI, 4>(p, stream);
-        tile = 3;
-    }
-    if (tile >= 6 && tile <= 8) {                       // scheduling experiments (bf16 plain store only)
-        if constexpr (sizeof(T) == 2 && !OUT_F32 && EPI == EPI_STORE) {
-            if (tile == 6) return launch_big<T, OUT_F32, EPI, 1>(p, stream);
-            if (tile == 7) return launch_big<T, OUT_F32, EPI, 2>(p, stream);
-            return launch_big<T, OUT_F32, EPI, 0>(p, stream);
-        }
         tile = 3;
     }
     if ((tile == 3 || tile == 5) && p.resid) tile = 4;  // the LDS-DMA kernels have no residual operand
