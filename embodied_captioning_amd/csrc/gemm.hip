@@ -280,6 +280,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(G
 //     under slab k's 32 MFMAs per wave;
 //   * the next tile's first slab is issued BEFORE this tile's epilogue, so the C write-back (through wave-private LDS
 //     strips that alias the stage buffer just drained) overlaps the DMA instead of leaving the CU idle.
+// s_barrier is IntrNoMem for the compiler: pin LDS accesses on their side of it with empty memory-clobber asm
+#define CAP_RAW_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #define CAP_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define CAP_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
                 const long long t0 = clock64();
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 const long long t1 = clock64();
-                __builtin_amdgcn_s_barrier();
+                CAP_RAW_BARRIER();
                 const long long t2 = clock64();
                 prof_dma += t1 - t0; prof_bar += t2 - t1;
             } else
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
         // reason to drain the DMA queue): bias / GELU / residual, convert, 16-byte (fp32) or 8-byte (bf16) stores.
         const long long prof_e0 = VAR == 4 ? clock64() : 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                       // every wave is done reading stage (cnt-1) & 1
+        CAP_RAW_BARRIER();                       // every wave is done reading stage (cnt-1) & 1
         float* strip = (float*)(smem + ((cnt + 1) & 1) * STAGE + wave * (32 * WN * 4));
         f32x4 tr[MI][NPS];
 #pragma unroll
@@ -477,6 +479,62 @@ __device__ __forceinline__ void epi_store_f32(const GemmParams& p, int row, int 
     void* base;
     const size_t o = epi_offset<EPI>(p, row, col, base);
     *(f32x4*)((float*)base + o) = v;
+}
+
+// Epilogue shared by the second-generation kernels.  acc[i][j][e] = C[row0 + 16 i + r16][col0 + 16 j + 4 kg + e]: bias /
+// GELU / convert in that layout, then a wave-private LDS strip (16 rows x 128 payload bytes, row pitch 144) turns "4
+// consecutive columns per lane" into "16 consecutive bytes per lane, 8 lanes per 128-byte row": every global store
+// instruction writes 8 whole cache lines.  The strip is outside the stage buffers, so no barrier is involved.
+// bias_w: LDS address of the fp32 bias of this wave's first column (nullptr: none).
+template <bool OUT_F32, int EPI, int MI, int NI>
+__device__ __forceinline__ void big2_epilogue(const GemmParams& p, const f32x4 (&acc)[MI][NI], char* strip,
+                                              const char* bias_w, int row0, int col0, int lane) {
+    using T = bf16_t;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const bool do_gelu = EPI != EPI_PARTIAL && p.gelu;
+    f32x4 biasv[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) biasv[j] = bias_w ? *(const f32x4*)(bias_w + (j * 16 + 4 * kg) * 4) : f32x4(0.f);
+    const int srow = lane >> 3, spiece = lane & 7;
+    constexpr bool F32OUT = OUT_F32 || EPI == EPI_PARTIAL || EPI == EPI_PATCH;
+    constexpr int NPB = F32OUT ? 2 : 4;                 // 16-column blocks per 128-byte strip row
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int jp = 0; jp < NI / NPB; ++jp) {
+#pragma unroll
+            for (int jj = 0; jj < NPB; ++jj) {
+                const int j = jp * NPB + jj;
+                f32x4 v = acc[i][j];
+                if (EPI != EPI_PARTIAL) v += biasv[j];
+                if (do_gelu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_for<T>(v[e]);
+                }
+                if constexpr (F32OUT) {
+                    *(f32x4*)(strip + r16 * 144 + (jj * 16 + 4 * kg) * 4) = v;
+                } else {
+                    bf16x4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = (bf16_t)v[e];
+                    *(bf16x4*)(strip + r16 * 144 + (jj * 16 + 4 * kg) * 2) = w;
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int row = row0 + i * 16 + rr * 8 + srow;
+                if constexpr (F32OUT) {
+                    const f32x4 v = *(const f32x4*)(strip + (rr * 8 + srow) * 144 + spiece * 16);
+                    const int col = col0 + jp * 32 + spiece * 4;
+                    if (row < p.M && col < p.N) epi_store_f32<EPI>(p, row, col, v);
+                } else {
+                    const u32x4 raw = *(const u32x4*)(strip + (rr * 8 + srow) * 144 + spiece * 16);
+                    const int col = col0 + jp * 64 + spiece * 8;
+                    if (row < p.M && col < p.N) epi_store_raw<T, EPI>(p, row, col, raw, col + 8 <= p.N);
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -586,11 +644,11 @@ __global__ __launch_bounds__(NWM * NWN * 64, NWM * NWN == 8 ? 2 : 1) void gemm_b
                     const long long t0 = clock64();
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     const long long t1 = clock64();
-                    __builtin_amdgcn_s_barrier();
+                    CAP_RAW_BARRIER();
                     prof_dma += t1 - t0; prof_bar += clock64() - t1;
                 } else {
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
+                    CAP_RAW_BARRIER();
                 }
             }
             if (itile < c1) {
@@ -620,61 +678,13 @@ __global__ __launch_bounds__(NWM * NWN * 64, NWM * NWN == 8 ? 2 : 1) void gemm_b
         // epilogue stores enter the same in-order counter.
         const long long prof_e0 = PROF ? clock64() : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // Epilogue.  acc[i][j][e] = C[m0 + wm0 + 16 i + r16][n0 + wn0 + 16 j + 4 kg + e]: bias / GELU / convert in that
-        // layout, then a wave-private LDS strip (16 rows x 128 payload bytes, row pitch 144) turns "4 consecutive columns
-        // per lane" into "16 consecutive bytes per lane, 8 lanes per 128-byte row": every global store instruction
-        // writes 8 whole cache lines.  The strip is outside the stage buffers, so no barrier is involved.
-        char* strip = smem + 2 * STAGE + 2048 + wave * (16 * 144);
-        const bool do_gelu = EPI != EPI_PARTIAL && p.gelu;
-        f32x4 biasv[NI];
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-            biasv[j] = has_bias ? *(const f32x4*)(bias_lds + (tcount & 1) * 1024 + (wn0 + j * 16 + 4 * kg) * 4) : f32x4(0.f);
-        const int srow = lane >> 3, spiece = lane & 7;
-        constexpr bool F32OUT = OUT_F32 || EPI == EPI_PARTIAL || EPI == EPI_PATCH;
-        constexpr int NPB = F32OUT ? 2 : 4;                 // 16-column blocks per 128-byte strip row
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-#pragma unroll
-            for (int jp = 0; jp < NI / NPB; ++jp) {
-#pragma unroll
-                for (int jj = 0; jj < NPB; ++jj) {
-                    const int j = jp * NPB + jj;
-                    f32x4 v = acc[i][j];
-                    if (EPI != EPI_PARTIAL) v += biasv[j];
-                    if (do_gelu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_for<T>(v[e]);
-                    }
-                    if constexpr (F32OUT) {
-                        *(f32x4*)(strip + r16 * 144 + (jj * 16 + 4 * kg) * 4) = v;
-                    } else {
-                        bf16x4 w;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) w[e] = (bf16_t)v[e];
-                        *(bf16x4*)(strip + r16 * 144 + (jj * 16 + 4 * kg) * 2) = w;
-                    }
-                }
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    const int row = m0 + wm0 + i * 16 + rr * 8 + srow;
-                    if constexpr (F32OUT) {
-                        const f32x4 v = *(const f32x4*)(strip + (rr * 8 + srow) * 144 + spiece * 16);
-                        const int col = n0 + wn0 + jp * 32 + spiece * 4;
-                        if (row < p.M && col < p.N) epi_store_f32<EPI>(p, row, col, v);
-                    } else {
-                        const u32x4 raw = *(const u32x4*)(strip + (rr * 8 + srow) * 144 + spiece * 16);
-                        const int col = n0 + wn0 + jp * 64 + spiece * 8;
-                        if (row < p.M && col < p.N) epi_store_raw<T, EPI>(p, row, col, raw, col + 8 <= p.N);
-                    }
-                }
-            }
-        }
+        big2_epilogue<OUT_F32, EPI, MI, NI>(p, acc, smem + 2 * STAGE + 2048 + wave * (16 * 144),
+                                            has_bias ? bias_lds + (tcount & 1) * 1024 + wn0 * 4 : nullptr, m0 + wm0, n0 + wn0, lane);
         if (tile + nl < c1) {
             // every wave is done reading the last slab's stage buffer and the bias slot, and has seen its own pieces of
             // the next tile's first slab land: that slab may be read and the other buffer overwritten
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            CAP_RAW_BARRIER();
         }
         if constexpr (PROF) prof_epi += clock64() - prof_e0;
     }
@@ -685,6 +695,180 @@ __global__ __launch_bounds__(NWM * NWN * 64, NWM * NWN == 8 ? 2 : 1) void gemm_b
             d[5] = tcount;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Third structure (A/B): FOUR 32 KiB stages of HALF K-slabs (256+256 rows x 32 k = 64-byte rows, one 16x16x32 MFMA
+// k-step each).  With three half-slabs of DMA look-ahead a half-slab has landed - and been confirmed by a barrier - one
+// whole iteration before it is multiplied, so its fragments are read into a second register set UNDER the previous
+// half-slab's MFMAs: after a barrier the matrix pipe has 32 MFMAs per wave whose operands are already in registers, the
+// ds_read latency that gemm_big2_kernel exposes at the start of every slab is gone.  Cost: a barrier every 32 MFMAs per
+// wave instead of every 64, counted vmcnt (one half-slab of this wave's DMA may stay in flight across the barrier).
+// Measured against gemm_big2_kernel (tools/gemm_cycles.py, interleaved rounds): +3..7 % on the K = 768 encoder shapes
+// (fragments of the NEXT tile's first half-slab are already in registers when a tile ends), equal at K = 3072, -20 % on
+// 8192^3 - so the dispatcher uses it for K <= 1024.  A variant with one barrier per 64-wide slab and the same prefetch
+// (two half-slabs issued per barrier, vmcnt(0)) was not better than gemm_big2_kernel anywhere and was dropped; iglp_opt(1)
+// (SCHED = 1) makes no difference here.
+//   64-byte rows: chunk c of row r is stored at chunk c ^ P[(r >> 2) & 3], P = {0, 2, 3, 1} - with that permutation the
+//   16 lanes of every ds_read_b128 service group ({0-3,12-15,20-27}, ...) hit 16 distinct 4-bank groups.
+__device__ __forceinline__ int swz64_off(int row, int chunk) {
+    return row * 64 + ((chunk ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3)) << 4);
+}
+
+template <bool OUT_F32, int EPI, int SCHED = 0>
+__global__ __launch_bounds__(512, 2) void gemm_big3_kernel(GemmParams p) {
+    using T = bf16_t;
+    using vec = bf16x8;
+    constexpr int BM = 256, BN = 256, WM = 128, WN = 64, MI = WM / 16, NI = WN / 16;
+    constexpr int EPC = 8, HSTAGE = (BM + BN) * 64;      // 32 KiB per half-slab
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 2) * WM, wn0 = (wave & 3) * WN;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
+    const int nh = p.K >> 5;                              // half-slabs per tile (even: K % 64 == 0)
+
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int nl = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
+    const int tq = ntiles >> 3, tr = ntiles & 7;
+    const int c0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int c1 = c0 + tq + (xcd < tr ? 1 : 0);
+
+    // DMA: a wave-instruction covers 16 rows x 64 B; wave w issues pieces 2w, 2w+1 of A and of W per half-slab
+    const int prow = lane >> 2, ppos = lane & 3;
+    const char* pa[2];
+    const char* pb[2];
+    auto set_ptrs = [&](int t) {
+        const int tm = t / ntn, tn = t - tm * ntn;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (wave * 2 + j) * 16 + prow;
+            const int gch = ppos ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3);
+            const int ga = min(tm * BM + row, p.M - 1), gb = min(tn * BN + row, p.N - 1);
+            pa[j] = (const char*)((const T*)p.A + (size_t)ga * p.lda + gch * EPC);
+            pb[j] = (const char*)((const T*)p.W + (size_t)gb * p.ldw + gch * EPC);
+        }
+    };
+    auto issue = [&](int h, char* stage) {                // half-slab h of the tile being fetched: k = 32 h .. 32 h + 31
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int off = (wave * 2 + j) * 1024;
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(pa[j] + (size_t)h * 64), CAP_LPTR(stage + off), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(pb[j] + (size_t)h * 64), CAP_LPTR(stage + BM * 64 + off), 16, 0, 0);
+        }
+    };
+    char* bias_lds = smem + 4 * HSTAGE;
+    const bool has_bias = EPI != EPI_PARTIAL && p.bias != nullptr;
+    // the bias DMA must not change the per-wave count of outstanding vector-memory operations that the counted waits
+    // rely on, so EVERY wave issues one (waves 1..7 re-fetch the same 1 KiB into a scratch slot of their own)
+    auto issue_bias = [&](int t, int slot) {
+        const int tn = t % ntn;
+        const float* sb = has_bias ? p.bias + min(tn * BN + lane * 4, p.N - 4) : (const float*)p.W;
+        char* dst = wave == 0 ? bias_lds + slot * 1024 : bias_lds + 2048 + wave * 1024;
+        __builtin_amdgcn_global_load_lds(CAP_GPTR(sb), CAP_LPTR(dst), 16, 0, 0);
+    };
+    auto load_frags = [&](const char* stage, vec (&af)[MI], vec (&bf)[NI]) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(stage + BM * 64 + swz64_off(wn0 + j * 16 + r16, kg));
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(stage + swz64_off(wm0 + i * 16 + r16, kg));
+    };
+
+    int g = 0;                                            // global half-slab counter of this block: stage = g & 3
+    int tcount = 0;
+    int tile = c0 + li;
+    int itile = tile, ih = 0;                             // issue side
+    auto issue_next = [&](int gi) {                       // fetch the issue side's next half-slab into stage gi & 3
+        if (itile < c1) {
+            issue(ih, smem + (gi & 3) * HSTAGE);
+            if (++ih == nh) {
+                ih = 0;
+                itile += nl;
+                if (itile < c1) set_ptrs(itile);
+            }
+        } else {
+            // past the end: a dummy 4-operation group keeps the counted waits exact (re-reads 1 KiB of the last tile's
+            // operands into a sink)
+            char* sink = smem + 4 * HSTAGE + 2048 + 8 * 1024;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds(CAP_GPTR(pa[0]), CAP_LPTR(sink), 16, 0, 0);
+        }
+    };
+    if (tile >= c1) return;
+    set_ptrs(itile);
+    issue_bias(itile, 0);
+    issue_next(0); issue_next(1); issue_next(2);          // half-slabs 0, 1, 2 in flight: 4 operations per group per wave
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // bias + half-slab 0 landed (this wave's pieces)
+    CAP_RAW_BARRIER();
+    vec fa0[MI], fb0[NI], fa1[MI], fb1[NI];
+    load_frags(smem, fa0, fb0);
+
+    for (; tile < c1; tile += nl, ++tcount) {
+        const int tm = tile / ntn, tn = tile - tm * ntn;
+        const int m0 = tm * BM, n0 = tn * BN;
+        f32x4 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = 0.f;
+
+        for (int h = 0; h < nh; h += 2, g += 2) {
+            // ---- even half-slab g: operands in (fa0, fb0).  Half-slab g+1 must have landed: outstanding groups of this
+            // wave, oldest first, are g+1, g+2 (+ younger epilogue stores at a tile start - waiting for them too is
+            // safe, only slower).
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            CAP_RAW_BARRIER();                 // everybody's pieces of g+1 landed; stage (g+3)&3 = (g-1)&3 is free
+            issue_next(g + 3);
+            if constexpr (SCHED == 1) __builtin_amdgcn_iglp_opt(1);
+            load_frags(smem + ((g + 1) & 3) * HSTAGE, fa1, fb1);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
+            // ---- odd half-slab g+1: operands in (fa1, fb1); half-slab g+2 must have landed (it may be the next tile's)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            CAP_RAW_BARRIER();
+            issue_next(g + 4);
+            if constexpr (SCHED == 1) __builtin_amdgcn_iglp_opt(1);
+            load_frags(smem + ((g + 2) & 3) * HSTAGE, fa0, fb0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
+        }
+        // bias of this tile: fetched with the tile's first half-slab (slot tcount & 1), long landed; the next tile's
+        // bias goes to the other slot now (one operation per wave, see issue_bias)
+        if (tile + nl < c1) issue_bias(tile + nl, (tcount + 1) & 1);
+        else issue_bias(tile, (tcount + 1) & 1);
+        big2_epilogue<OUT_F32, EPI, MI, NI>(p, acc, smem + 4 * HSTAGE + 2048 + 8 * 1024 + 2048 + wave * (16 * 144),
+                                            has_bias ? bias_lds + (tcount & 1) * 1024 + wn0 * 4 : nullptr, m0 + wm0, n0 + wn0, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the dummy groups before the LDS goes away
+}
+
+template <bool OUT_F32, int EPI, int SCHED = 0>
+int launch_big3(const GemmParams& p, hipStream_t stream) {
+    // four half-slab stages, bias ping-pong (2 KiB) + per-wave bias scratch (8 KiB), dummy DMA sink (2 KiB), strips
+    constexpr int LDS = 4 * 512 * 64 + 2048 + 8 * 1024 + 2048 + 8 * 16 * 144;
+    auto kern = gemm_big3_kernel<OUT_F32, EPI, SCHED>;
+    static bool attr_done = false;
+    static int n_cu = 0;
+    if (!attr_done) {
+        CAP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        int dev = 0;
+        CAP_HIP_CHECK(hipGetDevice(&dev));
+        CAP_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        attr_done = true;
+    }
+    const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const int grid = ntiles < n_cu ? ntiles : n_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, p);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 template <bool OUT_F32, int EPI, int VAR, bool PROF, int NWM = 2, int NWN = 4>
@@ -749,12 +933,14 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
 
 template <typename T, bool OUT_F32, int EPI>
 int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
-    if (tile >= 10 && tile <= 13) {                     // second-generation kernel (bf16): A/B ids, 13 = instrumented
+    if (tile >= 10 && tile <= 15) {                     // second-generation kernel (bf16): A/B ids, 13 = instrumented
         if constexpr (sizeof(T) == 2) {
             if (p.K >= 128 && !p.resid) {
                 if (tile == 10) return launch_big2<OUT_F32, EPI, 0, false>(p, stream);
                 if (tile == 11) return launch_big2<OUT_F32, EPI, 1, false>(p, stream);
                 if (tile == 12) return launch_big2<OUT_F32, EPI, 2, false>(p, stream);
+                if (tile == 14) return launch_big3<OUT_F32, EPI>(p, stream);
+                if (tile == 15) return launch_big3<OUT_F32, EPI, 1>(p, stream);
                 if constexpr (!OUT_F32 && EPI == EPI_STORE) return launch_big2<OUT_F32, EPI, 2, true>(p, stream);
             }
         }
@@ -769,6 +955,7 @@ int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
         // bf16: second-generation kernel (16x16x32 MFMA, register-layout epilogue); iglp_opt(1) interleaves the ds_reads
         // with the MFMAs (A/B: tools/gemm_cycles.py, profiles/)
         if constexpr (sizeof(T) == 2) {
+            if (p.K >= 128 && p.K <= 1024) return launch_big3<OUT_F32, EPI>(p, stream);   // short K: see gemm_big3_kernel
             if (p.K >= 128) return launch_big2<OUT_F32, EPI, 2, false>(p, stream);
             return launch_big<T, OUT_F32, EPI, 3>(p, stream);
         } else {

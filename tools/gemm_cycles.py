@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """A/B + in-kernel cycle accounting of the 256x256 LDS-DMA GEMMs.
 tile 3 = shipped default, 5 = first-generation kernel (LDS-transposed epilogue), 10/11/12 = second generation with the
-compiler / iglp_opt(0) / iglp_opt(1) schedule, 9 and 13 = instrumented builds of generation one and two: per wave, shader
+compiler / iglp_opt(0) / iglp_opt(1) schedule, 14/15 = four half-slab stages with cross-barrier fragment prefetch, 9 and 13 = instrumented builds of generation one and two: per wave, shader
 cycles in total / waiting for its own DMA / waiting at the slab barrier / in the epilogue, and the shader clock derived
 from the 100 MHz wall counter.  python tools/gemm_cycles.py [--check]"""
 import ctypes as C
@@ -38,7 +38,7 @@ def check():
         ref = A.float() @ W.float().t() + b
         if gelu:
             ref = torch.nn.functional.gelu(ref)
-        for tile in (10, 11, 12):
+        for tile in (10, 11, 12, 14, 15):
             out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32 if f32 else torch.bfloat16)
             gemm(A, W, b, out, tile, gelu)
             torch.cuda.synchronize()
@@ -58,7 +58,7 @@ for (M, N, K) in [(8192, 8192, 8192), (50432, 2304, 768), (50432, 768, 3072), (5
     out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
     dbg = torch.zeros(256 * 8 * 6, device="cuda", dtype=torch.int64)
     line = f"M={M} N={N} K={K}:"
-    for tile in (5, 10, 11, 12):
+    for tile in (5, 12, 14, 5, 12, 14):
         for _ in range(3):
             gemm(A, W, None, out, tile)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
