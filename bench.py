@@ -312,11 +312,12 @@ def main():
         # greedy token parity of rows 0..7 against the committed HF-derived golden (same seeds)
         try:
             from tests._util import load_golden, pad_to, token_parity
-            g, meta, _ = load_golden("blip_base")
+            g, meta, _ = load_golden("blip_base64")                 # 64 rows of the real HF greedy loop, same seeds
             ref = pad_to(g["greedy_sequences"], L, arch.pad)
-            ours = ids[:8].cpu().numpy()
-            exact, div, bad = token_parity(ours, ref, g["greedy_margin"], 1e-3 if a.dtype == "f32" else 0.3)
-            line["parity"] = {"rows": 8, "token_identical_rows": int(exact), "diverged_at_near_tie": int(div),
+            n = min(ref.shape[0], B)
+            ours = ids[:n].cpu().numpy()
+            exact, div, bad = token_parity(ours, ref[:n], g["greedy_margin"][:, :n], 1e-3 if a.dtype == "f32" else 0.3)
+            line["parity"] = {"rows": int(n), "token_identical_rows": int(exact), "diverged_at_near_tie": int(div),
                               "confident_mismatch": bad}
         except Exception as e:  # noqa: BLE001
             line["parity"] = {"error": repr(e)}

@@ -48,6 +48,16 @@ def test_oracle_matches_hf_golden(golden_dir, name):
     np.testing.assert_allclose(b["sequences_scores"].numpy(), g["beam_scores"], rtol=0, atol=1e-4)
 
 
+def test_oracle_matches_wide_hf_golden_slice(golden_dir):
+    """tests/golden/blip_base64.npz: 64 frames through the real HF greedy loop; the oracle is run on rows 8..23 here
+    (rows 0..7 are blip_base's), token-identical."""
+    g, meta, arch, sd, px = _load(golden_dir, "blip_base64")
+    out = R.greedy_generate(sd, arch, px[8:24], meta["max_length"])
+    seq = out["sequences"].numpy()
+    ref = g["greedy_sequences"][8:24]
+    assert np.array_equal(seq, ref[:, : seq.shape[1]]) and (ref[:, seq.shape[1]:] == arch.pad).all()
+
+
 def test_perplexity_known_answers(golden_dir):
     with open(os.path.join(golden_dir, "perplexity_kat.json")) as f:
         kats = json.load(f)

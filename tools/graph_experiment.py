@@ -15,7 +15,7 @@ from embodied_captioning_amd.weights import procedural_blip_state_dict, syntheti
 
 arch = BlipArch()
 sd = procedural_blip_state_dict(arch, 0, eos_boost=9.0)
-B, L = 256, 20
+B, L = int(os.environ.get("GE_BATCH", 256)), 20
 px = synthetic_pixels(B, arch.image_size, seed=0).cuda()
 eng = CaptionerEngine(arch, dtype="bf16", max_batch=B, max_beams=1, max_len=L)
 eng.load_state_dict(sd)

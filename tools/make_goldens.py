@@ -87,10 +87,36 @@ def run(arch: BlipArch, seed: int, batch: int, max_length: int, beams: int, full
     return out
 
 
+def run_greedy_only(arch: BlipArch, seed: int, batch: int, max_length: int, eos_boost: float):
+    """Wider greedy fixture (same weights and frames as blip_base, more rows): ids + per-step top-2 margins only."""
+    sd = procedural_blip_state_dict(arch, seed, eos_boost=eos_boost)
+    model = build_hf(arch, sd)
+    pixels = synthetic_pixels(batch, arch.image_size, seed=seed)
+    seqs, margins = [], []
+    with torch.no_grad():
+        for i in range(0, batch, 16):
+            g = model.generate(pixel_values=pixels[i:i + 16], max_length=max_length, num_beams=1, do_sample=False,
+                               output_logits=True, return_dict_in_generate=True)
+            seq = torch.full((g.sequences.shape[0], max_length), arch.pad, dtype=torch.long)
+            seq[:, : g.sequences.shape[1]] = g.sequences
+            top = torch.topk(torch.stack(list(g.logits), 0), k=2, dim=-1).values          # [T, b, 2]
+            m = torch.full((max_length - 1, seq.shape[0]), 1e9)
+            m[: top.shape[0]] = top[..., 0] - top[..., 1]
+            seqs.append(seq); margins.append(m)
+    return {"greedy_sequences": torch.cat(seqs).numpy().astype(np.int32), "greedy_margin": torch.cat(margins, 1).numpy(),
+            "meta": np.array(json.dumps(dict(seed=seed, eos_boost=eos_boost, batch=batch, max_length=max_length, beams=1,
+                                             arch=arch.__dict__, transformers="5.15.0", torch=torch.__version__)))}
+
+
 def main():
     torch.manual_seed(0)
     gold = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
+    if "--wide-only" in sys.argv:
+        print("blip_base64")
+        np.savez_compressed(os.path.join(gold, "blip_base64.npz"), **run_greedy_only(BlipArch(), seed=0, batch=64,
+                                                                                        max_length=20, eos_boost=9.0))
+        return
     print("blip_tiny")
     np.savez_compressed(os.path.join(gold, "blip_tiny.npz"), **run(BlipArch.tiny(), seed=3, batch=4,
                                                                      max_length=12, beams=3, full=True, eos_boost=2.0))
@@ -112,6 +138,9 @@ def main():
         kats.append({"input": inp, "expected": float(torch.exp(-lp.mean()))})
     with open(os.path.join(gold, "perplexity_kat.json"), "w") as f:
         json.dump(kats, f, indent=1)
+    print("blip_base64")
+    np.savez_compressed(os.path.join(gold, "blip_base64.npz"), **run_greedy_only(BlipArch(), seed=0, batch=64,
+                                                                                    max_length=20, eos_boost=9.0))
     print("done")
 
 
