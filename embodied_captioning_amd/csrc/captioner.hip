@@ -98,6 +98,14 @@ struct Captioner {
     std::vector<CBlock> cb;
     std::vector<void*> ccache;
     int ldl;
+    // fused split-K consumer (GemmParams::ln_counter): per-slice arrival counters (one int per 64-row tile, only ever
+    // incremented) and the value they reach after the launches issued so far.  OFF by default: measured on MI355X the
+    // in-kernel hand-over between blocks of different XCDs costs MORE than the ~5 us launch it removes (agent-scope
+    // fences: +35 us per GEMM; fence-free agent-scope stores/loads + counter: +6..11 us; batch 256: 46.7 vs 39.0 ms per
+    // generate, results identical run to run).  CAP_FUSE_LN=1 enables it for A/B runs (tools/fused_ln_stress.py).
+    int* ln_cnt[4] = {nullptr, nullptr, nullptr, nullptr};
+    int ln_total[4] = {0, 0, 0, 0};
+    bool fuse_ln = false;
     // ---- sentence encoder (CAP_ARCH_MINILM): token-type row 0, activations [max_batch * max_len, .]
     float *tok_type = nullptr, *te_x = nullptr, *te_y = nullptr;
     void *te_xt = nullptr, *te_qkv = nullptr, *te_ctx = nullptr, *te_h = nullptr;
@@ -403,6 +411,7 @@ int gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, int lda, c
          const float* bias, const float* resid, int M, int N, int K, int gelu, int out_f32, int epi = EPI_STORE,
          int p0 = 0, int p1 = 0, int p2 = 0, int p3 = 0, const float* aux = nullptr, void* C2 = nullptr) {
     GemmParams p;
+    memset(&p, 0, sizeof(p));
     p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.bias = bias; p.resid = resid; p.ldr = ldc;
     p.M = M; p.N = N; p.K = K; p.gelu = gelu; p.out_f32 = out_f32; p.epi = epi;
     p.p0 = p0; p.p1 = p1; p.p2 = p2; p.p3 = p3; p.aux = aux; p.C2 = C2; p.splitk = 1;
@@ -559,7 +568,7 @@ int run_coca_pool(Captioner* m, int B, float* tokens_out, hipStream_t s) {
 // indices inside the kernels are slice-local.  Slices are independent (no shared mutable state), so they can run on
 // different streams.
 struct Dec {
-    int b0, B, R, Btot;
+    int b0, B, R, Btot, idx;
     float *dx, *dy, *logits, *dpart;
     char *dx_t, *dq, *dctx, *dh;
     int *seq, *finished, *lens, *anc;
@@ -572,7 +581,7 @@ Dec make_slice(Captioner* m, int b0, int B, int Btot, int K, int Lm, int idx) {
     const size_t T = c.t_hidden, F = c.t_ffn, H = c.t_heads, e = m->esz;
     const size_t r0 = (size_t)b0 * K;
     Dec d;
-    d.b0 = b0; d.B = B; d.R = B * K; d.Btot = Btot;
+    d.b0 = b0; d.B = B; d.R = B * K; d.Btot = Btot; d.idx = idx;
     d.dx = m->dx + r0 * T; d.dy = m->dy + r0 * T; d.logits = m->logits + r0 * m->ldl; d.dpart = m->dpart + 12 * r0 * T;
     d.dx_t = (char*)m->dx_t + r0 * T * e; d.dq = (char*)m->dq + r0 * T * e; d.dctx = (char*)m->dctx + r0 * T * e;
     d.dh = (char*)m->dh + r0 * F * e;
@@ -598,14 +607,44 @@ int gemm_partial(Captioner* m, hipStream_t s, const char* tag, const void* A, co
     return launch_gemm(m->dt, p, 2, s);
 }
 
-// Decode-sized GEMM whose consumer is a post-LayerNorm: split K over S blocks per tile (every block's slabs are all in
-// flight at once -> one memory round trip), partial sums to dpart, then bias + residual + LayerNorm in one kernel.
+// Decode-sized GEMM whose consumer is a LayerNorm: split K over S blocks per tile (every block's slabs are all in flight
+// at once -> one memory round trip), partial sums to dpart, then y = sum + bias + resid (-> y_out) and LayerNorm(y) ->
+// out_t / out_f.  The consumer runs inside the GEMM kernel when the launch qualifies (GemmParams::ln_counter), else as the
+// block-per-row kernel.
+int gemm_splitk_reduce_ln(Captioner* m, hipStream_t s, const Dec& d, const char* tag, const void* A, const void* W,
+                          const float* bias, const float* g, const float* b, float eps, int N, int K, void* out_t,
+                          float* out_f, float* y_out) {
+    const int slab = m->dt == CAP_DT_BF16 ? 64 : 32;
+    const int nk = K / slab;
+    int S = 1;
+    for (int cand : {8, 4, 2})
+        if (nk % cand == 0 && nk / cand >= 3) { S = cand; break; }
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = d.dpart; p.ldc = N; p.M = d.R; p.N = N; p.K = K;
+    p.out_f32 = 1; p.epi = EPI_PARTIAL; p.splitk = S;
+    const int nb = ((N + 63) / 64) * S, grid = ((d.R + 63) / 64) * nb;
+    const bool fused = m->fuse_ln && m->ln_cnt[d.idx] && nb >= 16 && grid <= 512 && N <= 2048 && (d.R + 63) / 64 <= 64;
+    if (fused) {
+        m->ln_total[d.idx] = (int)((unsigned)m->ln_total[d.idx] + (unsigned)nb);
+        p.ln_counter = m->ln_cnt[d.idx]; p.ln_target = m->ln_total[d.idx];
+        p.bias = bias; p.resid = d.dx; p.ln_gamma = g; p.ln_beta = b; p.ln_eps = eps;
+        p.ln_out_t = out_t; p.ln_out_f = out_f; p.ln_y_out = y_out;
+        ProfScope ps(m, s, tag, 2.0 * d.R * N * K,
+                     ((double)d.R * K + (double)N * K) * m->esz + (double)(2 * S + 2) * d.R * N * 4 + (double)d.R * N * m->esz);
+        return launch_gemm(m->dt, p, 2, s);
+    }
+    {
+        ProfScope ps(m, s, tag, 2.0 * d.R * N * K, ((double)d.R * K + (double)N * K) * m->esz + (double)S * d.R * N * 4);
+        TRY(launch_gemm(m->dt, p, 2, s));
+    }
+    ProfScope ps(m, s, "dec_reduce_ln", 0, (double)(S + 2) * d.R * N * 4 + (double)d.R * N * m->esz);
+    return launch_reduce_layernorm(m->dt, d.dpart, S, bias, d.dx, g, b, eps, out_t, out_f, y_out, d.R, N, s, true);
+}
+
 int gemm_splitk_ln(Captioner* m, hipStream_t s, const Dec& d, const char* tag, const void* A, const void* W,
                    const float* bias, const float* g, const float* b, int N, int K) {
-    int S = 1;
-    TRY(gemm_partial(m, s, tag, A, W, d.dpart, d.R, N, K, 8, &S));
-    ProfScope ps(m, s, "dec_reduce_ln", 0, (double)(S + 2) * d.R * N * 4 + (double)d.R * N * m->esz);
-    return launch_reduce_layernorm(m->dt, d.dpart, S, bias, d.dx, g, b, m->c.t_eps, d.dx_t, d.dx, nullptr, d.R, N, s, true);
+    return gemm_splitk_reduce_ln(m, s, d, tag, A, W, bias, g, b, m->c.t_eps, N, K, d.dx_t, d.dx, nullptr);
 }
 
 int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, int t, int K, const int* anc, int Lm,
@@ -691,12 +730,10 @@ int run_coca_step(Captioner* m, const Dec& d, int t, int Lm, hipStream_t s) {
                                         0, 0));
         }
         // x += out_proj(ctx) ; ln = LayerNorm_2(x)
-        TRY(gemm_partial(m, s, "coca_gemm_o", d.dctx, b.w_o, d.dpart, R, E, E, 8, &S));
-        TRY(launch_reduce_layernorm(m->dt, d.dpart, S, b.b_o, d.dx, b.ln2_g, b.ln2_b, c.t_eps, d.dx_t, nullptr, d.dx, R, E, s, true));
+        TRY(gemm_splitk_reduce_ln(m, s, d, "coca_gemm_o", d.dctx, b.w_o, b.b_o, b.ln2_g, b.ln2_b, c.t_eps, E, E, d.dx_t, nullptr, d.dx));
         // x += c_proj(gelu(c_fc(ln))) ; ln = LayerNorm of the next block (or ln_final)
         TRY(gemm(m, s, "coca_gemm_fc", d.dx_t, E, b.w_fc, E, d.dh, F, b.b_fc, nullptr, R, F, E, 1, 0));
-        TRY(gemm_partial(m, s, "coca_gemm_pr", d.dh, b.w_pr, d.dpart, R, E, F, 8, &S));
-        TRY(launch_reduce_layernorm(m->dt, d.dpart, S, b.b_pr, d.dx, next_g, next_b, c.t_eps, d.dx_t, nullptr, d.dx, R, E, s, true));
+        TRY(gemm_splitk_reduce_ln(m, s, d, "coca_gemm_pr", d.dh, b.w_pr, b.b_pr, next_g, next_b, c.t_eps, E, F, d.dx_t, nullptr, d.dx));
     }
     TRY(gemm(m, s, "coca_gemm_vocab", d.dx_t, E, m->w_cvocab, E, d.logits, m->ldl, nullptr, nullptr, R, c.vocab, E, 0, 1));
     return 0;
@@ -856,6 +893,16 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
             ok = hipStreamCreateWithFlags(&m->aux[i], hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) { cap_set_error("cap_create: cannot create decode streams/events"); delete m; return -1; }
+        const char* fl = getenv("CAP_FUSE_LN");
+        m->fuse_ln = fl && atoi(fl) != 0;
+        for (int i = 0; i < m->nslices && !text_only; ++i) {
+            if (dev_alloc(m, (void**)&m->ln_cnt[i], 64 * sizeof(int)) != 0 || hipMemset(m->ln_cnt[i], 0, 64 * sizeof(int)) != hipSuccess) {
+                cap_set_error("cap_create: cannot allocate the split-K arrival counters");
+                for (void* q : m->allocs) (void)hipFree(q);
+                delete m;
+                return -1;
+            }
+        }
     }
     const int built = text_only ? (build_minilm(m) != 0)
                       : cfg->arch == CAP_ARCH_COCA ? (build_coca(m) != 0 || build_arena_coca(m) != 0)

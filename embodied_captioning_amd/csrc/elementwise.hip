@@ -74,43 +74,7 @@ __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __re
     X[(size_t)b * tokens * D + d] = cls[d] + pos[d];
 }
 
-// ------------------------------------------------------------------------------------------------
-// LayerNorm, one wave per row, row held in registers (D <= 64*4*MAXV).  Two-pass mean/variance in fp32,
-// biased variance, eps inside the sqrt (torch.nn.functional.layer_norm).
-constexpr int LN_MAXV = 8;
-
-template <typename T>
-__device__ __forceinline__ void ln_row(const float4 (&v)[LN_MAXV], int nv, int lane, int D, const float* gamma,
-                                       const float* beta, float eps, T* out_t, float* out_f) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i)
-        if (i < nv && lane * 4 + i * 256 < D) s += v[i].x + v[i].y + v[i].z + v[i].w;
-    const float mean = wave_sum(s) / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i)
-        if (i < nv && lane * 4 + i * 256 < D) {
-            float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-            q += a * a + b * b + c * c + d * d;
-        }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
-#pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane * 4 + i * 256;
-        if (i < nv && c < D) {
-            float4 g = *(const float4*)(gamma + c), bb = *(const float4*)(beta + c);
-            float4 o;
-            o.x = (v[i].x - mean) * rstd * g.x + bb.x; o.y = (v[i].y - mean) * rstd * g.y + bb.y;
-            o.z = (v[i].z - mean) * rstd * g.z + bb.z; o.w = (v[i].w - mean) * rstd * g.w + bb.w;
-            if (out_f) *(float4*)(out_f + c) = o;
-            if (out_t) {
-                out_t[c] = from_f32<T>(o.x); out_t[c + 1] = from_f32<T>(o.y);
-                out_t[c + 2] = from_f32<T>(o.z); out_t[c + 3] = from_f32<T>(o.w);
-            }
-        }
-    }
-}
+#include "ln.h"   // LN_MAXV, ln_row, reduce_ln_row_wave (shared with the fused split-K GEMM consumer)
 
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, int ld_in,

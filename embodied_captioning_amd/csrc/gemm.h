@@ -28,6 +28,18 @@ struct GemmParams {
     int p0, p1, p2, p3;
     const float* aux;
     void* C2;
+    // EPI_PARTIAL with ln_counter != nullptr (64x64 tile only): the split-K consumer runs INSIDE the GEMM kernel.  Every
+    // block bumps its M-tile's arrival counter after its partial slab is globally visible; the first 16 blocks of an
+    // M-tile wait for all ntn * splitk arrivals (the counters only grow: ln_target = value expected after this launch)
+    // and then each reduces + LayerNorms 4 of the tile's 64 rows (one per wave): y = sum_z partial[z] + bias + resid
+    // (slice order), LayerNorm(y) -> ln_out_t (T) / ln_out_f (fp32), y -> ln_y_out.  Removes one dependent launch, but the
+    // cross-XCD hand-over costs more than that launch on MI355X (captioner.hip, Captioner::fuse_ln): off by default.
+    int* ln_counter;
+    int ln_target;
+    const float *ln_gamma, *ln_beta;
+    float ln_eps;
+    void* ln_out_t;
+    float *ln_out_f, *ln_y_out;
 };
 
 // dtype: CAP_DT_F32 / CAP_DT_BF16.  tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 256x256 persistent LDS-DMA kernel

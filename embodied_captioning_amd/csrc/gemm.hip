@@ -20,6 +20,7 @@
 // Edge tiles clamp their load rows and guard their stores.  Workgroup ids are remapped so each XCD (blockIdx % 8) walks
 // a contiguous run of tiles that share A panels in its L2.
 #include "gemm.h"
+#include "ln.h"
 
 namespace {
 
@@ -62,7 +63,16 @@ __device__ __forceinline__ void epi_store4(const GemmParams& p, int row, int col
     }
     size_t o; void* base = p.C;
     if constexpr (EPI == EPI_PARTIAL) {          // split-K slice z: raw fp32 partial sums, reduced by the consumer
-        *(f32x4*)((float*)p.C + ((size_t)p.p3 * p.M + row) * p.ldc + col) = v;
+        float* dst = (float*)p.C + ((size_t)p.p3 * p.M + row) * p.ldc + col;
+        if (p.ln_counter) {
+            // consumer inside this kernel, possibly on another XCD (whose L2 is not coherent with this one): agent-scope
+            // stores go through to memory; no fence (a device-wide L2 write-back + invalidate per block costs far more
+            // than the launch it saves - measured +35 us per GEMM)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) __hip_atomic_store(dst + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            *(f32x4*)dst = v;
+        }
         return;
     } else if constexpr (EPI == EPI_STORE) {
         o = (size_t)row * p.ldc + col;
@@ -267,6 +277,35 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(G
             const int row = m0 + wm0 + i * 32 + rr;
             const f32x4 v = *(const f32x4*)(strip + rr * WN + cl);
             if (row < p.M && col < p.N) epi_store4<T, OUT_F32, EPI>(p, row, col, v, biasv);
+        }
+    }
+    if constexpr (EPI == EPI_PARTIAL && BM == 64 && BN == 64) {
+        if (p.ln_counter) {
+            // ---- fused split-K consumer (see GemmParams::ln_counter).  The partial slabs were written with agent-scope
+            // stores (epi_store4); once they are acknowledged (vmcnt(0)) and every wave of the block got here, the arrival
+            // is counted.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int nb = ntn * S, myb = tn * S + kz;
+            (void)nb;
+            if (tid == 0) __hip_atomic_fetch_add(p.ln_counter + tm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (myb < 16) {                               // nb >= 16 is checked by the launcher
+                if (tid == 0) {
+                    // every block of the launch is resident (the launcher bounds the grid), so the missing arrivals are
+                    // running or about to; the iteration bound only turns a broken assumption into a wrong answer instead
+                    // of a hung GPU
+                    int it = 0;
+                    while ((int)((unsigned)__hip_atomic_load(p.ln_counter + tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                                 (unsigned)p.ln_target) < 0 && ++it < (1 << 22))
+                        __builtin_amdgcn_s_sleep(1);
+                }
+                __syncthreads();
+                asm volatile("" ::: "memory");            // the slab reads below stay below the wait
+                const int row = m0 + myb * 4 + wave;
+                if (row < p.M)
+                    reduce_ln_row_wave<T, true>((const float*)p.C, S, p.M, p.N, row, lane, p.bias, p.resid, p.ln_gamma, p.ln_beta,
+                                                p.ln_eps, (T*)p.ln_out_t, p.ln_out_f, p.ln_y_out);
+            }
         }
     }
 }
@@ -1014,6 +1053,17 @@ int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream) {
     }
     if (p.N % 4 != 0 || (p.epi == EPI_STORE && p.ldc % 4 != 0) || (p.resid && p.ldr % 4 != 0)) {
         cap_set_error("launch_gemm: N / ldc / ldr must be multiples of 4 (N=%d ldc=%d ldr=%d)", p.N, p.ldc, p.ldr);
+        return -1;
+    }
+    if (p.epi == EPI_PARTIAL && p.ln_counter) {
+        const int nb = ((p.N + 63) / 64) * p.splitk, grid = ((p.M + 63) / 64) * nb;
+        if (tile != 2 || nb < 16 || p.ldc != p.N || p.N > 256 * LN_MAXV || grid > 512) {
+            cap_set_error("launch_gemm: fused split-K consumer needs the 64x64 tile, >= 16 blocks per 64-row tile, ldc == N "
+                          "and a grid that is resident at once (N=%d splitk=%d grid=%d)", p.N, p.splitk, grid);
+            return -1;
+        }
+    } else if (p.ln_counter) {
+        cap_set_error("launch_gemm: ln_counter is only meaningful with EPI_PARTIAL");
         return -1;
     }
     if (tile == 0) {
