@@ -48,7 +48,8 @@ def parse():
     ap.add_argument("--beams", type=int, default=1, help="> 1: extra line for SURVEY config 3 (HF beam search; use --batch 64)")
     ap.add_argument("--lite", action="store_true", help="timed steps only (profiler counter passes): no roofline / "
                     "encoder-only / parity / fp32 / CPU legs")
-    ap.add_argument("--image-size", type=int, default=224, help="--model coca only: 224 or 336 (SURVEY config 5)")
+    ap.add_argument("--image-size", type=int, default=224, help="coca: 224 or 336 (SURVEY config 5); blip: 224 (the "
+                    "BASELINE config) or 384 (what the published BLIP checkpoints ship - extra line, no golden)")
     return ap.parse_args()
 
 
@@ -256,6 +257,7 @@ def main():
         torch.distributed.init_process_group("nccl", device_id=dev)
 
     arch = BlipArch()
+    arch.image_size = a.image_size
     L, B = a.max_length, a.batch
     sd = procedural_blip_state_dict(arch, 0, eos_boost=9.0)       # same weights as tests/golden/blip_base.npz
     px = synthetic_pixels(B, arch.image_size, seed=0, first=rank * B).to(dev)
@@ -285,11 +287,12 @@ def main():
 
     if rank == 0:
         value = world * B * a.steps / dt
-        line = {"metric": f"captions/sec (224x224, beam={a.beams})", "value": round(value, 2), "unit": "captions/s",
+        S = arch.image_size
+        line = {"metric": f"captions/sec ({S}x{S}, beam={a.beams})", "value": round(value, 2), "unit": "captions/s",
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
                 "data": "synthetic frames (PCG64, seed = frame index), procedural weights (no checkpoint offline)",
-                "config": {"workload": f"BLIP-base ViT-B/16 encoder + {'greedy' if a.beams == 1 else f'beam-{a.beams}'} decode, {B} frames/GPU 224x224, "
+                "config": {"workload": f"BLIP-base ViT-B/16 encoder + {'greedy' if a.beams == 1 else f'beam-{a.beams}'} decode, {B} frames/GPU {S}x{S}, "
                                        f"max_length={L}, caption all-gather", "global_batch": world * B,
                            "parallelism": f"dp{world}"}}
         if a.beams > 1:                      # config 3 extra line: per-kernel profile of one beam generate, then stop
@@ -298,7 +301,7 @@ def main():
             rep = eng.profile_report()
             eng.profile(False)
             line["kernels_ms"] = {k: round(v["ms"], 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:14]}
-        if a.lite or a.beams > 1:
+        if a.lite or a.beams > 1 or S != 224:
             print(json.dumps(line))
             eng.close()
             return

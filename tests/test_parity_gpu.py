@@ -194,3 +194,34 @@ def test_full_size_batch_properties_bf16():
     seq_p = eng.generate(px[perm.cuda()], max_length=L)["sequences"].cpu().numpy()
     assert np.array_equal(seq_p, seq[perm.numpy()])
     eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_blip_base_at_384_like_the_published_checkpoint(dtype):
+    """`Salesforce/blip-image-captioning-base` ships image_size 384 (577 image tokens): the long-sequence ViT attention
+    kernel and a 577-key cross-attention, against the live oracle on 2 frames."""
+    import dataclasses
+    from embodied_captioning_amd.config import BlipArch
+    from embodied_captioning_amd.weights import procedural_blip_state_dict, synthetic_pixels
+    from oracle import blip_ref as R
+    arch = dataclasses.replace(BlipArch(), image_size=384)
+    assert arch.n_tokens == 577
+    sd = procedural_blip_state_dict(arch, 0, eos_boost=9.0)
+    px = synthetic_pixels(2, 384, seed=3)
+    L = 12
+    ref = R.greedy_generate(sd, arch, px, L)
+    eng = _engine(arch, dtype, 2, 1, L)
+    eng.load_state_dict(sd)
+    emb = eng.encode(px.cuda()).cpu()
+    err = (emb - ref["image_embeds"]).abs().max().item()
+    assert err < (3e-4 if dtype == "f32" else 0.15), err
+    seq = eng.generate(px.cuda(), max_length=L)["sequences"].cpu().numpy()
+    rseq = pad_to(ref["sequences"].numpy(), L, arch.pad)
+    if dtype == "f32":
+        assert np.array_equal(seq, rseq)
+    else:
+        lg = torch.stack(ref["logits"], 0)
+        t2 = torch.topk(lg, 2, dim=-1).values
+        exact, diverged, bad = token_parity(seq, rseq, (t2[..., 0] - t2[..., 1]).numpy(), BF16_TAU)
+        assert bad is None, bad
+    eng.close()
