@@ -109,6 +109,20 @@ class SentenceEncoder:
             out[torch.as_tensor(idx, device=self._device)] = self.engine.embed(torch.from_numpy(ids), torch.from_numpy(lens))
         return out
 
+    @torch.no_grad()
+    def encode_caption_tokens(self, sequences: torch.Tensor, lengths: torch.Tensor, eos: int) -> torch.Tensor:
+        """Embeddings straight from the captioner's token table (`generate` output: sequences [n, L] incl. the decoder
+        BOS, lengths [n]) without detokenising: row = [CLS] + caption tokens + [SEP].  Valid when captioner and embedder
+        share a WordPiece vocabulary - BLIP and all-MiniLM-L6-v2 both use bert-base-uncased's (BLIP adds two ids at the
+        end, its BOS among them, which never appears inside a caption) - and equal to decode -> encode whenever WordPiece
+        round-trips the caption text."""
+        seq, lens = sequences.cpu().tolist(), lengths.cpu().tolist()
+        rows = []
+        for r, n in zip(seq, lens):
+            body = [t for t in r[1:n] if t != eos]
+            rows.append([self.arch.cls] + body + [self.arch.sep])
+        return self.encode_ids(rows)
+
     def encode(self, sentences: Union[str, Sequence[str]], batch_size: int | None = None, convert_to_tensor: bool = False,
                convert_to_numpy: bool = True, normalize_embeddings: bool = False, **_):
         """all-MiniLM-L6-v2 ends in a Normalize module, so its embeddings are unit-norm whatever `normalize_embeddings` says."""

@@ -43,7 +43,8 @@ def record_name(episode: int, step: int) -> str:
 
 class BatchedBoxCaptioner:
     """`captioner` is the plugin (`Captioner` with `caption_batch`) or any callable list[PIL] -> list[str];
-    `encoder` (optional) maps a caption to its sentence embedding (the reference uses MiniLM `encode`)."""
+    `encoder` (optional): an object with `encode(list[str], convert_to_tensor=True)` (SentenceEncoder, or the reference's
+    SentenceTransformer) - called once for the whole batch - or a plain callable caption -> vector."""
 
     def __init__(self, captioner, encoder: Optional[Callable[[str], torch.Tensor]] = None, expand_factor: float = 0.2):
         self.captioner = captioner
@@ -68,10 +69,16 @@ class BatchedBoxCaptioner:
         out = [{"captions": [], "embeddings": torch.tensor([])} for _ in frames_bgr]
         for fi, cap in zip(owner, captions):
             out[fi]["captions"].append(cap)
-        if self.encoder is not None:
-            for o in out:
-                if o["captions"]:
-                    o["embeddings"] = torch.stack([torch.as_tensor(self.encoder(c)) for c in o["captions"]])
+        if self.encoder is not None and captions:
+            enc = getattr(self.encoder, "encode", None)
+            if enc is not None:                         # SentenceEncoder / SentenceTransformer: one batched call
+                emb = torch.as_tensor(enc(list(captions), convert_to_tensor=True)).cpu()
+            else:                                       # plain callable caption -> vector
+                emb = torch.stack([torch.as_tensor(self.encoder(c)).cpu() for c in captions])
+            for fi in range(len(out)):
+                idx = [i for i, o in enumerate(owner) if o == fi]
+                if idx:
+                    out[fi]["embeddings"] = emb[idx]
         return out
 
     def predict_caption(self, boxes: Sequence, image_bgr: np.ndarray):

@@ -68,3 +68,15 @@ def test_sentence_encoder_surface_and_errors():
         enc.engine.embed(torch.ones(5, 3, dtype=torch.int32), torch.full((5,), 3, dtype=torch.int32))   # batch > capacity
     with pytest.raises(RuntimeError):
         SentenceEncoder("all-MiniLM-L6-v2-not-here")
+
+
+def test_embeddings_from_caption_tokens_match_row_form():
+    from embodied_captioning_amd.captioner.sentence_encoder import SentenceEncoder
+    enc = SentenceEncoder("procedural-minilm-tiny:3", dtype="f32", batch_size=8)
+    a = enc.arch
+    eos, bos = 102, 290
+    seq = torch.tensor([[bos, 7, 9, 11, eos, 0, 0], [bos, 5, eos, 0, 0, 0, 0], [bos, 8, 9, 10, 12, 13, 14]], dtype=torch.int32)
+    lens = torch.tensor([5, 3, 7], dtype=torch.int32)
+    got = enc.encode_caption_tokens(seq, lens, eos)
+    want = enc.encode_ids([[a.cls, 7, 9, 11, a.sep], [a.cls, 5, a.sep], [a.cls, 8, 9, 10, 12, 13, 14, a.sep]])
+    assert torch.equal(got, want)
