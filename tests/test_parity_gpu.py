@@ -225,3 +225,35 @@ def test_blip_base_at_384_like_the_published_checkpoint(dtype):
         exact, diverged, bad = token_parity(seq, rseq, (t2[..., 0] - t2[..., 1]).numpy(), BF16_TAU)
         assert bad is None, bad
     eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_long_captions_past_the_fused_attention_window(dtype):
+    """max_length 40 with an EOS-suppressing bias: positions beyond 32 leave the fused split-K/attention kernel for the
+    cache-scatter GEMM epilogue + the chunked attention kernel, greedy and beam (ancestry table over 39 positions)."""
+    from embodied_captioning_amd.config import BlipArch
+    from embodied_captioning_amd.weights import procedural_blip_state_dict, synthetic_pixels
+    from oracle import blip_ref as R
+    arch = BlipArch.tiny()
+    sd = procedural_blip_state_dict(arch, 33, eos_boost=-6.0)
+    px = synthetic_pixels(3, arch.image_size, seed=33)
+    L = 40
+    ref = R.greedy_generate(sd, arch, px, L)
+    refb = R.beam_search_generate(sd, arch, px, 3, L, image_embeds=ref["image_embeds"])
+    assert (ref["sequences"].numpy()[:, -1] != arch.pad).any()          # at least one row really runs to the end
+    eng = _engine(arch, dtype, 3, 3, L)
+    eng.load_state_dict(sd)
+    seq = eng.generate(px.cuda(), max_length=L)["sequences"].cpu().numpy()
+    rseq = pad_to(ref["sequences"].numpy(), L, arch.pad)
+    if dtype == "f32":
+        assert np.array_equal(seq, rseq)
+        b = eng.generate(px.cuda(), num_beams=3, max_length=L)
+        assert np.array_equal(b["sequences"].cpu().numpy(), pad_to(refb["sequences"].numpy(), L, arch.pad or arch.eos))
+        np.testing.assert_allclose(b["sequences_scores"].cpu().numpy(), refb["sequences_scores"].numpy(), atol=2e-3)
+    else:
+        lg = torch.stack(ref["logits"], 0)
+        t2 = torch.topk(lg, 2, dim=-1).values
+        exact, diverged, bad = token_parity(seq, rseq, (t2[..., 0] - t2[..., 1]).numpy(), BF16_TAU)
+        assert bad is None, bad
+        _check_bf16_beams(eng, arch, sd, px, 3, L, refb["sequences_scores"].numpy())
+    eng.close()
