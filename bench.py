@@ -112,7 +112,10 @@ def roofline_pass(eng, px, L, dtype, arch, batch):
     peak = PEAK_TFLOPS[dtype]
     roof = {"bound": "mfma", "kernel": KERNEL_NAME[dtype], "achieved": round(achieved, 2),
             "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-            "flops_per_launch": fl / n, "avg_launch_us": round(1e3 * ms / n, 2), "launches_per_step": n // reps}
+            "flops_per_launch": fl / n, "avg_launch_us": round(1e3 * ms / n, 2), "launches_per_step": n // reps,
+            "note": "priced against the dense MFMA peak; in-kernel ablation (profiles/r01_gemm_ablation.txt) shows the slab "
+                    "time is set by the global->LDS fill (~17.7 B/clk per CU with all 256 CUs streaming), which caps a "
+                    "256x256 tile at ~1.3 PFLOP/s"}
     roof["traffic"] = pmc_traffic() if dtype == "bf16" else None   # the committed PMC passes are of the bf16 run
     total_ms = sum(r["ms"] for r in rep.values()) / reps
     return roof, kernels, total_ms
