@@ -763,12 +763,8 @@ __global__ __launch_bounds__(64) void text_attention_kernel(const T* __restrict_
 template <int KB>
 int launch_mfma_kb(const void* qkv, void* ctx, int B, int N, int H, hipStream_t s) {
     const int lds = 2 * KB * 32 * 128;
-    static bool attr_done = false;
     auto kern = vit_attention_mfma<KB>;
-    if (!attr_done && lds > 64 * 1024) {
-        CAP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_done = true;
-    }
+    if (cap_kernel_setup((const void*)kern, lds, nullptr) != 0) return -1;
     hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)ctx, N, H);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
@@ -777,12 +773,8 @@ int launch_mfma_kb(const void* qkv, void* ctx, int B, int N, int H, hipStream_t 
 template <int KB, int KC>
 int launch_flash_kb(const void* qkv, void* ctx, int B, int N, int H, hipStream_t s) {
     const int lds = 2 * KB * 32 * 128;
-    static bool attr_done = false;
     auto kern = vit_attention_flash<KB, KC>;
-    if (!attr_done && lds > 64 * 1024) {
-        CAP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_done = true;
-    }
+    if (cap_kernel_setup((const void*)kern, lds, nullptr) != 0) return -1;
     hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)ctx, N, H);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;

@@ -371,13 +371,10 @@ int launch_beam_step(void* state, const float* logits, int ld, int V, int B, int
     const int par = cur_len & 1;
     const size_t lds = (size_t)((V + 3) / 4) * 16 + (size_t)2 * K * 256 * 8;
     if (lds <= 150 * 1024 && (ld & 3) == 0 && V > 2 * K) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            CAP_HIP_CHECK(hipFuncSetAttribute((const void*)beam_rows_lds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            CAP_HIP_CHECK(hipFuncSetAttribute((const void*)beam_rows_lds_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            CAP_HIP_CHECK(hipFuncSetAttribute((const void*)beam_rows_lds_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            attr_done = true;
-        }
+        if (cap_kernel_setup((const void*)beam_rows_lds_kernel<4>, 150 * 1024, nullptr) != 0 ||
+            cap_kernel_setup((const void*)beam_rows_lds_kernel<8>, 150 * 1024, nullptr) != 0 ||
+            cap_kernel_setup((const void*)beam_rows_lds_kernel<16>, 150 * 1024, nullptr) != 0)
+            return -1;
         if (2 * K <= 4)
             hipLaunchKernelGGL(beam_rows_lds_kernel<4>, dim3(B * K), dim3(256), lds, s, (char*)state, lo, logits, ld, V, K, par);
         else if (2 * K <= 8)

@@ -8,6 +8,8 @@
 
 #include <map>
 #include <string>
+#include <set>
+#include <mutex>
 #include <vector>
 
 #include "../../include/captioner_hip.h"
@@ -21,6 +23,30 @@ void cap_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int cap_kernel_setup(const void* kernel, int lds_bytes, int* n_cu) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    static std::map<int, int> cus;
+    int dev = 0;
+    CAP_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (!done.count({kernel, dev})) {
+        if (lds_bytes > 64 * 1024)
+            CAP_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        done.insert({kernel, dev});
+    }
+    if (n_cu) {
+        auto it = cus.find(dev);
+        if (it == cus.end()) {
+            int n = 0;
+            CAP_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+            it = cus.emplace(dev, n).first;
+        }
+        *n_cu = it->second;
+    }
+    return 0;
 }
 
 namespace {

@@ -54,6 +54,11 @@ template <typename T> __device__ __forceinline__ float gelu_for(float x);
 template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
 template <> __device__ __forceinline__ float gelu_for<__bf16>(float x) { return gelu_erf_fast(x); }
 
+// One-time per (kernel, device) setup shared by the launchers: raises the kernel's dynamic-LDS limit when `lds_bytes`
+// exceeds the 64 KiB default and returns the device's CU count in *n_cu (may be null).  Thread-safe; a handle per GPU in
+// one process works.  Returns 0, or -1 with cap_set_error.
+int cap_kernel_setup(const void* kernel, int lds_bytes, int* n_cu);
+
 // Host-side error plumbing (captioner.cpp owns the storage).
 void cap_set_error(const char* fmt, ...);
 #define CAP_HIP_CHECK(expr)                                                                   \

@@ -894,15 +894,8 @@ int launch_big3(const GemmParams& p, hipStream_t stream) {
     // four half-slab stages, bias ping-pong (2 KiB) + per-wave bias scratch (8 KiB), dummy DMA sink (2 KiB), strips
     constexpr int LDS = 4 * 512 * 64 + 2048 + 8 * 1024 + 2048 + 8 * 16 * 144;
     auto kern = gemm_big3_kernel<OUT_F32, EPI, SCHED>;
-    static bool attr_done = false;
-    static int n_cu = 0;
-    if (!attr_done) {
-        CAP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        int dev = 0;
-        CAP_HIP_CHECK(hipGetDevice(&dev));
-        CAP_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        attr_done = true;
-    }
+    int n_cu = 0;
+    if (cap_kernel_setup((const void*)kern, LDS, &n_cu) != 0) return -1;
     const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int grid = ntiles < n_cu ? ntiles : n_cu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, p);
@@ -914,15 +907,8 @@ template <bool OUT_F32, int EPI, int VAR, bool PROF, int NWM = 2, int NWN = 4>
 int launch_big2(const GemmParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 512 * 128 + 2 * 1024 + 8 * 16 * 144;   // two stages + bias ping-pong + epilogue strips
     auto kern = gemm_big2_kernel<OUT_F32, EPI, VAR, PROF, NWM, NWN>;
-    static bool attr_done = false;
-    static int n_cu = 0;
-    if (!attr_done) {
-        CAP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        int dev = 0;
-        CAP_HIP_CHECK(hipGetDevice(&dev));
-        CAP_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        attr_done = true;
-    }
+    int n_cu = 0;
+    if (cap_kernel_setup((const void*)kern, LDS, &n_cu) != 0) return -1;
     const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int grid = ntiles < n_cu ? ntiles : n_cu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWM * NWN * 64), LDS, stream, p);
@@ -934,15 +920,8 @@ template <typename T, bool OUT_F32, int EPI, int VAR = 0>
 int launch_big(const GemmParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 512 * 128 + 2 * 1024;       // two stages + bias ping-pong
     auto kern = gemm_big_kernel<T, OUT_F32, EPI, VAR>;
-    static bool attr_done = false;
-    static int n_cu = 0;
-    if (!attr_done) {
-        CAP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        int dev = 0;
-        CAP_HIP_CHECK(hipGetDevice(&dev));
-        CAP_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        attr_done = true;
-    }
+    int n_cu = 0;
+    if (cap_kernel_setup((const void*)kern, LDS, &n_cu) != 0) return -1;
     const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int grid = ntiles < n_cu ? ntiles : n_cu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, p);
@@ -957,13 +936,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
     static_assert((BM / WM) * (BN / WN) * 32 * WN * 4 <= LDS, "epilogue strips must fit in the staging buffers");
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     auto kern = gemm_kernel<T, BM, BN, WM, WN, D, WPE, OUT_F32, EPI>;
-    if (LDS > 64 * 1024) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            CAP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-            attr_done = true;
-        }
-    }
+    if (cap_kernel_setup((const void*)kern, LDS, nullptr) != 0) return -1;
     const int S = EPI == EPI_PARTIAL ? p.splitk : 1;
     hipLaunchKernelGGL(kern, dim3(ntm * ntn * S), dim3(NT), LDS, stream, p);
     CAP_HIP_CHECK(hipGetLastError());
