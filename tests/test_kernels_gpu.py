@@ -167,3 +167,24 @@ def test_decode_attention_with_ancestry_and_shared_kv(lib, dtype, n_keys, beams,
             ref[r, h * 64:(h + 1) * 64] = p @ v
     err = (out.float().cpu().double() - ref).abs().max().item()
     assert err < (1e-5 if dtype == "f32" else 2e-2), err
+
+
+def test_lds_dma_gemm_kernels_match_generic_kernel_bitwise(lib):
+    """The persistent LDS-DMA kernels (raw barriers, counted vmcnt) share the generic kernel's accumulation order: any repeat
+    that differs from it bit for bit would be an LDS read overtaking its DMA (tools/gemm_race_screen.py is the long form)."""
+    torch.manual_seed(1)
+    for (M, N, K, f32, gelu) in [(12608, 2304, 768, 0, 0), (12608, 768, 3072, 1, 0), (3000, 516, 192, 0, 1)]:
+        A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+        W = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
+        b = torch.randn(N, device="cuda")
+        dt = torch.float32 if f32 else torch.bfloat16
+
+        def run(tile, out):
+            _check(lib, lib.cap_op_gemm(1, _p(A), _p(W), _p(b), None, _p(out), M, N, K, gelu, f32, tile, _stream()))
+        ref = torch.empty(M, N, device="cuda", dtype=dt)
+        run(1, ref)
+        for tile in (12, 14):
+            for _ in range(10):
+                out = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
+                run(tile, out)
+                assert torch.equal(out, ref), (M, N, K, tile)
