@@ -178,3 +178,52 @@ class MiniLMArch:
     def tiny() -> "MiniLMArch":
         return MiniLMArch(hidden=64, layers=2, heads=2, ffn=128, vocab=300, max_pos=40, cls=1, sep=2, pad=0,
                           max_seq_length=32)
+
+
+@dataclasses.dataclass
+class Blip2Arch:
+    """BLIP-2 OPT (reference `captioner/models/blip2/blip2.py:19-22`: `Salesforce/blip2-opt-2.7b`) - HF defaults of
+    `HF:models/blip_2/configuration_blip_2.py` for the vision tower (ViT-g/14: 39 x 1408, 16 heads of 88) and the
+    Q-Former (12 x 768, 32 queries, cross-attention every 2nd layer), `facebook/opt-2.7b` for the language model
+    (32 x 2560, 32 heads of 80, FFN 10240, ReLU, pre-LN, learned positions with offset 2, tied LM head)."""
+    image_size: int = 224
+    patch_size: int = 14
+    v_hidden: int = 1408
+    v_layers: int = 39
+    v_heads: int = 16
+    v_mlp: int = 6144
+    v_eps: float = 1e-6
+    q_hidden: int = 768
+    q_layers: int = 12
+    q_heads: int = 12
+    q_ffn: int = 3072
+    q_cross_freq: int = 2
+    q_eps: float = 1e-12
+    num_query_tokens: int = 32
+    t_hidden: int = 2560
+    t_layers: int = 32
+    t_heads: int = 32
+    t_ffn: int = 10240
+    vocab: int = 50272
+    max_pos: int = 2048
+    t_eps: float = 1e-5
+    bos: int = 2
+    eos: int = 50118          # generation_config of blip2-opt-2.7b ("\n"); OPT's own eos is 2
+    pad: int = 1
+    image_token: int = 50265
+    max_new_tokens: int = 20  # HF generate default when the caller gives no length (blip2.py:26 gives none)
+
+    @property
+    def n_patches(self) -> int:
+        return (self.image_size // self.patch_size) ** 2
+
+    @property
+    def n_tokens(self) -> int:
+        return self.n_patches + 1
+
+    @staticmethod
+    def tiny() -> "Blip2Arch":
+        # head dims of the real model's kinds: vision 24 (not a power of two, like 88), q-former 64, language model 16
+        return Blip2Arch(image_size=28, patch_size=14, v_hidden=96, v_layers=2, v_heads=4, v_mlp=192, q_hidden=128, q_layers=2,
+                         q_heads=2, q_ffn=256, num_query_tokens=8, t_hidden=64, t_layers=2, t_heads=4, t_ffn=128, vocab=512,
+                         max_pos=64, eos=3, image_token=511)

@@ -18,7 +18,7 @@ from typing import Dict, Iterable, List, Tuple
 import numpy as np
 import torch
 
-from .config import BlipArch, CocaArch, MiniLMArch
+from .config import Blip2Arch, BlipArch, CocaArch, MiniLMArch
 
 
 def blip_param_specs(a: BlipArch) -> List[Tuple[str, Tuple[int, ...], str, float]]:
@@ -205,6 +205,68 @@ def minilm_param_specs(a: MiniLMArch) -> List[Tuple[str, Tuple[int, ...], str, f
 
 def procedural_minilm_state_dict(arch: MiniLMArch, seed: int = 0) -> Dict[str, torch.Tensor]:
     return {name: torch.from_numpy(_draw(seed, name, shape, kind, scale)) for name, shape, kind, scale in minilm_param_specs(arch)}
+
+
+def blip2_param_specs(a: Blip2Arch) -> List[Tuple[str, Tuple[int, ...], str, float]]:
+    """`Blip2ForConditionalGeneration.state_dict()` names (transformers 5.x: one fused `qkv` Linear with bias in the ViT)."""
+    s: List[Tuple[str, Tuple[int, ...], str, float]] = []
+    D, M, P = a.v_hidden, a.v_mlp, a.patch_size
+    vm = "vision_model."
+    s.append((vm + "embeddings.class_embedding", (1, 1, D), "normal", 0.5))
+    s.append((vm + "embeddings.position_embedding", (1, a.n_tokens, D), "normal", 0.5))
+    s.append((vm + "embeddings.patch_embedding.weight", (D, 3, P, P), "normal", 1.0 / np.sqrt(3 * P * P)))
+    s.append((vm + "embeddings.patch_embedding.bias", (D,), "normal", 0.02))
+    for i in range(a.v_layers):
+        p = f"{vm}encoder.layers.{i}."
+        s += [(p + "self_attn.qkv.weight", (3 * D, D), "normal", 1.0 / np.sqrt(D)), (p + "self_attn.qkv.bias", (3 * D,), "normal", 0.02),
+              (p + "self_attn.projection.weight", (D, D), "normal", 0.5 / np.sqrt(D)), (p + "self_attn.projection.bias", (D,), "normal", 0.02),
+              (p + "layer_norm1.weight", (D,), "gamma", 0.1), (p + "layer_norm1.bias", (D,), "normal", 0.05),
+              (p + "mlp.fc1.weight", (M, D), "normal", 1.0 / np.sqrt(D)), (p + "mlp.fc1.bias", (M,), "normal", 0.02),
+              (p + "mlp.fc2.weight", (D, M), "normal", 0.5 / np.sqrt(M)), (p + "mlp.fc2.bias", (D,), "normal", 0.02),
+              (p + "layer_norm2.weight", (D,), "gamma", 0.1), (p + "layer_norm2.bias", (D,), "normal", 0.05)]
+    s += [(vm + "post_layernorm.weight", (D,), "gamma", 0.1), (vm + "post_layernorm.bias", (D,), "normal", 0.05)]
+    Q, F = a.q_hidden, a.q_ffn
+    s.append(("query_tokens", (1, a.num_query_tokens, Q), "normal", 0.5))
+    s += [("qformer.layernorm.weight", (Q,), "gamma", 0.1), ("qformer.layernorm.bias", (Q,), "normal", 0.05)]
+    for i in range(a.q_layers):
+        p = f"qformer.encoder.layer.{i}."
+        blocks = [("attention", Q)] + ([("crossattention", D)] if i % a.q_cross_freq == 0 else [])
+        for blk, kin in blocks:
+            for nm, fan in (("query", Q), ("key", kin), ("value", kin)):
+                s.append((p + f"{blk}.attention.{nm}.weight", (Q, fan), "normal", 1.2 / np.sqrt(fan)))
+                s.append((p + f"{blk}.attention.{nm}.bias", (Q,), "normal", 0.02))
+            s += [(p + f"{blk}.output.dense.weight", (Q, Q), "normal", 1.0 / np.sqrt(Q)), (p + f"{blk}.output.dense.bias", (Q,), "normal", 0.02),
+                  (p + f"{blk}.output.LayerNorm.weight", (Q,), "gamma", 0.1), (p + f"{blk}.output.LayerNorm.bias", (Q,), "normal", 0.05)]
+        s += [(p + "intermediate_query.dense.weight", (F, Q), "normal", 1.0 / np.sqrt(Q)), (p + "intermediate_query.dense.bias", (F,), "normal", 0.02),
+              (p + "output_query.dense.weight", (Q, F), "normal", 1.0 / np.sqrt(F)), (p + "output_query.dense.bias", (Q,), "normal", 0.02),
+              (p + "output_query.LayerNorm.weight", (Q,), "gamma", 0.1), (p + "output_query.LayerNorm.bias", (Q,), "normal", 0.05)]
+    T, G = a.t_hidden, a.t_ffn
+    s += [("language_projection.weight", (T, Q), "normal", 1.0 / np.sqrt(Q)), ("language_projection.bias", (T,), "normal", 0.02)]
+    lm = "language_model.model.decoder."
+    s += [(lm + "embed_tokens.weight", (a.vocab, T), "normal", 0.08), (lm + "embed_positions.weight", (a.max_pos + 2, T), "normal", 0.25)]
+    for i in range(a.t_layers):
+        p = f"{lm}layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj"):
+            s += [(p + f"self_attn.{nm}.weight", (T, T), "normal", 1.2 / np.sqrt(T)), (p + f"self_attn.{nm}.bias", (T,), "normal", 0.02)]
+        s += [(p + "self_attn.out_proj.weight", (T, T), "normal", 1.5 / np.sqrt(T)), (p + "self_attn.out_proj.bias", (T,), "normal", 0.02),
+              (p + "self_attn_layer_norm.weight", (T,), "gamma", 0.1), (p + "self_attn_layer_norm.bias", (T,), "normal", 0.05),
+              (p + "fc1.weight", (G, T), "normal", 1.0 / np.sqrt(T)), (p + "fc1.bias", (G,), "normal", 0.02),
+              (p + "fc2.weight", (T, G), "normal", 1.5 / np.sqrt(G)), (p + "fc2.bias", (T,), "normal", 0.02),
+              (p + "final_layer_norm.weight", (T,), "gamma", 0.1), (p + "final_layer_norm.bias", (T,), "normal", 0.05)]
+    s += [(lm + "final_layer_norm.weight", (T,), "gamma", 0.1), (lm + "final_layer_norm.bias", (T,), "normal", 0.05)]
+    return s
+
+
+def procedural_blip2_state_dict(arch: Blip2Arch, seed: int = 0, eos_boost: float = 0.0) -> Dict[str, torch.Tensor]:
+    """Seeded fp32 state dict; `language_model.lm_head.weight` is tied to the token table (shares storage).  The LM head has
+    no bias: `eos_boost` adds boost * beta / |beta|^2 (beta = bias of the final LayerNorm) to the EOS row of the tied table,
+    which raises the EOS logit by about `eos_boost` at every step so that some captions end early."""
+    sd = {name: torch.from_numpy(_draw(seed, name, shape, kind, scale)) for name, shape, kind, scale in blip2_param_specs(arch)}
+    if eos_boost:
+        beta = sd["language_model.model.decoder.final_layer_norm.bias"]
+        sd["language_model.model.decoder.embed_tokens.weight"][arch.eos] += eos_boost * beta / float(beta.pow(2).sum())
+    sd["language_model.lm_head.weight"] = sd["language_model.model.decoder.embed_tokens.weight"]
+    return sd
 
 
 def synthetic_token_batch(arch: MiniLMArch, batch: int, max_len: int, seed: int = 0):

@@ -1,0 +1,40 @@
+"""CPU: the BLIP-2 OPT restatement (oracle/blip2_ref.py) against vectors captured from the real HF
+Blip2ForConditionalGeneration (tools/make_goldens_blip2.py)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from embodied_captioning_amd.config import Blip2Arch
+from embodied_captioning_amd.weights import procedural_blip2_state_dict, synthetic_pixels
+from oracle import blip2_ref as R
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_blip2(name="blip2_tiny"):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(str(g["meta"]))
+    arch = Blip2Arch(**meta["arch"])
+    sd = procedural_blip2_state_dict(arch, meta["seed"], eos_boost=meta["eos_boost"])
+    px = synthetic_pixels(meta["batch"], arch.image_size, seed=meta["seed"])
+    return g, meta, arch, sd, px
+
+
+def test_restatement_matches_hf_golden():
+    g, meta, a, sd, px = load_blip2()
+    out = R.greedy_generate(sd, a, px)
+    assert np.abs(out["image_embeds"].numpy() - g["image_embeds"]).max() < 2e-5
+    assert np.abs(out["query_output"].numpy() - g["query_output"]).max() < 2e-5
+    seq = out["sequences"].numpy()
+    assert np.array_equal(seq, g["sequences"][:, : seq.shape[1]]) and (g["sequences"][:, seq.shape[1]:] == a.pad).all()
+    lg = torch.stack(out["logits"], 0).numpy()
+    # rows that finished feed pad tokens in HF and are not stepped here: compare the steps every row was still running
+    ref = g["logits"][: lg.shape[0]]
+    new = g["sequences"][:, a.num_query_tokens + 1:]
+    for b in range(meta["batch"]):
+        n = int(np.argmax(new[b] == a.eos)) + 1 if (new[b] == a.eos).any() else lg.shape[0]
+        assert np.abs(lg[:n, b] - ref[:n, b]).max() < 5e-5
+    # the fixture exercises both endings
+    assert (new == a.eos).any() and not (new == a.eos).any(axis=1).all()
