@@ -28,6 +28,8 @@ class CapConfig(C.Structure):
         ("pix_mean", C.c_float * 3), ("pix_std", C.c_float * 3),
         ("embed_dim", C.c_int32), ("pool_queries", C.c_int32), ("pool_heads", C.c_int32), ("mm_layers", C.c_int32),
         ("min_len", C.c_int32),
+        ("q_hidden", C.c_int32), ("q_layers", C.c_int32), ("q_heads", C.c_int32), ("q_ffn", C.c_int32),
+        ("q_cross_freq", C.c_int32), ("num_query_tokens", C.c_int32), ("q_eps", C.c_float),
     ]
 
 

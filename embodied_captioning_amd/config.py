@@ -224,6 +224,6 @@ class Blip2Arch:
     @staticmethod
     def tiny() -> "Blip2Arch":
         # head dims of the real model's kinds: vision 24 (not a power of two, like 88), q-former 64, language model 16
-        return Blip2Arch(image_size=28, patch_size=14, v_hidden=96, v_layers=2, v_heads=4, v_mlp=192, q_hidden=128, q_layers=2,
+        return Blip2Arch(image_size=28, patch_size=14, v_hidden=192, v_layers=2, v_heads=8, v_mlp=256, q_hidden=128, q_layers=2,
                          q_heads=2, q_ffn=256, num_query_tokens=8, t_hidden=64, t_layers=2, t_heads=4, t_ffn=128, vocab=512,
                          max_pos=64, eos=3, image_token=511)

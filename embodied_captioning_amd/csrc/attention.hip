@@ -760,6 +760,108 @@ __global__ __launch_bounds__(64) void text_attention_kernel(const T* __restrict_
     }
 }
 
+// ---- generic attention for the BLIP-2 path (head_dim 88 in ViT-g, 80 in OPT-2.7b, 64 in the Q-Former; query / key / value
+// live in differently strided buffers: fused qkv rows, a per-layer K/V cache, image tokens).  One wave per (batch, head, block
+// of 64 queries): lane = query, its q and output rows in registers (HDP = head_dim padded to 32/64/96/128), keys staged 32 at
+// a time into LDS as fp32, online softmax.  causal_off >= 0: query i sees keys j <= i + causal_off.  A correctness-first
+// kernel (VALU dot products); the hot ViT-B/L paths keep their MFMA kernels.
+template <typename T, int HDP>
+__global__ __launch_bounds__(64) void generic_attention_kernel(const T* __restrict__ q, long ldq, long qbs,
+                                                               const T* __restrict__ k, long ldk, long kbs,
+                                                               const T* __restrict__ v, long ldv, long vbs,
+                                                               T* __restrict__ out, long ldo, long obs, int Lq, int Lk,
+                                                               int H, int hd, int causal_off, float scale) {
+    __shared__ float Ks[32 * HDP], Vs[32 * HDP];
+    const int nqb = (Lq + 63) / 64;
+    const int qb = blockIdx.x % nqb, bh = blockIdx.x / nqb, h = bh % H, b = bh / H;
+    const int lane = threadIdx.x, qi = qb * 64 + lane;
+    const bool live = qi < Lq;
+    float qv[HDP], o[HDP];
+#pragma unroll
+    for (int d = 0; d < HDP; ++d) {
+        qv[d] = (live && d < hd) ? to_f32(q[(size_t)b * qbs + (size_t)qi * ldq + h * hd + d]) * scale : 0.f;
+        o[d] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    const int kmax = causal_off >= 0 ? min(Lk, qb * 64 + 63 + causal_off + 1) : Lk;      // last key any query of this block sees
+    for (int k0 = 0; k0 < kmax; k0 += 32) {
+        __syncthreads();
+        for (int i = lane; i < 32 * HDP; i += 64) {
+            const int j = i / HDP, d = i - j * HDP;
+            const bool ok = k0 + j < Lk && d < hd;
+            Ks[i] = ok ? to_f32(k[(size_t)b * kbs + (size_t)(k0 + j) * ldk + h * hd + d]) : 0.f;
+            Vs[i] = ok ? to_f32(v[(size_t)b * vbs + (size_t)(k0 + j) * ldv + h * hd + d]) : 0.f;
+        }
+        __syncthreads();
+        const int jn = min(32, Lk - k0);
+        for (int j = 0; j < jn; ++j) {
+            if (causal_off >= 0 && k0 + j > qi + causal_off) break;
+            float sc = 0.f;
+#pragma unroll
+            for (int d = 0; d < HDP; ++d) sc = fmaf(qv[d], Ks[j * HDP + d], sc);
+            const float mn = fmaxf(m, sc);
+            const float c = expf(m - mn), pj = expf(sc - mn);
+            l = l * c + pj;
+#pragma unroll
+            for (int d = 0; d < HDP; ++d) o[d] = fmaf(pj, Vs[j * HDP + d], o[d] * c);
+            m = mn;
+        }
+    }
+    if (live) {
+        const float inv = 1.0f / l;
+        T* op = out + (size_t)b * obs + (size_t)qi * ldo + h * hd;
+#pragma unroll
+        for (int d = 0; d < HDP; ++d)
+            if (d < hd) op[d] = from_f32<T>(o[d] * inv);
+    }
+}
+
+// OPT decoder inputs.  Prefill: row (b, j) of x[B, P, T] = (j < nq ? projected query (b, j) : token table[bos]) + position
+// table[j + 2] (HF OPTLearnedPositionalEmbedding offset).  Decode: x[b] = token table[seq[b][cur]] + position table[cur + 2].
+__global__ void opt_prefill_inputs_kernel(const float* __restrict__ proj, const float* __restrict__ tok, const float* __restrict__ pos,
+                                          float* __restrict__ x, int B, int nq, int T, int bos) {
+    const size_t n = (size_t)B * (nq + 1) * T;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = i % T;
+        const size_t r = i / T;
+        const int j = r % (nq + 1), b = r / (nq + 1);
+        const float e = j < nq ? proj[((size_t)b * nq + j) * T + d] : tok[(size_t)bos * T + d];
+        x[i] = e + pos[(size_t)(j + 2) * T + d];
+    }
+}
+__global__ void opt_token_inputs_kernel(const int* __restrict__ seq, int seq_ld, int cur, const float* __restrict__ tok,
+                                        const float* __restrict__ pos, float* __restrict__ x, int B, int T) {
+    const size_t n = (size_t)B * T;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = i % T, b = i / T;
+        x[i] = tok[(size_t)seq[(size_t)b * seq_ld + cur] * T + d] + pos[(size_t)(cur + 2) * T + d];
+    }
+}
+// k|v columns of fused qkv rows [B * L, 3T] -> caches [B][Lmax][T] at positions pos0 .. pos0 + L - 1
+template <typename T>
+__global__ void kv_append_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc, int B, int L, int Tw,
+                                 int Lmax, int pos0) {
+    const size_t n = (size_t)B * L * Tw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = i % Tw;
+        const size_t r = i / Tw;
+        const int j = r % L, b = r / L;
+        const size_t dst = ((size_t)b * Lmax + pos0 + j) * Tw + d;
+        kc[dst] = qkv[r * 3 * Tw + Tw + d];
+        vc[dst] = qkv[r * 3 * Tw + 2 * Tw + d];
+    }
+}
+// rows of a [n, D] table repeated for every batch item: dst_f / dst_t [B * n, D]
+template <typename T>
+__global__ void rows_broadcast_kernel(const float* __restrict__ src, float* __restrict__ dst_f, T* __restrict__ dst_t, int B, int n, int D) {
+    const size_t tot = (size_t)B * n * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = src[i % ((size_t)n * D)];
+        dst_f[i] = x;
+        dst_t[i] = from_f32<T>(x);
+    }
+}
+
 template <int KB>
 int launch_mfma_kb(const void* qkv, void* ctx, int B, int N, int H, hipStream_t s) {
     const int lds = 2 * KB * 32 * 128;
@@ -782,7 +884,14 @@ int launch_flash_kb(const void* qkv, void* ctx, int B, int N, int H, hipStream_t
 
 }  // namespace
 
-int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s) {
+int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s, int head_dim) {
+    if (head_dim != 64) {   // ViT-g/14 of BLIP-2 (88): generic kernel over the fused qkv rows
+        const long D = (long)H * head_dim;
+        const char* base = (const char*)qkv;
+        const size_t e = dtype == CAP_DT_BF16 ? 2 : 4;
+        return launch_generic_attention(dtype, base, 3 * D, (long)N * 3 * D, base + D * e, 3 * D, (long)N * 3 * D, base + 2 * D * e,
+                                        3 * D, (long)N * 3 * D, ctx, D, (long)N * D, B, N, N, H, head_dim, -1, s);
+    }
     const int kb = (N + 31) / 32;
     const bool mfma_ok = dtype == CAP_DT_BF16 && (kb == 1 || kb == 7 || kb == 9 || kb == 19);
     if (impl == 2 && !mfma_ok) {
@@ -862,6 +971,54 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
         hipLaunchKernelGGL(decode_attention_kernel<float>, grid, dim3(256), lds, s, (const float*)q,
                            (const float*)kbase, (const float*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys,
                            (float*)out, H);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_generic_attention(int dtype, const void* q, long ldq, long qbs, const void* k, long ldk, long kbs, const void* v,
+                             long ldv, long vbs, void* out, long ldo, long obs, int B, int Lq, int Lk, int H, int hd,
+                             int causal_off, hipStream_t s) {
+    if (hd < 8 || hd > 128 || B < 1 || Lq < 1 || Lk < 1) { cap_set_error("generic_attention: head_dim %d / shape unsupported", hd); return -1; }
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int hdp = hd <= 32 ? 32 : hd <= 64 ? 64 : hd <= 96 ? 96 : 128;
+    const dim3 grid(B * H * ((Lq + 63) / 64));
+#define CAP_GA(TT, HDP)                                                                                                \
+    hipLaunchKernelGGL((generic_attention_kernel<TT, HDP>), grid, dim3(64), 0, s, (const TT*)q, ldq, qbs, (const TT*)k, ldk, \
+                       kbs, (const TT*)v, ldv, vbs, (TT*)out, ldo, obs, Lq, Lk, H, hd, causal_off, scale)
+#define CAP_GA_T(TT)                                                                                                   \
+    do { if (hdp == 32) CAP_GA(TT, 32); else if (hdp == 64) CAP_GA(TT, 64); else if (hdp == 96) CAP_GA(TT, 96); else CAP_GA(TT, 128); } while (0)
+    if (dtype == CAP_DT_BF16) CAP_GA_T(bf16_t); else CAP_GA_T(float);
+#undef CAP_GA_T
+#undef CAP_GA
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_opt_prefill_inputs(const float* proj, const float* tok, const float* pos, float* x, int B, int nq, int T, int bos,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(opt_prefill_inputs_kernel, dim3(256), dim3(256), 0, s, proj, tok, pos, x, B, nq, T, bos);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_opt_token_inputs(const int* seq, int seq_ld, int cur, const float* tok, const float* pos, float* x, int B, int T,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(opt_token_inputs_kernel, dim3(64), dim3(256), 0, s, seq, seq_ld, cur, tok, pos, x, B, T);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_kv_append(int dtype, const void* qkv, void* kc, void* vc, int B, int L, int T, int Lmax, int pos0, hipStream_t s) {
+    if (dtype == CAP_DT_BF16)
+        hipLaunchKernelGGL(kv_append_kernel<bf16_t>, dim3(256), dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, B, L, T, Lmax, pos0);
+    else
+        hipLaunchKernelGGL(kv_append_kernel<float>, dim3(256), dim3(256), 0, s, (const float*)qkv, (float*)kc, (float*)vc, B, L, T, Lmax, pos0);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_rows_broadcast(int dtype, const float* src, float* dst_f, void* dst_t, int B, int n, int D, hipStream_t s) {
+    if (dtype == CAP_DT_BF16)
+        hipLaunchKernelGGL(rows_broadcast_kernel<bf16_t>, dim3(256), dim3(256), 0, s, src, dst_f, (bf16_t*)dst_t, B, n, D);
+    else
+        hipLaunchKernelGGL(rows_broadcast_kernel<float>, dim3(256), dim3(256), 0, s, src, dst_f, (float*)dst_t, B, n, D);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -65,6 +65,16 @@ struct VLayer {
     void *w_qkv, *w_proj, *w_fc1, *w_fc2;
     float *b_qkv, *b_proj, *b_fc1, *b_fc2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
 };
+struct QLayer {            // BLIP-2 Q-Former layer (queries only): self-attention, optional cross-attention, query FFN; post-LN
+    bool cross = false;
+    void *w_qkv = nullptr, *w_so = nullptr, *w_cq = nullptr, *w_ckv = nullptr, *w_co = nullptr, *w_f1 = nullptr, *w_f2 = nullptr;
+    float *b_qkv = nullptr, *b_so = nullptr, *so_g = nullptr, *so_b = nullptr, *b_cq = nullptr, *b_ckv = nullptr, *b_co = nullptr,
+          *co_g = nullptr, *co_b = nullptr, *b_f1 = nullptr, *b_f2 = nullptr, *f_g = nullptr, *f_b = nullptr;
+};
+struct OLayer {            // OPT decoder layer (pre-LN): fused q|k|v, out_proj, fc1 (ReLU), fc2; K/V caches [B][Lmax][T]
+    void *w_qkv, *w_o, *w_f1, *w_f2, *kc, *vc;
+    float *b_qkv, *b_o, *b_f1, *b_f2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+};
 struct TLayer {
     void *w_qkv, *w_so, *w_cq, *w_co, *w_f1, *w_f2;
     float *b_qkv, *b_so, *so_g, *so_b, *b_cq, *b_co, *co_g, *co_b, *b_f1, *b_f2, *f_g, *f_b;
@@ -132,6 +142,14 @@ struct Captioner {
     int* ln_cnt[4] = {nullptr, nullptr, nullptr, nullptr};
     int ln_total[4] = {0, 0, 0, 0};
     bool fuse_ln = false;
+    // ---- BLIP-2 (CAP_ARCH_BLIP2)
+    std::vector<QLayer> ql;
+    std::vector<OLayer> ol;
+    float *q_x0 = nullptr, *b_lproj = nullptr, *o_tok = nullptr, *o_pos = nullptr, *o_lnf_g = nullptr, *o_lnf_b = nullptr;
+    void *w_lproj = nullptr, *o_tok_t = nullptr;
+    float *qx = nullptr, *qy = nullptr, *lm_proj = nullptr, *ox = nullptr;      // activations
+    void *qx_t = nullptr, *qqkv = nullptr, *qctx = nullptr, *qh = nullptr, *qkvimg = nullptr, *oh_t = nullptr, *oqkv = nullptr,
+         *octx = nullptr, *off = nullptr;
     // ---- sentence encoder (CAP_ARCH_MINILM): token-type row 0, activations [max_batch * max_len, .]
     float *tok_type = nullptr, *te_x = nullptr, *te_y = nullptr;
     void *te_xt = nullptr, *te_qkv = nullptr, *te_ctx = nullptr, *te_h = nullptr;
@@ -446,6 +464,247 @@ int gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, int lda, c
     return launch_gemm(m->dt, p, 0, s);   // tile 0 = auto (stream kernel for encoder-sized problems without residual)
 }
 
+// ---------------------------------------------------------------------------------------------- BLIP-2 OPT
+int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_embeds, hipStream_t s);
+__global__ void init_seq_kernel(int* seq, int* fin, int* len, int R, int L, int bos, int pad);
+__global__ void copy_logits_kernel(const float* src, int ld, float* dst, int R, int V);
+__global__ void copy_new_tokens_kernel(const int* seq, int seq_ld, int P, const int* lens, int* out_ids, int* out_len, int B, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * n; i += gridDim.x * blockDim.x) out_ids[i] = seq[(size_t)(i / n) * seq_ld + P + i % n];
+    if (out_len)
+        for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) out_len[b] = min(lens[b] - P, n);
+}
+// HF `Blip2ForConditionalGeneration` state-dict names (transformers 5.x).  `derived.qformer_x0` = qformer.layernorm(
+// query_tokens), computed once by the host loader (a constant of the checkpoint).
+int build_blip2(Captioner* m) {
+    const CapConfig& c = m->c;
+    const int D = c.v_hidden, Mv = c.v_mlp, Q = c.q_hidden, F = c.q_ffn, T = c.t_hidden, G = c.t_ffn, V = c.vocab, nq = c.num_query_tokens;
+    const std::string vm = "vision_model.";
+    TRY(reg_f32(m, vm + "embeddings.class_embedding", &m->cls, D));
+    TRY(reg_f32(m, vm + "embeddings.position_embedding", &m->vpos, (int64_t)m->NT * D));
+    TRY(reg_mat(m, vm + "embeddings.patch_embedding.weight", &m->w_patch, D, m->Kpatch, m->Kpad));
+    TRY(reg_f32(m, vm + "embeddings.patch_embedding.bias", &m->b_patch, D));
+    m->vl.resize(c.v_layers);
+    for (int i = 0; i < c.v_layers; ++i) {
+        VLayer& L = m->vl[i];
+        const std::string p = vm + "encoder.layers." + std::to_string(i) + ".";
+        TRY(reg_mat(m, p + "self_attn.qkv.weight", &L.w_qkv, 3 * D, D));
+        TRY(reg_f32(m, p + "self_attn.qkv.bias", &L.b_qkv, 3 * D));
+        TRY(reg_mat(m, p + "self_attn.projection.weight", &L.w_proj, D, D));
+        TRY(reg_f32(m, p + "self_attn.projection.bias", &L.b_proj, D));
+        TRY(reg_f32(m, p + "layer_norm1.weight", &L.ln1_g, D));
+        TRY(reg_f32(m, p + "layer_norm1.bias", &L.ln1_b, D));
+        TRY(reg_mat(m, p + "mlp.fc1.weight", &L.w_fc1, Mv, D));
+        TRY(reg_f32(m, p + "mlp.fc1.bias", &L.b_fc1, Mv));
+        TRY(reg_mat(m, p + "mlp.fc2.weight", &L.w_fc2, D, Mv));
+        TRY(reg_f32(m, p + "mlp.fc2.bias", &L.b_fc2, D));
+        TRY(reg_f32(m, p + "layer_norm2.weight", &L.ln2_g, D));
+        TRY(reg_f32(m, p + "layer_norm2.bias", &L.ln2_b, D));
+    }
+    TRY(reg_f32(m, vm + "post_layernorm.weight", &m->post_g, D));
+    TRY(reg_f32(m, vm + "post_layernorm.bias", &m->post_b, D));
+
+    TRY(reg_f32(m, "derived.qformer_x0", &m->q_x0, (int64_t)nq * Q));
+    m->ql.resize(c.q_layers);
+    const char* nm[3] = {"query", "key", "value"};
+    for (int i = 0; i < c.q_layers; ++i) {
+        QLayer& L = m->ql[i];
+        L.cross = i % c.q_cross_freq == 0;
+        const std::string p = "qformer.encoder.layer." + std::to_string(i) + ".";
+        TRY(dev_alloc(m, &L.w_qkv, (size_t)3 * Q * Q * m->esz));
+        TRY(dev_alloc(m, (void**)&L.b_qkv, (size_t)3 * Q * 4));
+        for (int j = 0; j < 3; ++j) {
+            add_slot(m, p + "attention.attention." + nm[j] + ".weight", (char*)L.w_qkv + (size_t)j * Q * Q * m->esz, m->dt, Q, Q);
+            add_slot(m, p + "attention.attention." + nm[j] + ".bias", L.b_qkv + (size_t)j * Q, CAP_DT_F32, 1, Q);
+        }
+        TRY(reg_mat(m, p + "attention.output.dense.weight", &L.w_so, Q, Q));
+        TRY(reg_f32(m, p + "attention.output.dense.bias", &L.b_so, Q));
+        TRY(reg_f32(m, p + "attention.output.LayerNorm.weight", &L.so_g, Q));
+        TRY(reg_f32(m, p + "attention.output.LayerNorm.bias", &L.so_b, Q));
+        if (L.cross) {
+            TRY(reg_mat(m, p + "crossattention.attention.query.weight", &L.w_cq, Q, Q));
+            TRY(reg_f32(m, p + "crossattention.attention.query.bias", &L.b_cq, Q));
+            TRY(dev_alloc(m, &L.w_ckv, (size_t)2 * Q * D * m->esz));
+            TRY(dev_alloc(m, (void**)&L.b_ckv, (size_t)2 * Q * 4));
+            for (int j = 0; j < 2; ++j) {
+                add_slot(m, p + "crossattention.attention." + nm[j + 1] + ".weight", (char*)L.w_ckv + (size_t)j * Q * D * m->esz, m->dt, Q, D);
+                add_slot(m, p + "crossattention.attention." + nm[j + 1] + ".bias", L.b_ckv + (size_t)j * Q, CAP_DT_F32, 1, Q);
+            }
+            TRY(reg_mat(m, p + "crossattention.output.dense.weight", &L.w_co, Q, Q));
+            TRY(reg_f32(m, p + "crossattention.output.dense.bias", &L.b_co, Q));
+            TRY(reg_f32(m, p + "crossattention.output.LayerNorm.weight", &L.co_g, Q));
+            TRY(reg_f32(m, p + "crossattention.output.LayerNorm.bias", &L.co_b, Q));
+        }
+        TRY(reg_mat(m, p + "intermediate_query.dense.weight", &L.w_f1, F, Q));
+        TRY(reg_f32(m, p + "intermediate_query.dense.bias", &L.b_f1, F));
+        TRY(reg_mat(m, p + "output_query.dense.weight", &L.w_f2, Q, F));
+        TRY(reg_f32(m, p + "output_query.dense.bias", &L.b_f2, Q));
+        TRY(reg_f32(m, p + "output_query.LayerNorm.weight", &L.f_g, Q));
+        TRY(reg_f32(m, p + "output_query.LayerNorm.bias", &L.f_b, Q));
+    }
+    TRY(reg_mat(m, "language_projection.weight", &m->w_lproj, T, Q));
+    TRY(reg_f32(m, "language_projection.bias", &m->b_lproj, T));
+
+    const std::string lm = "language_model.model.decoder.";
+    // token table twice: fp32 rows for the lookup, compute dtype as the tied LM head
+    TRY(dev_alloc(m, (void**)&m->o_tok, (size_t)V * T * 4));
+    add_slot(m, lm + "embed_tokens.weight", m->o_tok, CAP_DT_F32, V, T);
+    if (m->dt == CAP_DT_F32) m->o_tok_t = m->o_tok;
+    else { TRY(dev_alloc(m, &m->o_tok_t, (size_t)V * T * m->esz)); add_slot(m, lm + "embed_tokens.weight", m->o_tok_t, m->dt, V, T); }
+    TRY(reg_f32(m, lm + "embed_positions.weight", &m->o_pos, (int64_t)(c.max_pos + 2) * T));
+    const size_t Bm = c.max_batch, Lmax = nq + 1 + c.max_len;
+    m->ol.resize(c.t_layers);
+    const char* pn[3] = {"q_proj", "k_proj", "v_proj"};
+    for (int i = 0; i < c.t_layers; ++i) {
+        OLayer& L = m->ol[i];
+        const std::string p = lm + "layers." + std::to_string(i) + ".";
+        TRY(dev_alloc(m, &L.w_qkv, (size_t)3 * T * T * m->esz));
+        TRY(dev_alloc(m, (void**)&L.b_qkv, (size_t)3 * T * 4));
+        for (int j = 0; j < 3; ++j) {
+            add_slot(m, p + "self_attn." + pn[j] + ".weight", (char*)L.w_qkv + (size_t)j * T * T * m->esz, m->dt, T, T);
+            add_slot(m, p + "self_attn." + pn[j] + ".bias", L.b_qkv + (size_t)j * T, CAP_DT_F32, 1, T);
+        }
+        TRY(reg_mat(m, p + "self_attn.out_proj.weight", &L.w_o, T, T));
+        TRY(reg_f32(m, p + "self_attn.out_proj.bias", &L.b_o, T));
+        TRY(reg_f32(m, p + "self_attn_layer_norm.weight", &L.ln1_g, T));
+        TRY(reg_f32(m, p + "self_attn_layer_norm.bias", &L.ln1_b, T));
+        TRY(reg_mat(m, p + "fc1.weight", &L.w_f1, G, T));
+        TRY(reg_f32(m, p + "fc1.bias", &L.b_f1, G));
+        TRY(reg_mat(m, p + "fc2.weight", &L.w_f2, T, G));
+        TRY(reg_f32(m, p + "fc2.bias", &L.b_f2, T));
+        TRY(reg_f32(m, p + "final_layer_norm.weight", &L.ln2_g, T));
+        TRY(reg_f32(m, p + "final_layer_norm.bias", &L.ln2_b, T));
+        TRY(dev_alloc(m, &L.kc, Bm * Lmax * T * m->esz));
+        TRY(dev_alloc(m, &L.vc, Bm * Lmax * T * m->esz));
+    }
+    TRY(reg_f32(m, lm + "final_layer_norm.weight", &m->o_lnf_g, T));
+    TRY(reg_f32(m, lm + "final_layer_norm.bias", &m->o_lnf_b, T));
+
+    // arena
+    const size_t NT = m->NT, M = Bm * NT, e = m->esz, P = nq + 1;
+    TRY(dev_alloc(m, &m->patches, Bm * m->P * m->Kpad * e));
+    CAP_HIP_CHECK(hipMemset(m->patches, 0, Bm * m->P * m->Kpad * e));
+    TRY(dev_alloc(m, (void**)&m->X, M * D * 4));
+    TRY(dev_alloc(m, (void**)&m->delta, M * D * (kDeltaInT ? e : 4)));
+    TRY(dev_alloc(m, &m->ln, M * D * e));
+    TRY(dev_alloc(m, &m->qkv, M * 3 * D * e));
+    TRY(dev_alloc(m, &m->ctx, M * D * e));
+    TRY(dev_alloc(m, &m->mlp, M * Mv * e));
+    TRY(dev_alloc(m, (void**)&m->emb_f, M * D * 4));
+    TRY(dev_alloc(m, &m->emb_t, M * D * e));
+    TRY(dev_alloc(m, (void**)&m->qx, Bm * nq * Q * 4));
+    TRY(dev_alloc(m, (void**)&m->qy, Bm * nq * Q * 4));
+    TRY(dev_alloc(m, &m->qx_t, Bm * nq * Q * e));
+    TRY(dev_alloc(m, &m->qqkv, Bm * nq * 3 * Q * e));
+    TRY(dev_alloc(m, &m->qctx, Bm * nq * Q * e));
+    TRY(dev_alloc(m, &m->qh, Bm * nq * F * e));
+    TRY(dev_alloc(m, &m->qkvimg, M * 2 * Q * e));
+    TRY(dev_alloc(m, (void**)&m->lm_proj, Bm * nq * T * 4));
+    TRY(dev_alloc(m, (void**)&m->ox, Bm * P * T * 4));
+    TRY(dev_alloc(m, &m->oh_t, Bm * P * T * e));
+    TRY(dev_alloc(m, &m->oqkv, Bm * P * 3 * T * e));
+    TRY(dev_alloc(m, &m->octx, Bm * P * T * e));
+    TRY(dev_alloc(m, &m->off, Bm * P * G * e));
+    TRY(dev_alloc(m, (void**)&m->seq, Bm * Lmax * 4));
+    TRY(dev_alloc(m, (void**)&m->finished, Bm * 4));
+    TRY(dev_alloc(m, (void**)&m->lens, Bm * 4));
+    m->ldl = (V + 3) & ~3;
+    TRY(dev_alloc(m, (void**)&m->logits, Bm * (size_t)m->ldl * 4));
+    return 0;
+}
+
+// Q-Former over the image tokens (emb_t [B * NT, D]) -> qx_t [B * nq, Q]
+int run_qformer(Captioner* m, int B, hipStream_t s) {
+    const CapConfig& c = m->c;
+    const int D = c.v_hidden, Q = c.q_hidden, F = c.q_ffn, H = c.q_heads, nq = c.num_query_tokens, NT = m->NT, R = B * nq, hd = Q / H;
+    const size_t e = m->esz;
+    TRY(launch_rows_broadcast(m->dt, m->q_x0, m->qx, m->qx_t, B, nq, Q, s));
+    for (int i = 0; i < c.q_layers; ++i) {
+        const QLayer& L = m->ql[i];
+        TRY(gemm(m, s, "qf_gemm_qkv", m->qx_t, Q, L.w_qkv, Q, m->qqkv, 3 * Q, L.b_qkv, nullptr, R, 3 * Q, Q, 0, 0));
+        {
+            ProfScope ps(m, s, "qf_self_attn", 4.0 * B * H * (double)nq * nq * hd, (double)R * 4 * Q * e);
+            const char* base = (const char*)m->qqkv;
+            TRY(launch_generic_attention(m->dt, base, 3 * Q, (long)nq * 3 * Q, base + Q * e, 3 * Q, (long)nq * 3 * Q, base + 2 * Q * e, 3 * Q,
+                                         (long)nq * 3 * Q, m->qctx, Q, (long)nq * Q, B, nq, nq, H, hd, -1, s));
+        }
+        TRY(gemm(m, s, "qf_gemm_so", m->qctx, Q, L.w_so, Q, m->qy, Q, L.b_so, m->qx, R, Q, Q, 0, 1));
+        TRY(launch_layernorm(m->dt, m->qy, Q, L.so_g, L.so_b, c.q_eps, m->qx_t, m->qx, R, Q, s));
+        if (L.cross) {
+            TRY(gemm(m, s, "qf_gemm_cq", m->qx_t, Q, L.w_cq, Q, m->qqkv, Q, L.b_cq, nullptr, R, Q, Q, 0, 0));
+            TRY(gemm(m, s, "qf_gemm_ckv", m->emb_t, D, L.w_ckv, D, m->qkvimg, 2 * Q, L.b_ckv, nullptr, B * NT, 2 * Q, D, 0, 0));
+            {
+                ProfScope ps(m, s, "qf_cross_attn", 4.0 * B * H * (double)nq * NT * hd, (double)B * NT * 2 * Q * e);
+                const char* kv = (const char*)m->qkvimg;
+                TRY(launch_generic_attention(m->dt, m->qqkv, Q, (long)nq * Q, kv, 2 * Q, (long)NT * 2 * Q, kv + Q * e, 2 * Q, (long)NT * 2 * Q,
+                                             m->qctx, Q, (long)nq * Q, B, nq, NT, H, hd, -1, s));
+            }
+            TRY(gemm(m, s, "qf_gemm_co", m->qctx, Q, L.w_co, Q, m->qy, Q, L.b_co, m->qx, R, Q, Q, 0, 1));
+            TRY(launch_layernorm(m->dt, m->qy, Q, L.co_g, L.co_b, c.q_eps, m->qx_t, m->qx, R, Q, s));
+        }
+        TRY(gemm(m, s, "qf_gemm_f1", m->qx_t, Q, L.w_f1, Q, m->qh, F, L.b_f1, nullptr, R, F, Q, 1, 0));
+        TRY(gemm(m, s, "qf_gemm_f2", m->qh, F, L.w_f2, F, m->qy, Q, L.b_f2, m->qx, R, Q, F, 0, 1));
+        TRY(launch_layernorm(m->dt, m->qy, Q, L.f_g, L.f_b, c.q_eps, m->qx_t, m->qx, R, Q, s));
+    }
+    return 0;
+}
+
+// OPT decoder over L new positions per row (x = ox [B * L, T] fp32 with positions already added), cached prefix of `past`
+// positions; leaves the logits of each row's last new position in m->logits.
+int run_opt(Captioner* m, int B, int L, int past, hipStream_t s) {
+    const CapConfig& c = m->c;
+    const int T = c.t_hidden, G = c.t_ffn, H = c.t_heads, hd = T / H, R = B * L;
+    const int Lmax = c.num_query_tokens + 1 + c.max_len;
+    const size_t e = m->esz;
+    for (int i = 0; i < c.t_layers; ++i) {
+        const OLayer& Ly = m->ol[i];
+        TRY(launch_layernorm(m->dt, m->ox, T, Ly.ln1_g, Ly.ln1_b, c.t_eps, m->oh_t, nullptr, R, T, s));
+        TRY(gemm(m, s, "opt_gemm_qkv", m->oh_t, T, Ly.w_qkv, T, m->oqkv, 3 * T, Ly.b_qkv, nullptr, R, 3 * T, T, 0, 0));
+        TRY(launch_kv_append(m->dt, m->oqkv, Ly.kc, Ly.vc, B, L, T, Lmax, past, s));
+        {
+            ProfScope ps(m, s, "opt_attn", 4.0 * B * H * (double)L * (past + L) * hd, 2.0 * B * (past + L) * T * e);
+            TRY(launch_generic_attention(m->dt, m->oqkv, 3 * T, (long)L * 3 * T, Ly.kc, T, (long)Lmax * T, Ly.vc, T, (long)Lmax * T, m->octx, T,
+                                         (long)L * T, B, L, past + L, H, hd, past, s));
+        }
+        TRY(gemm(m, s, "opt_gemm_o", m->octx, T, Ly.w_o, T, m->ox, T, Ly.b_o, m->ox, R, T, T, 0, 1));
+        TRY(launch_layernorm(m->dt, m->ox, T, Ly.ln2_g, Ly.ln2_b, c.t_eps, m->oh_t, nullptr, R, T, s));
+        TRY(gemm(m, s, "opt_gemm_f1", m->oh_t, T, Ly.w_f1, T, m->off, G, Ly.b_f1, nullptr, R, G, T, 2, 0));
+        TRY(gemm(m, s, "opt_gemm_f2", m->off, G, Ly.w_f2, G, m->ox, T, Ly.b_f2, m->ox, R, T, G, 0, 1));
+    }
+    // final LayerNorm of each row's last new position, then the tied LM head (no bias)
+    TRY(launch_layernorm(m->dt, m->ox + (size_t)(L - 1) * T, L * T, m->o_lnf_g, m->o_lnf_b, c.t_eps, m->oh_t, nullptr, B, T, s));
+    return gemm(m, s, "opt_gemm_vocab", m->oh_t, T, m->o_tok_t, T, m->logits, m->ldl, nullptr, nullptr, B, c.vocab, T, 0, 1);
+}
+
+// HF Blip2ForConditionalGeneration.generate, greedy: out_ids [B, max_len] = the new tokens (pad after EOS), out_len [B] =
+// their count incl. EOS, out_step_logits [max_len, B, vocab].
+int run_generate_blip2(Captioner* m, const void* pixels, int fmt, int B, int max_len, int32_t* out_ids, int32_t* out_len,
+                       float* out_step_logits, hipStream_t s) {
+    const CapConfig& c = m->c;
+    const int T = c.t_hidden, nq = c.num_query_tokens, P = nq + 1, Lmax = P + c.max_len;
+    TRY(run_encoder(m, pixels, fmt, B, nullptr, s));
+    TRY(run_qformer(m, B, s));
+    TRY(gemm(m, s, "b2_gemm_lproj", m->qx_t, c.q_hidden, m->w_lproj, c.q_hidden, m->lm_proj, T, m->b_lproj, nullptr, B * nq, T, c.q_hidden, 0, 1));
+    TRY(launch_opt_prefill_inputs(m->lm_proj, m->o_tok, m->o_pos, m->ox, B, nq, T, c.bos, s));
+    hipLaunchKernelGGL(init_seq_kernel, dim3(64), dim3(256), 0, s, m->seq, m->finished, m->lens, B, Lmax, c.bos, c.pad);
+    CAP_HIP_CHECK(hipGetLastError());
+    TRY(run_opt(m, B, P, 0, s));
+    for (int t = 0; t < max_len; ++t) {
+        if (out_step_logits) {
+            hipLaunchKernelGGL(copy_logits_kernel, dim3(1024), dim3(256), 0, s, m->logits, m->ldl,
+                               out_step_logits + (size_t)t * B * c.vocab, B, c.vocab);
+            CAP_HIP_CHECK(hipGetLastError());
+        }
+        // token of position P + t; a row finishes on EOS or at P + max_len tokens (greedy_select's `t` is the last filled index)
+        TRY(launch_greedy_select(m->logits, m->ldl, c.vocab, m->seq, Lmax, P - 1 + t, P + max_len, c.eos, c.pad, m->finished, m->lens, B, s, 0, 0));
+        if (t + 1 == max_len) break;
+        TRY(launch_opt_token_inputs(m->seq, Lmax, P + t, m->o_tok, m->o_pos, m->ox, B, T, s));
+        TRY(run_opt(m, B, 1, P + t, s));
+    }
+    hipLaunchKernelGGL(copy_new_tokens_kernel, dim3(64), dim3(256), 0, s, m->seq, Lmax, P, m->lens, out_ids, out_len, B, max_len);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- sentence encoder
 // HF BertModel state-dict names, as sentence-transformers stores all-MiniLM-L6-v2 (6 layers, 384 wide, 12 heads of 32,
 // FFN 1536, post-LN, eps 1e-12).  Replaces `SentenceTransformer("all-MiniLM-L6-v2").encode(caption)` - reference
@@ -558,7 +817,7 @@ int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_emb
         TRY(gemm(m, s, "gemm_qkv", m->ln, D, L.w_qkv, D, m->qkv, 3 * D, L.b_qkv, nullptr, M, 3 * D, D, 0, 0));
         {
             ProfScope ps(m, s, "vit_attention", 4.0 * B * H * (double)NT * NT * 64, (double)M * 4 * D * m->esz);
-            TRY(launch_vit_attention(m->dt, m->qkv, m->ctx, B, NT, H, 0, s));
+            TRY(launch_vit_attention(m->dt, m->qkv, m->ctx, B, NT, H, 0, s, D / H));
         }
         TRY(gemm(m, s, "gemm_proj", m->ctx, D, L.w_proj, D, m->delta, D, L.b_proj, nullptr, M, D, D, 0, kDeltaInT ? 0 : 1));
         pending = true;
@@ -864,7 +1123,7 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
         cap_set_error("cap_create: CapConfig size mismatch (caller %d, library %d)", cfg->struct_size, (int)sizeof(CapConfig));
         return -1;
     }
-    if (cfg->arch != CAP_ARCH_BLIP && cfg->arch != CAP_ARCH_COCA && cfg->arch != CAP_ARCH_MINILM) {
+    if (cfg->arch != CAP_ARCH_BLIP && cfg->arch != CAP_ARCH_COCA && cfg->arch != CAP_ARCH_MINILM && cfg->arch != CAP_ARCH_BLIP2) {
         cap_set_error("cap_create: unknown arch %d", cfg->arch);
         return -1;
     }
@@ -877,6 +1136,17 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
             cfg->max_len > 512 || cfg->vocab < 1) {
             cap_set_error("cap_create: sentence encoder needs head_dim 32 or 64, widths multiple of 64 (hidden <= 1024), "
                           "1 <= max_len <= min(max_pos, 512)");
+            return -1;
+        }
+    } else if (cfg->arch == CAP_ARCH_BLIP2) {
+        auto hd_ok = [](int w, int h) { return h > 0 && w % h == 0 && (w / h) % 8 == 0 && w / h >= 8 && w / h <= 128; };
+        if (!hd_ok(cfg->v_hidden, cfg->v_heads) || !hd_ok(cfg->q_hidden, cfg->q_heads) || !hd_ok(cfg->t_hidden, cfg->t_heads) ||
+            cfg->v_hidden % 64 || cfg->v_mlp % 64 || cfg->q_hidden % 64 || cfg->q_ffn % 64 || cfg->t_hidden % 64 || cfg->t_ffn % 64 ||
+            cfg->t_hidden > 256 * 12 || cfg->image_size % cfg->patch_size || cfg->q_layers < 1 || cfg->q_cross_freq < 1 ||
+            cfg->num_query_tokens < 1 || cfg->max_batch < 1 || cfg->max_beams != 1 || cfg->max_len < 1 ||
+            cfg->num_query_tokens + 1 + cfg->max_len > cfg->max_pos) {
+            cap_set_error("cap_create: BLIP-2 needs head dims that are multiples of 8 (<= 128), widths multiple of 64 (OPT hidden <= 3072), "
+                          "max_beams 1 and num_query_tokens + 1 + max_len <= max_pos");
             return -1;
         }
     } else {
@@ -931,6 +1201,7 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
         }
     }
     const int built = text_only ? (build_minilm(m) != 0)
+                      : cfg->arch == CAP_ARCH_BLIP2 ? (build_blip2(m) != 0)
                       : cfg->arch == CAP_ARCH_COCA ? (build_coca(m) != 0 || build_arena_coca(m) != 0)
                                                    : (build_blip(m) != 0 || build_arena(m) != 0);
     if (built) {
@@ -1010,7 +1281,7 @@ int cap_finalize_weights(CapHandle h) {
 static int check_call(Captioner* m, int B, int K, int Lm, int fmt) {
     if (!m) { cap_set_error("null handle"); return -1; }
     if (cap_finalize_weights((CapHandle)m) != 0) return -1;
-    if (B < 1 || B > m->c.max_batch || K < 1 || K > m->c.max_beams || Lm < 2 || Lm > m->c.max_len) {
+    if (B < 1 || B > m->c.max_batch || K < 1 || K > m->c.max_beams || Lm < (m->c.arch == CAP_ARCH_BLIP2 ? 1 : 2) || Lm > m->c.max_len) {
         cap_set_error("request B=%d beams=%d max_len=%d exceeds the handle's capacity (%d, %d, %d)", B, K, Lm,
                       m->c.max_batch, m->c.max_beams, m->c.max_len);
         return -1;
@@ -1049,6 +1320,10 @@ int cap_generate(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_
     Captioner* m = (Captioner*)h;
     TRY(check_call(m, B, num_beams, max_len, pixel_fmt));
     if (!pixels || !out_ids) { cap_set_error("cap_generate: null buffer"); return -1; }
+    if (m->c.arch == CAP_ARCH_BLIP2) {
+        if (num_beams != 1) { cap_set_error("cap_generate: BLIP-2 supports greedy decoding (num_beams = 1)"); return -1; }
+        return run_generate_blip2(m, pixels, pixel_fmt, B, max_len, out_ids, out_len, out_step_logits, (hipStream_t)stream);
+    }
     if (m->c.arch == CAP_ARCH_COCA && num_beams != 1) {
         cap_set_error("cap_generate: CoCa supports the reference's top-k(1) loop only (num_beams = 1)");
         return -1;

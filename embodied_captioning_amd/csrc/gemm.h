@@ -18,7 +18,7 @@ struct GemmParams {
     const float* bias;             // [N] fp32 or nullptr
     const float* resid; int ldr;   // fp32 [M,N] residual (may alias C) or nullptr
     int M, N, K;
-    int gelu;                      // exact-erf GELU after bias
+    int gelu;                      // activation after bias: 0 none, 1 exact-erf GELU, 2 ReLU
     int out_f32;                   // 1: C is fp32, 0: C is T
     int epi;
     int splitk;                    // EPI_PARTIAL only: number of K slices (K % (slab*splitk) == 0)

@@ -57,9 +57,9 @@ template <typename T, bool OUT_F32, int EPI, bool RESID = true>
 __device__ __forceinline__ void epi_store4(const GemmParams& p, int row, int col, f32x4 v, f32x4 biasv) {
     // bias is loaded once per lane by the caller (it depends on the column only); residual rows are loaded here
     if (EPI != EPI_PARTIAL) v += biasv;
-    if (EPI != EPI_PARTIAL && p.gelu) {
+    if (EPI != EPI_PARTIAL && p.gelu) {        // p.gelu: 1 = exact-erf GELU, 2 = ReLU (OPT)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = gelu_for<T>(v[i]);
+        for (int i = 0; i < 4; ++i) v[i] = p.gelu == 2 ? fmaxf(v[i], 0.f) : gelu_for<T>(v[i]);
     }
     size_t o; void* base = p.C;
     if constexpr (EPI == EPI_PARTIAL) {          // split-K slice z: raw fp32 partial sums, reduced by the consumer
@@ -548,7 +548,7 @@ __device__ __forceinline__ void big2_epilogue(const GemmParams& p, const f32x4 (
                 if (EPI != EPI_PARTIAL) v += biasv[j];
                 if (do_gelu) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_for<T>(v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = p.gelu == 2 ? fmaxf(v[e], 0.f) : gelu_for<T>(v[e]);
                 }
                 if constexpr (F32OUT) {
                     *(f32x4*)(strip + r16 * 144 + (jj * 16 + 4 * kg) * 4) = v;

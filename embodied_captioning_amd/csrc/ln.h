@@ -4,7 +4,7 @@
 
 // LayerNorm, one wave per row, row held in registers (D <= 64*4*MAXV).  Two-pass mean/variance in fp32,
 // biased variance, eps inside the sqrt (torch.nn.functional.layer_norm).
-constexpr int LN_MAXV = 8;
+constexpr int LN_MAXV = 12;   // rows up to 3072 wide (OPT-2.7b: 2560)
 
 template <typename T>
 __device__ __forceinline__ void ln_row(const float4 (&v)[LN_MAXV], int nv, int lane, int D, const float* gamma,

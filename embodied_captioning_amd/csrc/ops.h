@@ -43,7 +43,16 @@ int launch_copy_f32(const float* src, float* dst, size_t n, hipStream_t s);
 // ---- attention.hip ---------------------------------------------------------------------------
 // ViT self-attention over a fused qkv buffer [B*N, 3*H*64] (T) -> ctx [B*N, H*64] (T); scale = 1/8.
 // impl 0 = auto (MFMA for bf16 when N <= 256, scalar otherwise), 1 = scalar, 2 = MFMA.
-int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s);
+int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s, int head_dim = 64);
+int launch_generic_attention(int dtype, const void* q, long ldq, long qbs, const void* k, long ldk, long kbs, const void* v,
+                             long ldv, long vbs, void* out, long ldo, long obs, int B, int Lq, int Lk, int H, int hd,
+                             int causal_off, hipStream_t s);
+int launch_opt_prefill_inputs(const float* proj, const float* tok, const float* pos, float* x, int B, int nq, int T, int bos,
+                              hipStream_t s);
+int launch_opt_token_inputs(const int* seq, int seq_ld, int cur, const float* tok, const float* pos, float* x, int B, int T,
+                            hipStream_t s);
+int launch_kv_append(int dtype, const void* qkv, void* kc, void* vc, int B, int L, int T, int Lmax, int pos0, hipStream_t s);
+int launch_rows_broadcast(int dtype, const float* src, float* dst_f, void* dst_t, int B, int n, int D, hipStream_t s);
 // single-query decode attention. q [R, H*64] (T).  K/V of row r, head h, position j at
 //   kbase + (((size_t)src(r,j) * H + h) * kv_ld + j) * 64   where src(r,j) = anc ? anc[r*anc_ld + j] : r / rows_per_kv
 // n_keys positions; out [R, H*64] (T).  impl 0 = fast kernels (wave-per-head, chunked online softmax),

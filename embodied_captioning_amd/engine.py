@@ -12,7 +12,7 @@ from typing import Dict, Optional
 import torch
 
 from . import _native as N
-from .config import BlipArch, CocaArch, MiniLMArch
+from .config import Blip2Arch, BlipArch, CocaArch, MiniLMArch
 
 OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -42,7 +42,17 @@ class CaptionerEngine:
         cfg.compute_dtype = _DTYPES[dtype]
         cfg.image_size, cfg.patch_size = arch.image_size, arch.patch_size
         self.is_coca = isinstance(arch, CocaArch)
-        if self.is_coca:
+        self.is_blip2 = isinstance(arch, Blip2Arch)
+        if self.is_blip2:
+            cfg.arch = 3
+            cfg.v_hidden, cfg.v_layers, cfg.v_heads, cfg.v_mlp, cfg.v_eps = (arch.v_hidden, arch.v_layers, arch.v_heads,
+                                                                             arch.v_mlp, arch.v_eps)
+            cfg.q_hidden, cfg.q_layers, cfg.q_heads, cfg.q_ffn = arch.q_hidden, arch.q_layers, arch.q_heads, arch.q_ffn
+            cfg.q_cross_freq, cfg.num_query_tokens, cfg.q_eps = arch.q_cross_freq, arch.num_query_tokens, arch.q_eps
+            cfg.t_hidden, cfg.t_layers, cfg.t_heads, cfg.t_ffn = arch.t_hidden, arch.t_layers, arch.t_heads, arch.t_ffn
+            cfg.vocab, cfg.max_pos, cfg.t_eps = arch.vocab, arch.max_pos, arch.t_eps
+            cfg.bos, cfg.eos, cfg.pad = arch.bos, arch.eos, arch.pad
+        elif self.is_coca:
             cfg.arch = 1
             cfg.v_hidden, cfg.v_layers, cfg.v_heads, cfg.v_mlp, cfg.v_eps = (arch.v_hidden, arch.v_layers, arch.v_heads,
                                                                              arch.v_mlp, arch.eps)
@@ -89,6 +99,12 @@ class CaptionerEngine:
         if self.is_coca and "derived.pool_q" not in sd:
             from .coca_weights import coca_library_state_dict
             sd = coca_library_state_dict(sd, self.arch)
+        if getattr(self, "is_blip2", False) and "derived.qformer_x0" not in sd:
+            # the Q-Former's input = LayerNorm(query_tokens) is a constant of the checkpoint: computed once here
+            sd = dict(sd)
+            q = sd["query_tokens"].float()[0]
+            sd["derived.qformer_x0"] = torch.nn.functional.layer_norm(
+                q, (q.shape[-1],), sd["qformer.layernorm.weight"].float(), sd["qformer.layernorm.bias"].float(), self.arch.q_eps)
         with torch.cuda.device(self.device):
             s = _stream_ptr(self.device)
             for name, t in sd.items():
@@ -124,7 +140,7 @@ class CaptionerEngine:
     def encode(self, pixels: torch.Tensor) -> torch.Tensor:
         pixels, fmt = self._pixels(pixels)
         B = pixels.shape[0]
-        shape = (B, self.arch.pool_queries, self.arch.embed_dim) if self.is_coca else (B, self.arch.n_tokens, self.arch.v_hidden)
+        shape = (B, self.arch.pool_queries, self.arch.embed_dim) if self.is_coca else (B, self.arch.n_tokens, self.arch.v_hidden)   # BLIP / BLIP-2: ViT image_embeds
         out = torch.empty(shape, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             N.check(self.lib.cap_encode(self._h, C.c_void_p(pixels.data_ptr()), fmt, B, C.c_void_p(out.data_ptr()),
@@ -134,7 +150,9 @@ class CaptionerEngine:
     def generate(self, pixels: torch.Tensor, num_beams: int = 1, max_length: Optional[int] = None,
                  length_penalty: float = 1.0, output_logits: bool = False) -> Dict[str, torch.Tensor]:
         """Returns device tensors: sequences int32 [B, max_length] (incl. BOS), lengths int32 [B],
-        sequences_scores fp32 [B] (beams only), logits fp32 [max_length-1, B*num_beams, vocab] (optional)."""
+        sequences_scores fp32 [B] (beams only), logits fp32 [max_length-1, B*num_beams, vocab] (optional).
+        BLIP-2: max_length counts NEW tokens (HF max_new_tokens); sequences are those new tokens only (no image
+        placeholders / BOS), logits [max_length, B, vocab]."""
         pixels, fmt = self._pixels(pixels)
         B = pixels.shape[0]
         L = max_length or self.max_len
@@ -143,7 +161,8 @@ class CaptionerEngine:
         scores = torch.zeros((B,), dtype=torch.float32, device=self.device)
         logits = None
         if output_logits:
-            logits = torch.empty((L - 1, B * num_beams, self.arch.vocab), dtype=torch.float32, device=self.device)
+            steps = L if getattr(self, "is_blip2", False) else L - 1
+            logits = torch.empty((steps, B * num_beams, self.arch.vocab), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             N.check(self.lib.cap_generate(self._h, C.c_void_p(pixels.data_ptr()), fmt, B, num_beams, L,
                                           C.c_float(length_penalty), C.c_void_p(ids.data_ptr()),

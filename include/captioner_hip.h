@@ -13,7 +13,9 @@
  *                       HF modeling_blip.py:901-906 `vision_model(pixel_values)`
  *   generate            blip2.py:26 `model.generate(..., output_logits=True)`;       cap_generate
  *                       coca.py:29 `model.generate(x, generation_type=...)`;
- *                       coca_model.py:205-333 (greedy/top-k loop), :335-482 (beam)
+ *                       coca_model.py:205-333 (greedy/top-k loop), :335-482 (beam);
+ *                       blip2.py:26 BLIP-2 OPT (CAP_ARCH_BLIP2): out_ids = the max_len NEW tokens (HF's sequences
+ *                       minus the 32 image placeholders and BOS), logits as HF's `output_logits`
  *   caption embedding   agents/goal_exploration/goal_exploration.py:57,102 and                cap_embed_text
  *                       detector/pseudolabeler.py:568,677 `SentenceTransformer("all-MiniLM-L6-v2").encode(caption)`  (CAP_ARCH_MINILM handle)
  *   device move/free    predictor_utils.py:187 `.to(...)`; object lifetime            cap_destroy
@@ -36,7 +38,7 @@ extern "C" {
 
 typedef struct CapHandle_s* CapHandle;
 
-enum { CAP_ARCH_BLIP = 0, CAP_ARCH_COCA = 1, CAP_ARCH_MINILM = 2 };
+enum { CAP_ARCH_BLIP = 0, CAP_ARCH_COCA = 1, CAP_ARCH_MINILM = 2, CAP_ARCH_BLIP2 = 3 };
 enum { CAP_F32 = 0, CAP_BF16 = 1 };              /* arithmetic type of the GEMM/attention operands (accumulate: fp32) */
 enum { CAP_PIX_F32_NCHW = 0, CAP_PIX_U8_NHWC = 1 }; /* normalised fp32 [B,3,H,W] | raw RGB uint8 [B,H,W,3] */
 
@@ -60,6 +62,12 @@ typedef struct CapConfig {
      * multimodal decoder layers (t_layers = unimodal text layers), MinLength of the decode loop.  For CoCa
      * bos = start-of-text id, max_pos = context_length + 1, max_len = generate()'s seq_len. */
     int32_t embed_dim, pool_queries, pool_heads, mm_layers, min_len;
+    /* CAP_ARCH_BLIP2 only (HF Blip2Config): Q-Former geometry, cross-attention on layers i % q_cross_freq == 0, number of
+     * query tokens.  v_* = ViT-g (head_dim = v_hidden / v_heads, any multiple of 8 up to 128), t_* = OPT decoder (pre-LN,
+     * ReLU, learned positions with offset 2; max_pos = rows of embed_positions - 2), max_len = new tokens per caption,
+     * bos/eos/pad = OPT ids as generate() uses them. */
+    int32_t q_hidden, q_layers, q_heads, q_ffn, q_cross_freq, num_query_tokens;
+    float q_eps;
 } CapConfig;
 
 const char* cap_last_error(void);

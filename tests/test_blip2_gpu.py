@@ -1,0 +1,63 @@
+"""GPU: BLIP-2 OPT through the C ABI against the HF-captured golden and the restatement (oracle/blip2_ref.py)."""
+import numpy as np
+import pytest
+import torch
+
+from _util import token_parity
+from test_blip2_cpu import load_blip2
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(arch, dtype, batch):
+    from embodied_captioning_amd.engine import CaptionerEngine
+    return CaptionerEngine(arch, dtype=dtype, max_batch=batch, max_beams=1, max_len=arch.max_new_tokens)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_blip2_tiny_matches_hf_golden(dtype):
+    g, meta, a, sd, px = load_blip2()
+    B, n = meta["batch"], a.max_new_tokens
+    eng = _engine(a, dtype, B)
+    eng.load_state_dict(sd)
+    emb = eng.encode(px.cuda()).cpu().numpy()
+    assert np.abs(emb - g["image_embeds"]).max() < (3e-4 if dtype == "f32" else 0.12)
+    out = eng.generate(px.cuda(), max_length=n, output_logits=True)
+    seq = out["sequences"].cpu().numpy()
+    ref = g["sequences"][:, a.num_query_tokens + 1:]                       # HF returns image placeholders + BOS + new tokens
+    lens = out["lengths"].cpu().numpy()
+    ref_len = np.array([int(np.argmax(r == a.eos)) + 1 if (r == a.eos).any() else n for r in ref])
+    lg = out["logits"].cpu().numpy()
+    if dtype == "f32":
+        assert np.array_equal(seq, ref), (seq, ref)
+        assert np.array_equal(lens, ref_len)
+        for b in range(B):
+            assert np.abs(lg[: ref_len[b], b] - g["logits"][: ref_len[b], b]).max() < 1e-3
+    else:
+        full = np.concatenate([np.full((B, 1), a.bos), seq], 1)
+        exact, diverged, bad = token_parity(full, np.concatenate([np.full((B, 1), a.bos), ref], 1), g["margin"], 0.05)
+        assert bad is None, bad
+        assert np.abs(lg[0] - g["logits"][0]).max() < 0.1
+    eng.close()
+
+
+def test_blip2_real_head_dims_against_restatement():
+    """Head dims of the production model - ViT-g 88, Q-Former 64, OPT 80 - at reduced depth/width, fp32, live oracle."""
+    from embodied_captioning_amd.config import Blip2Arch
+    from embodied_captioning_amd.weights import procedural_blip2_state_dict, synthetic_pixels
+    from oracle import blip2_ref as R
+    a = Blip2Arch(image_size=42, patch_size=14, v_hidden=704, v_layers=2, v_heads=8, v_mlp=1408, q_hidden=128, q_layers=3, q_heads=2,
+                  q_ffn=256, num_query_tokens=6, t_hidden=320, t_layers=2, t_heads=4, t_ffn=640, vocab=1000, max_pos=64, eos=3,
+                  image_token=999, max_new_tokens=8)
+    sd = procedural_blip2_state_dict(a, 4, eos_boost=0.4)
+    px = synthetic_pixels(3, a.image_size, seed=4)
+    ref = R.greedy_generate(sd, a, px)
+    eng = _engine(a, "f32", 3)
+    eng.load_state_dict(sd)
+    out = eng.generate(px.cuda(), max_length=a.max_new_tokens, output_logits=True)
+    want = np.full((3, a.max_new_tokens), a.pad, dtype=np.int64)
+    new = ref["sequences"][:, a.num_query_tokens + 1:].numpy()
+    want[:, : new.shape[1]] = new
+    assert np.array_equal(out["sequences"].cpu().numpy(), want)
+    assert (out["logits"][0].cpu() - ref["logits"][0]).abs().max().item() < 1e-3
+    eng.close()
