@@ -1,16 +1,133 @@
-"""`BLIP2(cfg)` entry of the plugin factory (reference ``captioner/models/blip2/blip2.py:16-29``).
+"""`BLIP2(cfg)` entry of the plugin factory - reference ``captioner/models/blip2/blip2.py:16-29``:
+`Blip2ForConditionalGeneration.from_pretrained(cfg.model_name)` + `generate(**inputs, output_logits=True,
+return_dict_in_generate=True)` + `processor.batch_decode(..., skip_special_tokens=True)[0].strip()`.
 
-The reference's BLIP-2 (ViT-g/14 + Q-Former + OPT-2.7B, 8-bit) is listed as a later tier in SURVEY.md §8(f)-4; the
-MI355X-native kernels of this package cover the ViT encoder / cross-attention decoder family the north star names
-(BLIP-base).  Until the Q-Former and OPT decoder are wired to the same kernels, selecting ``arch_name: blip2`` with a
-BLIP(-base) checkpoint runs it through the BLIP path; a genuine BLIP-2 checkpoint raises."""
+Arithmetic: libcaptioner_hip.so (`CaptionerEngine` with a `Blip2Arch`: ViT-g/14, Q-Former, OPT decoder with a K/V cache).
+``model_name``:
+  * a local HF directory / cached hub id (``Salesforce/blip2-opt-2.7b``): config.json, model.safetensors or the sharded
+    ``model-0000x-of-0000y.safetensors`` + index, tokenizer files;
+  * ``procedural-blip2[-tiny][:seed[:eos_boost]]`` - seeded weights of the published / the fixture geometry (no vocabulary:
+    captions come back as space-separated token ids);
+  * a BLIP(-base) captioning checkpoint selected with ``arch_name: blip2`` still runs through the BLIP path (compatibility
+    with configs written before this class existed).
+The reference loads 8-bit weights / fp16 activations; here weights are bf16 (or fp32 with ``dtype: f32``).
+"""
+from __future__ import annotations
+
+import glob
+import json
+import logging
+import os
+from typing import List, Sequence
+
+import torch
+
+from ...captioning_predictor import CaptioningPredictor
+from ....config import Blip2Arch
+from ....engine import CaptionerEngine
+from ....weights import load_state_dict_file, procedural_blip2_state_dict, resolve_hf_dir
 from ..blip.blip import BLIP
+
+logger = logging.getLogger(__name__)
+
+
+def blip2_arch_from_hf_config(cfg: dict) -> Blip2Arch:
+    v, q, t = cfg.get("vision_config", {}), cfg.get("qformer_config", {}), cfg.get("text_config", {})
+    if t.get("model_type", "opt") != "opt":
+        raise RuntimeError(f"BLIP-2 language model '{t.get('model_type')}' is not supported (OPT only)")
+    if t.get("word_embed_proj_dim", t.get("hidden_size", 768)) != t.get("hidden_size", 768) or not t.get("do_layer_norm_before", True):
+        raise RuntimeError("OPT variants with project_in/out or post-LayerNorm (opt-350m) are not supported")
+    a = Blip2Arch()
+    a.image_size, a.patch_size = v.get("image_size", 224), v.get("patch_size", 14)
+    a.v_hidden, a.v_layers, a.v_heads = v.get("hidden_size", 1408), v.get("num_hidden_layers", 39), v.get("num_attention_heads", 16)
+    a.v_mlp, a.v_eps = v.get("intermediate_size", 6144), v.get("layer_norm_eps", 1e-6)
+    a.q_hidden, a.q_layers, a.q_heads = q.get("hidden_size", 768), q.get("num_hidden_layers", 12), q.get("num_attention_heads", 12)
+    a.q_ffn, a.q_cross_freq, a.q_eps = q.get("intermediate_size", 3072), q.get("cross_attention_frequency", 2), q.get("layer_norm_eps", 1e-12)
+    a.num_query_tokens = cfg.get("num_query_tokens", 32)
+    a.t_hidden, a.t_layers, a.t_heads = t.get("hidden_size", 768), t.get("num_hidden_layers", 12), t.get("num_attention_heads", 12)
+    a.t_ffn, a.vocab, a.max_pos = t.get("ffn_dim", 3072), t.get("vocab_size", 50272), t.get("max_position_embeddings", 2048)
+    a.bos, a.pad = t.get("bos_token_id", 2), t.get("pad_token_id", 1)
+    a.eos = t.get("eos_token_id", 2)
+    a.image_token = cfg.get("image_token_index") or cfg.get("image_token_id") or a.vocab - 1
+    return a
+
+
+def load_hf_blip2_checkpoint(model_dir: str):
+    """config.json (+ generation_config.json for the EOS id generate() uses) + single-file or sharded safetensors."""
+    cfg = json.load(open(os.path.join(model_dir, "config.json")))
+    arch = blip2_arch_from_hf_config(cfg)
+    gen = os.path.join(model_dir, "generation_config.json")
+    if os.path.exists(gen):
+        g = json.load(open(gen))
+        eos = g.get("eos_token_id", arch.eos)
+        arch.eos = eos[0] if isinstance(eos, list) else eos
+        arch.bos, arch.pad = g.get("bos_token_id", arch.bos), g.get("pad_token_id", arch.pad)
+    files = sorted(glob.glob(os.path.join(model_dir, "model*.safetensors"))) or sorted(glob.glob(os.path.join(model_dir, "pytorch_model*.bin")))
+    if not files:
+        raise RuntimeError(f"no model*.safetensors / pytorch_model*.bin under {model_dir}")
+    sd = {}
+    for f in files:
+        sd.update(load_state_dict_file(f))
+    if "language_model.lm_head.weight" not in sd:
+        sd["language_model.lm_head.weight"] = sd["language_model.model.decoder.embed_tokens.weight"]
+    return arch, sd
 
 
 class BLIP2(BLIP):
     def __init__(self, cfg=None):
-        name = (cfg.model_name or "").lower()
-        if "blip2" in name:
-            raise NotImplementedError("BLIP-2 (Q-Former + OPT) checkpoints are not supported by the HIP path yet; "
-                                      "use arch_name 'blip' with a BLIP captioning checkpoint")
-        super().__init__(cfg)
+        name = cfg.model_name or "Salesforce/blip2-opt-2.7b"
+        model_dir = None if name.startswith("procedural") else resolve_hf_dir(name)
+        is_blip2 = name.startswith("procedural-blip2")
+        if model_dir is not None:
+            try:
+                is_blip2 = json.load(open(os.path.join(model_dir, "config.json"))).get("model_type") == "blip-2"
+            except OSError:
+                pass
+        if not is_blip2:
+            if "blip2" in name.lower() and model_dir is None:
+                raise RuntimeError(f"Pretrained BLIP-2 checkpoint '{name}' not found locally (offline)")
+            super().__init__(cfg)                       # a BLIP captioning checkpoint under arch_name blip2
+            return
+        CaptioningPredictor.__init__(self, cfg)
+        self.num_beams = 1
+        self.batch_size = int(getattr(cfg, "batch_size", 8) or 8)
+        dtype = getattr(cfg, "dtype", "bf16") or "bf16"
+        self._device = torch.device(getattr(cfg, "device", "cuda:0") or "cuda:0")
+        self.tokenizer = None
+        if model_dir is None:
+            parts = name.split(":")
+            self.arch = Blip2Arch.tiny() if parts[0] == "procedural-blip2-tiny" else Blip2Arch()
+            sd = procedural_blip2_state_dict(self.arch, int(parts[1]) if len(parts) > 1 else 0,
+                                             eos_boost=float(parts[2]) if len(parts) > 2 else 0.0)
+        else:
+            self.arch, sd = load_hf_blip2_checkpoint(model_dir)
+            try:
+                from transformers import AutoTokenizer
+                self.tokenizer = AutoTokenizer.from_pretrained(model_dir)
+            except Exception as e:  # noqa: BLE001
+                logger.warning("no tokenizer under %s (%s): captions are returned as space-separated token ids", model_dir, e)
+        # the reference passes no length: HF then generates 20 new tokens; `max_length` in the config overrides that
+        self.max_length = int(getattr(cfg, "max_new_tokens", 0) or self.arch.max_new_tokens)
+        self.engine = CaptionerEngine(self.arch, dtype=dtype, max_batch=self.batch_size, max_beams=1, max_len=self.max_length,
+                                      device=self._device)
+        self.engine.load_state_dict(sd)
+
+    def decode(self, ids: Sequence[int]) -> str:
+        if not hasattr(self.arch, "num_query_tokens"):
+            return super().decode(ids)
+        ids = [int(i) for i in ids]
+        if self.tokenizer is not None:
+            return self.tokenizer.decode(ids, skip_special_tokens=True).strip()
+        a = self.arch
+        return " ".join(str(i) for i in ids if i not in (a.bos, a.eos, a.pad))
+
+    @torch.no_grad()
+    def forward(self, inputs):
+        if not hasattr(self.arch, "num_query_tokens"):
+            return super().forward(inputs)
+        px = self.preprocess(inputs)[:1]
+        out = self.engine.generate(px.to(self._device), max_length=self.max_length, output_logits=True)
+        n = int(out["lengths"][0])
+        # HF's `logits` tuple has one entry per generated token; new objects every call (callers keep references)
+        self.outputs = {"text": self.decode(out["sequences"][0, :n].tolist()), "logits": tuple(out["logits"][t] for t in range(n))}
+        return self.outputs

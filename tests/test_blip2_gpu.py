@@ -61,3 +61,19 @@ def test_blip2_real_head_dims_against_restatement():
     assert np.array_equal(out["sequences"].cpu().numpy(), want)
     assert (out["logits"][0].cpu() - ref["logits"][0]).abs().max().item() < 1e-3
     eng.close()
+
+
+def test_blip2_wrapper_dict_api_and_factory():
+    from PIL import Image
+    from embodied_captioning_amd.captioner.utils.utils import Configuration
+    from embodied_captioning_amd.captioner.utils.utils_captioner import select_captioner
+    rng = np.random.default_rng(0)
+    im = Image.fromarray(rng.integers(0, 256, size=(50, 41, 3), dtype=np.uint8), "RGB")
+    cfg = Configuration(arch_name="blip2", model_name="procedural-blip2-tiny:11:0.5", height=224, width=224, dtype="f32").captioner
+    model = select_captioner(cfg).eval()
+    out = model(im)
+    assert isinstance(out["text"], str) and 1 <= len(out["logits"]) <= model.arch.max_new_tokens
+    assert out["logits"][0].shape == (1, model.arch.vocab)
+    assert torch.isfinite(model.compute_perplexity())
+    res = model.generate_batch([im, im, im])
+    assert len(res["texts"]) == 3 and res["texts"][0] == res["texts"][1] == out["text"]
