@@ -816,6 +816,47 @@ __global__ __launch_bounds__(64) void generic_attention_kernel(const T* __restri
     }
 }
 
+// One query per (batch, head) against a short history (OPT decode step): lanes = keys for the scores, lanes = head
+// dimensions for the weighted sum; q and the probabilities pass through LDS.
+template <typename T>
+__global__ __launch_bounds__(64) void generic_decode_attention_kernel(const T* __restrict__ q, long qbs, const T* __restrict__ k,
+                                                                      long ldk, long kbs, const T* __restrict__ v, long ldv,
+                                                                      long vbs, T* __restrict__ out, long obs, int Lk, int H,
+                                                                      int hd, float scale) {
+    __shared__ float qs[128], ps[1024];
+    const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+    for (int d = lane; d < hd; d += 64) qs[d] = to_f32(q[(size_t)b * qbs + h * hd + d]) * scale;
+    __syncthreads();
+    float m = -INFINITY;
+    for (int j = lane; j < Lk; j += 64) {
+        const T* kr = k + (size_t)b * kbs + (size_t)j * ldk + h * hd;
+        float sc = 0.f;
+        for (int d = 0; d < hd; d += 8) {
+            float kk[8];
+            load8<T>(kr + d, kk);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sc = fmaf(qs[d + e], kk[e], sc);
+        }
+        ps[j] = sc;
+        m = fmaxf(m, sc);
+    }
+    m = wave_max(m);
+    float l = 0.f;
+    for (int j = lane; j < Lk; j += 64) {
+        const float pj = expf(ps[j] - m);
+        ps[j] = pj;
+        l += pj;
+    }
+    l = wave_sum(l);
+    __syncthreads();
+    const float inv = 1.0f / l;
+    for (int d = lane; d < hd; d += 64) {
+        float o = 0.f;
+        for (int j = 0; j < Lk; ++j) o = fmaf(ps[j], to_f32(v[(size_t)b * vbs + (size_t)j * ldv + h * hd + d]), o);
+        out[(size_t)b * obs + h * hd + d] = from_f32<T>(o * inv);
+    }
+}
+
 // OPT decoder inputs.  Prefill: row (b, j) of x[B, P, T] = (j < nq ? projected query (b, j) : token table[bos]) + position
 // table[j + 2] (HF OPTLearnedPositionalEmbedding offset).  Decode: x[b] = token table[seq[b][cur]] + position table[cur + 2].
 __global__ void opt_prefill_inputs_kernel(const float* __restrict__ proj, const float* __restrict__ tok, const float* __restrict__ pos,
@@ -980,6 +1021,16 @@ int launch_generic_attention(int dtype, const void* q, long ldq, long qbs, const
                              int causal_off, hipStream_t s) {
     if (hd < 8 || hd > 128 || B < 1 || Lq < 1 || Lk < 1) { cap_set_error("generic_attention: head_dim %d / shape unsupported", hd); return -1; }
     const float scale = 1.0f / sqrtf((float)hd);
+    if (Lq == 1 && Lk <= 1024 && hd % 8 == 0) {       // decode step: one query per (batch, head)
+        if (dtype == CAP_DT_BF16)
+            hipLaunchKernelGGL(generic_decode_attention_kernel<bf16_t>, dim3(B * H), dim3(64), 0, s, (const bf16_t*)q, qbs, (const bf16_t*)k,
+                               ldk, kbs, (const bf16_t*)v, ldv, vbs, (bf16_t*)out, obs, Lk, H, hd, scale);
+        else
+            hipLaunchKernelGGL(generic_decode_attention_kernel<float>, dim3(B * H), dim3(64), 0, s, (const float*)q, qbs, (const float*)k,
+                               ldk, kbs, (const float*)v, ldv, vbs, (float*)out, obs, Lk, H, hd, scale);
+        CAP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const int hdp = hd <= 32 ? 32 : hd <= 64 ? 64 : hd <= 96 ? 96 : 128;
     const dim3 grid(B * H * ((Lq + 63) / 64));
 #define CAP_GA(TT, HDP)                                                                                                \

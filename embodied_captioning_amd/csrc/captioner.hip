@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <set>
@@ -466,6 +467,8 @@ int gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, int lda, c
 
 // ---------------------------------------------------------------------------------------------- BLIP-2 OPT
 int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_embeds, hipStream_t s);
+int gemm_partial(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, float* part, int R, int N,
+                 int K, int max_S, int* S_out);
 __global__ void init_seq_kernel(int* seq, int* fin, int* len, int R, int L, int bos, int pad);
 __global__ void copy_logits_kernel(const float* src, int ld, float* dst, int R, int V);
 __global__ void copy_new_tokens_kernel(const int* seq, int seq_ld, int P, const int* lens, int* out_ids, int* out_len, int B, int n) {
@@ -604,6 +607,7 @@ int build_blip2(Captioner* m) {
     TRY(dev_alloc(m, &m->oqkv, Bm * P * 3 * T * e));
     TRY(dev_alloc(m, &m->octx, Bm * P * T * e));
     TRY(dev_alloc(m, &m->off, Bm * P * G * e));
+    TRY(dev_alloc(m, (void**)&m->dpart, (size_t)8 * Bm * std::max(3 * T, G) * 4));     // split-K slabs of the decode-step GEMMs
     TRY(dev_alloc(m, (void**)&m->seq, Bm * Lmax * 4));
     TRY(dev_alloc(m, (void**)&m->finished, Bm * 4));
     TRY(dev_alloc(m, (void**)&m->lens, Bm * 4));
@@ -675,6 +679,38 @@ int run_opt(Captioner* m, int B, int L, int past, hipStream_t s) {
     return gemm(m, s, "opt_gemm_vocab", m->oh_t, T, m->o_tok_t, T, m->logits, m->ldl, nullptr, nullptr, B, c.vocab, T, 0, 1);
 }
 
+// One decode step (one new position per row, x = ox [B, T] with its position added, oh_t = LayerNorm_1 of layer 0 already
+// applied): at a few dozen rows every GEMM is a weight stream, so K is split over blocks (all slabs of a block in flight at
+// once) and the consumers finish the sums - bias (+ ReLU) -> T for q|k|v and fc1; bias + residual + the NEXT LayerNorm for
+// out_proj and fc2 (pre-LN blocks: what follows a residual add is always a LayerNorm).
+int run_opt_step(Captioner* m, int B, int past, hipStream_t s) {
+    const CapConfig& c = m->c;
+    const int T = c.t_hidden, G = c.t_ffn, H = c.t_heads, hd = T / H;
+    const int Lmax = c.num_query_tokens + 1 + c.max_len;
+    const size_t e = m->esz;
+    int S = 1;
+    for (int i = 0; i < c.t_layers; ++i) {
+        const OLayer& Ly = m->ol[i];
+        TRY(gemm_partial(m, s, "opt_gemm_qkv", m->oh_t, Ly.w_qkv, m->dpart, B, 3 * T, T, 8, &S));
+        TRY(launch_reduce_bias_act(m->dt, m->dpart, S, Ly.b_qkv, m->oqkv, B, 3 * T, 0, s));
+        TRY(launch_kv_append(m->dt, m->oqkv, Ly.kc, Ly.vc, B, 1, T, Lmax, past, s));
+        {
+            ProfScope ps(m, s, "opt_attn", 4.0 * B * H * (double)(past + 1) * hd, 2.0 * B * (past + 1) * T * e);
+            TRY(launch_generic_attention(m->dt, m->oqkv, 3 * T, 3 * T, Ly.kc, T, (long)Lmax * T, Ly.vc, T, (long)Lmax * T, m->octx, T, T, B, 1,
+                                         past + 1, H, hd, past, s));
+        }
+        TRY(gemm_partial(m, s, "opt_gemm_o", m->octx, Ly.w_o, m->dpart, B, T, T, 8, &S));
+        TRY(launch_reduce_layernorm(m->dt, m->dpart, S, Ly.b_o, m->ox, Ly.ln2_g, Ly.ln2_b, c.t_eps, m->oh_t, nullptr, m->ox, B, T, s, true));
+        TRY(gemm_partial(m, s, "opt_gemm_f1", m->oh_t, Ly.w_f1, m->dpart, B, G, T, 8, &S));
+        TRY(launch_reduce_bias_act(m->dt, m->dpart, S, Ly.b_f1, m->off, B, G, 2, s));
+        const bool last = i + 1 == c.t_layers;
+        TRY(gemm_partial(m, s, "opt_gemm_f2", m->off, Ly.w_f2, m->dpart, B, T, G, 8, &S));
+        TRY(launch_reduce_layernorm(m->dt, m->dpart, S, Ly.b_f2, m->ox, last ? m->o_lnf_g : m->ol[i + 1].ln1_g,
+                                    last ? m->o_lnf_b : m->ol[i + 1].ln1_b, c.t_eps, m->oh_t, nullptr, m->ox, B, T, s, true));
+    }
+    return gemm(m, s, "opt_gemm_vocab", m->oh_t, T, m->o_tok_t, T, m->logits, m->ldl, nullptr, nullptr, B, c.vocab, T, 0, 1);
+}
+
 // HF Blip2ForConditionalGeneration.generate, greedy: out_ids [B, max_len] = the new tokens (pad after EOS), out_len [B] =
 // their count incl. EOS, out_step_logits [max_len, B, vocab].
 int run_generate_blip2(Captioner* m, const void* pixels, int fmt, int B, int max_len, int32_t* out_ids, int32_t* out_len,
@@ -698,7 +734,8 @@ int run_generate_blip2(Captioner* m, const void* pixels, int fmt, int B, int max
         TRY(launch_greedy_select(m->logits, m->ldl, c.vocab, m->seq, Lmax, P - 1 + t, P + max_len, c.eos, c.pad, m->finished, m->lens, B, s, 0, 0));
         if (t + 1 == max_len) break;
         TRY(launch_opt_token_inputs(m->seq, Lmax, P + t, m->o_tok, m->o_pos, m->ox, B, T, s));
-        TRY(run_opt(m, B, 1, P + t, s));
+        TRY(launch_layernorm(m->dt, m->ox, T, m->ol[0].ln1_g, m->ol[0].ln1_b, c.t_eps, m->oh_t, nullptr, B, T, s));
+        TRY(run_opt_step(m, B, P + t, s));
     }
     hipLaunchKernelGGL(copy_new_tokens_kernel, dim3(64), dim3(256), 0, s, m->seq, Lmax, P, m->lens, out_ids, out_len, B, max_len);
     CAP_HIP_CHECK(hipGetLastError());

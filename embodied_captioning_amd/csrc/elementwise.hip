@@ -1,5 +1,6 @@
 // HBM-bound helper kernels of the captioner path: dtype casts, patch gather, LayerNorm, decoder embeddings,
 // greedy token selection.  One wave (64 lanes) per row for the row-wise ops; 16-byte accesses where the layout allows.
+#include <algorithm>
 #include "ops.h"
 
 namespace {
@@ -459,6 +460,37 @@ int launch_reduce_layernorm(int dtype, const void* part, int S, const float* bia
     else
         hipLaunchKernelGGL((reduce_layernorm_kernel<float, float>), grid, block, 0, s, (const float*)part, S, bias, resid,
                            gamma, beta, eps, (float*)out_t, out_f, y_out, M, D);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Split-K consumer without LayerNorm: out[r][c] = act(sum_z part[z][r][c] + bias[c]) in the compute type (OPT decode: the
+// fused q|k|v projection and fc1 + ReLU).  act: 0 none, 2 ReLU.
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_bias_act_kernel(const float* __restrict__ part, int S, const float* __restrict__ bias,
+                                                              T* __restrict__ out, int M, int N, int act) {
+    const size_t n4 = (size_t)M * N / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        const int c = e % N;
+        float4 a = *(const float4*)(part + e);
+        for (int z = 1; z < S; ++z) {
+            const float4 b = *(const float4*)(part + (size_t)z * M * N + e);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (bias) { const float4 b = *(const float4*)(bias + c); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        if (act == 2) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+        out[e] = from_f32<T>(a.x); out[e + 1] = from_f32<T>(a.y); out[e + 2] = from_f32<T>(a.z); out[e + 3] = from_f32<T>(a.w);
+    }
+}
+
+int launch_reduce_bias_act(int dtype, const float* part, int S, const float* bias, void* out, int M, int N, int act, hipStream_t s) {
+    if (N % 4 != 0) { cap_set_error("reduce_bias_act: N must be a multiple of 4"); return -1; }
+    const int grid = (int)std::min<size_t>(((size_t)M * N / 4 + 255) / 256, 2048);
+    if (dtype == CAP_DT_BF16)
+        hipLaunchKernelGGL(reduce_bias_act_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, part, S, bias, (bf16_t*)out, M, N, act);
+    else
+        hipLaunchKernelGGL(reduce_bias_act_kernel<float>, dim3(grid), dim3(256), 0, s, part, S, bias, (float*)out, M, N, act);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }

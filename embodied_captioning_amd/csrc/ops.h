@@ -24,6 +24,7 @@ int launch_reduce_layernorm(int dtype, const void* part, int S, const float* bia
                             const float* gamma, const float* beta, float eps, void* out_t, float* out_f, float* y_out,
                             int M, int D, hipStream_t s, bool per_row_block = false, bool part_in_t = false);
 // decoder embeddings: x = LN(word[tok] + pos[t]); tok = seq[row*seq_ld + t]
+int launch_reduce_bias_act(int dtype, const float* part, int S, const float* bias, void* out, int M, int N, int act, hipStream_t s);
 int launch_embed_tokens(int dtype, const int* ids, int L, const float* word, const float* pos, const float* type0,
                         const float* gamma, const float* beta, float eps, void* out_t, float* out_f, int R, int D,
                         hipStream_t s);

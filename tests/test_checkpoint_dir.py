@@ -77,3 +77,41 @@ def test_wrapper_from_hf_directory_with_tokenizer(tmp_path):
     words = [f"w{t}" for t in ref[1:] if t not in (arch.eos, arch.pad)]
     assert out["text"] == " ".join(words), (out["text"], words)
     assert len(out["logits"]) >= 1 and out["logits"][0].shape == (1, arch.vocab)
+
+
+def test_blip2_hf_directory_round_trip_with_shards(tmp_path):
+    """`Salesforce/blip2-opt-2.7b` layout: config.json (model_type blip-2), generation_config.json with the EOS id generate()
+    uses, weights sharded over model-0000x-of-0000y.safetensors, tied lm_head absent from the files."""
+    from safetensors.torch import save_file
+    from embodied_captioning_amd.captioner.models.blip2.blip2 import load_hf_blip2_checkpoint
+    from embodied_captioning_amd.config import Blip2Arch
+    from embodied_captioning_amd.weights import procedural_blip2_state_dict
+    a = Blip2Arch.tiny()
+    sd = procedural_blip2_state_dict(a, 2)
+    d = tmp_path / "blip2"
+    os.makedirs(d)
+    cfg = {"model_type": "blip-2", "num_query_tokens": a.num_query_tokens, "image_token_index": a.image_token,
+           "vision_config": {"hidden_size": a.v_hidden, "intermediate_size": a.v_mlp, "num_hidden_layers": a.v_layers,
+                             "num_attention_heads": a.v_heads, "image_size": a.image_size, "patch_size": a.patch_size, "layer_norm_eps": a.v_eps},
+           "qformer_config": {"hidden_size": a.q_hidden, "num_hidden_layers": a.q_layers, "num_attention_heads": a.q_heads,
+                              "intermediate_size": a.q_ffn, "cross_attention_frequency": a.q_cross_freq, "layer_norm_eps": a.q_eps},
+           "text_config": {"model_type": "opt", "hidden_size": a.t_hidden, "num_hidden_layers": a.t_layers, "num_attention_heads": a.t_heads,
+                           "ffn_dim": a.t_ffn, "vocab_size": a.vocab, "max_position_embeddings": a.max_pos, "word_embed_proj_dim": a.t_hidden,
+                           "do_layer_norm_before": True, "bos_token_id": 2, "eos_token_id": 2, "pad_token_id": 1}}
+    json.dump(cfg, open(d / "config.json", "w"))
+    json.dump({"bos_token_id": 2, "eos_token_id": a.eos, "pad_token_id": 1}, open(d / "generation_config.json", "w"))
+    keys = [k for k in sd if k != "language_model.lm_head.weight"]
+    half = len(keys) // 2
+    save_file({k: sd[k].contiguous() for k in keys[:half]}, str(d / "model-00001-of-00002.safetensors"))
+    save_file({k: sd[k].contiguous() for k in keys[half:]}, str(d / "model-00002-of-00002.safetensors"))
+    a2, sd2 = load_hf_blip2_checkpoint(str(d))
+    for f in ("image_size", "patch_size", "v_hidden", "v_layers", "v_heads", "v_mlp", "q_hidden", "q_layers", "q_heads", "q_ffn",
+              "q_cross_freq", "num_query_tokens", "t_hidden", "t_layers", "t_heads", "t_ffn", "vocab", "max_pos", "bos", "eos", "pad",
+              "image_token"):
+        assert getattr(a2, f) == getattr(a, f), f
+    assert set(sd2) == set(sd)
+    assert all(torch.equal(sd2[k], sd[k]) for k in sd)
+    cfg["text_config"]["model_type"] = "t5"
+    json.dump(cfg, open(d / "config.json", "w"))
+    with pytest.raises(RuntimeError):
+        load_hf_blip2_checkpoint(str(d))
