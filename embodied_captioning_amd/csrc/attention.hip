@@ -278,6 +278,154 @@ __global__ __launch_bounds__(256, 1) void vit_attention_flash(const bf16_t* __re
     }
 }
 
+// Heads wider than 64 (BLIP-2's ViT-g/14: 88): the head is handled as TWO 64-wide halves, each with its own K and V
+// image in LDS (the swizzled 128-byte-row layout of the kernels above; columns beyond head_dim are zero - the images are
+// cleared first and the LDS-DMA lanes of missing columns are masked off).  S = Q_lo.K_lo^T + Q_hi.K_hi^T is one longer MFMA
+// chain, O has four 32-wide column blocks.  257 tokens: 4 x 288 x 128 B = 144 KiB, one workgroup per CU; keys in chunks of
+// KC blocks with the online softmax of vit_attention_flash.
+template <int KB, int KC>
+__global__ __launch_bounds__(256, 1) void vit_attention_flash_wide(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                                   int N, int H, int hd) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NP = KB * 32, IMG = NP * 128;
+    char* Ks = smem;                                   // [2][NP] rows of 128 B
+    char* Vs = smem + 2 * IMG;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int D = H * hd, ld = 3 * D;
+    const int tid = threadIdx.x, lane = tid & 63, r32 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bf16_t* base = qkv + (size_t)b * N * ld + h * hd;
+
+    if (hd < 128) {                                    // clear the upper-half images: their missing columns must read as zero
+        for (int i = tid; i < IMG / 16; i += 256) {
+            *(f32x4*)(Ks + IMG + i * 16) = f32x4(0.f);
+            *(f32x4*)(Vs + IMG + i * 16) = f32x4(0.f);
+        }
+        __syncthreads();
+    }
+    for (int p = wave; p < NP / 8; p += 4) {
+        const int row = p * 8 + (lane >> 3);
+        const int gch = (lane & 7) ^ ((row >> 1) & 7);
+        const bf16_t* src = base + (size_t)min(row, N - 1) * ld + gch * 8;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            if (hf * 64 + gch * 8 < hd) {              // whole 16-byte chunks: head_dim is a multiple of 8
+                __builtin_amdgcn_global_load_lds(CAP_GPTR(src + hf * 64 + D), CAP_LPTR(Ks + hf * IMG + p * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(CAP_GPTR(src + hf * 64 + 2 * D), CAP_LPTR(Vs + hf * IMG + p * 1024), 16, 0, 0);
+            }
+        }
+    }
+    const int nqt = (N + 31) / 32;
+    auto load_q = [&](int qt, bf16x8 (&qf)[8]) {
+        const int qc = min(qt * 32 + r32, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int col = ks * 16 + hh * 8;
+            if (col < hd) qf[ks] = *(const bf16x8*)(base + (size_t)qc * ld + col);
+            else
+#pragma unroll
+                for (int i = 0; i < 8; ++i) qf[ks][i] = (bf16_t)0.f;
+        }
+    };
+    bf16x8 qf[8];
+    __syncthreads();   // vmcnt(0) + barrier: every piece has landed
+
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
+    const float c1 = LOG2E / sqrtf((float)hd);
+    for (int qt = wave; qt < nqt; qt += 4) {
+        load_q(qt, qf);
+        const int q = qt * 32 + r32;
+        float m = -INFINITY, l = 0.f;
+        f32x16 o[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
+#pragma unroll
+        for (int c0 = 0; c0 < KB; c0 += KC) {
+            f32x16 s[KC];
+            float cm = -INFINITY;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const int kb = c0 + kc;
+                if (kb < KB) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) s[kc][e] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        bf16x8 a = *(const bf16x8*)(Ks + (ks >> 2) * IMG + swz_off(kb * 32 + r32, (ks & 3) * 2 + hh));
+                        s[kc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kc], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        if (kb == KB - 1) {
+                            const int key = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                            if (key >= N) s[kc][e] = -INFINITY;
+                        }
+                        cm = fmaxf(cm, s[kc][e]);
+                    }
+                }
+            }
+            cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+            const float mn = fmaxf(m, cm);
+            const float alpha = __builtin_amdgcn_exp2f((m - mn) * c1);
+            l *= alpha;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+            m = mn;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const int kb = c0 + kc;
+                if (kb < KB) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float pv = __builtin_amdgcn_exp2f((s[kc][e] - mn) * c1);
+                        s[kc][e] = pv;
+                        l += pv;
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        bf16x8 pb;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pb[j] = (bf16_t)s[kc][8 * s2 + j];
+#pragma unroll
+                        for (int db = 0; db < 4; ++db) {
+                            const int dcol = (db & 1) * 32 + (tg & 1) * 16 + tp * 4;          // column inside the 64-wide half db >> 1
+                            const int key0 = kb * 32 + 16 * s2 + 4 * (tg >> 1) + tq;
+                            const char* vimg = Vs + (db >> 1) * IMG;
+                            const char* a0 = vimg + swz_off(key0, dcol >> 3) + (dcol & 7) * 2;
+                            const char* a1 = vimg + swz_off(key0 + 8, dcol >> 3) + (dcol & 7) * 2;
+                            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+                            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+                            const bf16x8 a = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        l += __shfl_xor(l, 32, 64);
+        if (q < N) {
+            const float inv = 1.0f / l;
+            bf16_t* op = ctx + ((size_t)b * N + q) * D + h * hd;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = db * 32 + 8 * g + 4 * hh;
+                    if (d < hd) {                      // head_dim is a multiple of 8 and d of 4: d + 3 < head_dim whenever d < head_dim
+                        bf16x4 w;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) w[i] = (bf16_t)(o[db][4 * g + i] * inv);
+                        *(bf16x4*)(op + d) = w;
+                    }
+                }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 constexpr int SC_KT = 128;   // keys per LDS tile
 template <typename T>
@@ -923,10 +1071,22 @@ int launch_flash_kb(const void* qkv, void* ctx, int B, int N, int H, hipStream_t
     return 0;
 }
 
+template <int KB, int KC>
+int launch_flash_wide(const void* qkv, void* ctx, int B, int N, int H, int hd, hipStream_t s) {
+    const int lds = 4 * KB * 32 * 128;
+    auto kern = vit_attention_flash_wide<KB, KC>;
+    if (cap_kernel_setup((const void*)kern, lds, nullptr) != 0) return -1;
+    hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)ctx, N, H, hd);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s, int head_dim) {
-    if (head_dim != 64) {   // ViT-g/14 of BLIP-2 (88): generic kernel over the fused qkv rows
+    if (head_dim > 64 && head_dim <= 128 && head_dim % 8 == 0 && dtype == CAP_DT_BF16 && (N + 31) / 32 == 9 && impl != 1)
+        return launch_flash_wide<9, 5>(qkv, ctx, B, N, H, head_dim, s);     // ViT-g/14 of BLIP-2: 88-wide heads, 257 tokens
+    if (head_dim != 64) {   // any other width / length: generic kernel over the fused qkv rows
         const long D = (long)H * head_dim;
         const char* base = (const char*)qkv;
         const size_t e = dtype == CAP_DT_BF16 ? 2 : 4;

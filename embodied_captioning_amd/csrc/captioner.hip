@@ -1423,6 +1423,10 @@ int cap_op_layernorm(int dtype, const float* in, const float* gamma, const float
 int cap_op_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, void* stream) {
     return launch_vit_attention(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, qkv, ctx, B, N, H, impl, (hipStream_t)stream);
 }
+int cap_op_vit_attention_hd(int dtype, const void* qkv, void* ctx, int B, int N, int H, int head_dim, int impl, void* stream) {
+    return launch_vit_attention(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, qkv, ctx, B, N, H, impl, (hipStream_t)stream,
+                                head_dim);
+}
 int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int32_t* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             void* stream) {

@@ -136,6 +136,26 @@ def test_vit_attention_mfma_matches_scalar_kernel(lib):
     assert (a.float() - b.float()).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("hd", [72, 88, 128])
+def test_vit_attention_wide_heads(lib, hd):
+    """Heads wider than 64 at 257 tokens (BLIP-2's ViT-g/14 is 88): the two-half MFMA kernel against a float64 reference and
+    against the scalar kernel on the same bf16 inputs."""
+    B, H, N = 3, 5, 257
+    g = torch.Generator().manual_seed(hd)
+    qkv = (torch.randn(B * N, 3 * H * hd, generator=g) * 1.2).to(torch.bfloat16)
+    qd = qkv.cuda()
+    a = torch.full((B * N, H * hd), float("nan"), dtype=torch.bfloat16, device="cuda")
+    b = torch.full_like(a, float("nan"))
+    _check(lib, lib.cap_op_vit_attention_hd(1, _p(qd), _p(a), B, N, H, hd, 0, _stream()))
+    _check(lib, lib.cap_op_vit_attention_hd(1, _p(qd), _p(b), B, N, H, hd, 1, _stream()))
+    torch.cuda.synchronize()
+    x = qkv.double().view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    sc = (x[0] @ x[1].transpose(-1, -2)) / hd ** 0.5
+    ref = (torch.softmax(sc, -1) @ x[2]).permute(0, 2, 1, 3).reshape(B * N, H * hd)
+    assert (a.float().cpu().double() - ref).abs().max().item() < 3e-2
+    assert (a.float() - b.float()).abs().max().item() < 2e-2
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("impl", [0, 1])
 @pytest.mark.parametrize("n_keys,beams", [(1, 1), (7, 1), (20, 3), (33, 2), (197, 3), (255, 1)])
