@@ -1005,6 +1005,67 @@ __global__ __launch_bounds__(64) void generic_decode_attention_kernel(const T* _
     }
 }
 
+// Cached decode step of a pre-LN decoder (OPT): one query per (batch, head) taken from the fused q|k|v row; the step's new
+// key/value are appended to the caches [B][Lmax][T] at position `past` here (no separate append launch) and used from the
+// row directly.  One wave per (batch, head): lanes over keys for the scores, then (key group of 4) x (8-dim chunk) for
+// P.V with a 4-way sum through LDS.  head_dim a multiple of 8, <= 128; past + 1 <= 1024.
+template <typename T>
+__global__ __launch_bounds__(64) void opt_decode_attention_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
+                                                                  T* __restrict__ out, int Tw, int H, int hd, int Lmax, int past,
+                                                                  float scale) {
+    __shared__ float qs[128], ps[1024], os[4][128];
+    const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+    const T* row = qkv + (size_t)b * 3 * Tw + h * hd;
+    const T* kb = kc + (size_t)b * Lmax * Tw + h * hd;
+    const T* vb = vc + (size_t)b * Lmax * Tw + h * hd;
+    const int Lk = past + 1;
+    for (int d = lane; d < hd; d += 64) {
+        qs[d] = to_f32(row[d]) * scale;
+        kc[((size_t)b * Lmax + past) * Tw + h * hd + d] = row[Tw + d];
+        vc[((size_t)b * Lmax + past) * Tw + h * hd + d] = row[2 * Tw + d];
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int j = lane; j < Lk; j += 64) {
+        const T* kr = j == past ? row + Tw : kb + (size_t)j * Tw;
+        float sc = 0.f;
+        for (int d = 0; d < hd; d += 8) {
+            float kk[8];
+            load8<T>(kr + d, kk);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sc = fmaf(qs[d + e], kk[e], sc);
+        }
+        ps[j] = sc;
+        m = fmaxf(m, sc);
+    }
+    m = wave_max(m);
+    float l = 0.f;
+    for (int j = lane; j < Lk; j += 64) {
+        const float pj = expf(ps[j] - m);
+        ps[j] = pj;
+        l += pj;
+    }
+    l = wave_sum(l);
+    __syncthreads();
+    const int jg = lane >> 4, dc = (lane & 15) * 8;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    if (dc < hd)
+        for (int j = jg; j < Lk; j += 4) {
+            float vv[8];
+            load8<T>((j == past ? row + 2 * Tw : vb + (size_t)j * Tw) + dc, vv);
+            const float pj = ps[j];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(pj, vv[e], o[e]);
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) os[jg][dc + e] = o[e];
+    __syncthreads();
+    const float inv = 1.0f / l;
+    for (int d = lane; d < hd; d += 64) out[(size_t)b * Tw + h * hd + d] = from_f32<T>((os[0][d] + os[1][d] + os[2][d] + os[3][d]) * inv);
+}
+
 // OPT decoder inputs.  Prefill: row (b, j) of x[B, P, T] = (j < nq ? projected query (b, j) : token table[bos]) + position
 // table[j + 2] (HF OPTLearnedPositionalEmbedding offset).  Decode: x[b] = token table[seq[b][cur]] + position table[cur + 2].
 __global__ void opt_prefill_inputs_kernel(const float* __restrict__ proj, const float* __restrict__ tok, const float* __restrict__ pos,
@@ -1205,6 +1266,23 @@ int launch_generic_attention(int dtype, const void* q, long ldq, long qbs, const
     return 0;
 }
 
+int launch_opt_decode_attention(int dtype, const void* qkv, void* kc, void* vc, void* out, int B, int T, int H, int Lmax,
+                                int past, hipStream_t s) {
+    const int hd = H > 0 ? T / H : 0;
+    if (B < 1 || H < 1 || T % H != 0 || hd % 8 != 0 || hd > 128 || past < 0 || past + 1 > 1024 || past >= Lmax) {
+        cap_set_error("opt_decode_attention: unsupported shape T=%d H=%d past=%d Lmax=%d", T, H, past, Lmax);
+        return -1;
+    }
+    const float scale = 1.0f / sqrtf((float)hd);
+    if (dtype == CAP_DT_BF16)
+        hipLaunchKernelGGL(opt_decode_attention_kernel<bf16_t>, dim3(B * H), dim3(64), 0, s, (const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc,
+                           (bf16_t*)out, T, H, hd, Lmax, past, scale);
+    else
+        hipLaunchKernelGGL(opt_decode_attention_kernel<float>, dim3(B * H), dim3(64), 0, s, (const float*)qkv, (float*)kc, (float*)vc,
+                           (float*)out, T, H, hd, Lmax, past, scale);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 int launch_opt_prefill_inputs(const float* proj, const float* tok, const float* pos, float* x, int B, int nq, int T, int bos,
                               hipStream_t s) {
     hipLaunchKernelGGL(opt_prefill_inputs_kernel, dim3(256), dim3(256), 0, s, proj, tok, pos, x, B, nq, T, bos);

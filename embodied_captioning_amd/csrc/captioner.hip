@@ -683,6 +683,22 @@ int run_opt(Captioner* m, int B, int L, int past, hipStream_t s) {
 // applied): at a few dozen rows every GEMM is a weight stream, so K is split over blocks (all slabs of a block in flight at
 // once) and the consumers finish the sums - bias (+ ReLU) -> T for q|k|v and fc1; bias + residual + the NEXT LayerNorm for
 // out_proj and fc2 (pre-LN blocks: what follows a residual add is always a LayerNorm).
+// One projection of the decode step.  bf16 at a shape the weight-streaming kernel takes: that kernel, finished in place
+// (ln == false: bias + act -> out_t) or as slice sums for the reduce+LayerNorm consumer.  Otherwise the tiled split-K GEMM
+// with a reduce kernel.  The choice depends on dtype and (N, K) only - never on the row count.
+int opt_step_gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, const float* bias, int act,
+                  void* out_t, int B, int N, int K, bool ln, int* S_out) {
+    const int S = m->dt == CAP_DT_BF16 ? skinny_plan(N, K, !ln, nullptr) : 0;
+    if (S >= 1) {
+        ProfScope ps(m, s, tag, 2.0 * B * N * K, ((double)B * K + (double)N * K) * 2 + (ln ? (double)S * B * N * 4 : (double)B * N * 2));
+        *S_out = S;
+        return launch_gemm_skinny(A, K, W, K, bias, act, out_t, N, ln ? m->dpart : nullptr, B, N, K, s) == S ? 0 : -1;
+    }
+    TRY(gemm_partial(m, s, tag, A, W, m->dpart, B, N, K, 8, S_out));
+    if (!ln) TRY(launch_reduce_bias_act(m->dt, m->dpart, *S_out, bias, out_t, B, N, act, s));
+    return 0;
+}
+
 int run_opt_step(Captioner* m, int B, int past, hipStream_t s) {
     const CapConfig& c = m->c;
     const int T = c.t_hidden, G = c.t_ffn, H = c.t_heads, hd = T / H;
@@ -691,20 +707,22 @@ int run_opt_step(Captioner* m, int B, int past, hipStream_t s) {
     int S = 1;
     for (int i = 0; i < c.t_layers; ++i) {
         const OLayer& Ly = m->ol[i];
-        TRY(gemm_partial(m, s, "opt_gemm_qkv", m->oh_t, Ly.w_qkv, m->dpart, B, 3 * T, T, 8, &S));
-        TRY(launch_reduce_bias_act(m->dt, m->dpart, S, Ly.b_qkv, m->oqkv, B, 3 * T, 0, s));
-        TRY(launch_kv_append(m->dt, m->oqkv, Ly.kc, Ly.vc, B, 1, T, Lmax, past, s));
+        TRY(opt_step_gemm(m, s, "opt_gemm_qkv", m->oh_t, Ly.w_qkv, Ly.b_qkv, 0, m->oqkv, B, 3 * T, T, false, &S));
         {
             ProfScope ps(m, s, "opt_attn", 4.0 * B * H * (double)(past + 1) * hd, 2.0 * B * (past + 1) * T * e);
-            TRY(launch_generic_attention(m->dt, m->oqkv, 3 * T, 3 * T, Ly.kc, T, (long)Lmax * T, Ly.vc, T, (long)Lmax * T, m->octx, T, T, B, 1,
-                                         past + 1, H, hd, past, s));
+            if (hd % 8 == 0 && hd <= 128)
+                TRY(launch_opt_decode_attention(m->dt, m->oqkv, Ly.kc, Ly.vc, m->octx, B, T, H, Lmax, past, s));
+            else {
+                TRY(launch_kv_append(m->dt, m->oqkv, Ly.kc, Ly.vc, B, 1, T, Lmax, past, s));
+                TRY(launch_generic_attention(m->dt, m->oqkv, 3 * T, 3 * T, Ly.kc, T, (long)Lmax * T, Ly.vc, T, (long)Lmax * T, m->octx, T, T, B, 1,
+                                             past + 1, H, hd, past, s));
+            }
         }
-        TRY(gemm_partial(m, s, "opt_gemm_o", m->octx, Ly.w_o, m->dpart, B, T, T, 8, &S));
+        TRY(opt_step_gemm(m, s, "opt_gemm_o", m->octx, Ly.w_o, nullptr, 0, nullptr, B, T, T, true, &S));
         TRY(launch_reduce_layernorm(m->dt, m->dpart, S, Ly.b_o, m->ox, Ly.ln2_g, Ly.ln2_b, c.t_eps, m->oh_t, nullptr, m->ox, B, T, s, true));
-        TRY(gemm_partial(m, s, "opt_gemm_f1", m->oh_t, Ly.w_f1, m->dpart, B, G, T, 8, &S));
-        TRY(launch_reduce_bias_act(m->dt, m->dpart, S, Ly.b_f1, m->off, B, G, 2, s));
+        TRY(opt_step_gemm(m, s, "opt_gemm_f1", m->oh_t, Ly.w_f1, Ly.b_f1, 2, m->off, B, G, T, false, &S));
         const bool last = i + 1 == c.t_layers;
-        TRY(gemm_partial(m, s, "opt_gemm_f2", m->off, Ly.w_f2, m->dpart, B, T, G, 8, &S));
+        TRY(opt_step_gemm(m, s, "opt_gemm_f2", m->off, Ly.w_f2, nullptr, 0, nullptr, B, T, G, true, &S));
         TRY(launch_reduce_layernorm(m->dt, m->dpart, S, Ly.b_f2, m->ox, last ? m->o_lnf_g : m->ol[i + 1].ln1_g,
                                     last ? m->o_lnf_b : m->ol[i + 1].ln1_b, c.t_eps, m->oh_t, nullptr, m->ox, B, T, s, true));
     }
@@ -1427,6 +1445,17 @@ int cap_op_vit_attention_hd(int dtype, const void* qkv, void* ctx, int B, int N,
     return launch_vit_attention(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, qkv, ctx, B, N, H, impl, (hipStream_t)stream,
                                 head_dim);
 }
+int cap_op_reduce_layernorm(int dtype, const float* part, int S, const float* bias, const float* resid, const float* gamma,
+                            const float* beta, float eps, void* out_t, float* out_f, float* y_out, int M, int D,
+                            int per_row_block, void* stream) {
+    return launch_reduce_layernorm(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, part, S, bias, resid, gamma, beta, eps, out_t,
+                                   out_f, y_out, M, D, (hipStream_t)stream, per_row_block != 0, false);
+}
+int cap_op_gemm_skinny(const void* A, const void* W, const float* bias, int act, void* out, float* part, int M, int N, int K,
+                       void* stream) {
+    return launch_gemm_skinny(A, K, W, K, bias, act, out, N, part, M, N, K, (hipStream_t)stream);
+}
+int cap_op_gemm_skinny_slices(int N, int K, int finished) { return skinny_plan(N, K, finished != 0, nullptr); }
 int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int32_t* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             void* stream) {

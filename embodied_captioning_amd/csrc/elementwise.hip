@@ -203,6 +203,69 @@ __global__ __launch_bounds__(256) void reduce_layernorm_row_kernel(const float* 
     }
 }
 
+// The same consumer for rows wider than 1024 (OPT-2.7b: 2560) when there are only a few of them (a decode step: 32 rows):
+// one 256-thread workgroup per row, up to 3 vectors per thread, every slice load in flight at once.  (The wave-per-row
+// kernel walks such a row with 64 lanes: 19 us per launch at 32 x 2560 x 4 slices, measured; this one is bound by the launch.)
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_layernorm_wide_kernel(const float* __restrict__ part, int S,
+                                                                     const float* __restrict__ bias,
+                                                                     const float* resid,   // may alias y_out (in-place residual stream)
+                                                                     const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, float eps, T* out_t,
+                                                                     float* out_f, float* y_out, int M, int D) {
+    __shared__ float sp[2][4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a[3];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = tid * 4 + i * 1024;
+        a[i] = z4;
+        if (c < D) {
+            a[i] = *(const float4*)(part + (size_t)row * D + c);
+            for (int z = 1; z < S; ++z) {
+                const float4 b = *(const float4*)(part + ((size_t)z * M + row) * D + c);
+                a[i].x += b.x; a[i].y += b.y; a[i].z += b.z; a[i].w += b.w;
+            }
+            if (bias) { const float4 b = *(const float4*)(bias + c); a[i].x += b.x; a[i].y += b.y; a[i].z += b.z; a[i].w += b.w; }
+            if (resid) { const float4 b = *(const float4*)(resid + (size_t)row * D + c); a[i].x += b.x; a[i].y += b.y; a[i].z += b.z; a[i].w += b.w; }
+            if (y_out) *(float4*)(y_out + (size_t)row * D + c) = a[i];
+            s += (a[i].x + a[i].y) + (a[i].z + a[i].w);
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) sp[0][wv] = s;
+    __syncthreads();
+    const float mean = (((sp[0][0] + sp[0][1]) + sp[0][2]) + sp[0][3]) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (tid * 4 + i * 1024 < D) {
+            const float dx = a[i].x - mean, dy = a[i].y - mean, dz = a[i].z - mean, dw = a[i].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    q = wave_sum(q);
+    if (lane == 0) sp[1][wv] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((((sp[1][0] + sp[1][1]) + sp[1][2]) + sp[1][3]) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = tid * 4 + i * 1024;
+        if (c < D) {
+            const float4 g = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
+            float4 o;
+            o.x = (a[i].x - mean) * rstd * g.x + be.x; o.y = (a[i].y - mean) * rstd * g.y + be.y;
+            o.z = (a[i].z - mean) * rstd * g.z + be.z; o.w = (a[i].w - mean) * rstd * g.w + be.w;
+            if (out_f) *(float4*)(out_f + (size_t)row * D + c) = o;
+            if (out_t) {
+                T* ot = out_t + (size_t)row * D + c;
+                ot[0] = from_f32<T>(o.x); ot[1] = from_f32<T>(o.y); ot[2] = from_f32<T>(o.z); ot[3] = from_f32<T>(o.w);
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ seq, int seq_ld, int t,
                                                     const float* __restrict__ word, const float* __restrict__ pos,
@@ -445,6 +508,16 @@ int launch_reduce_layernorm(int dtype, const void* part, int S, const float* bia
                                beta, eps, (bf16_t*)out_t, out_f, y_out, M, D);
         else
             hipLaunchKernelGGL(reduce_layernorm_row_kernel<float>, dim3(M), dim3(256), 0, s, (const float*)part, S, bias, resid, gamma,
+                               beta, eps, (float*)out_t, out_f, y_out, M, D);
+        CAP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    if (per_row_block && D <= 3072) {     // wide rows, decode-sized row count (the caller's choice, as above)
+        if (dtype == CAP_DT_BF16)
+            hipLaunchKernelGGL(reduce_layernorm_wide_kernel<bf16_t>, dim3(M), dim3(256), 0, s, (const float*)part, S, bias, resid, gamma,
+                               beta, eps, (bf16_t*)out_t, out_f, y_out, M, D);
+        else
+            hipLaunchKernelGGL(reduce_layernorm_wide_kernel<float>, dim3(M), dim3(256), 0, s, (const float*)part, S, bias, resid, gamma,
                                beta, eps, (float*)out_t, out_f, y_out, M, D);
         CAP_HIP_CHECK(hipGetLastError());
         return 0;

@@ -1,0 +1,189 @@
+// Weight-streaming GEMM for a handful of rows (the cached decode step of a large language model: BLIP-2's OPT-2.7b,
+// 32 rows against 13-52 MB of weights per projection).  C[M, N] = A[M, K] . W[N, K]^T, bf16 operands, fp32 accumulation.
+//
+// The operation is bound by reading W once from HBM, so the kernel is built around that stream and nothing else:
+//   * a workgroup owns 32 weight rows and a K range; its waves split that range (at most 320 k each), so a wave's whole
+//     share is in flight at once - one memory round trip;
+//   * the activations (a few rows, L2-resident) go straight to registers in the MFMA operand layout
+//     (v_mfma_f32_16x16x32_bf16, W as the A operand so a lane ends up with 4 consecutive output columns);
+//   * the waves' fp32 tiles are summed through LDS in wave order (deterministic), then either finished in place
+//     (bias, ReLU/GELU, cast - one slice) or written as split-K slice `z` for the reduce+LayerNorm consumer.
+// Rows beyond 32 are further grid.y groups (W is re-read from L2/MALL); the k-order of a row's sum depends on (N, K) and
+// the output form only, never on the row count.
+#include "common.h"
+#include "ops.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SK_MAXKS = 10, SK_PITCH = 36;   // LDS row pitch in floats (144 B: the 16 rows of a tile spread over the banks)
+
+struct SkinnyParams {
+    const bf16_t* A; int lda;
+    const bf16_t* W; int ldw;
+    const float* bias;        // finished output only
+    bf16_t* out; int ldc;     // part == null (S == 1): act(sum + bias) as bf16
+    float* part;              // non-null: part[z][M][N] fp32 slice sums instead of `out`
+    int M, N, S, nks, act;    // nks = k-steps of 32 per wave; act 0 none, 1 GELU(erf), 2 ReLU
+};
+
+// W is staged through LDS: loading it straight into the MFMA operand layout asks for 64 bytes per weight row per
+// instruction (4 lanes per row), and half-line requests cap the stream near 2 TB/s (measured, tools/skinny_bench.py); a
+// wave's LDS-DMA instruction moves 8 rows x 128 bytes (whole lines) into a wave-private ring of 64-wide slabs instead, and
+// the fragments are read back through the XOR swizzle.  No workgroup barrier in the stream: a wave only reads what it
+// fetched itself, ordered by counted s_waitcnt vmcnt.
+__device__ __forceinline__ int skl_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+#define SKL_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define SKL_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int NW, int SKL_RING>   // SKL_RING: 64-k slabs (32 rows x 128 B) in flight per wave
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(SkinnyParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = blockIdx.x / p.S, z = blockIdx.x % p.S;
+    const int n0 = nt * 32, m0 = blockIdx.y * 32;
+    const int kw = (z * NW + wave) * p.nks * 32;                    // first k of this wave
+    const int nsl = p.nks >> 1;                                     // slabs of 64 k
+    char* ring = smem + wave * (SKL_RING * 4096);
+
+    // activations: every fragment of the wave's K range, straight to registers (L2 hits)
+    const bf16_t* ap[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) ap[t] = p.A + (size_t)min(m0 + t * 16 + r16, p.M - 1) * p.lda + kw + kg * 8;
+    bf16x8 af[2][SK_MAXKS];
+#pragma unroll
+    for (int j = 0; j < SK_MAXKS; ++j)
+        if (j < p.nks) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) af[t][j] = *(const bf16x8*)(ap[t] + j * 32);
+        }
+    // weights: lane -> (row q*8 + lane/8, 16-byte position lane%8); the swizzle is applied on the source side
+    const bf16_t* wsrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = q * 8 + (lane >> 3);
+        wsrc[q] = p.W + (size_t)(n0 + row) * p.ldw + kw + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+    }
+    auto issue = [&](int sl) {
+        char* dst = ring + (sl % SKL_RING) * 4096;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) __builtin_amdgcn_global_load_lds(SKL_GPTR(wsrc[q] + sl * 64), SKL_LPTR(dst + q * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int sl = 0; sl < SKL_RING; ++sl)
+        if (sl < nsl) issue(sl);
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4(0.f);
+#pragma unroll
+    for (int sl = 0; sl < SK_MAXKS / 2; ++sl)
+        if (sl < nsl) {
+            // slabs still allowed in flight behind slab `sl`: those issued so far minus sl + 1
+            const int behind = min(nsl, sl + SKL_RING) - sl - 1;
+            if (behind >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (behind == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char* buf = ring + (sl % SKL_RING) * 4096;
+            bf16x8 wf[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) wf[t][ks] = *(const bf16x8*)(buf + skl_swz(t * 16 + r16, ks * 4 + kg));
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int wt = 0; wt < 2; ++wt)
+#pragma unroll
+                    for (int xt = 0; xt < 2; ++xt)
+                        acc[wt][xt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[wt][ks], af[xt][2 * sl + ks], acc[wt][xt], 0, 0, 0);
+            if (sl + SKL_RING < nsl) {                  // refill the buffer just read (its ds_reads have returned: the MFMAs used them)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                issue(sl + SKL_RING);
+            }
+        }
+    __syncthreads();                                    // every wave is done with its ring: the sums reuse the space
+    float* red = (float*)smem;
+#pragma unroll
+    for (int wt = 0; wt < 2; ++wt)
+#pragma unroll
+        for (int xt = 0; xt < 2; ++xt)
+            *(f32x4*)(red + (wave * 32 + xt * 16 + r16) * SK_PITCH + wt * 16 + 4 * kg) = acc[wt][xt];
+    __syncthreads();
+    for (int o = tid; o < 512; o += NW * 64) {
+        const int m = o >> 4, n = (o & 15) * 2;
+        f32x2 v = *(const f32x2*)(red + m * SK_PITCH + n);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += *(const f32x2*)(red + (w * 32 + m) * SK_PITCH + n);
+        if (m0 + m >= p.M) continue;
+        if (p.part) {
+            *(f32x2*)(p.part + ((size_t)z * p.M + m0 + m) * p.N + n0 + n) = v;
+            continue;
+        }
+        if (p.bias) v += *(const f32x2*)(p.bias + n0 + n);
+        if (p.act == 2) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }
+        else if (p.act == 1) { v[0] = gelu_erf_fast(v[0]); v[1] = gelu_erf_fast(v[1]); }
+        bf16x2 ob;
+        ob[0] = (bf16_t)v[0]; ob[1] = (bf16_t)v[1];
+        *(bf16x2*)(p.out + (size_t)(m0 + m) * p.ldc + n0 + n) = ob;
+    }
+}
+
+}  // namespace
+
+// Launch plan for a (N, K) projection: K slices S and waves per workgroup NW, with K / (S NW) <= 320 and a multiple of
+// 64.  finished: the epilogue needs the whole K in one workgroup (S = 1).  Otherwise the fewest waves per row tile, split
+// into more slices while the grid is small.  Returns S, or 0 when the shape does not fit.
+int skinny_plan(int N, int K, bool finished, int* nw_out) {
+    if (N % 32 != 0 || K % 64 != 0) return 0;
+    const int tiles = N / 32;
+    int bestS = 0, bestNW = 0;
+    for (int S = 1; S <= (finished ? 1 : 16); S *= 2)
+        for (int nw : {8, 4}) {
+            if (K % (S * nw * 64) != 0 || K / (S * nw * 32) > SK_MAXKS) continue;
+            const bool fewer = bestS == 0 || S * nw < bestS * bestNW;
+            const bool same_but_wider = bestS != 0 && S * nw == bestS * bestNW && tiles * bestS < 128;
+            if (fewer || same_but_wider) { bestS = S; bestNW = nw; }
+        }
+    if (nw_out) *nw_out = bestNW;
+    return bestS;
+}
+
+template <int NW, int RING>
+static int skinny_launch(const SkinnyParams& p, dim3 grid, hipStream_t s) {
+    const int lds = NW * RING * 4096 > NW * 32 * SK_PITCH * 4 ? NW * RING * 4096 : NW * 32 * SK_PITCH * 4;
+    auto kern = gemm_skinny_kernel<NW, RING>;
+    if (cap_kernel_setup((const void*)kern, lds, nullptr) != 0) return -1;
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// part == nullptr: out = act(A W^T + bias) as bf16 (plan with finished = true).  part != nullptr: part[z] = the S slice
+// sums, fp32 (bias / act are the consumer's).  Returns the slice count (>= 1), or -1.
+int launch_gemm_skinny(const void* A, int lda, const void* W, int ldw, const float* bias, int act, void* out, int ldc,
+                       float* part, int M, int N, int K, hipStream_t s) {
+    int nw = 0;
+    const int S = skinny_plan(N, K, part == nullptr, &nw);
+    if (S < 1 || M < 1 || (lda & 7) || (ldw & 7) || (!part && (!out || (ldc & 1)))) {
+        cap_set_error("gemm_skinny: unsupported shape M=%d N=%d K=%d", M, N, K);
+        return -1;
+    }
+    SkinnyParams p;
+    p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.bias = bias; p.out = (bf16_t*)out; p.ldc = ldc;
+    p.part = part; p.M = M; p.N = N; p.S = S; p.nks = K / (nw * 32 * S); p.act = act;
+    const dim3 grid((N / 32) * S, (M + 31) / 32);
+    static const int ring = getenv("CAP_SKINNY_RING") ? atoi(getenv("CAP_SKINNY_RING")) : 0;
+    // more workgroups than CUs: a two-slab ring (64 KiB per workgroup) lets two share a CU, so the grid is still one round
+    const bool small = ring ? ring == 2 : (int)(grid.x * grid.y) > 256;
+    int rc;
+    if (nw == 8) rc = small ? skinny_launch<8, 2>(p, grid, s) : skinny_launch<8, 4>(p, grid, s);
+    else rc = small ? skinny_launch<4, 2>(p, grid, s) : skinny_launch<4, 4>(p, grid, s);
+    return rc == 0 ? S : rc;
+}

@@ -52,6 +52,9 @@ int launch_opt_prefill_inputs(const float* proj, const float* tok, const float* 
                               hipStream_t s);
 int launch_opt_token_inputs(const int* seq, int seq_ld, int cur, const float* tok, const float* pos, float* x, int B, int T,
                             hipStream_t s);
+// decode step of a pre-LN decoder: q|k|v row [B, 3T] -> appends k, v to caches [B][Lmax][T] at `past`, out [B, T]
+int launch_opt_decode_attention(int dtype, const void* qkv, void* kc, void* vc, void* out, int B, int T, int H, int Lmax,
+                                int past, hipStream_t s);
 int launch_kv_append(int dtype, const void* qkv, void* kc, void* vc, int B, int L, int T, int Lmax, int pos0, hipStream_t s);
 int launch_rows_broadcast(int dtype, const float* src, float* dst_f, void* dst_t, int B, int n, int D, hipStream_t s);
 // single-query decode attention. q [R, H*64] (T).  K/V of row r, head h, position j at
@@ -70,6 +73,15 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
 // columns [0,E) and V in [E,2E); heads of E/heads dims (64 or 96); out (T) [B*Q, E].  scale = 1/sqrt(head_dim).
 int launch_pool_attention(int dtype, const float* qp, const void* kv, void* out, int B, int N, int Q, int E, int heads,
                           hipStream_t s);
+
+// ---- gemm_skinny.hip ---------------------------------------------------------------------------
+// Weight-streaming bf16 GEMM for a handful of rows (decode step of a large LM).  skinny_plan: K slices for (N, K) in the
+// finished (bias + act -> bf16, one slice) or partial form, 0 if the shape does not fit.  launch: part == nullptr ->
+// out (bf16) = act(A W^T + bias), act 0 none / 1 GELU / 2 ReLU; part != nullptr -> part[z][M][N] fp32 slice sums for
+// launch_reduce_layernorm / launch_reduce_bias_act.  Returns the slice count, or -1.
+int skinny_plan(int N, int K, bool finished, int* nw_out);
+int launch_gemm_skinny(const void* A, int lda, const void* W, int ldw, const float* bias, int act, void* out, int ldc,
+                       float* part, int M, int N, int K, hipStream_t s);
 
 // ---- beam.hip --------------------------------------------------------------------------------
 size_t beam_state_bytes(int B, int K, int max_len);

@@ -128,6 +128,17 @@ int cap_op_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
 /* heads of any width (BLIP-2's ViT-g/14: 88); impl 1 forces the scalar kernel, 0 picks the MFMA kernel where one exists */
 int cap_op_vit_attention_hd(int dtype, const void* qkv, void* ctx, int B, int N, int H, int head_dim, int impl,
                             void* stream);
+/* split-K consumer: y = sum_z part[z][M][D] + bias + resid (-> y_out, may alias resid), LayerNorm(y) -> out_t (dtype) /
+ * out_f (fp32); any output may be NULL.  per_row_block: the decoder's workgroup-per-row kernels (few rows). */
+int cap_op_reduce_layernorm(int dtype, const float* part, int S, const float* bias, const float* resid,
+                            const float* gamma, const float* beta, float eps, void* out_t, float* out_f, float* y_out,
+                            int M, int D, int per_row_block, void* stream);
+/* bf16 weight-streaming GEMM for a handful of rows (decode step of a large LM): out (bf16) = act(A W^T + bias) when part
+ * is NULL, else part[z][M][N] fp32 slice sums.  Returns the slice count used (>= 1) or -1; cap_op_gemm_skinny_slices
+ * tells it beforehand (0 = the shape does not fit the kernel). */
+int cap_op_gemm_skinny(const void* A, const void* W, const float* bias, int act, void* out, float* part, int M, int N,
+                       int K, void* stream);
+int cap_op_gemm_skinny_slices(int N, int K, int finished);
 int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int32_t* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             void* stream);

@@ -136,6 +136,66 @@ def test_vit_attention_mfma_matches_scalar_kernel(lib):
     assert (a.float() - b.float()).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(32, 7680, 2560), (2, 2560, 2560), (40, 2560, 10240), (7, 96, 512), (32, 64, 256),
+                                   (5, 10240, 2560)])
+def test_gemm_skinny(lib, M, N, K):
+    """Weight-streaming decode GEMM: finished output (bias + ReLU) and split-K slice sums against float64; a row's result
+    does not depend on the rows it rides with (bitwise)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().T
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    S = lib.cap_op_gemm_skinny_slices(N, K, 0)
+    assert S >= 1
+    part = torch.full((S, M, N), float("nan"), device="cuda")
+    assert lib.cap_op_gemm_skinny(_p(Ad), _p(Wd), None, 0, None, _p(part), M, N, K, _stream()) == S, lib.cap_last_error()
+    torch.cuda.synchronize()
+    assert (part.sum(0).cpu().double() - ref).abs().max().item() < 1e-3 * (K / 256) ** 0.5
+    if lib.cap_op_gemm_skinny_slices(N, K, 1) == 1:      # one workgroup can hold the whole K: the finished form
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        assert lib.cap_op_gemm_skinny(_p(Ad), _p(Wd), _p(bd), 2, _p(out), None, M, N, K, _stream()) == 1
+        want = torch.relu(ref + bias.double())
+        assert (out.float().cpu().double() - want).abs().max().item() < 2e-2 * max(1.0, want.abs().max().item())
+        one = torch.full((1, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        assert lib.cap_op_gemm_skinny(_p(Ad[M - 1:]), _p(Wd), _p(bd), 2, _p(one), None, 1, N, K, _stream()) == 1
+        assert torch.equal(one[0], out[M - 1])
+    else:
+        assert K > 2560
+
+
+@pytest.mark.parametrize("M,D,S,row_block", [(32, 2560, 4, 1), (32, 2560, 2, 1), (5, 3072, 1, 1), (7, 1028, 3, 1), (64, 768, 8, 1),
+                                              (32, 2560, 4, 0), (300, 768, 4, 0)])
+def test_reduce_layernorm(lib, M, D, S, row_block):
+    """Split-K consumer (sum of slices + bias + residual, LayerNorm) in its three kernels, residual stream updated in place."""
+    g = torch.Generator().manual_seed(M * D + S)
+    part = torch.randn(S, M, D, generator=g)
+    bias, resid = torch.randn(D, generator=g), torch.randn(M, D, generator=g)
+    gamma, beta = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g)
+    y = part.double().sum(0) + bias.double() + resid.double()
+    ref = torch.nn.functional.layer_norm(y, (D,), gamma.double(), beta.double(), 1e-5)
+    x, pd, bd, gd, btd = resid.cuda(), part.cuda(), bias.cuda(), gamma.cuda(), beta.cuda()
+    out_t = torch.full((M, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    out_f = torch.full((M, D), float("nan"), device="cuda")
+    _check(lib, lib.cap_op_reduce_layernorm(1, _p(pd), S, _p(bd), _p(x), _p(gd), _p(btd), C.c_float(1e-5), _p(out_t), _p(out_f),
+                                            _p(x), M, D, row_block, _stream()))
+    torch.cuda.synchronize()
+    assert (x.cpu().double() - y).abs().max().item() < 1e-5
+    assert (out_f.cpu().double() - ref).abs().max().item() < 3e-5
+    assert (out_t.float().cpu().double() - ref).abs().max().item() < 5e-2
+
+
+def test_gemm_skinny_rejects_bad_shapes(lib):
+    x = torch.zeros(64, 512, dtype=torch.bfloat16, device="cuda")
+    f = torch.zeros(16 * 64 * 64, device="cuda")
+    assert lib.cap_op_gemm_skinny(_p(x), _p(x), None, 0, _p(x), None, 4, 48, 512, _stream()) == -1     # N % 32
+    assert lib.cap_op_gemm_skinny(_p(x), _p(x), None, 0, None, _p(f), 4, 64, 320, _stream()) == -1     # K % 256
+    assert lib.cap_op_gemm_skinny(_p(x), _p(x), None, 0, _p(x), None, 4, 64, 10240, _stream()) == -1   # finished form: K > 2560
+    assert b"gemm_skinny" in lib.cap_last_error()
+    assert lib.cap_op_gemm_skinny_slices(64, 320, 0) == 0
+
+
 @pytest.mark.parametrize("hd", [72, 88, 128])
 def test_vit_attention_wide_heads(lib, hd):
     """Heads wider than 64 at 257 tokens (BLIP-2's ViT-g/14 is 88): the two-half MFMA kernel against a float64 reference and
