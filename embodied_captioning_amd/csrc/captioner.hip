@@ -688,7 +688,7 @@ int run_opt(Captioner* m, int B, int L, int past, hipStream_t s) {
 // with a reduce kernel.  The choice depends on dtype and (N, K) only - never on the row count.
 int opt_step_gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, const float* bias, int act,
                   void* out_t, int B, int N, int K, bool ln, int* S_out) {
-    const int S = m->dt == CAP_DT_BF16 ? skinny_plan(N, K, !ln, nullptr) : 0;
+    const int S = m->dt == CAP_DT_BF16 ? skinny_plan(N, K, !ln) : 0;
     if (S >= 1) {
         ProfScope ps(m, s, tag, 2.0 * B * N * K, ((double)B * K + (double)N * K) * 2 + (ln ? (double)S * B * N * 4 : (double)B * N * 2));
         *S_out = S;
@@ -1455,7 +1455,7 @@ int cap_op_gemm_skinny(const void* A, const void* W, const float* bias, int act,
                        void* stream) {
     return launch_gemm_skinny(A, K, W, K, bias, act, out, N, part, M, N, K, (hipStream_t)stream);
 }
-int cap_op_gemm_skinny_slices(int N, int K, int finished) { return skinny_plan(N, K, finished != 0, nullptr); }
+int cap_op_gemm_skinny_slices(int N, int K, int finished) { return skinny_plan(N, K, finished != 0); }
 int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int32_t* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             void* stream) {

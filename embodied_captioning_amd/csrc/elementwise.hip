@@ -223,8 +223,14 @@ __global__ __launch_bounds__(256) void reduce_layernorm_wide_kernel(const float*
         const int c = tid * 4 + i * 1024;
         a[i] = z4;
         if (c < D) {
-            a[i] = *(const float4*)(part + (size_t)row * D + c);
-            for (int z = 1; z < S; ++z) {
+            float4 pz[4];                          // the first four slices are loaded before the first add
+#pragma unroll
+            for (int z = 0; z < 4; ++z) pz[z] = z < S ? *(const float4*)(part + ((size_t)z * M + row) * D + c) : z4;
+            a[i] = pz[0];
+#pragma unroll
+            for (int z = 1; z < 4; ++z)
+                if (z < S) { a[i].x += pz[z].x; a[i].y += pz[z].y; a[i].z += pz[z].z; a[i].w += pz[z].w; }
+            for (int z = 4; z < S; ++z) {
                 const float4 b = *(const float4*)(part + ((size_t)z * M + row) * D + c);
                 a[i].x += b.x; a[i].y += b.y; a[i].z += b.z; a[i].w += b.w;
             }

@@ -18,7 +18,7 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int SK_MAXKS = 10, SK_PITCH = 36;   // LDS row pitch in floats (144 B: the 16 rows of a tile spread over the banks)
+constexpr int SK_MAXKS = 10;   // LDS row pitch in floats (144 B: the 16 rows of a tile spread over the banks)
 
 struct SkinnyParams {
     const bf16_t* A; int lda;
@@ -39,16 +39,19 @@ __device__ __forceinline__ int skl_swz(int row, int chunk) { return row * 128 + 
 #define SKL_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define SKL_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int NW, int SKL_RING>   // SKL_RING: 64-k slabs (32 rows x 128 B) in flight per wave
+// NW waves; SKL_RING 64-k slabs (TR rows x 128 B) in flight per wave; TR = weight rows per workgroup (32, or 40 when that
+// makes the grid exactly one workgroup per CU: the third 16-row MFMA tile is then half empty, which costs nothing here).
+template <int NW, int SKL_RING, int TR>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(SkinnyParams p) {
+    constexpr int QN = TR / 8, WT = (TR + 15) / 16, SLAB = TR * 128, PITCH = WT * 16 + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = blockIdx.x / p.S, z = blockIdx.x % p.S;
-    const int n0 = nt * 32, m0 = blockIdx.y * 32;
+    const int n0 = nt * TR, m0 = blockIdx.y * 32;
     const int kw = (z * NW + wave) * p.nks * 32;                    // first k of this wave
     const int nsl = p.nks >> 1;                                     // slabs of 64 k
-    char* ring = smem + wave * (SKL_RING * 4096);
+    char* ring = smem + wave * (SKL_RING * SLAB);
 
     // activations: every fragment of the wave's K range, straight to registers (L2 hits)
     const bf16_t* ap[2];
@@ -62,24 +65,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(SkinnyParams p) {
             for (int t = 0; t < 2; ++t) af[t][j] = *(const bf16x8*)(ap[t] + j * 32 * p.xk);
         }
     // weights: lane -> (row q*8 + lane/8, 16-byte position lane%8); the swizzle is applied on the source side
-    const bf16_t* wsrc[4];
+    const bf16_t* wsrc[QN];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < QN; ++q) {
         const int row = q * 8 + (lane >> 3);
         wsrc[q] = p.W + (size_t)(n0 + row) * p.ldw + kw + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
     }
     auto issue = [&](int sl) {
-        char* dst = ring + (sl % SKL_RING) * 4096;
+        char* dst = ring + (sl % SKL_RING) * SLAB;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) __builtin_amdgcn_global_load_lds(SKL_GPTR(wsrc[q] + sl * 64), SKL_LPTR(dst + q * 1024), 16, 0, 0);
+        for (int q = 0; q < QN; ++q) __builtin_amdgcn_global_load_lds(SKL_GPTR(wsrc[q] + sl * 64), SKL_LPTR(dst + q * 1024), 16, 0, 0);
     };
 #pragma unroll
     for (int sl = 0; sl < SKL_RING; ++sl)
         if (sl < nsl) issue(sl);
 
-    f32x4 acc[2][2];
+    f32x4 acc[WT][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < WT; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x4(0.f);
 #pragma unroll
@@ -87,20 +90,28 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(SkinnyParams p) {
         if (sl < nsl) {
             // slabs still allowed in flight behind slab `sl`: those issued so far minus sl + 1
             const int behind = min(nsl, sl + SKL_RING) - sl - 1;
-            if (behind >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if (behind == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const char* buf = ring + (sl % SKL_RING) * 4096;
-            bf16x8 wf[2][2];
+            static_assert(QN == 4 || QN == 5, "vmcnt ladder below is written for 4 or 5 DMA instructions per slab");
+            if constexpr (QN == 4) {
+                if (behind >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if (behind == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (behind >= 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                else if (behind == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else if (behind == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const char* buf = ring + (sl % SKL_RING) * SLAB;
+            bf16x8 wf[WT][2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) wf[t][ks] = *(const bf16x8*)(buf + skl_swz(t * 16 + r16, ks * 4 + kg));
+                for (int t = 0; t < WT; ++t) wf[t][ks] = *(const bf16x8*)(buf + skl_swz(min(t * 16 + r16, TR - 1), ks * 4 + kg));
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int wt = 0; wt < 2; ++wt)
+                for (int wt = 0; wt < WT; ++wt)
 #pragma unroll
                     for (int xt = 0; xt < 2; ++xt)
                         acc[wt][xt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[wt][ks], af[xt][2 * sl + ks], acc[wt][xt], 0, 0, 0);
@@ -112,16 +123,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(SkinnyParams p) {
     __syncthreads();                                    // every wave is done with its ring: the sums reuse the space
     float* red = (float*)smem;
 #pragma unroll
-    for (int wt = 0; wt < 2; ++wt)
+    for (int wt = 0; wt < WT; ++wt)
 #pragma unroll
         for (int xt = 0; xt < 2; ++xt)
-            *(f32x4*)(red + (wave * 32 + xt * 16 + r16) * SK_PITCH + wt * 16 + 4 * kg) = acc[wt][xt];
+            *(f32x4*)(red + (wave * 32 + xt * 16 + r16) * PITCH + wt * 16 + 4 * kg) = acc[wt][xt];
     __syncthreads();
-    for (int o = tid; o < 512; o += NW * 64) {
-        const int m = o >> 4, n = (o & 15) * 2;
-        f32x2 v = *(const f32x2*)(red + m * SK_PITCH + n);
+    for (int o = tid; o < 16 * TR; o += NW * 64) {
+        const int m = o / (TR / 2), n = (o % (TR / 2)) * 2;
+        f32x2 v = *(const f32x2*)(red + m * PITCH + n);
 #pragma unroll
-        for (int w = 1; w < NW; ++w) v += *(const f32x2*)(red + (w * 32 + m) * SK_PITCH + n);
+        for (int w = 1; w < NW; ++w) v += *(const f32x2*)(red + (w * 32 + m) * PITCH + n);
         if (m0 + m >= p.M) continue;
         if (p.part) {
             *(f32x2*)(p.part + ((size_t)z * p.M + m0 + m) * p.N + n0 + n) = v;
@@ -138,28 +149,34 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(SkinnyParams p) {
 
 }  // namespace
 
-// Launch plan for a (N, K) projection: K slices S and waves per workgroup NW, with K / (S NW) <= 320 and a multiple of
-// 64.  finished: the epilogue needs the whole K in one workgroup (S = 1).  Otherwise the fewest waves per row tile, split
-// into more slices while the grid is small.  Returns S, or 0 when the shape does not fit.
-int skinny_plan(int N, int K, bool finished, int* nw_out) {
-    if (N % 32 != 0 || K % 64 != 0) return 0;
-    const int tiles = N / 32;
+// Launch plan for a (N, K) projection: K slices S, waves per workgroup NW and weight rows per workgroup TR, with
+// K / (S NW) <= 320 and a multiple of 64.  finished: the epilogue needs the whole K in one workgroup (S = 1).  Otherwise
+// the fewest waves per row tile, split into more slices while the grid is small.  40-row workgroups when 32-row ones
+// overflow the 256 CUs and 40-row ones fill them exactly or stay inside.  Returns S, or 0 when the shape does not fit.
+int skinny_plan(int N, int K, bool finished, int* nw_out, int* tr_out) {
+    if (N % 8 != 0 || K % 64 != 0) return 0;
     int bestS = 0, bestNW = 0;
     for (int S = 1; S <= (finished ? 1 : 16); S *= 2)
         for (int nw : {8, 4}) {
             if (K % (S * nw * 64) != 0 || K / (S * nw * 32) > SK_MAXKS) continue;
             const bool fewer = bestS == 0 || S * nw < bestS * bestNW;
-            const bool same_but_wider = bestS != 0 && S * nw == bestS * bestNW && tiles * bestS < 128;
+            const bool same_but_wider = bestS != 0 && S * nw == bestS * bestNW && (N / 32) * bestS < 128;
             if (fewer || same_but_wider) { bestS = S; bestNW = nw; }
         }
+    if (bestS == 0) return 0;
+    int tr = 32;
+    if (N % 40 == 0 && bestNW == 8 && (N % 32 != 0 || ((N / 32) * bestS > 256 && (N / 40) * bestS <= 256))) tr = 40;
+    if (N % tr != 0) return 0;
     if (nw_out) *nw_out = bestNW;
+    if (tr_out) *tr_out = tr;
     return bestS;
 }
 
-template <int NW, int RING>
+template <int NW, int RING, int TR>
 static int skinny_launch(const SkinnyParams& p, dim3 grid, hipStream_t s) {
-    const int lds = NW * RING * 4096 > NW * 32 * SK_PITCH * 4 ? NW * RING * 4096 : NW * 32 * SK_PITCH * 4;
-    auto kern = gemm_skinny_kernel<NW, RING>;
+    constexpr int ring_b = NW * RING * TR * 128, red_b = NW * 32 * (((TR + 15) / 16) * 16 + 4) * 4;
+    constexpr int lds = ring_b > red_b ? ring_b : red_b;
+    auto kern = gemm_skinny_kernel<NW, RING, TR>;
     if (cap_kernel_setup((const void*)kern, lds, nullptr) != 0) return -1;
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
     CAP_HIP_CHECK(hipGetLastError());
@@ -170,8 +187,8 @@ static int skinny_launch(const SkinnyParams& p, dim3 grid, hipStream_t s) {
 // sums, fp32 (bias / act are the consumer's).  Returns the slice count (>= 1), or -1.
 int launch_gemm_skinny(const void* A, int lda, const void* W, int ldw, const float* bias, int act, void* out, int ldc,
                        float* part, int M, int N, int K, hipStream_t s) {
-    int nw = 0;
-    const int S = skinny_plan(N, K, part == nullptr, &nw);
+    int nw = 0, tr = 32;
+    const int S = skinny_plan(N, K, part == nullptr, &nw, &tr);
     if (S < 1 || M < 1 || (lda & 7) || (ldw & 7) || (!part && (!out || (ldc & 1)))) {
         cap_set_error("gemm_skinny: unsupported shape M=%d N=%d K=%d", M, N, K);
         return -1;
@@ -181,12 +198,12 @@ int launch_gemm_skinny(const void* A, int lda, const void* W, int ldw, const flo
     static const int abl = getenv("CAP_SKINNY_ABL") ? atoi(getenv("CAP_SKINNY_ABL")) : 0;
     p.xk = abl == 1 ? 0 : 1;
     p.part = part; p.M = M; p.N = N; p.S = S; p.nks = K / (nw * 32 * S); p.act = act;
-    const dim3 grid((N / 32) * S, (M + 31) / 32);
-    static const int ring = getenv("CAP_SKINNY_RING") ? atoi(getenv("CAP_SKINNY_RING")) : 0;
+    const dim3 grid((N / tr) * S, (M + 31) / 32);
     // more workgroups than CUs: a two-slab ring (64 KiB per workgroup) lets two share a CU, so the grid is still one round
-    const bool small = ring ? ring == 2 : (int)(grid.x * grid.y) > 256;
+    const bool small = (int)(grid.x * grid.y) > 256;
     int rc;
-    if (nw == 8) rc = small ? skinny_launch<8, 2>(p, grid, s) : skinny_launch<8, 4>(p, grid, s);
-    else rc = small ? skinny_launch<4, 2>(p, grid, s) : skinny_launch<4, 4>(p, grid, s);
+    if (tr == 40) rc = skinny_launch<8, 3, 40>(p, grid, s);
+    else if (nw == 8) rc = small ? skinny_launch<8, 2, 32>(p, grid, s) : skinny_launch<8, 4, 32>(p, grid, s);
+    else rc = small ? skinny_launch<4, 2, 32>(p, grid, s) : skinny_launch<4, 4, 32>(p, grid, s);
     return rc == 0 ? S : rc;
 }
