@@ -1040,11 +1040,13 @@ int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream) {
         return -1;
     }
     if (tile == 0) {
-        // 256x256 (one 8-wave block per CU) once every CU gets at least one tile; 128x128 while that still gives
-        // every CU work; 64x64 with a deep register prefetch ring for the decode-sized (M <= a few hundred) GEMMs
+        // 256x256 (one 8-wave block per CU) once at least half the CUs get a tile: between 128 and 255 such tiles the
+        // 128x128 kernel would need two rounds of its 512 resident blocks (measured on the OPT prefill, 1056 x 7680 x 2560:
+        // 99 us against one round of the big kernel); 128x128 while that still gives every CU work; 64x64 with a deep
+        // register prefetch ring for the decode-sized (M <= a few hundred) GEMMs
         const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-        tile = t256 >= 256 ? 3 : (t128 >= 256 ? 1 : 2);
+        tile = (t256 >= 256 || (t256 >= 128 && p.M >= 256)) ? 3 : (t128 >= 256 ? 1 : 2);   // few rows: a 256-row tile is mostly padding
     }
     if (dtype == CAP_DT_BF16) return launch_t<bf16_t>(p, tile, stream);
     if (dtype == CAP_DT_F32) return launch_t<float>(p, tile, stream);

@@ -8,8 +8,8 @@
 //     (v_mfma_f32_16x16x32_bf16, W as the A operand so a lane ends up with 4 consecutive output columns);
 //   * the waves' fp32 tiles are summed through LDS in wave order (deterministic), then either finished in place
 //     (bias, ReLU/GELU, cast - one slice) or written as split-K slice `z` for the reduce+LayerNorm consumer.
-// Rows beyond 32 are further grid.y groups (W is re-read from L2/MALL); the k-order of a row's sum depends on (N, K) and
-// the output form only, never on the row count.
+// Rows beyond 32 are further workgroups placed on the same XCD as the first (W is re-read from that L2); the k-order of a
+// row's sum depends on (N, K) and the output form only, never on the row count.
 #include "common.h"
 #include "ops.h"
 #include <stdlib.h>
@@ -27,7 +27,8 @@ struct SkinnyParams {
     bf16_t* out; int ldc;     // part == null (S == 1): act(sum + bias) as bf16
     float* part;              // non-null: part[z][M][N] fp32 slice sums instead of `out`
     int xk;                   // 1; 0 = bandwidth ablation (every activation fragment from k = 0: L1 hits, wrong sums)
-    int M, N, S, nks, act;    // nks = k-steps of 32 per wave; act 0 none, 1 GELU(erf), 2 ReLU
+    int M, N, S, nks, act;
+    int G, units;             // row groups of 32 (ceil(M / 32)); units = row tiles x S    // nks = k-steps of 32 per wave; act 0 none, 1 GELU(erf), 2 ReLU
 };
 
 // W is staged through LDS: loading it straight into the MFMA operand layout asks for 64 bytes per weight row per
@@ -47,8 +48,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(SkinnyParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = blockIdx.x / p.S, z = blockIdx.x % p.S;
-    const int n0 = nt * TR, m0 = blockIdx.y * 32;
+    // Workgroup id -> (unit = row tile x K slice, row group g of 32 activation rows).  Ids are dealt round-robin to the 8
+    // XCDs, so the G groups of one unit take ids 8 apart: same XCD, dispatched together - the unit's weights come from HBM
+    // once and the other groups find them in that XCD's L2.
+    const int per = 8 * p.G, rr = blockIdx.x % per;
+    const int unit = (blockIdx.x / per) * 8 + (rr & 7);
+    if (unit >= p.units) return;
+    const int nt = unit / p.S, z = unit % p.S;
+    const int n0 = nt * TR, m0 = (rr >> 3) * 32;
     const int kw = (z * NW + wave) * p.nks * 32;                    // first k of this wave
     const int nsl = p.nks >> 1;                                     // slabs of 64 k
     char* ring = smem + wave * (SKL_RING * SLAB);
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(SkinnyParams p) {
 // K / (S NW) <= 320 and a multiple of 64.  finished: the epilogue needs the whole K in one workgroup (S = 1).  Otherwise
 // the fewest waves per row tile, split into more slices while the grid is small.  40-row workgroups when 32-row ones
 // overflow the 256 CUs and 40-row ones fill them exactly or stay inside.  Returns S, or 0 when the shape does not fit.
-int skinny_plan(int N, int K, bool finished, int* nw_out, int* tr_out) {
+int skinny_plan(int N, int K, bool finished, int* nw_out, int* tr_out, int M) {
     if (N % 8 != 0 || K % 64 != 0) return 0;
     int bestS = 0, bestNW = 0;
     for (int S = 1; S <= (finished ? 1 : 16); S *= 2)
@@ -165,7 +172,8 @@ int skinny_plan(int N, int K, bool finished, int* nw_out, int* tr_out) {
         }
     if (bestS == 0) return 0;
     int tr = 32;
-    if (N % 40 == 0 && bestNW == 8 && (N % 32 != 0 || ((N / 32) * bestS > 256 && (N / 40) * bestS <= 256))) tr = 40;
+    // (the row count only picks the partition of N - S, NW and with them every row's k-order do not depend on it)
+    if (N % 40 == 0 && bestNW == 8 && (N % 32 != 0 || (M <= 32 && (N / 32) * bestS > 256 && (N / 40) * bestS <= 256))) tr = 40;
     if (N % tr != 0) return 0;
     if (nw_out) *nw_out = bestNW;
     if (tr_out) *tr_out = tr;
@@ -188,7 +196,7 @@ static int skinny_launch(const SkinnyParams& p, dim3 grid, hipStream_t s) {
 int launch_gemm_skinny(const void* A, int lda, const void* W, int ldw, const float* bias, int act, void* out, int ldc,
                        float* part, int M, int N, int K, hipStream_t s) {
     int nw = 0, tr = 32;
-    const int S = skinny_plan(N, K, part == nullptr, &nw, &tr);
+    const int S = skinny_plan(N, K, part == nullptr, &nw, &tr, M);
     if (S < 1 || M < 1 || (lda & 7) || (ldw & 7) || (!part && (!out || (ldc & 1)))) {
         cap_set_error("gemm_skinny: unsupported shape M=%d N=%d K=%d", M, N, K);
         return -1;
@@ -198,9 +206,10 @@ int launch_gemm_skinny(const void* A, int lda, const void* W, int ldw, const flo
     static const int abl = getenv("CAP_SKINNY_ABL") ? atoi(getenv("CAP_SKINNY_ABL")) : 0;
     p.xk = abl == 1 ? 0 : 1;
     p.part = part; p.M = M; p.N = N; p.S = S; p.nks = K / (nw * 32 * S); p.act = act;
-    const dim3 grid((N / tr) * S, (M + 31) / 32);
+    p.G = (M + 31) / 32; p.units = (N / tr) * S;
+    const dim3 grid(((p.units + 7) / 8) * 8 * p.G);
     // more workgroups than CUs: a two-slab ring (64 KiB per workgroup) lets two share a CU, so the grid is still one round
-    const bool small = (int)(grid.x * grid.y) > 256;
+    const bool small = (int)grid.x > 256;
     int rc;
     if (tr == 40) rc = skinny_launch<8, 3, 40>(p, grid, s);
     else if (nw == 8) rc = small ? skinny_launch<8, 2, 32>(p, grid, s) : skinny_launch<8, 4, 32>(p, grid, s);

@@ -79,7 +79,7 @@ int launch_pool_attention(int dtype, const float* qp, const void* kv, void* out,
 // finished (bias + act -> bf16, one slice) or partial form, 0 if the shape does not fit.  launch: part == nullptr ->
 // out (bf16) = act(A W^T + bias), act 0 none / 1 GELU / 2 ReLU; part != nullptr -> part[z][M][N] fp32 slice sums for
 // launch_reduce_layernorm / launch_reduce_bias_act.  Returns the slice count, or -1.
-int skinny_plan(int N, int K, bool finished, int* nw_out = nullptr, int* tr_out = nullptr);
+int skinny_plan(int N, int K, bool finished, int* nw_out = nullptr, int* tr_out = nullptr, int M = 32);
 int launch_gemm_skinny(const void* A, int lda, const void* W, int ldw, const float* bias, int act, void* out, int ldc,
                        float* part, int M, int N, int K, hipStream_t s);
 

@@ -137,7 +137,7 @@ def test_vit_attention_mfma_matches_scalar_kernel(lib):
 
 
 @pytest.mark.parametrize("M,N,K", [(32, 7680, 2560), (2, 2560, 2560), (40, 2560, 10240), (7, 96, 512), (32, 64, 256),
-                                   (5, 10240, 2560)])
+                                   (5, 10240, 2560), (128, 10240, 2560), (97, 2560, 10240), (70, 160, 512)])
 def test_gemm_skinny(lib, M, N, K):
     """Weight-streaming decode GEMM: finished output (bias + ReLU) and split-K slice sums against float64; a row's result
     does not depend on the rows it rides with (bitwise)."""
