@@ -46,6 +46,10 @@ def parse():
                     help="blip = BASELINE.json metric workload (default); coca = extra line for config 5's model "
                          "(CoCa ViT-L/14, reference top-k(1) loop, seq_len 30)")
     ap.add_argument("--beams", type=int, default=1, help="> 1: extra line for SURVEY config 3 (HF beam search; use --batch 64)")
+    ap.add_argument("--early-exit", type=int, default=0, help="poll the device every N decode steps and leave the loop when "
+                    "every caption is finished (HF's stopping rule; 0 = never, the default: no host sync in generate)")
+    ap.add_argument("--eos-boost", type=float, default=9.0, help="blip: EOS logit offset of the procedural weights (9 = the "
+                    "golden's weights; larger values end every caption early)")
     ap.add_argument("--lite", action="store_true", help="timed steps only (profiler counter passes): no roofline / "
                     "encoder-only / parity / fp32 / CPU legs")
     ap.add_argument("--image-size", type=int, default=224, help="coca: 224 or 336 (SURVEY config 5); blip: 224 (the "
@@ -312,7 +316,7 @@ def main():
     arch = BlipArch()
     arch.image_size = a.image_size
     L, B = a.max_length, a.batch
-    sd = procedural_blip_state_dict(arch, 0, eos_boost=9.0)       # same weights as tests/golden/blip_base.npz
+    sd = procedural_blip_state_dict(arch, 0, eos_boost=a.eos_boost)       # 9.0: same weights as tests/golden/blip_base.npz
     px = synthetic_pixels(B, arch.image_size, seed=0, first=rank * B).to(dev)
 
     if world > 1:
@@ -330,8 +334,10 @@ def main():
     log(f"rank {rank}/{world}: weights + {B} frames ready, host cores usable: {host_cores()}")
     eng = CaptionerEngine(arch, dtype=a.dtype, max_batch=B, max_beams=a.beams, max_len=L, device=dev)
     eng.load_state_dict(sd)
+    eng.set_early_exit(a.early_exit)
     log("weights loaded; timing")
     dt, (ids, lens) = timed_steps(eng, px, L, a.steps, a.warmup, world, gather, a.beams)
+    decode_steps = eng.last_decode_steps
     log(f"timed region: {dt:.3f}s for {a.steps} steps")
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -348,6 +354,10 @@ def main():
                 "config": {"workload": f"BLIP-base ViT-B/16 encoder + {'greedy' if a.beams == 1 else f'beam-{a.beams}'} decode, {B} frames/GPU {S}x{S}, "
                                        f"max_length={L}, caption all-gather", "global_batch": world * B,
                            "parallelism": f"dp{world}"}}
+        if a.early_exit or a.eos_boost != 9.0:
+            line["config"]["early_exit_poll"] = a.early_exit
+            line["config"]["eos_boost"] = a.eos_boost
+            line["decode_steps_run"] = decode_steps
         if a.beams > 1:                      # config 3 extra line: per-kernel profile of one beam generate, then stop
             eng.profile(True)
             eng.generate(px, num_beams=a.beams, max_length=L)

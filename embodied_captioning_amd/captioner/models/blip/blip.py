@@ -66,6 +66,9 @@ class BLIP(CaptioningPredictor):
             logger.info("Captioner model checkpoint loaded successfully from %s", cfg.checkpoint_name)
         self.engine = CaptionerEngine(self.arch, dtype=dtype, max_batch=self.batch_size, max_beams=self.num_beams,
                                       max_len=self.max_length, device=self._device)
+        # HF generate stops once every caption has its EOS; look every few steps (cfg early_exit_poll, 0 = never)
+        poll = getattr(cfg, "early_exit_poll", None)
+        self.engine.set_early_exit(4 if poll is None else int(poll))
         self.engine.load_state_dict(sd)
 
     # nn.Module surface the callers use; weights live in the engine, so .to() only re-targets host-side tensors

@@ -110,6 +110,9 @@ class BLIP2(BLIP):
         self.max_length = int(getattr(cfg, "max_new_tokens", 0) or self.arch.max_new_tokens)
         self.engine = CaptionerEngine(self.arch, dtype=dtype, max_batch=self.batch_size, max_beams=1, max_len=self.max_length,
                                       device=self._device)
+        # HF generate stops once every caption has its EOS; look every few steps (cfg early_exit_poll, 0 = never)
+        poll = getattr(cfg, "early_exit_poll", None)
+        self.engine.set_early_exit(4 if poll is None else int(poll))
         self.engine.load_state_dict(sd)
 
     def decode(self, ids: Sequence[int]) -> str:

@@ -61,6 +61,9 @@ class CoCa(CaptioningPredictor):
                 logger.warning("open_clip is not installed: captions are returned as space-separated token ids")
         self.engine = CaptionerEngine(self.arch, dtype=dtype, max_batch=self.batch_size, max_beams=1,
                                       max_len=self.arch.seq_len, device=self._device)
+        # HF generate stops once every caption has its EOS; look every few steps (cfg early_exit_poll, 0 = never)
+        poll = getattr(cfg, "early_exit_poll", None)
+        self.engine.set_early_exit(4 if poll is None else int(poll))
         self.engine.load_state_dict(sd)
 
     @property

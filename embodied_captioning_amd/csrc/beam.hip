@@ -404,6 +404,9 @@ int launch_beam_finalize(void* state, int B, int K, int max_len, int* out_ids, i
     return 0;
 }
 
+const int* beam_active_flag_p(void* state, int B, int K, int max_len) {
+    return (const int*)((char*)state + beam_layout(B, K, max_len).active);
+}
 const int* beam_running_tokens_p(void* state, int B, int K, int max_len, int parity) {
     return (const int*)((char*)state + beam_layout(B, K, max_len).run_seq[parity]);
 }

@@ -101,6 +101,9 @@ struct Captioner {
     std::vector<void*> allocs;
     std::multimap<std::string, Slot> slots;
     float* stage = nullptr; size_t stage_elems = 0;
+    // early exit of the decode loop (cap_set_early_exit): poll every `poll` steps through a host-mapped word
+    int poll = 0; int* host_flag = nullptr; int* host_flag_dev = nullptr;
+    int last_steps = 0;          // decode steps the last cap_generate ran (cap_last_decode_steps)
     // vision weights
     float *cls, *vpos, *b_patch, *post_g, *post_b;
     void* w_patch;
@@ -465,6 +468,33 @@ int gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, int lda, c
     return launch_gemm(m->dt, p, 0, s);   // tile 0 = auto (stream kernel for encoder-sized problems without residual)
 }
 
+// Decode loops stop when every caption is finished, as HF generate does (`unfinished_sequences.max() == 0` /
+// `is_done.all()`); the remaining steps would only write pad.  The device keeps the state, the host looks at it every
+// `poll` steps: one tiny kernel writes the number of open rows (greedy) or the beam loop's active flag to a host-mapped
+// word, then the stream is synchronised.  Off by default (poll = 0): the loop is then free of host synchronisation and
+// can be captured in a graph.
+__global__ void poll_open_kernel(const int* __restrict__ finished, int R, const int* __restrict__ beam_active, int* host_out) {
+    if (beam_active) { if (threadIdx.x == 0) *host_out = *beam_active; return; }
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int c = 0;
+    for (int r = threadIdx.x; r < R; r += blockDim.x) c += finished[r] == 0;
+    if (c) atomicAdd(&cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) *host_out = cnt;
+}
+// true = every row is finished (the caller leaves its loop).  step = index of the step just completed, steps = loop length.
+int poll_all_finished(Captioner* m, int step, int steps, const int* finished, int R, const int* beam_active, hipStream_t s, bool* done) {
+    *done = false;
+    if (m->poll <= 0 || !m->host_flag || (step + 1) % m->poll != 0 || step + 2 >= steps) return 0;
+    hipLaunchKernelGGL(poll_open_kernel, dim3(1), dim3(256), 0, s, finished, R, beam_active, m->host_flag_dev);
+    CAP_HIP_CHECK(hipGetLastError());
+    CAP_HIP_CHECK(hipStreamSynchronize(s));
+    *done = *(volatile int*)m->host_flag == 0;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- BLIP-2 OPT
 int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_embeds, hipStream_t s);
 int gemm_partial(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, float* part, int R, int N,
@@ -743,6 +773,7 @@ int run_generate_blip2(Captioner* m, const void* pixels, int fmt, int B, int max
     CAP_HIP_CHECK(hipGetLastError());
     TRY(run_opt(m, B, P, 0, s));
     for (int t = 0; t < max_len; ++t) {
+        m->last_steps = t + 1;
         if (out_step_logits) {
             hipLaunchKernelGGL(copy_logits_kernel, dim3(1024), dim3(256), 0, s, m->logits, m->ldl,
                                out_step_logits + (size_t)t * B * c.vocab, B, c.vocab);
@@ -751,6 +782,11 @@ int run_generate_blip2(Captioner* m, const void* pixels, int fmt, int B, int max
         // token of position P + t; a row finishes on EOS or at P + max_len tokens (greedy_select's `t` is the last filled index)
         TRY(launch_greedy_select(m->logits, m->ldl, c.vocab, m->seq, Lmax, P - 1 + t, P + max_len, c.eos, c.pad, m->finished, m->lens, B, s, 0, 0));
         if (t + 1 == max_len) break;
+        {
+            bool done;
+            TRY(poll_all_finished(m, t, max_len, m->finished, B, nullptr, s, &done));
+            if (done) break;
+        }
         TRY(launch_opt_token_inputs(m->seq, Lmax, P + t, m->o_tok, m->o_pos, m->ox, B, T, s));
         TRY(launch_layernorm(m->dt, m->ox, T, m->ol[0].ln1_g, m->ol[0].ln1_b, c.t_eps, m->oh_t, nullptr, B, T, s));
         TRY(run_opt_step(m, B, P + t, s));
@@ -1132,6 +1168,7 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
         CAP_HIP_CHECK(hipGetLastError());
         for (int t = 0; t + 1 < Lm; ++t) {
             const int cur_len = t + 1;
+            if (si == 0) m->last_steps = t + 1;
             const int* tokens = K == 1 ? d.seq : beam_running_tokens_p(d.beam, Bs, K, Lm, cur_len & 1);
             const int* anc = K == 1 ? nullptr : d.anc + (size_t)(cur_len & 1) * Rs * Lm;
             if (coca) TRY(run_coca_step(m, d, t, Lm, st));
@@ -1147,6 +1184,11 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
                                          coca ? c.min_len : 0, coca ? 1 : 0));
             else
                 TRY(launch_beam_step(d.beam, d.logits, m->ldl, c.vocab, Bs, K, Lm, cur_len, c.eos, lp, d.anc, Lm, st));
+            if (ns == 1) {
+                bool done;
+                TRY(poll_all_finished(m, t, Lm - 1, d.finished, Rs, K == 1 ? nullptr : beam_active_flag_p(d.beam, Bs, K, Lm), st, &done));
+                if (done) break;
+            }
         }
         if (K == 1) {
             hipLaunchKernelGGL(copy_i32_kernel, dim3(64), dim3(256), 0, st, d.seq, out_ids + (size_t)b0 * Lm, (size_t)Rs * Lm);
@@ -1275,6 +1317,7 @@ int cap_destroy(CapHandle h) {
     for (auto& r : m->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->stage) (void)hipFree(m->stage);
+    if (m->host_flag) (void)hipHostFree(m->host_flag);
     for (int i = 0; i < 3; ++i) {
         if (m->aux[i]) (void)hipStreamDestroy(m->aux[i]);
         if (m->ev_join[i]) (void)hipEventDestroy(m->ev_join[i]);
@@ -1283,6 +1326,20 @@ int cap_destroy(CapHandle h) {
     delete m;
     return 0;
 }
+
+int cap_set_early_exit(CapHandle h, int poll_steps) {
+    Captioner* m = (Captioner*)h;
+    if (!m || poll_steps < 0) { cap_set_error("cap_set_early_exit: null handle or negative interval"); return -1; }
+    if (poll_steps > 0 && !m->host_flag) {
+        CAP_HIP_CHECK(hipHostMalloc((void**)&m->host_flag, sizeof(int), hipHostMallocMapped));
+        CAP_HIP_CHECK(hipHostGetDevicePointer((void**)&m->host_flag_dev, m->host_flag, 0));
+        *m->host_flag = 1;
+    }
+    m->poll = poll_steps;
+    return 0;
+}
+
+int cap_last_decode_steps(CapHandle h) { return h ? ((Captioner*)h)->last_steps : -1; }
 
 size_t cap_device_bytes(CapHandle h) { return h ? ((Captioner*)h)->dev_bytes : 0; }
 

@@ -90,5 +90,7 @@ int launch_beam_step(void* state, const float* logits, int ld, int V, int B, int
                      int eos, float length_penalty, int* anc, int anc_ld, hipStream_t s);
 int launch_beam_finalize(void* state, int B, int K, int max_len, int* out_ids, int* out_len, float* out_scores,
                          hipStream_t s);
+// device pointer: int32, 1 while the beam loop of this state is still running (HF `is_done.all()` not yet true)
+const int* beam_active_flag_p(void* state, int B, int K, int max_len);
 // device pointer: int32 [B*K, max_len] running sequences of the given parity (= cur_len & 1)
 const int* beam_running_tokens_p(void* state, int B, int K, int max_len, int parity);

@@ -92,6 +92,15 @@ class CaptionerEngine:
     def device_bytes(self) -> int:
         return int(self.lib.cap_device_bytes(self._h))
 
+    def set_early_exit(self, poll_steps: int) -> None:
+        """Leave the decode loop once every caption is finished, as HF generate does; the device state is looked at every
+        `poll_steps` steps (one stream synchronisation each).  0 = never (default): no host sync inside generate."""
+        N.check(self.lib.cap_set_early_exit(self._h, int(poll_steps)), "cap_set_early_exit")
+
+    @property
+    def last_decode_steps(self) -> int:
+        return int(self.lib.cap_last_decode_steps(self._h))
+
     # ------------------------------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
         """HF BLIP key names or an open_clip CoCa state dict (derived tensors are added here).

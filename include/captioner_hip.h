@@ -90,6 +90,16 @@ int cap_load_weight(CapHandle h, const char* name, const float* data, int on_dev
  * (names in cap_last_error()). */
 int cap_finalize_weights(CapHandle h);
 
+/* Early exit of cap_generate's decode loop, as HF generate stops once every caption is finished (the remaining steps
+ * would only write pad, so the outputs are the same either way).  poll_steps > 0: after every poll_steps-th step one
+ * tiny kernel reports the number of open captions through a host-mapped word and the stream is synchronised.
+ * 0 (default): never look - no host synchronisation inside cap_generate, which can then be captured in a graph.  With early
+ * exit, rows of out_step_logits beyond the last executed step are left untouched.  Reference: HF
+ * GenerationMixin._sample / _beam_search stopping criteria behind captioner/models/blip/blip.py:30 `model.generate`. */
+int cap_set_early_exit(CapHandle h, int poll_steps);
+/* Decode steps the last cap_generate on this handle ran (max_len - 1 without early exit; diagnostics and tests). */
+int cap_last_decode_steps(CapHandle h);
+
 /* Image tower.  pixels: B frames in `pixel_fmt`; out_embeds: fp32 [B, tokens, v_hidden] (device). */
 int cap_encode(CapHandle h, const void* pixels, int pixel_fmt, int B, float* out_embeds, void* stream);
 

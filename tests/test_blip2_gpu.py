@@ -77,3 +77,24 @@ def test_blip2_wrapper_dict_api_and_factory():
     assert torch.isfinite(model.compute_perplexity())
     res = model.generate_batch([im, im, im])
     assert len(res["texts"]) == 3 and res["texts"][0] == res["texts"][1] == out["text"]
+
+
+def test_blip2_early_exit_leaves_the_loop():
+    """Every caption ends within a few tokens (EOS logit raised): the polled OPT loop runs fewer steps, same captions."""
+    from embodied_captioning_amd.config import Blip2Arch
+    from embodied_captioning_amd.weights import procedural_blip2_state_dict, synthetic_pixels
+    a = Blip2Arch.tiny()
+    sd = procedural_blip2_state_dict(a, seed=2, eos_boost=12.0)
+    px = synthetic_pixels(4, a.image_size, seed=4).cuda()
+    res = []
+    for poll in (0, 3):
+        eng = _engine(a, "f32", 4)
+        eng.load_state_dict(sd)
+        eng.set_early_exit(poll)
+        o = eng.generate(px, max_length=a.max_new_tokens)
+        res.append(({k: v.cpu() for k, v in o.items()}, eng.last_decode_steps))
+        eng.close()
+    (x, sx), (y, sy) = res
+    assert sx == a.max_new_tokens and sy < sx, (sx, sy)
+    assert int(x["lengths"].max()) < a.max_new_tokens // 2
+    assert torch.equal(x["sequences"], y["sequences"]) and torch.equal(x["lengths"], y["lengths"])

@@ -257,3 +257,51 @@ def test_long_captions_past_the_fused_attention_window(dtype):
         assert bad is None, bad
         _check_bf16_beams(eng, arch, sd, px, 3, L, refb["sequences_scores"].numpy())
     eng.close()
+
+
+@pytest.mark.parametrize("beams", [1, 0])
+def test_early_exit_gives_the_same_captions(beams):
+    """HF generate leaves its loop once every caption has its EOS (GenerationMixin stopping criteria); cap_set_early_exit
+    does the same by polling the device state.  On the golden whose EOS logit is boosted: sequences, lengths and beam
+    scores are those of the full-length loop (which test_fp32_matches_golden_exactly pins to HF)."""
+    g, meta, arch, sd, px = golden_inputs("blip_tiny_eos")
+    B, L = meta["batch"], meta["max_length"]
+    K = 1 if beams == 1 else meta["beams"]
+    outs = []
+    for poll in (0, 2):
+        eng = _engine(arch, "f32", B, K, L)
+        eng.load_state_dict(sd)
+        eng.set_early_exit(poll)
+        o = eng.generate(px.cuda(), num_beams=K, max_length=L)
+        outs.append({k: v.cpu() for k, v in o.items()})
+        eng.close()
+    a, b = outs
+    assert torch.equal(a["sequences"], b["sequences"]) and torch.equal(a["lengths"], b["lengths"])
+    if K > 1:
+        assert torch.equal(a["sequences_scores"], b["sequences_scores"])
+    assert int(a["lengths"].min()) < L, "no caption of this golden ends early: the test would show nothing"
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_early_exit_leaves_the_loop(K):
+    """Every caption ends within a few tokens (EOS logit raised by 12): the polled loop runs fewer steps and returns the
+    full-length loop's captions."""
+    from embodied_captioning_amd.config import BlipArch
+    from embodied_captioning_amd.weights import procedural_blip_state_dict, synthetic_pixels
+    arch = BlipArch.tiny()
+    sd = procedural_blip_state_dict(arch, seed=5, eos_boost=12.0)
+    px = synthetic_pixels(5, arch.image_size, seed=9).cuda()
+    L, res = 20, []
+    for poll in (0, 3):
+        eng = _engine(arch, "f32", 5, K, L)
+        eng.load_state_dict(sd)
+        eng.set_early_exit(poll)
+        o = eng.generate(px, num_beams=K, max_length=L)
+        res.append(({k: v.cpu() for k, v in o.items()}, eng.last_decode_steps))
+        eng.close()
+    (a, sa), (b, sb) = res
+    assert sa == L - 1 and sb < sa, (sa, sb)
+    assert int(a["lengths"].max()) < 10
+    assert torch.equal(a["sequences"], b["sequences"]) and torch.equal(a["lengths"], b["lengths"])
+    if K > 1:
+        assert torch.equal(a["sequences_scores"], b["sequences_scores"])
