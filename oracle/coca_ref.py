@@ -19,7 +19,8 @@ and the decode loop that IS in the reference tree (``coca_model.py:205-333``, ge
 rows whose last token is EOS/pad emit pad, per-step logits of the active rows.
 
 What the tests can establish for CoCa is therefore self-consistency (KV-cached step == full-prefix recompute, the
-reference's way) and HIP-vs-this-restatement parity - not identity with open_clip's code.
+reference's way), HIP-vs-this-restatement parity, and identity of the building blocks (`_mha`, `_block`) with the torch.nn
+modules open_clip composes (tests/test_coca_cpu.py) - not identity of the whole composition with open_clip's code.
 """
 from __future__ import annotations
 

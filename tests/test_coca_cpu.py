@@ -1,4 +1,5 @@
-"""CPU: CoCa oracle restatement (parity UNPINNED - open_clip is not available) - self-consistency only."""
+"""CPU: CoCa oracle restatement (parity UNPINNED - open_clip is not available): self-consistency, and its building blocks
+against the torch.nn modules open_clip composes."""
 import pytest
 import torch
 
@@ -74,3 +75,63 @@ def test_pos_embed_resize_matches_open_clip_recipe():
     assert torch.allclose(out[1:], want)
     with pytest.raises(ValueError):
         resize_visual_pos_embed(torch.zeros(7, a.v_hidden), b)
+
+
+def _mha_state(mod, prefix):
+    return {prefix + "." + k: v.detach() for k, v in mod.state_dict().items()}
+
+
+def test_attention_and_block_equal_the_torch_modules_open_clip_composes():
+    """open_clip is not installed here, so CoCa's towers cannot be run - but they are compositions of torch.nn modules
+    (`nn.MultiheadAttention`, `nn.LayerNorm`, Linear-GELU-Linear) whose real implementations ARE here.  This pins the
+    restatement's attention (packed in_proj, causal mask; separate q/k/v projections with kdim/vdim != embed_dim as the
+    attentional pooler uses) and its pre-LN residual block (self and cross form) to those modules."""
+    import torch.nn as nn
+    torch.manual_seed(0)
+    E, H, B, T, S, Ck = 48, 4, 3, 7, 11, 80
+    x, ctx = torch.randn(B, T, E), torch.randn(B, S, Ck)
+    # 1. packed self-attention with a causal mask
+    m = nn.MultiheadAttention(E, H, batch_first=True).eval()
+    nn.init.normal_(m.in_proj_bias, std=0.2); nn.init.normal_(m.out_proj.bias, std=0.2)
+    mask = torch.full((T, T), float("-inf")).triu(1)
+    want = m(x, x, x, need_weights=False, attn_mask=mask)[0]
+    got = R._mha(x, x, x, _mha_state(m, "a"), "a", H, causal=True)
+    assert (got - want).abs().max().item() < 2e-6
+    # 2. separate projections, keys/values from a wider context (AttentionalPooler: kdim = vdim = context_dim)
+    p = nn.MultiheadAttention(E, H, kdim=Ck, vdim=Ck, batch_first=True).eval()
+    nn.init.normal_(p.in_proj_bias, std=0.2)
+    q = torch.randn(B, 5, E)
+    want = p(q, ctx, ctx, need_weights=False)[0]
+    sd = _mha_state(p, "a")
+    got = R._mha(q, ctx, ctx, sd, "a", H, wq=sd["a.q_proj_weight"], wk=sd["a.k_proj_weight"], wv=sd["a.v_proj_weight"])
+    assert (got - want).abs().max().item() < 2e-6
+
+    # 3. the residual block as open_clip writes it: x + attn(ln_1(x)[, ln_1_kv(kv)]) ; x + mlp(ln_2(x))
+    class Block(nn.Module):
+        def __init__(self, cross):
+            super().__init__()
+            self.ln_1, self.ln_2 = nn.LayerNorm(E), nn.LayerNorm(E)
+            self.attn = nn.MultiheadAttention(E, H, batch_first=True)
+            self.mlp = nn.Sequential()
+            self.mlp.add_module("c_fc", nn.Linear(E, 4 * E)); self.mlp.add_module("gelu", nn.GELU())
+            self.mlp.add_module("c_proj", nn.Linear(4 * E, E))
+            if cross:
+                self.ln_1_kv = nn.LayerNorm(E)
+
+        def forward(self, x, kv=None, mask=None):
+            k = self.ln_1_kv(kv) if kv is not None else None
+            h = self.ln_1(x)
+            x = x + self.attn(h, k if k is not None else h, k if k is not None else h, need_weights=False, attn_mask=mask)[0]
+            return x + self.mlp(self.ln_2(x))
+
+    for cross in (False, True):
+        blk = Block(cross).eval()
+        for prm in blk.parameters():
+            if prm.dim() == 1:
+                nn.init.normal_(prm, std=0.3)
+        bsd = {"b." + k: v.detach() for k, v in blk.state_dict().items()}
+        kv = torch.randn(B, S, E) if cross else None
+        with torch.no_grad():
+            want = blk(x, kv, None if cross else mask)
+        got = R._block(x, bsd, "b", H, 1e-5, causal=not cross, kv=kv)
+        assert (got - want).abs().max().item() < 5e-6
