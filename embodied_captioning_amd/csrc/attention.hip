@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void vit_attention_flash(const bf16_t* __re
 // KC blocks with the online softmax of vit_attention_flash.
 template <int KB, int KC>
 __global__ __launch_bounds__(256, 1) void vit_attention_flash_wide(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                                   int N, int H, int hd) {
+                                                                   int N, int H, int hd, int causal) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP = KB * 32, IMG = NP * 128;
     char* Ks = smem;                                   // [2][NP] rows of 128 B
@@ -358,9 +358,9 @@ __global__ __launch_bounds__(256, 1) void vit_attention_flash_wide(const bf16_t*
                     }
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        if (kb == KB - 1) {
+                        if (kb == KB - 1 || causal) {      // causal (decoder prefill): a query sees the keys up to itself
                             const int key = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                            if (key >= N) s[kc][e] = -INFINITY;
+                            if (key >= N || (causal && key > q)) s[kc][e] = -INFINITY;
                         }
                         cm = fmaxf(cm, s[kc][e]);
                     }
@@ -1009,7 +1009,9 @@ __global__ __launch_bounds__(64) void generic_decode_attention_kernel(const T* _
 // key/value are appended to the caches [B][Lmax][T] at position `past` here (no separate append launch) and used from the
 // row directly.  One wave per (batch, head): lanes over keys for the scores, then (key group of 4) x (8-dim chunk) for
 // P.V with a 4-way sum through LDS.  head_dim a multiple of 8, <= 128; past + 1 <= 1024.
-template <typename T>
+// HD8 = head_dim / 8 when it is known at compile time (10: OPT-2.7b, 8, 16), 0 = any: with a constant trip count a lane's
+// 16-byte loads of a key row are all issued before the first FMA (a runtime loop serialises load -> fma, 10 round trips).
+template <typename T, int HD8>
 __global__ __launch_bounds__(64) void opt_decode_attention_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
                                                                   T* __restrict__ out, int Tw, int H, int hd, int Lmax, int past,
                                                                   float scale) {
@@ -1019,6 +1021,7 @@ __global__ __launch_bounds__(64) void opt_decode_attention_kernel(const T* __res
     const T* kb = kc + (size_t)b * Lmax * Tw + h * hd;
     const T* vb = vc + (size_t)b * Lmax * Tw + h * hd;
     const int Lk = past + 1;
+    const int n8 = HD8 ? HD8 : hd >> 3;
     for (int d = lane; d < hd; d += 64) {
         qs[d] = to_f32(row[d]) * scale;
         kc[((size_t)b * Lmax + past) * Tw + h * hd + d] = row[Tw + d];
@@ -1029,11 +1032,21 @@ __global__ __launch_bounds__(64) void opt_decode_attention_kernel(const T* __res
     for (int j = lane; j < Lk; j += 64) {
         const T* kr = j == past ? row + Tw : kb + (size_t)j * Tw;
         float sc = 0.f;
-        for (int d = 0; d < hd; d += 8) {
-            float kk[8];
-            load8<T>(kr + d, kk);
+        if constexpr (HD8 > 0) {
+            float kk[HD8][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sc = fmaf(qs[d + e], kk[e], sc);
+            for (int c = 0; c < HD8; ++c) load8<T>(kr + c * 8, kk[c]);
+#pragma unroll
+            for (int c = 0; c < HD8; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sc = fmaf(qs[c * 8 + e], kk[c][e], sc);
+        } else {
+            for (int c = 0; c < n8; ++c) {
+                float kk[8];
+                load8<T>(kr + c * 8, kk);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sc = fmaf(qs[c * 8 + e], kk[e], sc);
+            }
         }
         ps[j] = sc;
         m = fmaxf(m, sc);
@@ -1051,14 +1064,27 @@ __global__ __launch_bounds__(64) void opt_decode_attention_kernel(const T* __res
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    if (dc < hd)
-        for (int j = jg; j < Lk; j += 4) {
+    if (dc < hd) {
+        int j = jg;
+        for (; j + 12 < Lk; j += 16) {            // four keys of this lane's group per trip, loads first
+            float vv[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load8<T>((j + 4 * u == past ? row + 2 * Tw : vb + (size_t)(j + 4 * u) * Tw) + dc, vv[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float pj = ps[j + 4 * u];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = fmaf(pj, vv[u][e], o[e]);
+            }
+        }
+        for (; j < Lk; j += 4) {
             float vv[8];
             load8<T>((j == past ? row + 2 * Tw : vb + (size_t)j * Tw) + dc, vv);
             const float pj = ps[j];
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = fmaf(pj, vv[e], o[e]);
         }
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) os[jg][dc + e] = o[e];
     __syncthreads();
@@ -1133,26 +1159,28 @@ int launch_flash_kb(const void* qkv, void* ctx, int B, int N, int H, hipStream_t
 }
 
 template <int KB, int KC>
-int launch_flash_wide(const void* qkv, void* ctx, int B, int N, int H, int hd, hipStream_t s) {
+int launch_flash_wide(const void* qkv, void* ctx, int B, int N, int H, int hd, int causal, hipStream_t s) {
     const int lds = 4 * KB * 32 * 128;
     auto kern = vit_attention_flash_wide<KB, KC>;
     if (cap_kernel_setup((const void*)kern, lds, nullptr) != 0) return -1;
-    hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)ctx, N, H, hd);
+    hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)ctx, N, H, hd, causal);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 }  // namespace
 
-int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s, int head_dim) {
-    if (head_dim > 64 && head_dim <= 128 && head_dim % 8 == 0 && dtype == CAP_DT_BF16 && (N + 31) / 32 == 9 && impl != 1)
-        return launch_flash_wide<9, 5>(qkv, ctx, B, N, H, head_dim, s);     // ViT-g/14 of BLIP-2: 88-wide heads, 257 tokens
-    if (head_dim != 64) {   // any other width / length: generic kernel over the fused qkv rows
+int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s, int head_dim, int causal) {
+    if (head_dim > 64 && head_dim <= 128 && head_dim % 8 == 0 && dtype == CAP_DT_BF16 && impl != 1) {
+        if ((N + 31) / 32 == 9) return launch_flash_wide<9, 5>(qkv, ctx, B, N, H, head_dim, causal, s);   // ViT-g/14 of BLIP-2: 88-wide heads, 257 tokens
+        if (N <= 64) return launch_flash_wide<2, 2>(qkv, ctx, B, N, H, head_dim, causal, s);               // OPT prefill: 80-wide heads, 33 positions, causal
+    }
+    if (head_dim != 64 || causal) {   // any other width / length, or a causal mask at width 64: generic kernel over the fused qkv rows
         const long D = (long)H * head_dim;
         const char* base = (const char*)qkv;
         const size_t e = dtype == CAP_DT_BF16 ? 2 : 4;
         return launch_generic_attention(dtype, base, 3 * D, (long)N * 3 * D, base + D * e, 3 * D, (long)N * 3 * D, base + 2 * D * e,
-                                        3 * D, (long)N * 3 * D, ctx, D, (long)N * D, B, N, N, H, head_dim, -1, s);
+                                        3 * D, (long)N * 3 * D, ctx, D, (long)N * D, B, N, N, H, head_dim, causal ? 0 : -1, s);
     }
     const int kb = (N + 31) / 32;
     const bool mfma_ok = dtype == CAP_DT_BF16 && (kb == 1 || kb == 7 || kb == 9 || kb == 19);
@@ -1274,12 +1302,15 @@ int launch_opt_decode_attention(int dtype, const void* qkv, void* kc, void* vc, 
         return -1;
     }
     const float scale = 1.0f / sqrtf((float)hd);
-    if (dtype == CAP_DT_BF16)
-        hipLaunchKernelGGL(opt_decode_attention_kernel<bf16_t>, dim3(B * H), dim3(64), 0, s, (const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc,
-                           (bf16_t*)out, T, H, hd, Lmax, past, scale);
-    else
-        hipLaunchKernelGGL(opt_decode_attention_kernel<float>, dim3(B * H), dim3(64), 0, s, (const float*)qkv, (float*)kc, (float*)vc,
-                           (float*)out, T, H, hd, Lmax, past, scale);
+#define CAP_ODA(TT, H8)                                                                                                 \
+    hipLaunchKernelGGL((opt_decode_attention_kernel<TT, H8>), dim3(B * H), dim3(64), 0, s, (const TT*)qkv, (TT*)kc, (TT*)vc,  \
+                       (TT*)out, T, H, hd, Lmax, past, scale)
+    if (dtype == CAP_DT_BF16) {
+        if (hd == 80) CAP_ODA(bf16_t, 10); else if (hd == 64) CAP_ODA(bf16_t, 8); else if (hd == 128) CAP_ODA(bf16_t, 16); else CAP_ODA(bf16_t, 0);
+    } else {
+        if (hd == 80) CAP_ODA(float, 10); else if (hd == 64) CAP_ODA(float, 8); else if (hd == 128) CAP_ODA(float, 16); else CAP_ODA(float, 0);
+    }
+#undef CAP_ODA
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -696,8 +696,11 @@ int run_opt(Captioner* m, int B, int L, int past, hipStream_t s) {
         TRY(launch_kv_append(m->dt, m->oqkv, Ly.kc, Ly.vc, B, L, T, Lmax, past, s));
         {
             ProfScope ps(m, s, "opt_attn", 4.0 * B * H * (double)L * (past + L) * hd, 2.0 * B * (past + L) * T * e);
-            TRY(launch_generic_attention(m->dt, m->oqkv, 3 * T, (long)L * 3 * T, Ly.kc, T, (long)Lmax * T, Ly.vc, T, (long)Lmax * T, m->octx, T,
-                                         (long)L * T, B, L, past + L, H, hd, past, s));
+            if (past == 0)      // the prompt: causal self-attention over the fused q|k|v rows (MFMA kernel for bf16 heads wider than 64)
+                TRY(launch_vit_attention(m->dt, m->oqkv, m->octx, B, L, H, 0, s, hd, 1));
+            else
+                TRY(launch_generic_attention(m->dt, m->oqkv, 3 * T, (long)L * 3 * T, Ly.kc, T, (long)Lmax * T, Ly.vc, T, (long)Lmax * T, m->octx, T,
+                                             (long)L * T, B, L, past + L, H, hd, past, s));
         }
         TRY(gemm(m, s, "opt_gemm_o", m->octx, T, Ly.w_o, T, m->ox, T, Ly.b_o, m->ox, R, T, T, 0, 1));
         TRY(launch_layernorm(m->dt, m->ox, T, Ly.ln2_g, Ly.ln2_b, c.t_eps, m->oh_t, nullptr, R, T, s));
@@ -1499,8 +1502,9 @@ int cap_op_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
     return launch_vit_attention(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, qkv, ctx, B, N, H, impl, (hipStream_t)stream);
 }
 int cap_op_vit_attention_hd(int dtype, const void* qkv, void* ctx, int B, int N, int H, int head_dim, int impl, void* stream) {
-    return launch_vit_attention(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, qkv, ctx, B, N, H, impl, (hipStream_t)stream,
-                                head_dim);
+    // impl bit 8: causal mask (decoder prefill)
+    return launch_vit_attention(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, qkv, ctx, B, N, H, impl & 7, (hipStream_t)stream,
+                                head_dim, (impl >> 3) & 1);
 }
 int cap_op_reduce_layernorm(int dtype, const float* part, int S, const float* bias, const float* resid, const float* gamma,
                             const float* beta, float eps, void* out_t, float* out_f, float* y_out, int M, int D,

@@ -44,7 +44,8 @@ int launch_copy_f32(const float* src, float* dst, size_t n, hipStream_t s);
 // ---- attention.hip ---------------------------------------------------------------------------
 // ViT self-attention over a fused qkv buffer [B*N, 3*H*64] (T) -> ctx [B*N, H*64] (T); scale = 1/8.
 // impl 0 = auto (MFMA for bf16 when N <= 256, scalar otherwise), 1 = scalar, 2 = MFMA.
-int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s, int head_dim = 64);
+int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s, int head_dim = 64,
+                         int causal = 0);   // causal: query i sees keys 0..i (decoder prefill over fused q|k|v rows)
 int launch_generic_attention(int dtype, const void* q, long ldq, long qbs, const void* k, long ldk, long kbs, const void* v,
                              long ldv, long vbs, void* out, long ldo, long obs, int B, int Lq, int Lk, int H, int hd,
                              int causal_off, hipStream_t s);

@@ -135,7 +135,8 @@ int cap_op_gemm(int dtype, const void* A, const void* W, const float* bias, cons
 int cap_op_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps, void* out_t,
                      float* out_f, int M, int D, void* stream);
 int cap_op_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, void* stream);
-/* heads of any width (BLIP-2's ViT-g/14: 88); impl 1 forces the scalar kernel, 0 picks the MFMA kernel where one exists */
+/* heads of any width (BLIP-2's ViT-g/14: 88); impl 1 forces the scalar kernel, 0 picks the MFMA kernel where one exists;
+ * impl | 8: causal mask (query i sees keys 0..i: the OPT prefill) */
 int cap_op_vit_attention_hd(int dtype, const void* qkv, void* ctx, int B, int N, int H, int head_dim, int impl,
                             void* stream);
 /* split-K consumer: y = sum_z part[z][M][D] + bias + resid (-> y_out, may alias resid), LayerNorm(y) -> out_t (dtype) /

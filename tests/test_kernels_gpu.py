@@ -216,6 +216,23 @@ def test_vit_attention_wide_heads(lib, hd):
     assert (a.float() - b.float()).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("N,hd", [(33, 80), (64, 128), (17, 72), (33, 64)])
+def test_causal_prefill_attention(lib, N, hd):
+    """Decoder prefill over fused q|k|v rows (OPT: 33 positions, 80-wide heads): MFMA kernel and scalar kernel against float64."""
+    B, H = 3, 4
+    g = torch.Generator().manual_seed(N * hd)
+    qkv = (torch.randn(B * N, 3 * H * hd, generator=g) * 1.2).to(torch.bfloat16)
+    qd = qkv.cuda()
+    x = qkv.double().view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    sc = (x[0] @ x[1].transpose(-1, -2)) / hd ** 0.5 + torch.full((N, N), float("-inf"), dtype=torch.float64).triu(1)
+    ref = (torch.softmax(sc, -1) @ x[2]).permute(0, 2, 1, 3).reshape(B * N, H * hd)
+    for impl in (8, 9):
+        out = torch.full((B * N, H * hd), float("nan"), dtype=torch.bfloat16, device="cuda")
+        _check(lib, lib.cap_op_vit_attention_hd(1, _p(qd), _p(out), B, N, H, hd, impl, _stream()))
+        torch.cuda.synchronize()
+        assert (out.float().cpu().double() - ref).abs().max().item() < 3e-2, impl
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("impl", [0, 1])
 @pytest.mark.parametrize("n_keys,beams", [(1, 1), (7, 1), (20, 3), (33, 2), (197, 3), (255, 1)])
