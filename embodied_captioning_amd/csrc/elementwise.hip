@@ -77,19 +77,19 @@ __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __re
 
 #include "ln.h"   // LN_MAXV, ln_row, reduce_ln_row_wave (shared with the fused split-K GEMM consumer)
 
-template <typename T>
+template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, int ld_in,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, T* out_t, float* out_f, int M, int D) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     const int nv = (D + 255) / 256;
-    float4 v[LN_MAXV];
+    float4 v[MAXV];
     const float* x = in + (size_t)row * ld_in;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i)
+    for (int i = 0; i < MAXV; ++i)
         if (i < nv && lane * 4 + i * 256 < D) v[i] = *(const float4*)(x + lane * 4 + i * 256);
-    ln_row<T>(v, nv, lane, D, gamma, beta, eps, out_t ? out_t + (size_t)row * D : nullptr,
+    ln_row<T, MAXV>(v, nv, lane, D, gamma, beta, eps, out_t ? out_t + (size_t)row * D : nullptr,
               out_f ? out_f + (size_t)row * D : nullptr);
 }
 
@@ -103,7 +103,7 @@ template <> __device__ __forceinline__ float4 load4f<bf16_t>(const bf16_t* p) {
 }
 
 // P = element type of the partial sums: fp32 (split-K slices) or the compute type (the ViT branch outputs in `delta`).
-template <typename T, typename P>
+template <typename T, typename P, int MAXV>
 __global__ __launch_bounds__(256) void reduce_layernorm_kernel(const P* __restrict__ part, int S,
                                                                 const float* __restrict__ bias,
                                                                 const float* __restrict__ resid,
@@ -115,9 +115,9 @@ __global__ __launch_bounds__(256) void reduce_layernorm_kernel(const P* __restri
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     const int nv = (D + 255) / 256;
-    float4 v[LN_MAXV];
+    float4 v[MAXV];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
         const int c = lane * 4 + i * 256;
         if (i < nv && c < D) {
             float4 a = load4f<P>(part + (size_t)row * D + c);
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void reduce_layernorm_kernel(const P* __restri
             if (y_out) *(float4*)(y_out + (size_t)row * D + c) = a;     // pre-LN residual stream (ViT blocks)
         }
     }
-    ln_row<T>(v, nv, lane, D, gamma, beta, eps, out_t ? out_t + (size_t)row * D : nullptr,
+    ln_row<T, MAXV>(v, nv, lane, D, gamma, beta, eps, out_t ? out_t + (size_t)row * D : nullptr,
               out_f ? out_f + (size_t)row * D : nullptr);
 }
 
@@ -490,12 +490,13 @@ int launch_layernorm(int dtype, const float* in, int ld_in, const float* gamma, 
         cap_set_error("layernorm: unsupported width %d (ld %d)", D, ld_in);
         return -1;
     }
-    if (dtype == CAP_DT_BF16)
-        hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3((M + 3) / 4), dim3(256), 0, s, in, ld_in, gamma, beta, eps,
-                           (bf16_t*)out_t, out_f, M, D);
-    else
-        hipLaunchKernelGGL(layernorm_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, s, in, ld_in, gamma, beta, eps,
-                           (float*)out_t, out_f, M, D);
+#define CAP_LN(TT, MV)                                                                                                  \
+    hipLaunchKernelGGL((layernorm_kernel<TT, MV>), dim3((M + 3) / 4), dim3(256), 0, s, in, ld_in, gamma, beta, eps,    \
+                       (TT*)out_t, out_f, M, D)
+#define CAP_LN_T(TT) do { if (D <= 1024) CAP_LN(TT, 4); else if (D <= 2048) CAP_LN(TT, 8); else CAP_LN(TT, LN_MAXV); } while (0)
+    if (dtype == CAP_DT_BF16) CAP_LN_T(bf16_t); else CAP_LN_T(float);
+#undef CAP_LN_T
+#undef CAP_LN
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -530,15 +531,15 @@ int launch_reduce_layernorm(int dtype, const void* part, int S, const float* bia
     }
     const int wpb = M >= 2048 ? 4 : 1;
     const dim3 grid((M + wpb - 1) / wpb), block(64 * wpb);
-    if (dtype == CAP_DT_BF16 && part_in_t)
-        hipLaunchKernelGGL((reduce_layernorm_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)part, S, bias, resid,
-                           gamma, beta, eps, (bf16_t*)out_t, out_f, y_out, M, D);
-    else if (dtype == CAP_DT_BF16)
-        hipLaunchKernelGGL((reduce_layernorm_kernel<bf16_t, float>), grid, block, 0, s, (const float*)part, S, bias, resid,
-                           gamma, beta, eps, (bf16_t*)out_t, out_f, y_out, M, D);
-    else
-        hipLaunchKernelGGL((reduce_layernorm_kernel<float, float>), grid, block, 0, s, (const float*)part, S, bias, resid,
-                           gamma, beta, eps, (float*)out_t, out_f, y_out, M, D);
+#define CAP_RLN(TT, PP, MV)                                                                                             \
+    hipLaunchKernelGGL((reduce_layernorm_kernel<TT, PP, MV>), grid, block, 0, s, (const PP*)part, S, bias, resid, gamma,  \
+                       beta, eps, (TT*)out_t, out_f, y_out, M, D)
+#define CAP_RLN_T(TT, PP) do { if (D <= 1024) CAP_RLN(TT, PP, 4); else if (D <= 2048) CAP_RLN(TT, PP, 8); else CAP_RLN(TT, PP, LN_MAXV); } while (0)
+    if (dtype == CAP_DT_BF16 && part_in_t) CAP_RLN_T(bf16_t, bf16_t);
+    else if (dtype == CAP_DT_BF16) CAP_RLN_T(bf16_t, float);
+    else CAP_RLN_T(float, float);
+#undef CAP_RLN_T
+#undef CAP_RLN
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }
