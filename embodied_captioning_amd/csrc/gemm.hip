@@ -57,9 +57,12 @@ template <typename T, bool OUT_F32, int EPI, bool RESID = true>
 __device__ __forceinline__ void epi_store4(const GemmParams& p, int row, int col, f32x4 v, f32x4 biasv) {
     // bias is loaded once per lane by the caller (it depends on the column only); residual rows are loaded here
     if (EPI != EPI_PARTIAL) v += biasv;
-    if (EPI != EPI_PARTIAL && p.gelu) {        // p.gelu: 1 = exact-erf GELU, 2 = ReLU (OPT)
+    if (EPI != EPI_PARTIAL && p.gelu == 1) {   // p.gelu: 1 = exact-erf GELU, 2 = ReLU (OPT).  Two uniform branches: a
+#pragma unroll                                 // per-element select computes the GELU polynomial for ReLU launches too
+        for (int i = 0; i < 4; ++i) v[i] = gelu_for<T>(v[i]);
+    } else if (EPI != EPI_PARTIAL && p.gelu == 2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = p.gelu == 2 ? fmaxf(v[i], 0.f) : gelu_for<T>(v[i]);
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
     }
     size_t o; void* base = p.C;
     if constexpr (EPI == EPI_PARTIAL) {          // split-K slice z: raw fp32 partial sums, reduced by the consumer
@@ -530,7 +533,7 @@ __device__ __forceinline__ void big2_epilogue(const GemmParams& p, const f32x4 (
                                               const char* bias_w, int row0, int col0, int lane) {
     using T = bf16_t;
     const int r16 = lane & 15, kg = lane >> 4;
-    const bool do_gelu = EPI != EPI_PARTIAL && p.gelu;
+    const int act = EPI != EPI_PARTIAL ? p.gelu : 0;     // uniform: 1 = exact-erf GELU, 2 = ReLU
     f32x4 biasv[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) biasv[j] = bias_w ? *(const f32x4*)(bias_w + (j * 16 + 4 * kg) * 4) : f32x4(0.f);
@@ -546,9 +549,12 @@ __device__ __forceinline__ void big2_epilogue(const GemmParams& p, const f32x4 (
                 const int j = jp * NPB + jj;
                 f32x4 v = acc[i][j];
                 if (EPI != EPI_PARTIAL) v += biasv[j];
-                if (do_gelu) {
+                if (act == 1) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = p.gelu == 2 ? fmaxf(v[e], 0.f) : gelu_for<T>(v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_for<T>(v[e]);
+                } else if (act == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
                 if constexpr (F32OUT) {
                     *(f32x4*)(strip + r16 * 144 + (jj * 16 + 4 * kg) * 4) = v;
