@@ -305,3 +305,29 @@ def test_early_exit_leaves_the_loop(K):
     assert torch.equal(a["sequences"], b["sequences"]) and torch.equal(a["lengths"], b["lengths"])
     if K > 1:
         assert torch.equal(a["sequences_scores"], b["sequences_scores"])
+
+
+def test_generate_is_graph_capturable():
+    """cap_generate launches on the caller's stream and neither allocates nor synchronises (early exit off): captured in a
+    HIP graph and replayed on new pixels it gives the eager result (launch structure)."""
+    g, meta, arch, sd, px = golden_inputs("blip_tiny")
+    B, L = meta["batch"], meta["max_length"]
+    eng = _engine(arch, "f32", B, 1, L)
+    eng.load_state_dict(sd)
+    static_px = px.cuda().clone()
+    eager = eng.generate(static_px, num_beams=1, max_length=L)["sequences"].clone()   # also the warm-up: kernel attributes are set here
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = eng.generate(static_px, num_beams=1, max_length=L)
+    other = torch.roll(px, 1, 0).cuda()                   # frames in another order: the replay must follow its inputs
+    static_px.copy_(other)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out["sequences"], torch.roll(eager, 1, 0))
+    static_px.copy_(px.cuda())
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out["sequences"], eager)
+    del graph
+    eng.close()
