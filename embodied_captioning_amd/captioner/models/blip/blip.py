@@ -76,6 +76,12 @@ class BLIP(CaptioningPredictor):
     def device(self):
         return self._device
 
+    @property
+    def direct_resize_size(self) -> int:
+        """Side of the square the processor resizes every image to, with no aspect handling (HF BlipImageProcessor): callers
+        that hold uint8 frames may resize crops on the device (preprocess.crop_resize_u8) and pass uint8 [n, S, S, 3]."""
+        return self.arch.image_size
+
     def to(self, *args, **kwargs):
         return self
 
@@ -90,10 +96,10 @@ class BLIP(CaptioningPredictor):
             if t.dtype == torch.uint8:
                 if t.dim() == 3:
                     t = t[None]
-                if t.shape[1] != S or t.shape[2] != S:
-                    from PIL import Image
-                    t = torch.stack([torch.from_numpy(np.asarray(Image.fromarray(f.cpu().numpy(), "RGB").resize(
-                        (S, S), resample=Image.BICUBIC))) for f in t])
+                if t.shape[1] != S or t.shape[2] != S:         # Pillow's bicubic, bit-exact, on the device
+                    from ....preprocess import crop_resize_u8
+                    H, W = int(t.shape[1]), int(t.shape[2])
+                    t = torch.cat([crop_resize_u8(f, [(0, 0, W, H)], S, device=self._device) for f in t])
                 return t
             return t if t.dim() == 4 else t[None]
         from PIL import Image

@@ -84,6 +84,13 @@ int skinny_plan(int N, int K, bool finished, int* nw_out = nullptr, int* tr_out 
 int launch_gemm_skinny(const void* A, int lda, const void* W, int ldw, const float* bias, int act, void* out, int ldc,
                        float* part, int M, int N, int K, hipStream_t s);
 
+// ---- preprocess.hip ----------------------------------------------------------------------------
+// n boxes of one uint8 HWC frame -> out uint8 [n, S, S, 3] RGB, bit-exact with Pillow's crop + BICUBIC resize.
+// rects int32 [n, 4] (x1, y1, x2, y2, inside the frame); hb/vb int32 [n, S, 2] (first tap, tap count) and hk/vk int32
+// [n, S, KH|KV] integer coefficients built by the host (embodied_captioning_amd/preprocess.py).  All device pointers.
+int launch_crop_resize_u8(const uint8_t* frame, int H, int W, int bgr, const int* rects, const int* hb, const int* hk, int KH,
+                          const int* vb, const int* vk, int KV, int n, int S, uint8_t* out, hipStream_t s);
+
 // ---- beam.hip --------------------------------------------------------------------------------
 size_t beam_state_bytes(int B, int K, int max_len);
 int launch_beam_init(void* state, int B, int K, int max_len, int bos, int pad, int eos, hipStream_t s);

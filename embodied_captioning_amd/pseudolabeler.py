@@ -46,13 +46,32 @@ class BatchedBoxCaptioner:
     `encoder` (optional): an object with `encode(list[str], convert_to_tensor=True)` (SentenceEncoder, or the reference's
     SentenceTransformer) - called once for the whole batch - or a plain callable caption -> vector."""
 
-    def __init__(self, captioner, encoder: Optional[Callable[[str], torch.Tensor]] = None, expand_factor: float = 0.2):
+    def __init__(self, captioner, encoder: Optional[Callable[[str], torch.Tensor]] = None, expand_factor: float = 0.2,
+                 device_resize: Optional[bool] = None):
         self.captioner = captioner
         self.encoder = encoder
         self.expand_factor = expand_factor
+        # Crop + bicubic resize on the device (bit-exact with the PIL path, preprocess.crop_resize_u8) when the captioner's
+        # processor is a plain square resize (BLIP / BLIP-2 plugins expose `direct_resize_size`); None = use it if possible.
+        size = getattr(captioner, "direct_resize_size", None)
+        can = size is not None and torch.cuda.is_available()
+        if device_resize and not can:
+            raise ValueError("device_resize needs a GPU and a captioner with `direct_resize_size`")
+        self.device_resize = can if device_resize is None else bool(device_resize)
+        self._size = int(size) if size is not None else None
 
-    def _caption(self, crops: list) -> List[str]:
-        if not crops:
+    def _device_crops(self, boxes, image_bgr: np.ndarray):
+        """uint8 [n, S, S, 3] RGB on the device, or None when a rectangle is empty (the PIL path then raises as the
+        reference does)."""
+        from .preprocess import crop_resize_u8
+        rects = [expand_box(b, self.expand_factor, image_bgr.shape) for b in boxes]
+        if any(r[2] <= r[0] or r[3] <= r[1] for r in rects):
+            return None
+        dev = getattr(self.captioner, "crop_device", None) or getattr(self.captioner, "device", "cuda:0")
+        return crop_resize_u8(image_bgr, rects, self._size, bgr=True, device=dev)
+
+    def _caption(self, crops) -> List[str]:
+        if len(crops) == 0:
             return []
         fn = getattr(self.captioner, "caption_batch", None)
         return list(fn(crops)) if fn is not None else list(self.captioner(crops))
@@ -61,10 +80,20 @@ class BatchedBoxCaptioner:
         """One captioner call for the whole dataloader batch.  Returns per frame
         {"captions": [str], "embeddings": tensor [n, d] | tensor([])} in box order (reference :664-688)."""
         crops, owner = [], []
+        on_device = self.device_resize
         for fi, (boxes, img) in enumerate(zip(boxes_per_frame, frames_bgr)):
-            cs = crop_boxes(img, boxes, self.expand_factor)
-            crops += cs
-            owner += [fi] * len(cs)
+            if len(boxes) == 0:
+                continue
+            cs = self._device_crops(boxes, img) if on_device else None
+            if on_device and cs is None:                # an empty rectangle somewhere: everything through the PIL path
+                return BatchedBoxCaptioner(self.captioner, self.encoder, self.expand_factor, device_resize=False) \
+                    .predict_captions(boxes_per_frame, frames_bgr)
+            if cs is None:
+                cs = crop_boxes(img, boxes, self.expand_factor)
+            crops.append(cs) if on_device else crops.extend(cs)
+            owner += [fi] * len(boxes)
+        if on_device and crops:
+            crops = torch.cat(crops)
         captions = self._caption(crops)
         out = [{"captions": [], "embeddings": torch.tensor([])} for _ in frames_bgr]
         for fi, cap in zip(owner, captions):

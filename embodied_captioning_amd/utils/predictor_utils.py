@@ -47,3 +47,13 @@ class Captioner(_Base):
     def caption_batch(self, images):
         """Batched extension: list of PIL images / uint8 tensor -> list of captions."""
         return self.model.generate_batch(images)["texts"]
+
+    @property
+    def direct_resize_size(self):
+        """Side of the processor's plain square resize (BLIP / BLIP-2), or None (CoCa: aspect-preserving resize + centre
+        crop): lets the box driver crop + resize on the device (pseudolabeler.BatchedBoxCaptioner)."""
+        return getattr(self.model, "direct_resize_size", None)
+
+    @property
+    def crop_device(self):
+        return getattr(self.model, "device", "cuda:0")

@@ -100,6 +100,21 @@ int cap_set_early_exit(CapHandle h, int poll_steps);
 /* Decode steps the last cap_generate on this handle ran (max_len - 1 without early exit; diagnostics and tests). */
 int cap_last_decode_steps(CapHandle h);
 
+/* Object crops of one frame, resized for the captioner ON THE DEVICE, bit-exact with Pillow's
+ * `Image.crop(box).resize((S, S), Image.BICUBIC)` - what the reference does to every detected box on the host before the
+ * captioner sees it (detector/pseudolabeler.py:670-675 expand + crop, BGR->RGB at :670; HF BlipImageProcessor.resize).
+ *   frame  uint8 [H, W, 3] (device), bgr != 0: channels are swapped to RGB on the way
+ *   rects  int32 [n, 4] = x1, y1, x2, y2 of each (already expanded) box; parts outside the frame read as zeros, as
+ *          Image.crop pads them
+ *   hb, vb int32 [n, S, 2] = first input index (relative to the crop) and tap count of every output column / row
+ *   hk, vk int32 [n, S, KH] / [n, S, KV] = Pillow's 22-bit integer coefficients (normalize_coeffs_8bpc), zero padded
+ *   out    uint8 [n, S, S, 3] RGB -> feed to cap_generate / cap_encode as CAP_PIX_U8_NHWC
+ * The tables are O(S) doubles per box and are built by the host (embodied_captioning_amd/preprocess.py::
+ * pil_bicubic_coeffs restates Resample.c precompute_coeffs); all pointers are device pointers. */
+int cap_crop_resize_u8(const uint8_t* frame, int H, int W, int bgr, const int32_t* rects, const int32_t* hb,
+                       const int32_t* hk, int KH, const int32_t* vb, const int32_t* vk, int KV, int n, int S, uint8_t* out,
+                       void* stream);
+
 /* Image tower.  pixels: B frames in `pixel_fmt`; out_embeds: fp32 [B, tokens, v_hidden] (device). */
 int cap_encode(CapHandle h, const void* pixels, int pixel_fmt, int B, float* out_embeds, void* stream);
 

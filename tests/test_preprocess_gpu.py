@@ -1,0 +1,46 @@
+"""GPU: cap_crop_resize_u8 against Pillow itself (crop + BICUBIC resize), bit-exact."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+
+def _pil(frame_rgb, r, S):
+    return np.asarray(Image.fromarray(frame_rgb).crop(tuple(int(v) for v in r)).resize((S, S), resample=Image.BICUBIC))
+
+
+@pytest.mark.parametrize("S", [224, 384])
+def test_crops_equal_pillow_bitwise(S):
+    from embodied_captioning_amd.preprocess import crop_resize_u8
+    rng = np.random.default_rng(S)
+    H, W = 480, 640
+    frame = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    rects = [(0, 0, W, H), (10, 20, 234, 244), (100, 50, 130, 470), (600, 400, 640, 480), (5, 5, 7, 8), (0, 0, 1, 1),
+             (17, 300, 630, 333), (200, 100, 424, 324), (320, 0, 321, 480),
+             (500, 400, 700, 520), (-20, -10, 90, 60), (0, 0, 480, 640)]       # leaving the frame: Image.crop pads with zeros
+    out = crop_resize_u8(frame, rects, S).cpu().numpy()
+    for i, r in enumerate(rects):
+        assert np.array_equal(out[i], _pil(frame, r, S)), r
+
+
+def test_bgr_swap_and_device_frame():
+    """The reference swaps BGR -> RGB before cropping (pseudolabeler.py:670): same result from a BGR device tensor."""
+    from embodied_captioning_amd.preprocess import crop_resize_u8
+    rng = np.random.default_rng(1)
+    frame_bgr = rng.integers(0, 256, size=(256, 300, 3), dtype=np.uint8)
+    rgb = np.ascontiguousarray(frame_bgr[:, :, ::-1])
+    rects = [(3, 4, 250, 200), (100, 100, 160, 130)]
+    out = crop_resize_u8(torch.from_numpy(frame_bgr).cuda(), rects, 224, bgr=True).cpu().numpy()
+    for i, r in enumerate(rects):
+        assert np.array_equal(out[i], _pil(rgb, r, 224))
+
+
+def test_rejects_empty_rectangles():
+    from embodied_captioning_amd.preprocess import crop_resize_u8
+    frame = np.zeros((64, 64, 3), dtype=np.uint8)
+    for bad in [(5, 5, 5, 9), (9, 5, 3, 9), (0, 0, 10, 0)]:
+        with pytest.raises(ValueError):
+            crop_resize_u8(frame, [bad], 224)
+    assert crop_resize_u8(frame, [], 224).shape == (0, 224, 224, 3)
