@@ -73,6 +73,12 @@ class CoCa(CaptioningPredictor):
     def to(self, *args, **kwargs):
         return self
 
+    @property
+    def shorter_side_resize_size(self) -> int:
+        """Side of the transform's shorter-side resize + centre crop: callers that hold uint8 frames may do it on the device
+        (preprocess.crop_resize_u8(..., center_crop=True)) and pass uint8 [n, S, S, 3]."""
+        return self.arch.image_size
+
     def preprocess(self, images) -> torch.Tensor:
         """open_clip `image_transform(is_train=False)`: bicubic resize of the shorter side to the model size, centre
         crop, RGB; rescale + OPENAI mean/std are fused into the patch-gather kernel (uint8 in)."""
@@ -83,13 +89,11 @@ class CoCa(CaptioningPredictor):
         if isinstance(images, Image.Image):
             images = [images]
         frames = []
+        from ....preprocess import shorter_side_geometry
         for im in images:
             im = im.convert("RGB")
-            w, h = im.size
-            scale = S / min(w, h)
-            nw, nh = max(S, round(w * scale)), max(S, round(h * scale))
+            nw, nh, left, top = shorter_side_geometry(im.size[0], im.size[1], S)
             im = im.resize((nw, nh), resample=Image.BICUBIC)
-            left, top = (nw - S) // 2, (nh - S) // 2
             frames.append(np.asarray(im.crop((left, top, left + S, top + S))))
         return torch.from_numpy(np.stack(frames))
 

@@ -55,11 +55,21 @@ def pil_bicubic_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndar
     return bounds, fixed
 
 
+def shorter_side_geometry(w: int, h: int, size: int) -> Tuple[int, int, int, int]:
+    """open_clip's inference transform as the CoCa plugin applies it (captioner/models/coca/coca.py::preprocess): bicubic
+    resize of the shorter side to `size`, then a centre crop.  -> (resized width, resized height, left, top)."""
+    scale = size / min(w, h)
+    nw, nh = max(size, round(w * scale)), max(size, round(h * scale))
+    return nw, nh, (nw - size) // 2, (nh - size) // 2
+
+
 def crop_resize_u8(frame, rects: Sequence[Sequence[int]], size: int, bgr: bool = False,
-                   device: str | torch.device = "cuda:0") -> torch.Tensor:
-    """frame uint8 [H, W, 3] (numpy or torch, host or device) + integer rectangles (x1, y1, x2, y2) (parts outside the frame read as zeros, as Image.crop pads) ->
-    uint8 [n, size, size, 3] RGB on the device, equal to ``Image.fromarray(rgb).crop(r).resize((size, size), BICUBIC)``
-    for every rectangle."""
+                   device: str | torch.device = "cuda:0", center_crop: bool = False) -> torch.Tensor:
+    """frame uint8 [H, W, 3] (numpy or torch, host or device) + integer rectangles (x1, y1, x2, y2) (parts outside the
+    frame read as zeros, as Image.crop pads) -> uint8 [n, size, size, 3] RGB on the device, equal to
+    ``Image.fromarray(rgb).crop(r).resize((size, size), BICUBIC)`` for every rectangle; with `center_crop` to the
+    aspect-preserving form ``resize(shorter side -> size)`` + centre crop (`shorter_side_geometry`): only the kept
+    size x size window of the resized crop is computed - its rows of the two filter tables."""
     if not torch.cuda.is_available():
         raise N.CaptionerHipError("crop_resize_u8 needs a GPU; there is no CPU fallback in the product path")
     lib = N.load_library()
@@ -78,8 +88,17 @@ def crop_resize_u8(frame, rects: Sequence[Sequence[int]], size: int, bgr: bool =
         raise ValueError(f"empty or absurd crop rectangle: {rects.tolist()}")
     # a rectangle may leave the frame: Image.crop pads with zeros and so does the kernel (the reference's expand_box clamps
     # x to the frame height and y to its width, so this happens on non-square frames)
-    tabs_h = [pil_bicubic_coeffs(int(w), size) for w in (x2 - x1)]
-    tabs_v = [pil_bicubic_coeffs(int(h), size) for h in (y2 - y1)]
+    if center_crop:
+        tabs_h, tabs_v = [], []
+        for w, h in zip((x2 - x1).tolist(), (y2 - y1).tolist()):
+            nw, nh, left, top = shorter_side_geometry(int(w), int(h), size)
+            bh, kh = pil_bicubic_coeffs(int(w), nw)
+            bv, kv = pil_bicubic_coeffs(int(h), nh)
+            tabs_h.append((bh[left:left + size], kh[left:left + size]))
+            tabs_v.append((bv[top:top + size], kv[top:top + size]))
+    else:
+        tabs_h = [pil_bicubic_coeffs(int(w), size) for w in (x2 - x1)]
+        tabs_v = [pil_bicubic_coeffs(int(h), size) for h in (y2 - y1)]
     KH = max(t[1].shape[1] for t in tabs_h)
     KV = max(t[1].shape[1] for t in tabs_v)
     hb = np.stack([t[0] for t in tabs_h]); vb = np.stack([t[0] for t in tabs_v])

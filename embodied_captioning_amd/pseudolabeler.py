@@ -52,8 +52,12 @@ class BatchedBoxCaptioner:
         self.encoder = encoder
         self.expand_factor = expand_factor
         # Crop + bicubic resize on the device (bit-exact with the PIL path, preprocess.crop_resize_u8) when the captioner's
-        # processor is a plain square resize (BLIP / BLIP-2 plugins expose `direct_resize_size`); None = use it if possible.
+        # processor is a plain square resize (BLIP / BLIP-2 plugins expose `direct_resize_size`) or the shorter-side resize + centre crop of CoCa
+        # (`shorter_side_resize_size`); None = use it if possible.
         size = getattr(captioner, "direct_resize_size", None)
+        self._center_crop = False
+        if size is None and getattr(captioner, "shorter_side_resize_size", None) is not None:   # CoCa's transform
+            size, self._center_crop = captioner.shorter_side_resize_size, True
         can = size is not None and torch.cuda.is_available()
         if device_resize and not can:
             raise ValueError("device_resize needs a GPU and a captioner with `direct_resize_size`")
@@ -68,7 +72,7 @@ class BatchedBoxCaptioner:
         if any(r[2] <= r[0] or r[3] <= r[1] for r in rects):
             return None
         dev = getattr(self.captioner, "crop_device", None) or getattr(self.captioner, "device", "cuda:0")
-        return crop_resize_u8(image_bgr, rects, self._size, bgr=True, device=dev)
+        return crop_resize_u8(image_bgr, rects, self._size, bgr=True, device=dev, center_crop=self._center_crop)
 
     def _caption(self, crops) -> List[str]:
         if len(crops) == 0:

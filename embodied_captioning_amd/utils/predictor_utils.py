@@ -55,5 +55,10 @@ class Captioner(_Base):
         return getattr(self.model, "direct_resize_size", None)
 
     @property
+    def shorter_side_resize_size(self):
+        """CoCa: side of the aspect-preserving resize + centre crop (None for the square-resize processors)."""
+        return getattr(self.model, "shorter_side_resize_size", None)
+
+    @property
     def crop_device(self):
         return getattr(self.model, "device", "cuda:0")

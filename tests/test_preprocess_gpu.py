@@ -44,3 +44,19 @@ def test_rejects_empty_rectangles():
         with pytest.raises(ValueError):
             crop_resize_u8(frame, [bad], 224)
     assert crop_resize_u8(frame, [], 224).shape == (0, 224, 224, 3)
+
+
+def test_shorter_side_resize_and_centre_crop_equals_pillow():
+    """CoCa's transform (aspect-preserving bicubic resize of the shorter side, centre crop) on the device: the kept window
+    of the resized crop, byte for byte."""
+    from embodied_captioning_amd.preprocess import crop_resize_u8, shorter_side_geometry
+    rng = np.random.default_rng(7)
+    frame = rng.integers(0, 256, size=(300, 500, 3), dtype=np.uint8)
+    rects = [(0, 0, 500, 300), (10, 10, 110, 290), (200, 100, 460, 180), (50, 60, 274, 284), (3, 3, 40, 30)]
+    S = 224
+    out = crop_resize_u8(frame, rects, S, center_crop=True).cpu().numpy()
+    for i, r in enumerate(rects):
+        im = Image.fromarray(frame).crop(r)
+        nw, nh, left, top = shorter_side_geometry(im.size[0], im.size[1], S)
+        ref = np.asarray(im.resize((nw, nh), resample=Image.BICUBIC).crop((left, top, left + S, top + S)))
+        assert np.array_equal(out[i], ref), r
