@@ -1506,6 +1506,10 @@ int cap_op_vit_attention_hd(int dtype, const void* qkv, void* ctx, int B, int N,
     return launch_vit_attention(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, qkv, ctx, B, N, H, impl & 7, (hipStream_t)stream,
                                 head_dim, (impl >> 3) & 1);
 }
+int cap_crop_resize_tables(const int32_t* rects, const int32_t* geom, int n, int S, int KH, int KV, int32_t* hb, int32_t* hk,
+                           int32_t* vb, int32_t* vk, void* stream) {
+    return launch_crop_resize_tables(rects, geom, n, S, KH, KV, hb, hk, vb, vk, (hipStream_t)stream);
+}
 int cap_crop_resize_u8(const uint8_t* frame, int H, int W, int bgr, const int32_t* rects, const int32_t* hb, const int32_t* hk,
                        int KH, const int32_t* vb, const int32_t* vk, int KV, int n, int S, uint8_t* out, void* stream) {
     return launch_crop_resize_u8(frame, H, W, bgr, rects, hb, hk, KH, vb, vk, KV, n, S, out, (hipStream_t)stream);

@@ -88,6 +88,10 @@ int launch_gemm_skinny(const void* A, int lda, const void* W, int ldw, const flo
 // n boxes of one uint8 HWC frame -> out uint8 [n, S, S, 3] RGB, bit-exact with Pillow's crop + BICUBIC resize.
 // rects int32 [n, 4] (x1, y1, x2, y2, inside the frame); hb/vb int32 [n, S, 2] (first tap, tap count) and hk/vk int32
 // [n, S, KH|KV] integer coefficients built by the host (embodied_captioning_amd/preprocess.py).  All device pointers.
+// the tables themselves, on the device (fp64, no contraction: equal to the host's bit for bit); geom int32 [n, 4] =
+// (resized width, resized height, left, top) of the kept S x S window
+int launch_crop_resize_tables(const int* rects, const int* geom, int n, int S, int KH, int KV, int* hb, int* hk, int* vb, int* vk,
+                              hipStream_t s);
 int launch_crop_resize_u8(const uint8_t* frame, int H, int W, int bgr, const int* rects, const int* hb, const int* hk, int KH,
                           const int* vb, const int* vk, int KV, int n, int S, uint8_t* out, hipStream_t s);
 

@@ -56,7 +56,69 @@ __global__ __launch_bounds__(256) void crop_resize_u8_kernel(const uint8_t* __re
     }
 }
 
+// Pillow's coefficient tables on the device (Resample.c: precompute_coeffs + normalize_coeffs_8bpc), one thread per
+// (box, axis, output index).  Doubles, the same operations in the same order as the C source, and NO fused multiply-add:
+// Pillow's wheels are plain x86-64 (every product and sum rounded separately), and a contracted a*b+c would round once.
+// gfx950's fp64 add / mul / div are IEEE, so the tables equal the host's bit for bit (tests/test_preprocess_gpu.py).
+// geom[b] = (resized width, resized height, left, top): the S x S output is the window [left, left+S) x [top, top+S) of the
+// crop resized to (width, height) - (S, S, 0, 0) for the plain square resize.
+__device__ __forceinline__ double pil_bicubic(double x) {
+#pragma clang fp contract(off)
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+__global__ __launch_bounds__(256) void crop_resize_tables_kernel(const int* __restrict__ rects, const int* __restrict__ geom, int n,
+                                                                 int S, int KH, int KV, int* __restrict__ hb, int* __restrict__ hk,
+                                                                 int* __restrict__ vb, int* __restrict__ vk) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y, axis = blockIdx.z;
+    if (i >= S) return;
+    const int in_size = rects[b * 4 + 2 + axis] - rects[b * 4 + axis];
+    const int out_size = geom[b * 4 + axis], xx = i + geom[b * 4 + 2 + axis];
+    const int K = axis ? KV : KH;
+    int* bounds = (axis ? vb : hb) + ((size_t)b * S + i) * 2;
+    int* k = (axis ? vk : hk) + ((size_t)b * S + i) * K;
+    const double scale = (double)in_size / (double)out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 2.0 * filterscale, ss = 1.0 / filterscale;
+    const double center = (xx + 0.5) * scale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    if (xmax > K) xmax = K;                 // cannot happen when the host sized K = 2 ceil(support) + 1; never write past the row
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) ww += pil_bicubic((x + xmin - center + 0.5) * ss);
+    for (int x = 0; x < K; ++x) {
+        int v = 0;
+        if (x < xmax) {
+            double w = pil_bicubic((x + xmin - center + 0.5) * ss);
+            if (ww != 0.0) w /= ww;
+            v = w < 0 ? (int)(-0.5 + w * (double)(1 << PR_BITS)) : (int)(0.5 + w * (double)(1 << PR_BITS));
+        }
+        k[x] = v;
+    }
+    bounds[0] = xmin; bounds[1] = xmax;
+}
+
 }  // namespace
+
+int launch_crop_resize_tables(const int* rects, const int* geom, int n, int S, int KH, int KV, int* hb, int* hk, int* vb, int* vk,
+                              hipStream_t s) {
+    if (!rects || !geom || !hb || !hk || !vb || !vk || n < 1 || S < 1 || S > 4096 || KH < 1 || KV < 1) {
+        cap_set_error("crop_resize_tables: null pointer or bad shape (n=%d S=%d KH=%d KV=%d)", n, S, KH, KV);
+        return -1;
+    }
+    hipLaunchKernelGGL(crop_resize_tables_kernel, dim3((S + 255) / 256, n, 2), dim3(256), 0, s, rects, geom, n, S, KH, KV, hb, hk, vb, vk);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 int launch_crop_resize_u8(const uint8_t* frame, int H, int W, int bgr, const int* rects, const int* hb, const int* hk, int KH,
                           const int* vb, const int* vk, int KV, int n, int S, uint8_t* out, hipStream_t s) {

@@ -63,13 +63,21 @@ def shorter_side_geometry(w: int, h: int, size: int) -> Tuple[int, int, int, int
     return nw, nh, (nw - size) // 2, (nh - size) // 2
 
 
+def _ksize(in_size: np.ndarray, out_size: np.ndarray) -> int:
+    """Widest tap row any of the boxes needs: Pillow's ksize = 2 ceil(support) + 1, support = 2 max(in / out, 1)."""
+    scale = np.maximum(in_size.astype(np.float64) / out_size.astype(np.float64), 1.0)
+    return int((np.ceil(2.0 * scale).astype(np.int64) * 2 + 1).max())
+
+
 def crop_resize_u8(frame, rects: Sequence[Sequence[int]], size: int, bgr: bool = False,
-                   device: str | torch.device = "cuda:0", center_crop: bool = False) -> torch.Tensor:
+                   device: str | torch.device = "cuda:0", center_crop: bool = False, tables: str = "device") -> torch.Tensor:
     """frame uint8 [H, W, 3] (numpy or torch, host or device) + integer rectangles (x1, y1, x2, y2) (parts outside the
     frame read as zeros, as Image.crop pads) -> uint8 [n, size, size, 3] RGB on the device, equal to
     ``Image.fromarray(rgb).crop(r).resize((size, size), BICUBIC)`` for every rectangle; with `center_crop` to the
     aspect-preserving form ``resize(shorter side -> size)`` + centre crop (`shorter_side_geometry`): only the kept
-    size x size window of the resized crop is computed - its rows of the two filter tables."""
+    size x size window of the resized crop is computed - its rows of the two filter tables.
+    tables: "device" (default) - the filter tables are filled by `cap_crop_resize_tables` (the host only sends rectangles);
+    "host" - built here with `pil_bicubic_coeffs` and uploaded (same bits; kept as the cross-check)."""
     if not torch.cuda.is_available():
         raise N.CaptionerHipError("crop_resize_u8 needs a GPU; there is no CPU fallback in the product path")
     lib = N.load_library()
@@ -88,37 +96,43 @@ def crop_resize_u8(frame, rects: Sequence[Sequence[int]], size: int, bgr: bool =
         raise ValueError(f"empty or absurd crop rectangle: {rects.tolist()}")
     # a rectangle may leave the frame: Image.crop pads with zeros and so does the kernel (the reference's expand_box clamps
     # x to the frame height and y to its width, so this happens on non-square frames)
+    ws, hs = x2 - x1, y2 - y1
     if center_crop:
-        tabs_h, tabs_v = [], []
-        for w, h in zip((x2 - x1).tolist(), (y2 - y1).tolist()):
-            nw, nh, left, top = shorter_side_geometry(int(w), int(h), size)
-            bh, kh = pil_bicubic_coeffs(int(w), nw)
-            bv, kv = pil_bicubic_coeffs(int(h), nh)
-            tabs_h.append((bh[left:left + size], kh[left:left + size]))
-            tabs_v.append((bv[top:top + size], kv[top:top + size]))
+        geom = np.array([shorter_side_geometry(int(w), int(h), size) for w, h in zip(ws.tolist(), hs.tolist())], dtype=np.int64)
     else:
-        tabs_h = [pil_bicubic_coeffs(int(w), size) for w in (x2 - x1)]
-        tabs_v = [pil_bicubic_coeffs(int(h), size) for h in (y2 - y1)]
-    KH = max(t[1].shape[1] for t in tabs_h)
-    KV = max(t[1].shape[1] for t in tabs_v)
-    hb = np.stack([t[0] for t in tabs_h]); vb = np.stack([t[0] for t in tabs_v])
-    hk = np.zeros((n, size, KH), dtype=np.int32); vk = np.zeros((n, size, KV), dtype=np.int32)
-    for i in range(n):
-        hk[i, :, :tabs_h[i][1].shape[1]] = tabs_h[i][1]
-        vk[i, :, :tabs_v[i][1].shape[1]] = tabs_v[i][1]
-    # one upload for all tables
-    blob = np.concatenate([rects.astype(np.int32).ravel(), hb.ravel(), hk.ravel(), vb.ravel(), vk.ravel()])
+        geom = np.tile(np.array([size, size, 0, 0], dtype=np.int64), (n, 1))
+    KH, KV = _ksize(ws, geom[:, 0]), _ksize(hs, geom[:, 1])
+    stream = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)   # noqa: E731
     with torch.cuda.device(dev):
         frame_d = frame.to(dev, non_blocking=True).contiguous()
-        tab = torch.from_numpy(blob).to(dev, non_blocking=True)
         out = torch.empty((n, size, size, 3), dtype=torch.uint8, device=dev)
-        base, o = tab.data_ptr(), 0
-        ptrs = []
-        for cnt in (n * 4, hb.size, hk.size, vb.size, vk.size):
-            ptrs.append(C.c_void_p(base + 4 * o)); o += cnt
-        N.check(lib.cap_crop_resize_u8(C.c_void_p(frame_d.data_ptr()), H, W, int(bool(bgr)), ptrs[0], ptrs[1], ptrs[2], KH,
-                                       ptrs[3], ptrs[4], KV, n, size, C.c_void_p(out.data_ptr()),
-                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "cap_crop_resize_u8")
-        out.record_stream(torch.cuda.current_stream(dev))
-        tab.record_stream(torch.cuda.current_stream(dev)); frame_d.record_stream(torch.cuda.current_stream(dev))
+        sizes = (n * 4, n * 4, n * size * 2, n * size * KH, n * size * 2, n * size * KV)   # rects, geom, hb, hk, vb, vk
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        if tables == "device":
+            head = torch.from_numpy(np.concatenate([rects.ravel(), geom.ravel()]).astype(np.int32))
+            ws_t = torch.empty(int(offs[-1]), dtype=torch.int32, device=dev)
+            ws_t[: 8 * n].copy_(head, non_blocking=True)
+        elif tables == "host":
+            blob = np.zeros(int(offs[-1]), dtype=np.int32)
+            blob[: 4 * n] = rects.ravel(); blob[4 * n: 8 * n] = geom.ravel()
+            hb = blob[offs[2]:offs[3]].reshape(n, size, 2); hk = blob[offs[3]:offs[4]].reshape(n, size, KH)
+            vb = blob[offs[4]:offs[5]].reshape(n, size, 2); vk = blob[offs[5]:offs[6]].reshape(n, size, KV)
+            for i in range(n):
+                nw, nh, left, top = (int(v) for v in geom[i])
+                bh, kh = pil_bicubic_coeffs(int(ws[i]), nw)
+                bv, kv = pil_bicubic_coeffs(int(hs[i]), nh)
+                hb[i] = bh[left:left + size]; hk[i, :, :kh.shape[1]] = kh[left:left + size]
+                vb[i] = bv[top:top + size]; vk[i, :, :kv.shape[1]] = kv[top:top + size]
+            ws_t = torch.from_numpy(blob).to(dev, non_blocking=True)
+        else:
+            raise ValueError(f"tables must be 'device' or 'host', got {tables!r}")
+        p = [C.c_void_p(ws_t.data_ptr() + 4 * int(o)) for o in offs[:-1]]
+        if tables == "device":
+            N.check(lib.cap_crop_resize_tables(p[0], p[1], n, size, KH, KV, p[2], p[3], p[4], p[5], stream()),
+                    "cap_crop_resize_tables")
+        N.check(lib.cap_crop_resize_u8(C.c_void_p(frame_d.data_ptr()), H, W, int(bool(bgr)), p[0], p[2], p[3], KH, p[4], p[5],
+                                       KV, n, size, C.c_void_p(out.data_ptr()), stream()), "cap_crop_resize_u8")
+        cur = torch.cuda.current_stream(dev)
+        for t in (out, ws_t, frame_d):
+            t.record_stream(cur)
     return out

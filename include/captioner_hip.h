@@ -109,8 +109,14 @@ int cap_last_decode_steps(CapHandle h);
  *   hb, vb int32 [n, S, 2] = first input index (relative to the crop) and tap count of every output column / row
  *   hk, vk int32 [n, S, KH] / [n, S, KV] = Pillow's 22-bit integer coefficients (normalize_coeffs_8bpc), zero padded
  *   out    uint8 [n, S, S, 3] RGB -> feed to cap_generate / cap_encode as CAP_PIX_U8_NHWC
- * The tables are O(S) doubles per box and are built by the host (embodied_captioning_amd/preprocess.py::
- * pil_bicubic_coeffs restates Resample.c precompute_coeffs); all pointers are device pointers. */
+ * The tables are O(S) doubles per box: cap_crop_resize_tables fills them on the device (fp64 without contraction - equal
+ * to Pillow's bit for bit), or the host builds them (embodied_captioning_amd/preprocess.py::pil_bicubic_coeffs).  All
+ * pointers are device pointers. */
+/* geom int32 [n, 4] = (resized width, resized height, left, top): out = the window [left, left+S) x [top, top+S) of the crop
+ * resized to (width, height); (S, S, 0, 0) for the plain square resize.  KH / KV >= 2 ceil(2 max(scale, 1)) + 1 of the
+ * widest / tallest box (scale = crop size / resized size). */
+int cap_crop_resize_tables(const int32_t* rects, const int32_t* geom, int n, int S, int KH, int KV, int32_t* hb, int32_t* hk,
+                           int32_t* vb, int32_t* vk, void* stream);
 int cap_crop_resize_u8(const uint8_t* frame, int H, int W, int bgr, const int32_t* rects, const int32_t* hb,
                        const int32_t* hk, int KH, const int32_t* vb, const int32_t* vk, int KV, int n, int S, uint8_t* out,
                        void* stream);

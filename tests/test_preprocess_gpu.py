@@ -11,9 +11,46 @@ def _pil(frame_rgb, r, S):
     return np.asarray(Image.fromarray(frame_rgb).crop(tuple(int(v) for v in r)).resize((S, S), resample=Image.BICUBIC))
 
 
+def test_device_tables_equal_host_tables_bitwise():
+    """cap_crop_resize_tables (fp64 on the device, contraction off) against the host's numpy tables, which
+    tests/test_preprocess_cpu.py holds to the restatement that Pillow pins: every crop size 1..600 and a few large ones."""
+    import ctypes as C
+    from embodied_captioning_amd import _native as N
+    from embodied_captioning_amd.preprocess import pil_bicubic_coeffs, shorter_side_geometry
+    lib = N.load_library()
+    S = 224
+    sizes = list(range(1, 601)) + [640, 719, 1080, 1919, 4000]
+    n = len(sizes)
+    rects = np.array([[3, 5, 3 + w, 5 + sizes[(i * 7) % n]] for i, w in enumerate(sizes)], dtype=np.int32)
+    for center in (False, True):
+        geom = np.array([shorter_side_geometry(int(r[2] - r[0]), int(r[3] - r[1]), S) if center else (S, S, 0, 0) for r in rects],
+                        dtype=np.int32)
+        sc = lambda a, b: np.maximum(a / b, 1.0)                                                     # noqa: E731
+        KH = int((np.ceil(2 * sc((rects[:, 2] - rects[:, 0]).astype(float), geom[:, 0].astype(float))) * 2 + 1).max())
+        KV = int((np.ceil(2 * sc((rects[:, 3] - rects[:, 1]).astype(float), geom[:, 1].astype(float))) * 2 + 1).max())
+        rd, gd = torch.from_numpy(rects).cuda(), torch.from_numpy(geom).cuda()
+        hb = torch.full((n, S, 2), -1, dtype=torch.int32, device="cuda"); vb = torch.full_like(hb, -1)
+        hk = torch.full((n, S, KH), -1, dtype=torch.int32, device="cuda")
+        vk = torch.full((n, S, KV), -1, dtype=torch.int32, device="cuda")
+        p = lambda t: C.c_void_p(t.data_ptr())                                                      # noqa: E731
+        rc = lib.cap_crop_resize_tables(p(rd), p(gd), n, S, KH, KV, p(hb), p(hk), p(vb), p(vk),
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, lib.cap_last_error()
+        torch.cuda.synchronize()
+        hb, hk, vb, vk = (t.cpu().numpy() for t in (hb, hk, vb, vk))
+        for i, r in enumerate(rects):
+            for size_in, tot, off, b_d, k_d in ((r[2] - r[0], geom[i, 0], geom[i, 2], hb[i], hk[i]),
+                                                (r[3] - r[1], geom[i, 1], geom[i, 3], vb[i], vk[i])):
+                b_h, k_h = pil_bicubic_coeffs(int(size_in), int(tot))
+                assert np.array_equal(b_d, b_h[off:off + S]), (center, r)
+                assert np.array_equal(k_d[:, :k_h.shape[1]], k_h[off:off + S]) and not k_d[:, k_h.shape[1]:].any(), (center, r)
+
+
+@pytest.mark.parametrize("tables", ["device", "host"])
 @pytest.mark.parametrize("S", [224, 384])
-def test_crops_equal_pillow_bitwise(S):
-    from embodied_captioning_amd.preprocess import crop_resize_u8
+def test_crops_equal_pillow_bitwise(S, tables):
+    from embodied_captioning_amd.preprocess import crop_resize_u8 as _cr
+    crop_resize_u8 = lambda *a, **k: _cr(*a, tables=tables, **k)                                    # noqa: E731
     rng = np.random.default_rng(S)
     H, W = 480, 640
     frame = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
