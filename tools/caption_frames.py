@@ -29,6 +29,10 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=256)
     ap.add_argument("--max-length", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--boxes", type=int, default=0, help="> 0: every unit is an object crop - raw 512x512 BGR frames made on "
+                    "the device, this many boxes per frame (host RNG, seed = frame index), the reference's expand_box, crop + "
+                    "Pillow-exact bicubic resize on the device (preprocess.crop_resize_u8), then the captioner; --frames "
+                    "counts crops")
     a = ap.parse_args()
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
     torch.cuda.set_device(local)
@@ -46,6 +50,28 @@ def main():
         # as long as micro-batches start at multiples of --micro-batch within a shard)
         gen.manual_seed(1_000_003 * first + 17)
         return torch.randint(0, 256, (count, arch.image_size, arch.image_size, 3), dtype=torch.uint8, device=dev, generator=gen)
+
+    if a.boxes > 0:
+        import numpy as np
+        from embodied_captioning_amd.preprocess import crop_resize_u8
+        from embodied_captioning_amd.pseudolabeler import expand_box
+        if a.micro_batch % a.boxes:
+            raise SystemExit("--micro-batch must be a multiple of --boxes")
+        FH, FW = 512, 512          # square, as the habitat frames are: the reference's expand_box swaps the clamps of x and y
+
+        def frames_of(first, count):      # noqa: F811 - `count` crops = count / boxes raw frames
+            out = []
+            for f in range(first // a.boxes, (first + count) // a.boxes):
+                gen.manual_seed(1_000_003 * f + 17)
+                frame = torch.randint(0, 256, (FH, FW, 3), dtype=torch.uint8, device=dev, generator=gen)
+                rng = np.random.default_rng(f)
+                rects = []
+                for _ in range(a.boxes):
+                    w, h = int(rng.integers(24, 400)), int(rng.integers(24, 400))
+                    x, y = int(rng.integers(0, FW - w)), int(rng.integers(0, FH - h))
+                    rects.append(expand_box((x, y, x + w, y + h), 0.2, (FH, FW, 3)))
+                out.append(crop_resize_u8(frame, rects, arch.image_size, bgr=True, device=dev))
+            return torch.cat(out)
 
     eng.generate(frames_of(0, a.micro_batch), max_length=a.max_length)          # warm-up (allocations, code load)
     if world > 1:
@@ -67,7 +93,8 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     if rank == 0:
-        print(json.dumps({"metric": "captions/sec end to end (config 4: frames made on device, caption, all-gather)",
+        what = "frames made on device" if a.boxes == 0 else f"512x512 frames made on device, {a.boxes} boxes each expanded / cropped / resized on device"
+        print(json.dumps({"metric": f"captions/sec end to end (config 4: {what}, caption, all-gather)",
                           "value": round(a.frames / float(t[0]), 1), "unit": "captions/s", "n_gpus": world,
                           "frames": a.frames, "shard": [first, last], "caption_and_gather_s": round(float(t[0]), 3),
                           "grouping_s": round(float(t[1]), 3), "objects": len(best),
