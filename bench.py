@@ -46,6 +46,8 @@ def parse():
                     help="blip = BASELINE.json metric workload (default); coca = extra line for config 5's model "
                          "(CoCa ViT-L/14, reference top-k(1) loop, seq_len 30)")
     ap.add_argument("--beams", type=int, default=1, help="> 1: extra line for SURVEY config 3 (HF beam search; use --batch 64)")
+    ap.add_argument("--streams", type=int, default=3, help="blip: engines (own arena + HIP stream each) the timed steps rotate "
+                    "over, so that consecutive batches overlap; 1 = one engine, one stream (the profiling passes always use one)")
     ap.add_argument("--early-exit", type=int, default=0, help="poll the device every N decode steps and leave the loop when "
                     "every caption is finished (HF's stopping rule; 0 = never, the default: no host sync in generate)")
     ap.add_argument("--eos-boost", type=float, default=9.0, help="blip: EOS logit offset of the procedural weights (9 = the "
@@ -58,17 +60,29 @@ def parse():
 
 
 def timed_steps(eng, px, L, steps, warmup, world, gather, beams=1):
-    def one():
-        out = eng.generate(px, num_beams=beams, max_length=L)
-        return gather(out["sequences"], out["lengths"])
-    for _ in range(warmup):
-        one()
+    """`eng`: a CaptionerEngine, or an EnginePool - consecutive steps then run on the pool's engines / streams and overlap
+    (each step is still one whole batch through encoder + decode + gather; all of them finish inside the timed region)."""
+    pool = eng if hasattr(eng, "submit") else None
+
+    def run(n):
+        if pool is None:
+            for _ in range(n):
+                out = eng.generate(px, num_beams=beams, max_length=L)
+                res = gather(out["sequences"], out["lengths"])
+            return res
+        # the batches overlap on the pool's streams; the caption all-gathers (one per step, as before) are issued in step
+        # order on the caller's stream once the batches are joined - every rank issues its collectives in the same order
+        outs = [pool.submit(px, num_beams=beams, max_length=L) for _ in range(n)]
+        pool.join()
+        for out in outs:
+            res = gather(out["sequences"], out["lengths"])
+        return res
+    run(max(warmup, len(pool)) if pool is not None else warmup)       # every engine of a pool runs once untimed
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        res = one()
+    res = run(steps)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -335,9 +349,17 @@ def main():
     eng = CaptionerEngine(arch, dtype=a.dtype, max_batch=B, max_beams=a.beams, max_len=L, device=dev)
     eng.load_state_dict(sd)
     eng.set_early_exit(a.early_exit)
-    log("weights loaded; timing")
-    dt, (ids, lens) = timed_steps(eng, px, L, a.steps, a.warmup, world, gather, a.beams)
-    decode_steps = eng.last_decode_steps
+    runner = eng
+    if a.streams > 1:
+        from embodied_captioning_amd.engine import EnginePool
+        runner = EnginePool(arch, n=a.streams, device=dev, dtype=a.dtype, max_batch=B, max_beams=a.beams, max_len=L)
+        runner.load_state_dict(sd)
+        runner.set_early_exit(a.early_exit)
+    log(f"weights loaded ({a.streams} engine(s) / stream(s)); timing")
+    dt, (ids, lens) = timed_steps(runner, px, L, a.steps, a.warmup, world, gather, a.beams)
+    decode_steps = (runner.engines[0] if a.streams > 1 else eng).last_decode_steps
+    if a.streams > 1:
+        runner.close()
     log(f"timed region: {dt:.3f}s for {a.steps} steps")
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -353,7 +375,7 @@ def main():
                 "data": "synthetic frames (PCG64, seed = frame index), procedural weights (no checkpoint offline)",
                 "config": {"workload": f"BLIP-base ViT-B/16 encoder + {'greedy' if a.beams == 1 else f'beam-{a.beams}'} decode, {B} frames/GPU {S}x{S}, "
                                        f"max_length={L}, caption all-gather", "global_batch": world * B,
-                           "parallelism": f"dp{world}"}}
+                           "parallelism": f"dp{world}", "streams": a.streams}}
         if a.early_exit or a.eos_boost != 9.0:
             line["config"]["early_exit_poll"] = a.early_exit
             line["config"]["eos_boost"] = a.eos_boost

@@ -68,9 +68,11 @@ def gather_caption_records(ids: torch.Tensor, lens: torch.Tensor, n_pad: int, pa
 
 
 def caption_shard(generate: Callable[[torch.Tensor], Dict[str, torch.Tensor]], frames_of: Callable[[int, int], torch.Tensor],
-                  n_frames: int, micro_batch: int, max_len: int, pad_id: int = 0):
+                  n_frames: int, micro_batch: int, max_len: int, pad_id: int = 0, join: Callable[[], None] | None = None):
     """Caption frames [first, last) of this rank in micro-batches and gather everything.
     `frames_of(first, count)` returns the device tensor of frames; `generate(frames)` returns {"sequences","lengths"}.
+    `join`: called once after the last micro-batch was issued - for a `generate` that only starts the work on another stream
+    (engine.EnginePool.submit / .join: consecutive micro-batches overlap).
     Returns (ids_all, lens_all) trimmed to n_frames rows, in global frame order."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
@@ -81,6 +83,8 @@ def caption_shard(generate: Callable[[torch.Tensor], Dict[str, torch.Tensor]], f
         out = generate(frames_of(i, n))
         ids_parts.append(out["sequences"][:, :max_len])
         len_parts.append(out["lengths"])
+    if join is not None:
+        join()
     if ids_parts:
         ids = torch.cat(ids_parts)
         lens = torch.cat(len_parts)

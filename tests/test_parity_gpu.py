@@ -331,3 +331,26 @@ def test_generate_is_graph_capturable():
     assert torch.equal(out["sequences"], eager)
     del graph
     eng.close()
+
+
+def test_engine_pool_gives_single_engine_results():
+    """EnginePool: consecutive batches on their own engines / streams (they overlap on the GPU); every batch must come out
+    exactly as from a single engine, whatever the interleaving - greedy and beams, more batches than engines."""
+    from embodied_captioning_amd.engine import EnginePool
+    g, meta, arch, sd, px = golden_inputs("blip_tiny_eos")
+    B, L, K = meta["batch"], meta["max_length"], meta["beams"]
+    batches = [torch.roll(px, i, 0).cuda() for i in range(7)]
+    single = _engine(arch, "f32", B, K, L)
+    single.load_state_dict(sd)
+    for beams in (1, K):
+        want = [{k: v.clone() for k, v in single.generate(b, num_beams=beams, max_length=L).items()} for b in batches]
+        pool = EnginePool(arch, n=3, dtype="f32", max_batch=B, max_beams=K, max_len=L)
+        pool.load_state_dict(sd)
+        got = pool.generate_many(batches, num_beams=beams, max_length=L)
+        torch.cuda.synchronize()
+        for w, o in zip(want, got):
+            assert torch.equal(w["sequences"], o["sequences"]) and torch.equal(w["lengths"], o["lengths"])
+            if beams > 1:
+                assert torch.equal(w["sequences_scores"], o["sequences_scores"])
+        pool.close()
+    single.close()

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=256)
     ap.add_argument("--max-length", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--streams", type=int, default=3, help="engines / HIP streams the micro-batches rotate over (engine.EnginePool)")
     ap.add_argument("--boxes", type=int, default=0, help="> 0: every unit is an object crop - raw 512x512 BGR frames made on "
                     "the device, this many boxes per frame (host RNG, seed = frame index), the reference's expand_box, crop + "
                     "Pillow-exact bicubic resize on the device (preprocess.crop_resize_u8), then the captioner; --frames "
@@ -41,7 +42,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", device_id=dev)
     arch = BlipArch()
-    eng = CaptionerEngine(arch, dtype=a.dtype, max_batch=a.micro_batch, max_beams=1, max_len=a.max_length, device=dev)
+    from embodied_captioning_amd.engine import EnginePool
+    eng = EnginePool(arch, n=a.streams, device=dev, dtype=a.dtype, max_batch=a.micro_batch, max_beams=1, max_len=a.max_length)
     eng.load_state_dict(procedural_blip_state_dict(arch, 0, eos_boost=9.0))
     gen = torch.Generator(device=dev)
 
@@ -73,14 +75,14 @@ def main():
                 out.append(crop_resize_u8(frame, rects, arch.image_size, bgr=True, device=dev))
             return torch.cat(out)
 
-    eng.generate(frames_of(0, a.micro_batch), max_length=a.max_length)          # warm-up (allocations, code load)
+    eng.generate_many([frames_of(0, a.micro_batch)] * a.streams, max_length=a.max_length)   # warm-up (allocations, code load)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     first, last, _ = shard_range(a.frames, rank, world)
-    ids, lens = caption_shard(lambda f: eng.generate(f, max_length=a.max_length), frames_of, a.frames, a.micro_batch,
-                              a.max_length, arch.pad)
+    ids, lens = caption_shard(lambda f: eng.submit(f, max_length=a.max_length), frames_of, a.frames, a.micro_batch,
+                              a.max_length, arch.pad, join=eng.join)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     ids_h, lens_h = ids.cpu().numpy(), lens.cpu().numpy()
@@ -98,7 +100,7 @@ def main():
                           "value": round(a.frames / float(t[0]), 1), "unit": "captions/s", "n_gpus": world,
                           "frames": a.frames, "shard": [first, last], "caption_and_gather_s": round(float(t[0]), 3),
                           "grouping_s": round(float(t[1]), 3), "objects": len(best),
-                          "mean_caption_tokens": round(float(lens_h.mean()), 2), "dtype": a.dtype}))
+                          "mean_caption_tokens": round(float(lens_h.mean()), 2), "dtype": a.dtype, "streams": a.streams}))
     eng.close()
     if world > 1:
         torch.distributed.barrier()
