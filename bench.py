@@ -9,6 +9,11 @@ One step = one pass of the hot path (ViT encoder -> cross-K/V -> 19 greedy decod
 synthetic 224x224 frames per GPU that are already resident in HBM, followed by the RCCL all-gather of the caption
 records (ids int32 [256,20] + lengths) that feeds the consensus step.  Frames and weights are synthetic/procedural
 (no dataset or checkpoint exists offline).  Rank 0 prints ONE JSON line.
+
+The K timed steps rotate over --streams engines (default 3), each with its own arena and HIP stream: batches are
+independent, a single generate leaves most of the GPU idle (launch-bound decode chain), and kernels of different streams
+overlap here - every step is still one whole batch and all K finish inside the timed region; --streams 1 times them one
+after the other.  The roofline / per-kernel pass, the encoder-only, fp32 and CPU legs run one engine on one stream.
 """
 import argparse
 import json
