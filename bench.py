@@ -95,6 +95,16 @@ def timed_steps(eng, px, L, steps, warmup, world, gather, beams=1):
     return dt, res
 
 
+def pooled(a, arch, sd, **kw):
+    """EnginePool of --streams engines for the timed steps of the auxiliary lines (None for --streams 1)."""
+    if a.streams <= 1:
+        return None
+    from embodied_captioning_amd.engine import EnginePool
+    pool = EnginePool(arch, n=a.streams, dtype=a.dtype, **kw)
+    pool.load_state_dict(sd)
+    return pool
+
+
 KERNEL_NAME = {"bf16": "gemm_big3_kernel (K=768: qkv/proj/fc1) + gemm_big2_kernel (K=3072: fc2), 256x256 LDS-DMA, 16x16x32 bf16 MFMA",
                "f32": "gemm_big_kernel 256x256 LDS-DMA, 32x32x2 fp32 MFMA (ViT qkv/proj/fc1/fc2 launches)"}
 
@@ -203,7 +213,10 @@ def main_coca(a):
     px = synthetic_pixels(B, arch.image_size, seed=0).cuda()
     eng = CaptionerEngine(arch, dtype=a.dtype, max_batch=B, max_beams=1, max_len=arch.seq_len)
     eng.load_state_dict(sd)
-    dt, _ = timed_steps(eng, px, arch.seq_len, a.steps, a.warmup, 1, lambda i, l: (i, l))
+    pool = pooled(a, arch, sd, max_batch=B, max_beams=1, max_len=arch.seq_len)
+    dt, _ = timed_steps(pool or eng, px, arch.seq_len, a.steps, a.warmup, 1, lambda i, l: (i, l))
+    if pool is not None:
+        pool.close()
     eng.profile(True)
     eng.generate(px, max_length=arch.seq_len)
     rep = eng.profile_report()
@@ -214,7 +227,7 @@ def main_coca(a):
     line = {"metric": f"captions/sec (CoCa ViT-L/14 {S}x{S}, top_k=1, seq_len=30)", "value": round(B * a.steps / dt, 2),
             "unit": "captions/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "dtype": a.dtype, "data": "synthetic frames, procedural weights",
-            "config": {"workload": f"CoCa ViT-L/14 encoder + attentional pooler + 29 KV-cached decode steps, {B} frames"},
+            "config": {"workload": f"CoCa ViT-L/14 encoder + attentional pooler + 29 KV-cached decode steps, {B} frames", "streams": a.streams},
             "roofline": {"bound": "mfma", "kernel": "gemm_big3_kernel / gemm_big2_kernel (ViT-L qkv/proj/fc1/fc2)",
                          "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
                          "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_TFLOPS[a.dtype], 4), "traffic": None},
@@ -237,12 +250,23 @@ def main_minilm(a):
     idd, lnd = ids.cuda(), lens.cuda()
     for _ in range(a.warmup):
         eng.embed(idd, lnd)
+    pool = None
+    if a.streams > 1:
+        from embodied_captioning_amd.engine import EnginePool, TextEncoderEngine
+        pool = EnginePool(arch, n=a.streams, engine_cls=TextEncoderEngine, dtype=a.dtype, max_batch=B, max_len=L)
+        pool.load_state_dict(sd)
+        pool.run(max(a.warmup, a.streams), idd, lnd, method="embed")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = eng.embed(idd, lnd)
+    if pool is not None:
+        out = pool.run(a.steps, idd, lnd, method="embed")
+    else:
+        for _ in range(a.steps):
+            out = eng.embed(idd, lnd)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if pool is not None:
+        pool.close()
     eng.profile(True)
     eng.embed(idd, lnd)
     rep = eng.profile_report()
@@ -250,7 +274,7 @@ def main_minilm(a):
     line = {"metric": "caption embeddings/sec (all-MiniLM-L6-v2 shapes, 3..24 tokens)", "value": round(B * a.steps / dt, 1),
             "unit": "sentences/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "dtype": a.dtype, "data": "synthetic token rows, procedural weights",
-            "config": {"workload": f"6-layer BERT encoder + mean pool + L2 norm, {B} sentences x {L} padded tokens"},
+            "config": {"workload": f"6-layer BERT encoder + mean pool + L2 norm, {B} sentences x {L} padded tokens", "streams": a.streams},
             "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}}
     if not a.no_cpu_baseline:
         from oracle import minilm_ref as R
@@ -281,7 +305,10 @@ def main_blip2(a):
     eng = CaptionerEngine(arch, dtype=a.dtype, max_batch=B, max_beams=1, max_len=arch.max_new_tokens)
     eng.load_state_dict(sd)
     log(f"weights loaded ({eng.device_bytes / 2**30:.1f} GiB on device); timing")
-    dt, (ids, lens) = timed_steps(eng, px, arch.max_new_tokens, a.steps, a.warmup, 1, lambda i, l: (i, l))
+    pool = pooled(a, arch, sd, max_batch=B, max_beams=1, max_len=arch.max_new_tokens)
+    dt, (ids, lens) = timed_steps(pool or eng, px, arch.max_new_tokens, a.steps, a.warmup, 1, lambda i, l: (i, l))
+    if pool is not None:
+        pool.close()
     eng.profile(True)
     eng.generate(px, max_length=arch.max_new_tokens)
     rep = eng.profile_report()
@@ -291,7 +318,7 @@ def main_blip2(a):
     line = {"metric": "captions/sec (BLIP-2 OPT-2.7b geometry, 224x224, greedy, 20 new tokens)", "value": round(B * a.steps / dt, 2),
             "unit": "captions/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "dtype": a.dtype, "data": "synthetic frames, procedural weights",
-            "config": {"workload": f"ViT-g/14 + Q-Former + OPT-2.7b prefill (33 positions) + 19 cached decode steps, {B} frames"},
+            "config": {"workload": f"ViT-g/14 + Q-Former + OPT-2.7b prefill (33 positions) + 19 cached decode steps, {B} frames", "streams": a.streams},
             "roofline": {"bound": "mfma", "kernel": "gemm_big2/big3_kernel (ViT-g qkv/proj/fc1/fc2)",
                          "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
                          "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_TFLOPS[a.dtype], 4), "traffic": None},

@@ -210,11 +210,12 @@ class EnginePool:
         outs = pool.generate_many(batches)            # or: out = pool.submit(px) ... pool.join()
     """
 
-    def __init__(self, arch, n: int = 2, device: str | torch.device = "cuda:0", **engine_kw):
+    def __init__(self, arch, n: int = 2, device: str | torch.device = "cuda:0", engine_cls=None, **engine_kw):
         if n < 1:
             raise ValueError("EnginePool needs at least one engine")
         self.device = torch.device(device)
-        self.engines = [CaptionerEngine(arch, device=device, **engine_kw) for _ in range(n)]
+        engine_cls = engine_cls or CaptionerEngine           # TextEncoderEngine: submit(ids, lens, method="embed")
+        self.engines = [engine_cls(arch, device=device, **engine_kw) for _ in range(n)]
         with torch.cuda.device(self.device):
             self.streams = [torch.cuda.Stream(self.device) for _ in range(n)]
         self.arch, self._next = arch, 0
@@ -238,16 +239,26 @@ class EnginePool:
     def device_bytes(self) -> int:
         return sum(e.device_bytes for e in self.engines)
 
-    def submit(self, pixels: torch.Tensor, then=None, **generate_kw):
-        """Start one batch on the next engine / stream and return its output dict (or `then(out)`, run on that stream) at
-        once; the tensors are valid for the caller's stream after `join()`.  `pixels` may come from the caller's stream."""
+    def run(self, n: int, *inputs: torch.Tensor, **kw):
+        """The same batch n times, rotating over the engines (benchmarks); returns the last output after join()."""
+        out = None
+        for _ in range(n):
+            out = self.submit(*inputs, **kw)
+        self.join()
+        return out
+
+    def submit(self, *inputs: torch.Tensor, then=None, method: str = "generate", **kw):
+        """Start one batch on the next engine / stream - `engine.<method>(*inputs, **kw)` - and return its output (or
+        `then(out)`, run on that stream) at once; the tensors are valid for the caller's stream after `join()`.  The inputs
+        may come from the caller's stream."""
         i, self._next = self._next, (self._next + 1) % len(self.engines)
         s = self.streams[i]
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
-            out = self.engines[i].generate(pixels, **generate_kw)
-            if pixels.is_cuda:
-                pixels.record_stream(s)
+            out = getattr(self.engines[i], method)(*inputs, **kw)
+            for t in inputs:
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(s)
             return then(out) if then is not None else out
 
     def join(self) -> None:
