@@ -68,8 +68,19 @@ class BLIP(CaptioningPredictor):
                                       max_len=self.max_length, device=self._device)
         # HF generate stops once every caption has its EOS; look every few steps (cfg early_exit_poll, 0 = never)
         poll = getattr(cfg, "early_exit_poll", None)
-        self.engine.set_early_exit(4 if poll is None else int(poll))
+        poll = 4 if poll is None else int(poll)
+        self.engine.set_early_exit(poll)
         self.engine.load_state_dict(sd)
+        # cfg.streams > 1: micro-batches of one generate_batch call rotate over that many engines / HIP streams and overlap
+        # (engine.EnginePool; same captions, more memory: one arena and one weight copy per engine)
+        self.pool = None
+        n_streams = int(getattr(cfg, "streams", 1) or 1)
+        if n_streams > 1:
+            from ....engine import EnginePool
+            self.pool = EnginePool(self.arch, n=n_streams, device=self._device, dtype=dtype, max_batch=self.batch_size,
+                                   max_beams=getattr(self, "num_beams", 1), max_len=self.engine.max_len)
+            self.pool.load_state_dict(sd)
+            self.pool.set_early_exit(poll)
 
     # nn.Module surface the callers use; weights live in the engine, so .to() only re-targets host-side tensors
     @property
@@ -122,9 +133,13 @@ class BLIP(CaptioningPredictor):
         px = self.preprocess(images)
         texts: List[str] = []
         seqs, lens, scores, logits = [], [], [], []
-        for i in range(0, px.shape[0], self.batch_size):
-            out = self.engine.generate(px[i:i + self.batch_size].to(self._device), num_beams=self.num_beams,
-                                       max_length=self.max_length, output_logits=output_logits)
+        chunks = [px[i:i + self.batch_size].to(self._device) for i in range(0, px.shape[0], self.batch_size)]
+        if getattr(self, "pool", None) is not None and len(chunks) > 1 and not output_logits:
+            outs = self.pool.generate_many(chunks, threads=True, num_beams=self.num_beams, max_length=self.max_length)
+        else:
+            outs = [self.engine.generate(c, num_beams=self.num_beams, max_length=self.max_length, output_logits=output_logits)
+                    for c in chunks]
+        for out in outs:
             seqs.append(out["sequences"]); lens.append(out["lengths"])
             if "sequences_scores" in out:
                 scores.append(out["sequences_scores"])

@@ -1,6 +1,7 @@
 """Plugin configuration objects - same fields as the reference's ``experimenting_env/captioner/utils/utils.py:2-12``
 plus optional keys (defaults keep existing yamls working): num_beams, max_length, dtype, batch_size, device,
-image_size (CoCa: open_clip's force_image_size)."""
+image_size (CoCa: open_clip's force_image_size), streams (engines / HIP streams the micro-batches of one call rotate over,
+engine.EnginePool; 1 = one engine), early_exit_poll (look for "every caption finished" every n decode steps; None = 4)."""
 
 
 class Configuration:
@@ -11,7 +12,8 @@ class Configuration:
 
 class CaptionerField:
     def __init__(self, arch_name=None, model_name=None, checkpoint_name=None, height=None, width=None,
-                 num_beams=1, max_length=20, dtype="bf16", batch_size=8, device="cuda:0", image_size=None):
+                 num_beams=1, max_length=20, dtype="bf16", batch_size=8, device="cuda:0", image_size=None, streams=1,
+                 early_exit_poll=None):
         self.arch_name = arch_name
         self.model_name = model_name
         self.checkpoint_name = checkpoint_name
@@ -23,3 +25,5 @@ class CaptionerField:
         self.batch_size = batch_size
         self.device = device
         self.image_size = image_size
+        self.streams = streams
+        self.early_exit_poll = early_exit_poll

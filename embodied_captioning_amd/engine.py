@@ -267,9 +267,42 @@ class EnginePool:
         for s in self.streams:
             cur.wait_stream(s)
 
-    def generate_many(self, batches, **generate_kw):
-        outs = [self.submit(b, **generate_kw) for b in batches]
+    def generate_many(self, batches, threads: bool = False, **generate_kw):
+        """All batches, in order.  threads=True: one host thread per engine (batch j goes to engine j % n) - needed when
+        the engines poll for early exit (cap_set_early_exit synchronises its stream: from a single host thread that would
+        stall the launches of the other streams; ctypes releases the GIL during cap_generate, so the threads do overlap)."""
+        batches = list(batches)
+        if not threads or len(self.engines) == 1 or len(batches) <= 1:
+            outs = [self.submit(b, **generate_kw) for b in batches]
+            self.join()
+            return outs
+        import threading
+        n = len(self.engines)
+        outs: list = [None] * len(batches)
+        errors: list = []
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            s.wait_stream(cur)
+
+        def work(i):
+            try:
+                with torch.cuda.device(self.device), torch.cuda.stream(self.streams[i]):
+                    for j in range(i, len(batches), n):
+                        outs[j] = self.engines[i].generate(batches[j], **generate_kw)
+                        if batches[j].is_cuda:
+                            batches[j].record_stream(self.streams[i])
+            except Exception as e:  # noqa: BLE001 - re-raised on the caller's thread
+                errors.append(e)
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(min(n, len(batches)))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errors:
+            raise errors[0]
         self.join()
+        self._next = len(batches) % n
         return outs
 
 

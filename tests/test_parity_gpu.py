@@ -346,11 +346,13 @@ def test_engine_pool_gives_single_engine_results():
         want = [{k: v.clone() for k, v in single.generate(b, num_beams=beams, max_length=L).items()} for b in batches]
         pool = EnginePool(arch, n=3, dtype="f32", max_batch=B, max_beams=K, max_len=L)
         pool.load_state_dict(sd)
-        got = pool.generate_many(batches, num_beams=beams, max_length=L)
-        torch.cuda.synchronize()
-        for w, o in zip(want, got):
-            assert torch.equal(w["sequences"], o["sequences"]) and torch.equal(w["lengths"], o["lengths"])
-            if beams > 1:
-                assert torch.equal(w["sequences_scores"], o["sequences_scores"])
+        for threads, poll in ((False, 0), (True, 0), (True, 2)):     # one host thread; a thread per engine; + early-exit polling
+            pool.set_early_exit(poll)
+            got = pool.generate_many(batches, threads=threads, num_beams=beams, max_length=L)
+            torch.cuda.synchronize()
+            for w, o in zip(want, got):
+                assert torch.equal(w["sequences"], o["sequences"]) and torch.equal(w["lengths"], o["lengths"])
+                if beams > 1:
+                    assert torch.equal(w["sequences_scores"], o["sequences_scores"])
         pool.close()
     single.close()

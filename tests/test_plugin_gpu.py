@@ -78,3 +78,19 @@ def test_box_driver_device_resize_equals_pil_path():
     assert [d["captions"] for d in dev] == [p["captions"] for p in pil]
     assert [len(d["captions"]) for d in dev] == [2, 0, 3]
     assert BatchedBoxCaptioner(model).device_resize is True            # the default picks the device path for this plugin
+
+
+def test_plugin_streams_option_gives_the_same_captions():
+    """cfg.streams = 3: the micro-batches of one caption_batch call rotate over three engines / streams (a host thread each,
+    early-exit polling on): the captions are those of the single-engine plugin."""
+    import types
+    from embodied_captioning_amd.utils.predictor_utils import Captioner
+    crops = [_pil(i) for i in range(20, 31)]                      # 11 crops, micro-batches of 2 -> 6 batches over 3 engines
+
+    def build(streams):
+        cap_cfg = types.SimpleNamespace(arch_name="blip", model_name="procedural-tiny:4:2.0", checkpoint_name=None,
+                                        height=224, width=224, dtype="f32", max_length=12, batch_size=2, streams=streams)
+        return Captioner(types.SimpleNamespace(captioner=cap_cfg)).to("cuda:0").eval()
+    one, three = build(1), build(3)
+    assert three.model.pool is not None and len(three.model.pool) == 3 and one.model.pool is None
+    assert three.caption_batch(crops) == one.caption_batch(crops)
