@@ -29,7 +29,25 @@ def _worker(rank, world, port, n_frames, q):
         ids = torch.stack([(frames * 7 + j) % 1000 for j in range(L)], dim=1).int()
         return {"sequences": ids, "lengths": (frames % L + 1).int()}
 
-    ids, lens = D.caption_shard(generate, frames_of, n_frames, micro_batch=4, max_len=L)
+    # `generate` may only START the work (EnginePool.submit): the results are filled in by `join`, which caption_shard must
+    # call once, after the last micro-batch and before it touches the outputs
+    pending, joined = [], []
+
+    def submit(frames):
+        out = {"sequences": torch.zeros((frames.shape[0], L), dtype=torch.int32), "lengths": torch.zeros(frames.shape[0], dtype=torch.int32)}
+        pending.append((frames, out))
+        return out
+
+    def join():
+        joined.append(len(pending))
+        for frames, out in pending:
+            ref = generate(frames)
+            out["sequences"].copy_(ref["sequences"]); out["lengths"].copy_(ref["lengths"])
+
+    ids, lens = D.caption_shard(submit, frames_of, n_frames, micro_batch=4, max_len=L, join=join)
+    assert len(joined) == 1 and joined[0] == len(pending)
+    ids2, lens2 = D.caption_shard(generate, frames_of, n_frames, micro_batch=4, max_len=L)
+    assert torch.equal(ids, ids2) and torch.equal(lens, lens2)
     q.put((rank, ids.clone(), lens.clone()))
     dist.barrier()
     dist.destroy_process_group()
