@@ -1278,9 +1278,11 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
     m->Kpatch = text_only ? 0 : 3 * cfg->patch_size * cfg->patch_size;
     m->Kpad = (m->Kpatch + 63) / 64 * 64;
     {
-        // decode slices: 1 by default. Measured on MI355X (eager and captured into a hipGraph): kernels of different
-        // streams / graph branches do not overlap for this workload, so 2 slices tie and 4 lose to launch overhead;
-        // CAP_DECODE_SLICES=1..4 keeps the knob for A/B runs.
+        // decode slices: 1 by default.  Measured on MI355X (eager and captured into a hipGraph): row slices of ONE batch on
+        // their own streams tie at 2 (38.5 vs 39.1 ms) and lose at 3-4 - every slice is the same chain of ~2700 short
+        // dependent kernels and two such chains gain nothing from each other.  What does pay is overlapping WHOLE batches
+        // (engine.EnginePool: another batch's image tower fills the chain's idle CUs, +26-32 %); slices on top of the pool
+        // lose (7380 vs 8510 captions/s).  CAP_DECODE_SLICES=1..4 keeps the knob for A/B runs.
         const char* env = getenv("CAP_DECODE_SLICES");
         int ns = env ? atoi(env) : 1;
         m->nslices = ns < 1 ? 1 : (ns > 4 ? 4 : ns);
