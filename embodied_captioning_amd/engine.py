@@ -198,11 +198,11 @@ class CaptionerEngine:
 class EnginePool:
     """Several CaptionerEngines (own arenas, same weights) on their own streams: consecutive batches overlap.
 
-    One `cap_generate` leaves most of the GPU idle most of the time - after the image tower, 19 decode steps x ~140
-    dependent launches, each a few microseconds of work on a few CUs.  Independent batches do not depend on
-    each other, and kernels of different HIP streams do run concurrently on this GPU, so batch i+1's image tower and
-    batch i+2's decode chain fill the gaps of batch i's (measured, tools/two_stream_experiment.py: 6 570 -> 8 260
-    captions/s with two streams, 8 670 with three).  Every batch is computed by exactly the kernels of a single engine:
+    One `cap_generate` is a chain of ~2 800 dependent kernels; between two dependent kernels of one HIP queue the GPU
+    idles for the dispatch hand-over.  Independent batches do not depend on each other, so another
+    queue's kernel can run in that gap: measured (tools/two_stream_experiment.py) 6 570 -> 8 260 captions/s with two
+    streams, 8 670 with three.  (The kernels themselves time-slice rather than co-run - tools/phase_overlap_probe.py -
+    so the floor is one batch's summed kernel time.)  Every batch is computed by exactly the kernels of a single engine:
     results are the same bits.
 
         pool = EnginePool(arch, n=3, dtype="bf16", max_batch=256)
