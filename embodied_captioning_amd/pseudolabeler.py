@@ -41,6 +41,17 @@ def record_name(episode: int, step: int) -> str:
     return f"episode_{episode}_step_{step}.npz"
 
 
+def save_record(output_path: str, info: str, instances, image) -> str:
+    """Write one pseudo-label record the way the reference does (:833-842): `np.savez_compressed(<output_path>/<info>.npz,
+    {'instances': instances, 'image': image})` - a single pickled dict under `arr_0` (`np.load(f, allow_pickle=True)
+    ['arr_0'].item()` gives it back).  `instances` is whatever carries `.captions` / `.embeddings` downstream (detectron2
+    `Instances` in the reference; any picklable object here).  Returns the file name."""
+    import os
+    filename = os.path.join(output_path, f"{info}.npz")
+    np.savez_compressed(filename, {"instances": instances, "image": image})
+    return filename
+
+
 class BatchedBoxCaptioner:
     """`captioner` is the plugin (`Captioner` with `caption_batch`) or any callable list[PIL] -> list[str];
     `encoder` (optional): an object with `encode(list[str], convert_to_tensor=True)` (SentenceEncoder, or the reference's

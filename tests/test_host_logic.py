@@ -112,3 +112,15 @@ def test_batched_box_captioner_keeps_frame_and_box_order():
     red = int(frames[2][..., 2].mean())                # channel 2 of BGR is red
     assert out[2]["captions"][0] == f"64x64:{red}"
     assert out[1]["embeddings"].numel() == 0 and out[0]["embeddings"].shape == (2, 4)
+
+
+def test_save_record_round_trip(tmp_path):
+    """Reference record format (pseudolabeler.py:833-842): one pickled dict {'instances', 'image'} under arr_0."""
+    import numpy as np
+    from embodied_captioning_amd.pseudolabeler import record_name, save_record
+    inst = {"captions": ["a chair", "a lamp"], "embeddings": np.ones((2, 4), dtype=np.float32)}
+    img = np.arange(24, dtype=np.uint8).reshape(2, 4, 3)
+    f = save_record(str(tmp_path), record_name(3, 17)[:-4], inst, img)
+    assert f.endswith("episode_3_step_17.npz")
+    back = np.load(f, allow_pickle=True)["arr_0"].item()
+    assert back["instances"]["captions"] == inst["captions"] and np.array_equal(back["image"], img)
