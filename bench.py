@@ -77,8 +77,7 @@ def timed_steps(eng, px, L, steps, warmup, world, gather, beams=1):
             return res
         # the batches overlap on the pool's streams; the caption all-gathers (one per step, as before) are issued in step
         # order on the caller's stream once the batches are joined - every rank issues its collectives in the same order
-        outs = [pool.submit(px, num_beams=beams, max_length=L) for _ in range(n)]
-        pool.join()
+        outs = pool.generate_many([px] * n, threads=True, num_beams=beams, max_length=L)   # a host thread per engine
         for out in outs:
             res = gather(out["sequences"], out["lengths"])
         return res
