@@ -32,7 +32,8 @@ from embodied_captioning_amd.config import BlipArch                             
 from embodied_captioning_amd.engine import CaptionerEngine                            # noqa: E402
 from embodied_captioning_amd.weights import procedural_blip_state_dict, synthetic_pixels  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}          # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "f32s": 2500.0}          # dense MFMA peaks, MI355X_MICROARCH.md (f32s runs on the fp16 pipe)
+MFMA_PER_PRODUCT = {"bf16": 1, "f32": 1, "f32s": 3}                     # f32s: hi.hi + hi.lo + lo.hi
 ENC_GEMM_TAGS = ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2")
 
 
@@ -43,7 +44,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--max-length", type=int, default=20)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32s"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the extra strict-fp32 measurement")
     ap.add_argument("--cpu-sample", type=int, default=64, help="captions timed on the host CPU oracle")
@@ -105,7 +106,8 @@ def pooled(a, arch, sd, **kw):
 
 
 KERNEL_NAME = {"bf16": "gemm_big3_kernel (K=768: qkv/proj/fc1) + gemm_big2_kernel (K=3072: fc2), 256x256 LDS-DMA, 16x16x32 bf16 MFMA",
-               "f32": "gemm_big_kernel 256x256 LDS-DMA, 32x32x2 fp32 MFMA (ViT qkv/proj/fc1/fc2 launches)"}
+               "f32": "gemm_big_kernel 256x256 LDS-DMA, 32x32x2 fp32 MFMA (ViT qkv/proj/fc1/fc2 launches)",
+               "f32s": "gemm_big2_kernel<g8_t> 256x256 LDS-DMA, split fp16: 3 x 16x16x32 f16 MFMA per product (ViT qkv/proj/fc1/fc2)"}
 
 
 def encoder_only(eng, px, arch, steps=5):

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcaptioner_hip.so")
 
-CAP_F32, CAP_BF16 = 0, 1
+CAP_F32, CAP_BF16, CAP_F32_SPLIT = 0, 1, 2
 CAP_PIX_F32_NCHW, CAP_PIX_U8_NHWC = 0, 1
 
 
@@ -68,6 +68,7 @@ _SIGNATURES = {
     "cap_op_decode_attention": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "cap_op_convert": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cap_op_convert_weight": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -428,8 +428,8 @@ __global__ __launch_bounds__(256, 1) void vit_attention_flash_wide(const bf16_t*
 
 // ------------------------------------------------------------------------------------------------
 constexpr int SC_KT = 128;   // keys per LDS tile
-template <typename T>
-__global__ __launch_bounds__(256) void vit_attention_scalar(const T* __restrict__ qkv, T* __restrict__ ctx, int N, int H) {
+template <typename T, typename TO = T>
+__global__ __launch_bounds__(256) void vit_attention_scalar(const T* __restrict__ qkv, TO* __restrict__ ctx, int N, int H) {
     __shared__ float Ks[SC_KT][65];
     __shared__ float Vs[SC_KT][65];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -465,9 +465,114 @@ __global__ __launch_bounds__(256) void vit_attention_scalar(const T* __restrict_
     }
     if (q < N) {
         const float inv = 1.0f / l;
-        T* op = ctx + ((size_t)b * N + q) * D + h * 64;
+        TO* op = ctx + ((size_t)b * N + q) * D;
 #pragma unroll
-        for (int d = 0; d < 64; ++d) op[d] = from_f32<T>(o[d] * inv);
+        for (int d = 0; d < 64; d += 4)
+            store4(op, h * 64 + d, make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 ViT attention on the matrix pipe (strict-fp32 and split-fp16 modes: qkv arrives as fp32).  v_mfma_f32_32x32x2_f32
+// multiplies exact fp32 products (157 TFLOP/s peak, 1/16 of the bf16 rate - still ~10x the one-thread-per-query kernel
+// above, which it replaces for 1 / 7 / 9 key blocks).  Same dataflow as vit_attention_mfma: K and V of the (image, head)
+// sit in LDS, S^T = K.Q^T so a lane owns one query column and the S^T accumulators are the B operand of O^T = V^T.P^T.
+//   * LDS rows of 64 fp32 with a pitch of 68 floats: lane (r32, hh) reads the 16-byte chunk 2 ks + hh of key row r32
+//     (its 4 values feed 4 MFMAs as the k-pair (hh = 0, hh = 1); Q uses the same k permutation, so the sum is unchanged)
+//     - with pitch 68 the 16 lanes of a ds_read_b128 phase hit 16 distinct 4-bank groups;
+//   * P.V: MFMA #e of a key block takes keys {kappa_e, kappa_e + 4} = exactly what accumulator register e of the two lane
+//     halves holds, so P never leaves its registers; V^T[d][key] is a ds_read_b32 of 32 consecutive floats per half.
+// One workgroup per (image, head), one wave per SIMD (the MFMA chains are long: 32 dependent MFMAs per score tile).
+template <int KB, typename TO>
+__global__ __launch_bounds__(256, 1) void vit_attention_f32_mfma(const float* __restrict__ qkv, TO* __restrict__ ctx, int N, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NP = KB * 32, PITCH = 68;
+    float* Ks = (float*)smem;
+    float* Vs = Ks + NP * PITCH;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int D = H * 64, ld = 3 * D;
+    const int tid = threadIdx.x, lane = tid & 63, r32 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* base = qkv + (size_t)b * N * ld + h * 64;
+
+    for (int i = tid; i < NP * 16; i += 256) {
+        const int row = i >> 4, ch = i & 15;
+        const float* src = base + (size_t)min(row, N - 1) * ld + ch * 4;
+        *(f32x4*)(Ks + row * PITCH + ch * 4) = *(const f32x4*)(src + D);
+        *(f32x4*)(Vs + row * PITCH + ch * 4) = *(const f32x4*)(src + 2 * D);
+    }
+    __syncthreads();
+
+    const int nqt = (N + 31) / 32;
+    const float c1 = 0.125f * LOG2E;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 32 + r32, qc = min(q, N - 1);
+        f32x4 qf[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const f32x4*)(base + (size_t)qc * ld + (2 * ks + hh) * 4);
+
+        f32x16 s[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const f32x4 a = *(const f32x4*)(Ks + (kb * 32 + r32) * PITCH + (2 * ks + hh) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], qf[ks][j], s[kb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);     // keep the next block's K reads from being hoisted over this chain (spills)
+        }
+        // softmax over keys for query column r32: key(kb, e) = kb*32 + (e&3) + 8*(e>>2) + 4*hh
+        float m = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if (kb == KB - 1) {
+                    const int key = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (key >= N) s[kb][e] = -INFINITY;
+                }
+                m = fmaxf(m, s[kb][e]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = __builtin_amdgcn_exp2f((s[kb][e] - m) * c1);
+                s[kb][e] = p;
+                l += p;
+            }
+        l += __shfl_xor(l, 32, 64);
+
+        f32x16 o[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * PITCH + db * 32 + r32], s[kb][e], o[db], 0, 0, 0);
+                if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        if (q < N) {
+            const float inv = 1.0f / l;
+            TO* op = ctx + ((size_t)b * N + q) * D;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    store4(op, h * 64 + db * 32 + 8 * g + 4 * hh,
+                           make_float4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
+        }
     }
 }
 
@@ -618,12 +723,12 @@ template <> struct Raw8<float> {
     __device__ __forceinline__ void set(int i, float x) { if (i < 4) a[i] = x; else b[i - 4] = x; }
 };
 
-template <typename T, int NI>
+template <typename T, int NI, typename TO = T>
 __global__ __launch_bounds__(256, 3) void decode_attention_wave_kernel(const T* __restrict__ q, T* __restrict__ kbase,
                                                                     T* __restrict__ vbase,
                                                                     const int* __restrict__ anc, int anc_ld,
                                                                     int rows_per_kv, int kv_ld, int n_keys,
-                                                                    T* __restrict__ out, int R, int H, QSource qs) {
+                                                                    TO* __restrict__ out, int R, int H, QSource qs) {
     const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (unit >= R * H) return;
     const int row = unit / H, h = unit - row * H, Dh = H * 64;
@@ -705,9 +810,9 @@ __global__ __launch_bounds__(256, 3) void decode_attention_wave_kernel(const T* 
     }
     if (ksub == 0) {
         const float inv = 1.0f / l;
-        T* op = out + (size_t)row * Dh + h * 64 + dch * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) op[e] = from_f32<T>(o[e] * inv);
+        TO* op = out + (size_t)row * Dh;
+        store4(op, h * 64 + dch * 8, make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv));
+        store4(op, h * 64 + dch * 8 + 4, make_float4(o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv));
     }
 }
 
@@ -715,12 +820,12 @@ __global__ __launch_bounds__(256, 3) void decode_attention_wave_kernel(const T* 
 // walked in chunks of 64 keys.  A chunk's 8 K loads and 8 V loads (16 B per lane, one 128-byte key row per 8 lanes)
 // are all issued into raw registers before any arithmetic; with ~4 waves per SIMD that keeps >100 KB in flight per
 // CU, which is what streaming the beam-shared K/V cache at HBM rate needs.  Online softmax across chunks (fp32).
-template <typename T, int G, bool DB, bool NT = false>
+template <typename T, int G, bool DB, bool NT = false, typename TO = T>
 __global__ __launch_bounds__(256, 3) void decode_attention_online_kernel(const T* __restrict__ q, const T* __restrict__ kbase,
                                                                       const T* __restrict__ vbase,
                                                                       const int* __restrict__ anc, int anc_ld,
                                                                       int rows_per_kv, int kv_ld, int n_keys,
-                                                                      T* __restrict__ out, int R, int H, QSource qs) {
+                                                                      TO* __restrict__ out, int R, int H, QSource qs) {
     // G = key groups (of 8 keys) per chunk, chosen by the launcher so the chunks are balanced (197 keys -> 4 x 56).
     // DB: two register buffers, the next chunk's loads are in flight while the current one is consumed.
     constexpr int CH = 8 * G;
@@ -811,9 +916,9 @@ __global__ __launch_bounds__(256, 3) void decode_attention_online_kernel(const T
     }
     if (ksub == 0) {
         const float inv = 1.0f / l;
-        T* op = out + (size_t)row * Dh + h * 64 + dch * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) op[e] = from_f32<T>(o[e] * inv);
+        TO* op = out + (size_t)row * Dh;
+        store4(op, h * 64 + dch * 8, make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv));
+        store4(op, h * 64 + dch * 8 + 4, make_float4(o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv));
     }
 }
 
@@ -1168,9 +1273,25 @@ int launch_flash_wide(const void* qkv, void* ctx, int B, int N, int H, int hd, i
     return 0;
 }
 
+template <int KB, typename TO>
+int launch_f32_mfma_kb(const void* qkv, void* ctx, int B, int N, int H, hipStream_t s) {
+    const int lds = 2 * KB * 32 * 68 * 4;
+    auto kern = vit_attention_f32_mfma<KB, TO>;
+    if (cap_kernel_setup((const void*)kern, lds, nullptr) != 0) return -1;
+    hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), lds, s, (const float*)qkv, (TO*)ctx, N, H);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
-int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s, int head_dim, int causal) {
+int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s, int head_dim, int causal,
+                         int out_dtype) {
+    if (out_dtype < 0) out_dtype = dtype;
+    if (out_dtype != dtype && !(dtype == CAP_DT_F32 && out_dtype == CAP_DT_G8 && head_dim == 64 && !causal)) {
+        cap_set_error("vit_attention: output type %d for input type %d is not supported here", out_dtype, dtype);
+        return -1;
+    }
     if (head_dim > 64 && head_dim <= 128 && head_dim % 8 == 0 && dtype == CAP_DT_BF16 && impl != 1) {
         if ((N + 31) / 32 == 9) return launch_flash_wide<9, 5>(qkv, ctx, B, N, H, head_dim, causal, s);   // ViT-g/14 of BLIP-2: 88-wide heads, 257 tokens
         if (N <= 64) return launch_flash_wide<2, 2>(qkv, ctx, B, N, H, head_dim, causal, s);               // OPT prefill: 80-wide heads, 33 positions, causal
@@ -1188,6 +1309,12 @@ int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
         cap_set_error("vit_attention: MFMA path needs bf16 and 1, 7, 9 or 19 key blocks (N=%d)", N);
         return -1;
     }
+    if (dtype == CAP_DT_F32 && impl != 1 && (kb == 1 || kb == 7 || kb == 9)) {      // fp32 MFMA kernel (impl 1 forces the scalar one)
+        const bool g8 = out_dtype == CAP_DT_G8;
+        if (kb == 1) return g8 ? launch_f32_mfma_kb<1, g8_t>(qkv, ctx, B, N, H, s) : launch_f32_mfma_kb<1, float>(qkv, ctx, B, N, H, s);
+        if (kb == 7) return g8 ? launch_f32_mfma_kb<7, g8_t>(qkv, ctx, B, N, H, s) : launch_f32_mfma_kb<7, float>(qkv, ctx, B, N, H, s);
+        return g8 ? launch_f32_mfma_kb<9, g8_t>(qkv, ctx, B, N, H, s) : launch_f32_mfma_kb<9, float>(qkv, ctx, B, N, H, s);
+    }
     if (impl == 0) impl = mfma_ok ? 2 : 1;
     if (impl == 2) {
         if (kb == 1) return launch_mfma_kb<1>(qkv, ctx, B, N, H, s);
@@ -1198,6 +1325,8 @@ int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
     dim3 grid(B * H, (N + 255) / 256);
     if (dtype == CAP_DT_BF16)
         hipLaunchKernelGGL(vit_attention_scalar<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)ctx, N, H);
+    else if (out_dtype == CAP_DT_G8)
+        hipLaunchKernelGGL((vit_attention_scalar<float, g8_t>), grid, dim3(256), 0, s, (const float*)qkv, (g8_t*)ctx, N, H);
     else
         hipLaunchKernelGGL(vit_attention_scalar<float>, grid, dim3(256), 0, s, (const float*)qkv, (float*)ctx, N, H);
     CAP_HIP_CHECK(hipGetLastError());
@@ -1207,7 +1336,12 @@ int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
 int launch_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             hipStream_t s, const float* q_part, int q_S, const float* q_bias, int q_ld, int q_col0,
-                            int append_kv) {
+                            int append_kv, int out_dtype) {
+    if (out_dtype < 0) out_dtype = dtype;
+    if (out_dtype != dtype && !(dtype == CAP_DT_F32 && out_dtype == CAP_DT_G8 && impl == 0)) {
+        cap_set_error("decode_attention: output type %d for input type %d is not supported here", out_dtype, dtype);
+        return -1;
+    }
     QSource qs;
     qs.part = q_part; qs.bias = q_bias; qs.S = q_S; qs.part_ld = q_ld; qs.col0 = q_col0; qs.append_kv = append_kv;
     if (q_part && (impl != 0 || q_S < 1 || !q_bias || (q_ld & 3) || (q_col0 & 3))) {
@@ -1215,9 +1349,10 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
         return -1;
     }
     if (n_keys <= 0 || n_keys > 8192) { cap_set_error("decode_attention: bad key count %d", n_keys); return -1; }
-#define CAP_DA_WAVE(TT, NI)                                                                                            \
-    hipLaunchKernelGGL((decode_attention_wave_kernel<TT, NI>), dim3((R * H + 3) / 4), dim3(256), 0, s, (const TT*)q,  \
-                       (TT*)kbase, (TT*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, (TT*)out, R, H, qs)
+#define CAP_DA_WAVE_O(TT, NI, TOO)                                                                                     \
+    hipLaunchKernelGGL((decode_attention_wave_kernel<TT, NI, TOO>), dim3((R * H + 3) / 4), dim3(256), 0, s, (const TT*)q,  \
+                       (TT*)kbase, (TT*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, (TOO*)out, R, H, qs)
+#define CAP_DA_WAVE(TT, NI) CAP_DA_WAVE_O(TT, NI, TT)
     // bf16: chunks of 40 keys, double-buffered (168 VGPRs -> 3 waves/SIMD, all of a 256-row launch resident at once;
     // 197 image tokens = 5 chunks).  fp32: chunks of 56 keys, single buffer (same register budget).
     // greedy (one row per K/V block): the stream is read exactly once per launch, non-temporal loads keep it from displacing
@@ -1240,6 +1375,13 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
         if (dtype == CAP_DT_BF16) {
             if (ng8 <= 1) CAP_DA_WAVE(bf16_t, 1); else if (ng8 <= 2) CAP_DA_WAVE(bf16_t, 2);
             else if (ng8 <= 4) CAP_DA_WAVE(bf16_t, 4); else CAP_DA_ONLINE(bf16_t, true);
+        } else if (out_dtype == CAP_DT_G8) {      // split mode: fp32 caches, the context row is the next GEMM's G8 operand
+            if (ng8 <= 1) CAP_DA_WAVE_O(float, 1, g8_t); else if (ng8 <= 2) CAP_DA_WAVE_O(float, 2, g8_t);
+            else if (ng8 <= 4) CAP_DA_WAVE_O(float, 4, g8_t);
+            else
+                hipLaunchKernelGGL((decode_attention_online_kernel<float, 7, false, false, g8_t>), dim3((R * H + 3) / 4), dim3(256), 0,
+                                   s, (const float*)q, (const float*)kbase, (const float*)vbase, anc, anc_ld, rows_per_kv, kv_ld,
+                                   n_keys, (g8_t*)out, R, H, qs);
         } else {
             if (ng8 <= 1) CAP_DA_WAVE(float, 1); else if (ng8 <= 2) CAP_DA_WAVE(float, 2);
             else if (ng8 <= 4) CAP_DA_WAVE(float, 4); else CAP_DA_ONLINE(float, false);
@@ -1248,6 +1390,7 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
         return 0;
     }
 #undef CAP_DA_WAVE
+#undef CAP_DA_WAVE_O
 #undef CAP_DA_ONLINE
 #undef CAP_DA_ONLINE_NT
     // impl 1: the simple two-pass kernel (kept as an independent implementation for the tests)

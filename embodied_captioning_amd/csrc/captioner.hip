@@ -95,7 +95,9 @@ constexpr bool kDeltaInT = false;
 
 struct Captioner {
     CapConfig c;
-    int dt; size_t esz;
+    int dt; size_t esz;          // storage type of activations / K-V caches that kernels other than the GEMMs read
+    int gdt;                     // type of every GEMM operand (A and W): == dt, except CAP_F32_SPLIT: dt = fp32, gdt = G8
+                                 // (split fp16, common.h) - there every kernel whose output feeds a GEMM writes G8
     int NT, P, Kpatch, Kpad;
     size_t dev_bytes = 0;
     std::vector<void*> allocs;
@@ -189,7 +191,7 @@ int reg_mat(Captioner* m, const std::string& name, void** p, int64_t rows, int64
     if (!ld) ld = (int)cols;
     TRY(dev_alloc(m, p, (size_t)rows * ld * m->esz));
     if (ld != cols) CAP_HIP_CHECK(hipMemset(*p, 0, (size_t)rows * ld * m->esz));
-    return add_slot(m, name, *p, m->dt, rows, cols, ld);
+    return add_slot(m, name, *p, m->gdt, rows, cols, ld);
 }
 
 int build_blip(Captioner* m) {
@@ -224,11 +226,11 @@ int build_blip(Captioner* m) {
     // the embedding table is read twice: fp32 rows for the lookup, compute-dtype [V,T] as the (tied) LM-head weight
     TRY(dev_alloc(m, (void**)&m->word_f32, (size_t)V * T * 4));
     add_slot(m, tb + "embeddings.word_embeddings.weight", m->word_f32, CAP_DT_F32, V, T);
-    if (m->dt == CAP_DT_F32) {
+    if (m->gdt == CAP_DT_F32) {
         m->word_t = m->word_f32;
     } else {
         TRY(dev_alloc(m, &m->word_t, (size_t)V * T * m->esz));
-        add_slot(m, tb + "embeddings.word_embeddings.weight", m->word_t, m->dt, V, T);
+        add_slot(m, tb + "embeddings.word_embeddings.weight", m->word_t, m->gdt, V, T);
     }
     TRY(reg_f32(m, tb + "embeddings.position_embeddings.weight", &m->tpos, (int64_t)c.max_pos * T));
     TRY(reg_f32(m, tb + "embeddings.LayerNorm.weight", &m->emb_g, T));
@@ -244,7 +246,7 @@ int build_blip(Captioner* m) {
         TRY(dev_alloc(m, (void**)&L.b_qkv, (size_t)3 * T * 4));
         const char* nm[3] = {"query", "key", "value"};
         for (int j = 0; j < 3; ++j) {
-            add_slot(m, p + "attention.self." + nm[j] + ".weight", (char*)L.w_qkv + (size_t)j * T * T * m->esz, m->dt, T, T);
+            add_slot(m, p + "attention.self." + nm[j] + ".weight", (char*)L.w_qkv + (size_t)j * T * T * m->esz, m->gdt, T, T);
             add_slot(m, p + "attention.self." + nm[j] + ".bias", L.b_qkv + (size_t)j * T, CAP_DT_F32, 1, T);
         }
         TRY(reg_mat(m, p + "attention.output.dense.weight", &L.w_so, T, T));
@@ -255,7 +257,7 @@ int build_blip(Captioner* m) {
         TRY(reg_f32(m, p + "crossattention.self.query.bias", &L.b_cq, T));
         for (int j = 0; j < 2; ++j) {
             add_slot(m, p + "crossattention.self." + nm[j + 1] + ".weight",
-                     (char*)m->w_ckv + ((size_t)i * 2 + j) * T * D * m->esz, m->dt, T, D);
+                     (char*)m->w_ckv + ((size_t)i * 2 + j) * T * D * m->esz, m->gdt, T, D);
             add_slot(m, p + "crossattention.self." + nm[j + 1] + ".bias", m->b_ckv + ((size_t)i * 2 + j) * T, CAP_DT_F32, 1, T);
         }
         TRY(reg_mat(m, p + "crossattention.output.dense.weight", &L.w_co, T, T));
@@ -465,7 +467,7 @@ int gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, int lda, c
     p.p0 = p0; p.p1 = p1; p.p2 = p2; p.p3 = p3; p.aux = aux; p.C2 = C2; p.splitk = 1;
     const double osz = out_f32 ? 4.0 : (double)m->esz;
     ProfScope ps(m, s, tag, 2.0 * M * N * K, ((double)M * K + (double)N * K) * m->esz + (double)M * N * osz);
-    return launch_gemm(m->dt, p, 0, s);   // tile 0 = auto (stream kernel for encoder-sized problems without residual)
+    return launch_gemm(m->gdt, p, 0, s);   // tile 0 = auto (stream kernel for encoder-sized problems without residual)
 }
 
 // Decode loops stop when every caption is finished, as HF generate does (`unfinished_sequences.max() == 0` /
@@ -890,7 +892,7 @@ int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_emb
     const int D = c.v_hidden, NT = m->NT, M = B * NT, H = c.v_heads;
     {
         ProfScope ps(m, s, "patchify", 0, (double)B * 3 * c.image_size * c.image_size * (fmt ? 1 : 4) + (double)B * m->P * m->Kpad * m->esz);
-        TRY(launch_patchify(m->dt, pixels, fmt, B, c.image_size, c.patch_size, m->Kpad, m->patches, c.pix_mean, c.pix_std, s));
+        TRY(launch_patchify(m->gdt, pixels, fmt, B, c.image_size, c.patch_size, m->Kpad, m->patches, c.pix_mean, c.pix_std, s));
     }
     TRY(gemm(m, s, "gemm_patch", m->patches, m->Kpad, m->w_patch, m->Kpad, m->X, D, m->b_patch, nullptr, B * m->P, D,
              m->Kpad, 0, 1, EPI_PATCH, m->P, 0, 0, 0, m->vpos));
@@ -902,16 +904,17 @@ int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_emb
     auto add_ln = [&](const float* g, const float* b, void* out_t, float* out_f) -> int {
         ProfScope ps(m, s, "layernorm", 0, (double)M * D * ((pending ? 8 + (kDeltaInT ? m->esz : 4) : 4) + m->esz + (out_f ? 4 : 0)));
         if (pending)
-            return launch_reduce_layernorm(m->dt, m->delta, 1, nullptr, m->X, g, b, c.v_eps, out_t, out_f, m->X, M, D, s, false, kDeltaInT);
-        return launch_layernorm(m->dt, m->X, D, g, b, c.v_eps, out_t, out_f, M, D, s);
+            return launch_reduce_layernorm(m->gdt, m->delta, 1, nullptr, m->X, g, b, c.v_eps, out_t, out_f, m->X, M, D, s, false, kDeltaInT);
+        return launch_layernorm(m->gdt, m->X, D, g, b, c.v_eps, out_t, out_f, M, D, s);
     };
     for (int i = 0; i < c.v_layers; ++i) {
         const VLayer& L = m->vl[i];
         TRY(add_ln(L.ln1_g, L.ln1_b, m->ln, nullptr));
-        TRY(gemm(m, s, "gemm_qkv", m->ln, D, L.w_qkv, D, m->qkv, 3 * D, L.b_qkv, nullptr, M, 3 * D, D, 0, 0));
+        // (split mode: the attention kernel is not a GEMM - it reads q|k|v as fp32 and writes the context as G8)
+        TRY(gemm(m, s, "gemm_qkv", m->ln, D, L.w_qkv, D, m->qkv, 3 * D, L.b_qkv, nullptr, M, 3 * D, D, 0, m->gdt == CAP_DT_G8 ? 1 : 0));
         {
             ProfScope ps(m, s, "vit_attention", 4.0 * B * H * (double)NT * NT * 64, (double)M * 4 * D * m->esz);
-            TRY(launch_vit_attention(m->dt, m->qkv, m->ctx, B, NT, H, 0, s, D / H));
+            TRY(launch_vit_attention(m->dt, m->qkv, m->ctx, B, NT, H, 0, s, D / H, 0, m->gdt));
         }
         TRY(gemm(m, s, "gemm_proj", m->ctx, D, L.w_proj, D, m->delta, D, L.b_proj, nullptr, M, D, D, 0, kDeltaInT ? 0 : 1));
         pending = true;
@@ -983,7 +986,7 @@ int gemm_partial(Captioner* m, hipStream_t s, const char* tag, const void* A, co
     p.out_f32 = 1; p.epi = EPI_PARTIAL; p.splitk = S;
     *S_out = S;
     ProfScope ps(m, s, tag, 2.0 * R * N * K, ((double)R * K + (double)N * K) * m->esz + (double)S * R * N * 4);
-    return launch_gemm(m->dt, p, 2, s);
+    return launch_gemm(m->gdt, p, 2, s);
 }
 
 // Decode-sized GEMM whose consumer is a LayerNorm: split K over S blocks per tile (every block's slabs are all in flight
@@ -1011,14 +1014,14 @@ int gemm_splitk_reduce_ln(Captioner* m, hipStream_t s, const Dec& d, const char*
         p.ln_out_t = out_t; p.ln_out_f = out_f; p.ln_y_out = y_out;
         ProfScope ps(m, s, tag, 2.0 * d.R * N * K,
                      ((double)d.R * K + (double)N * K) * m->esz + (double)(2 * S + 2) * d.R * N * 4 + (double)d.R * N * m->esz);
-        return launch_gemm(m->dt, p, 2, s);
+        return launch_gemm(m->gdt, p, 2, s);
     }
     {
         ProfScope ps(m, s, tag, 2.0 * d.R * N * K, ((double)d.R * K + (double)N * K) * m->esz + (double)S * d.R * N * 4);
-        TRY(launch_gemm(m->dt, p, 2, s));
+        TRY(launch_gemm(m->gdt, p, 2, s));
     }
     ProfScope ps(m, s, "dec_reduce_ln", 0, (double)(S + 2) * d.R * N * 4 + (double)d.R * N * m->esz);
-    return launch_reduce_layernorm(m->dt, d.dpart, S, bias, d.dx, g, b, eps, out_t, out_f, y_out, d.R, N, s, true);
+    return launch_reduce_layernorm(m->gdt, d.dpart, S, bias, d.dx, g, b, eps, out_t, out_f, y_out, d.R, N, s, true);
 }
 
 int gemm_splitk_ln(Captioner* m, hipStream_t s, const Dec& d, const char* tag, const void* A, const void* W,
@@ -1031,7 +1034,7 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
     const CapConfig& c = m->c;
     const int T = c.t_hidden, F = c.t_ffn, H = c.t_heads, R = d.R, NT = m->NT;
     const size_t e = m->esz;
-    TRY(launch_embed(m->dt, tokens, tok_ld, t, m->word_f32, m->tpos, m->emb_g, m->emb_b, c.t_eps, d.dx_t, d.dx, R, T, s));
+    TRY(launch_embed(m->gdt, tokens, tok_ld, t, m->word_f32, m->tpos, m->emb_g, m->emb_b, c.t_eps, d.dx_t, d.dx, R, T, s));
     for (int i = 0; i < c.t_layers; ++i) {
         const TLayer& L = m->tl[i];
         char* kc = (char*)L.self_cache + d.cache_off;
@@ -1043,12 +1046,12 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
             TRY(gemm_partial(m, s, "dec_gemm_qkv", d.dx_t, L.w_qkv, d.dpart, R, 3 * T, T, 4, &S));
             ProfScope ps(m, s, "dec_self_attn", 4.0 * R * H * (t + 1) * 64, 2.0 * R * H * (t + 1) * 64 * e + (double)S * R * 3 * T * 4);
             TRY(launch_decode_attention(m->dt, nullptr, kc, vc, anc, Lm, 1, Lm, t + 1, d.dctx, R, H, 0, s, d.dpart, S,
-                                        L.b_qkv, 3 * T, 0, 1));
+                                        L.b_qkv, 3 * T, 0, 1, m->gdt));
         } else {
             TRY(gemm(m, s, "dec_gemm_qkv", d.dx_t, T, L.w_qkv, T, d.dq, T, L.b_qkv, nullptr, R, 3 * T, T, 0, 0, EPI_QKVCACHE,
                      R, H, Lm, t, nullptr, kc));
             ProfScope ps(m, s, "dec_self_attn", 4.0 * R * H * (t + 1) * 64, 2.0 * R * H * (t + 1) * 64 * e);
-            TRY(launch_decode_attention(m->dt, d.dq, kc, vc, anc, Lm, 1, Lm, t + 1, d.dctx, R, H, 0, s));
+            TRY(launch_decode_attention(m->dt, d.dq, kc, vc, anc, Lm, 1, Lm, t + 1, d.dctx, R, H, 0, s, nullptr, 0, nullptr, 0, 0, 0, m->gdt));
         }
         TRY(gemm_splitk_ln(m, s, d, "dec_gemm_so", d.dctx, L.w_so, L.b_so, L.so_g, L.so_b, T, T));
         {
@@ -1059,7 +1062,7 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
             const char* cv = (char*)m->cross + (((size_t)i * 2 + 1) * d.Btot + d.b0) * H * NT * 64 * e;
             ProfScope ps(m, s, "dec_cross_attn", 4.0 * R * H * NT * 64, 2.0 * d.B * H * NT * 64 * e);
             TRY(launch_decode_attention(m->dt, nullptr, ck, cv, nullptr, 0, K, NT, NT, d.dctx, R, H, 0, s, d.dpart, S, L.b_cq,
-                                        T, 0, 0));
+                                        T, 0, 0, m->gdt));
         }
         TRY(gemm_splitk_ln(m, s, d, "dec_gemm_co", d.dctx, L.w_co, L.b_co, L.co_g, L.co_b, T, T));
         TRY(gemm(m, s, "dec_gemm_f1", d.dx_t, T, L.w_f1, T, d.dh, F, L.b_f1, nullptr, R, F, T, 1, 0));
@@ -1068,7 +1071,7 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
     TRY(gemm(m, s, "dec_gemm_tr", d.dx_t, T, m->w_tr, T, d.dy, T, m->b_tr, nullptr, R, T, T, 1, 1));
     {
         ProfScope ps(m, s, "dec_layernorm", 0, (double)R * T * (8 + e));
-        TRY(launch_layernorm(m->dt, d.dy, T, m->tr_g, m->tr_b, c.t_eps, d.dx_t, d.dx, R, T, s));
+        TRY(launch_layernorm(m->gdt, d.dy, T, m->tr_g, m->tr_b, c.t_eps, d.dx_t, d.dx, R, T, s));
     }
     TRY(gemm(m, s, "dec_gemm_vocab", d.dx_t, T, m->word_t, T, d.logits, m->ldl, m->b_vocab, nullptr, R, c.vocab, T, 0, 1));
     return 0;
@@ -1227,7 +1230,14 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
         cap_set_error("cap_create: unknown arch %d", cfg->arch);
         return -1;
     }
-    if (cfg->compute_dtype != CAP_F32 && cfg->compute_dtype != CAP_BF16) { cap_set_error("cap_create: unknown dtype"); return -1; }
+    if (cfg->compute_dtype != CAP_F32 && cfg->compute_dtype != CAP_BF16 && cfg->compute_dtype != CAP_F32_SPLIT) {
+        cap_set_error("cap_create: unknown dtype");
+        return -1;
+    }
+    if (cfg->compute_dtype == CAP_F32_SPLIT && cfg->arch != CAP_ARCH_BLIP) {
+        cap_set_error("cap_create: CAP_F32_SPLIT is built for CAP_ARCH_BLIP (the other architectures take CAP_F32 or CAP_BF16)");
+        return -1;
+    }
     const bool text_only = cfg->arch == CAP_ARCH_MINILM;
     if (text_only) {
         const int hd = cfg->t_heads > 0 ? cfg->t_hidden / cfg->t_heads : 0;
@@ -1272,7 +1282,8 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
     Captioner* m = new Captioner();
     m->c = *cfg;
     m->dt = cfg->compute_dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32;
-    m->esz = m->dt == CAP_DT_BF16 ? 2 : 4;
+    m->gdt = cfg->compute_dtype == CAP_F32_SPLIT ? CAP_DT_G8 : m->dt;
+    m->esz = m->dt == CAP_DT_BF16 ? 2 : 4;            // a G8 element is 4 bytes like fp32
     const int g = text_only ? 0 : cfg->image_size / cfg->patch_size;
     m->P = g * g; m->NT = m->P + 1;
     m->Kpatch = text_only ? 0 : 3 * cfg->patch_size * cfg->patch_size;
@@ -1374,7 +1385,7 @@ int cap_load_weight(CapHandle h, const char* name, const float* data, int on_dev
                           (long long)sl.rows, (long long)sl.cols);
             return -1;
         }
-        TRY(launch_convert2d(sl.dtype, src, sl.dst, (int)sl.rows, (int)sl.cols, sl.dst_ld, s));
+        TRY(launch_convert2d(sl.dtype, src, sl.dst, (int)sl.rows, (int)sl.cols, sl.dst_ld, s, sl.dtype == CAP_DT_G8 ? G8_WSCALE : 1.0f));
         sl.loaded = true;
     }
     CAP_HIP_CHECK(hipStreamSynchronize(s));
@@ -1485,7 +1496,10 @@ int cap_profile_report(CapHandle h, char* buf, size_t buf_bytes) {
     return 0;
 }
 
-// ---- single-kernel entry points
+// ---- single-kernel entry points.  dtype 2 (CAP_F32_SPLIT) = the split mode's convention: GEMM operands / kernel outputs
+// that feed a GEMM are G8 (weights scaled by G8_WSCALE = 4096: cap_op_convert_weight), everything else is fp32.
+static int dt_of(int dtype) { return dtype == CAP_BF16 ? CAP_DT_BF16 : dtype == CAP_F32_SPLIT ? CAP_DT_G8 : CAP_DT_F32; }
+static int in_dt_of(int dtype) { return dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32; }
 int cap_op_gemm(int dtype, const void* A, const void* W, const float* bias, const float* resid, void* C, int M, int N,
                 int K, int gelu, int out_f32, int tile, void* stream) {
     GemmParams p;
@@ -1493,20 +1507,19 @@ int cap_op_gemm(int dtype, const void* A, const void* W, const float* bias, cons
     p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = C; p.ldc = N; p.bias = bias; p.resid = resid; p.ldr = N;
     p.M = M; p.N = N; p.K = K; p.gelu = gelu; p.out_f32 = out_f32; p.epi = EPI_STORE; p.splitk = 1;
     if (tile == 9 || tile == 13) { p.aux = resid; p.resid = nullptr; }   // instrumented kernel: `resid` is the cycle-count buffer
-    return launch_gemm(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, p, tile, (hipStream_t)stream);
+    return launch_gemm(dt_of(dtype), p, tile, (hipStream_t)stream);
 }
 int cap_op_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps, void* out_t,
                      float* out_f, int M, int D, void* stream) {
-    return launch_layernorm(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, in, D, gamma, beta, eps, out_t, out_f, M, D,
-                            (hipStream_t)stream);
+    return launch_layernorm(dt_of(dtype), in, D, gamma, beta, eps, out_t, out_f, M, D, (hipStream_t)stream);
 }
 int cap_op_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, void* stream) {
-    return launch_vit_attention(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, qkv, ctx, B, N, H, impl, (hipStream_t)stream);
+    return launch_vit_attention(in_dt_of(dtype), qkv, ctx, B, N, H, impl, (hipStream_t)stream, 64, 0, dt_of(dtype));
 }
 int cap_op_vit_attention_hd(int dtype, const void* qkv, void* ctx, int B, int N, int H, int head_dim, int impl, void* stream) {
     // impl bit 8: causal mask (decoder prefill)
-    return launch_vit_attention(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, qkv, ctx, B, N, H, impl & 7, (hipStream_t)stream,
-                                head_dim, (impl >> 3) & 1);
+    return launch_vit_attention(in_dt_of(dtype), qkv, ctx, B, N, H, impl & 7, (hipStream_t)stream, head_dim, (impl >> 3) & 1,
+                                dt_of(dtype));
 }
 int cap_crop_resize_tables(const int32_t* rects, const int32_t* geom, int n, int S, int KH, int KV, int32_t* hb, int32_t* hk,
                            int32_t* vb, int32_t* vk, void* stream) {
@@ -1519,8 +1532,8 @@ int cap_crop_resize_u8(const uint8_t* frame, int H, int W, int bgr, const int32_
 int cap_op_reduce_layernorm(int dtype, const float* part, int S, const float* bias, const float* resid, const float* gamma,
                             const float* beta, float eps, void* out_t, float* out_f, float* y_out, int M, int D,
                             int per_row_block, void* stream) {
-    return launch_reduce_layernorm(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, part, S, bias, resid, gamma, beta, eps, out_t,
-                                   out_f, y_out, M, D, (hipStream_t)stream, per_row_block != 0, false);
+    return launch_reduce_layernorm(dt_of(dtype), part, S, bias, resid, gamma, beta, eps, out_t, out_f, y_out, M, D,
+                                   (hipStream_t)stream, per_row_block != 0, false);
 }
 int cap_op_gemm_skinny(const void* A, const void* W, const float* bias, int act, void* out, float* part, int M, int N, int K,
                        void* stream) {
@@ -1530,11 +1543,14 @@ int cap_op_gemm_skinny_slices(int N, int K, int finished) { return skinny_plan(N
 int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int32_t* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             void* stream) {
-    return launch_decode_attention(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, q, kbase, vbase, anc, anc_ld, rows_per_kv,
-                                   kv_ld, n_keys, out, R, H, impl, (hipStream_t)stream, nullptr, 0, nullptr, 0, 0, 0);
+    return launch_decode_attention(in_dt_of(dtype), q, kbase, vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, out, R, H, impl,
+                                   (hipStream_t)stream, nullptr, 0, nullptr, 0, 0, 0, dt_of(dtype));
 }
 int cap_op_convert(int dtype, const float* src, void* dst, size_t n, void* stream) {
-    return launch_convert(dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32, src, dst, n, (hipStream_t)stream);
+    return launch_convert(dt_of(dtype), src, dst, n, (hipStream_t)stream);
+}
+int cap_op_convert_weight(int dtype, const float* src, void* dst, int rows, int cols, void* stream) {
+    return launch_convert2d(dt_of(dtype), src, dst, rows, cols, cols, (hipStream_t)stream, dtype == CAP_F32_SPLIT ? G8_WSCALE : 1.0f);
 }
 
 }  // extern "C"

@@ -12,18 +12,78 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CAP_WAVE 64
 
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
 // compute dtype tags (match include/captioner_hip.h)
-enum { CAP_DT_F32 = 0, CAP_DT_BF16 = 1 };
+enum { CAP_DT_F32 = 0, CAP_DT_BF16 = 1, CAP_DT_G8 = 2 };
+
+// ---- G8: the GEMM-operand layout of the split-fp16 mode (CAP_F32_SPLIT) -------------------------------------------
+// An fp32 value x travels as two fp16 halves, hi = rn16(x) and lo = rn16(x - hi) (x - hi is exact in fp32), so
+// hi + lo = x (1 + e), |e| <= 2^-23 inside fp16's normal range.  A GEMM forms a.w as a_hi.w_hi + a_hi.w_lo + a_lo.w_hi
+// on the fp16 MFMA pipe with fp32 accumulation (the dropped a_lo.w_lo term is <= 2^-22 |a w|): fp32-grade products at
+// 3/16 of the cost of the fp32 MFMA.  Storage is 4 bytes per element like fp32, rows of ld elements = 4 ld bytes, but
+// inside a row every group of 8 consecutive elements is 32 bytes = [8 hi halves | 8 lo halves]: a lane's MFMA operand
+// (8 consecutive k) is one 16-byte LDS read per half, with no unpacking.  Rows therefore need ld % 8 == 0.
+// Weights are stored scaled by G8_WSCALE (a power of two: exact) so that the lo halves of typical weights (|w| ~ 1e-2)
+// stay in fp16's normal range; the GEMM epilogue multiplies the accumulator by 1 / G8_WSCALE.  Activations are unscaled
+// and clamped to +-G8_AMAX (fp16's range) - values beyond that do not occur on this path.
+struct g8_t { unsigned int w; };                         // never dereferenced as a scalar: see store4 / g8_put
+constexpr float G8_WSCALE = 4096.0f;
+constexpr float G8_AMAX = 65000.0f;
 
 template <typename T> struct DT;
 template <> struct DT<float> { static constexpr int tag = CAP_DT_F32; static constexpr int per16B = 4; };
 template <> struct DT<bf16_t> { static constexpr int tag = CAP_DT_BF16; static constexpr int per16B = 8; };
+template <> struct DT<g8_t> { static constexpr int tag = CAP_DT_G8; static constexpr int per16B = 4; };
 
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// ---- typed stores of GEMM operands: `row` points at element 0 of a row (a multiple of 8 elements from the buffer start
+// for g8_t), c is the column.  store4: c % 4 == 0, four consecutive columns.
+__device__ __forceinline__ void g8_split(float x, f16_t& hi, f16_t& lo) {
+    x = __builtin_amdgcn_fmed3f(x, -G8_AMAX, G8_AMAX);
+    hi = (f16_t)x;
+    lo = (f16_t)(x - (float)hi);
+}
+__device__ __forceinline__ void store4(float* row, int c, float4 v) { *(float4*)(row + c) = v; }
+__device__ __forceinline__ void store4(bf16_t* row, int c, float4 v) {
+    bf16x4 w;
+    w[0] = (bf16_t)v.x; w[1] = (bf16_t)v.y; w[2] = (bf16_t)v.z; w[3] = (bf16_t)v.w;
+    *(bf16x4*)(row + c) = w;
+}
+__device__ __forceinline__ void store4(g8_t* row, int c, float4 v) {
+    f16x4 hi, lo;
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f16_t h, l;
+        g8_split(x[i], h, l);
+        hi[i] = h; lo[i] = l;
+    }
+    char* g = (char*)row + (c >> 3) * 32 + (c & 7) * 2;
+    *(f16x4*)g = hi;
+    *(f16x4*)(g + 16) = lo;
+}
+__device__ __forceinline__ void store1(float* row, int c, float v) { row[c] = v; }
+__device__ __forceinline__ void store1(bf16_t* row, int c, float v) { row[c] = (bf16_t)v; }
+__device__ __forceinline__ void store1(g8_t* row, int c, float v) {
+    f16_t hi, lo;
+    g8_split(v, hi, lo);
+    char* g = (char*)row + (c >> 3) * 32 + (c & 7) * 2;
+    *(f16_t*)g = hi;
+    *(f16_t*)(g + 16) = lo;
+}
+__device__ __forceinline__ float g8_get(const g8_t* row, int c) {       // tests / slow paths only
+    const char* g = (const char*)row + (c >> 3) * 32 + (c & 7) * 2;
+    return (float)*(const f16_t*)g + (float)*(const f16_t*)(g + 16);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -53,6 +113,7 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 template <typename T> __device__ __forceinline__ float gelu_for(float x);
 template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
 template <> __device__ __forceinline__ float gelu_for<__bf16>(float x) { return gelu_erf_fast(x); }
+template <> __device__ __forceinline__ float gelu_for<g8_t>(float x) { return gelu_erf(x); }
 
 // One-time per (kernel, device) setup shared by the launchers: raises the kernel's dynamic-LDS limit when `lds_bytes`
 // exceeds the 64 KiB default and returns the device's CU count in *n_cu (may be null).  Thread-safe; a handle per GPU in

@@ -10,31 +10,28 @@ template <typename T>
 __global__ void convert_kernel(const float* __restrict__ src, T* __restrict__ dst, size_t n) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
-    for (; i + 3 < n; i += stride) {
-        float4 v = *(const float4*)(src + i);
-        dst[i] = from_f32<T>(v.x); dst[i + 1] = from_f32<T>(v.y);
-        dst[i + 2] = from_f32<T>(v.z); dst[i + 3] = from_f32<T>(v.w);
-    }
+    for (; i + 3 < n; i += stride) store4(dst + (i & ~(size_t)7), (int)(i & 7), *(const float4*)(src + i));
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (size_t j = n & ~(size_t)3; j < n; ++j) dst[j] = from_f32<T>(src[j]);
+        for (size_t j = n & ~(size_t)3; j < n; ++j) store1(dst + (j & ~(size_t)7), (int)(j & 7), src[j]);
 }
 
+// scale: 1 except for G8 weights (G8_WSCALE, see common.h)
 template <typename T>
-__global__ void convert2d_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int cols, int dst_ld) {
+__global__ void convert2d_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int cols, int dst_ld, float scale) {
     const size_t n = (size_t)rows * cols;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t r = i / cols, c = i - r * cols;
-        dst[r * dst_ld + c] = from_f32<T>(src[i]);
+        store1(dst + r * dst_ld, (int)c, src[i] * scale);
     }
 }
 
 template <typename T>
-__global__ void convert2d_t_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int cols) {
+__global__ void convert2d_t_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int cols, float scale) {
     // dst[c][r] = src[r][c]  (one-off weight transposition, e.g. CoCa's text_projection [width, vocab])
     const size_t n = (size_t)rows * cols;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t c = i / rows, r = i - c * rows;
-        dst[i] = from_f32<T>(src[r * cols + c]);
+        store1(dst + c * rows, (int)r, src[r * cols + c] * scale);
     }
 }
 
@@ -63,7 +60,7 @@ __global__ void patchify_kernel(const void* __restrict__ pixels, int fmt, int B,
         }
         int py = y / ps, dy = y - py * ps, px = x / ps, dx = x - px * ps;
         size_t row = (size_t)b * G * G + (size_t)py * G + px;
-        out[row * Kpad + (size_t)c * ps * ps + dy * ps + dx] = from_f32<T>(v);
+        store1(out + row * Kpad, c * ps * ps + dy * ps + dx, v);
     }
 }
 
@@ -196,10 +193,7 @@ __global__ __launch_bounds__(256) void reduce_layernorm_row_kernel(const float* 
         float4 o;
         o.x = dx * rstd * g.x + be.x; o.y = dy * rstd * g.y + be.y; o.z = dz * rstd * g.z + be.z; o.w = dw * rstd * g.w + be.w;
         if (out_f) *(float4*)(out_f + (size_t)row * D + c) = o;
-        if (out_t) {
-            T* ot = out_t + (size_t)row * D + c;
-            ot[0] = from_f32<T>(o.x); ot[1] = from_f32<T>(o.y); ot[2] = from_f32<T>(o.z); ot[3] = from_f32<T>(o.w);
-        }
+        if (out_t) store4(out_t + (size_t)row * D, c, o);
     }
 }
 
@@ -264,10 +258,7 @@ __global__ __launch_bounds__(256) void reduce_layernorm_wide_kernel(const float*
             o.x = (a[i].x - mean) * rstd * g.x + be.x; o.y = (a[i].y - mean) * rstd * g.y + be.y;
             o.z = (a[i].z - mean) * rstd * g.z + be.z; o.w = (a[i].w - mean) * rstd * g.w + be.w;
             if (out_f) *(float4*)(out_f + (size_t)row * D + c) = o;
-            if (out_t) {
-                T* ot = out_t + (size_t)row * D + c;
-                ot[0] = from_f32<T>(o.x); ot[1] = from_f32<T>(o.y); ot[2] = from_f32<T>(o.z); ot[3] = from_f32<T>(o.w);
-            }
+            if (out_t) store4(out_t + (size_t)row * D, c, o);
         }
     }
 }
@@ -423,6 +414,9 @@ __global__ void copy_f32_kernel(const float* s, float* d, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
 }
 
+#define CAP_DISPATCH_T(dtype, MACRO)                                                                                  \
+    do { if ((dtype) == CAP_DT_BF16) MACRO(bf16_t); else if ((dtype) == CAP_DT_G8) MACRO(g8_t); else MACRO(float); } while (0)
+
 inline int grid_for(size_t n, int per_block) {
     size_t g = (n + per_block - 1) / per_block;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -431,30 +425,30 @@ inline int grid_for(size_t n, int per_block) {
 }  // namespace
 
 int launch_convert(int dtype, const float* src, void* dst, size_t n, hipStream_t s) {
-    if (dtype == CAP_DT_BF16)
-        hipLaunchKernelGGL(convert_kernel<bf16_t>, dim3(grid_for(n, 1024)), dim3(256), 0, s, src, (bf16_t*)dst, n);
-    else
-        hipLaunchKernelGGL(convert_kernel<float>, dim3(grid_for(n, 1024)), dim3(256), 0, s, src, (float*)dst, n);
+    if (dtype == CAP_DT_G8 && n % 8 != 0) { cap_set_error("convert: a G8 buffer holds whole groups of 8 elements (n=%zu)", n); return -1; }
+#define CAP_CV(TT) hipLaunchKernelGGL(convert_kernel<TT>, dim3(grid_for(n, 1024)), dim3(256), 0, s, src, (TT*)dst, n)
+    CAP_DISPATCH_T(dtype, CAP_CV);
+#undef CAP_CV
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-int launch_convert2d(int dtype, const float* src, void* dst, int rows, int cols, int dst_ld, hipStream_t s) {
+int launch_convert2d(int dtype, const float* src, void* dst, int rows, int cols, int dst_ld, hipStream_t s, float scale) {
     const size_t n = (size_t)rows * cols;
-    if (dtype == CAP_DT_BF16)
-        hipLaunchKernelGGL(convert2d_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, (bf16_t*)dst, rows, cols, dst_ld);
-    else
-        hipLaunchKernelGGL(convert2d_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, (float*)dst, rows, cols, dst_ld);
+    if (dtype == CAP_DT_G8 && dst_ld % 8 != 0) { cap_set_error("convert2d: G8 rows need ld %% 8 == 0 (ld=%d)", dst_ld); return -1; }
+#define CAP_CV(TT) hipLaunchKernelGGL(convert2d_kernel<TT>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, (TT*)dst, rows, cols, dst_ld, scale)
+    CAP_DISPATCH_T(dtype, CAP_CV);
+#undef CAP_CV
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-int launch_convert2d_t(int dtype, const float* src, void* dst, int rows, int cols, hipStream_t s) {
+int launch_convert2d_t(int dtype, const float* src, void* dst, int rows, int cols, hipStream_t s, float scale) {
     const size_t n = (size_t)rows * cols;
-    if (dtype == CAP_DT_BF16)
-        hipLaunchKernelGGL(convert2d_t_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, (bf16_t*)dst, rows, cols);
-    else
-        hipLaunchKernelGGL(convert2d_t_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, (float*)dst, rows, cols);
+    if (dtype == CAP_DT_G8 && rows % 8 != 0) { cap_set_error("convert2d_t: G8 rows need ld %% 8 == 0 (ld=%d)", rows); return -1; }
+#define CAP_CV(TT) hipLaunchKernelGGL(convert2d_t_kernel<TT>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, (TT*)dst, rows, cols, scale)
+    CAP_DISPATCH_T(dtype, CAP_CV);
+#undef CAP_CV
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -468,12 +462,9 @@ int launch_patchify(int dtype, const void* pixels, int fmt, int B, int img, int 
     const size_t n = (size_t)B * 3 * img * img;
     const float m0 = mean ? mean[0] : 0.f, m1 = mean ? mean[1] : 0.f, m2 = mean ? mean[2] : 0.f;
     const float s0 = stdv ? stdv[0] : 1.f, s1 = stdv ? stdv[1] : 1.f, s2 = stdv ? stdv[2] : 1.f;
-    if (dtype == CAP_DT_BF16)
-        hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, pixels, fmt, B, img, ps,
-                           Kpad, (bf16_t*)out, m0, m1, m2, s0, s1, s2);
-    else
-        hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, pixels, fmt, B, img, ps,
-                           Kpad, (float*)out, m0, m1, m2, s0, s1, s2);
+#define CAP_PF(TT) hipLaunchKernelGGL(patchify_kernel<TT>, dim3(grid_for(n, 256)), dim3(256), 0, s, pixels, fmt, B, img, ps, Kpad, (TT*)out, m0, m1, m2, s0, s1, s2)
+    CAP_DISPATCH_T(dtype, CAP_PF);
+#undef CAP_PF
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -486,7 +477,7 @@ int launch_cls_rows(const float* cls, const float* pos, float* X, int B, int tok
 
 int launch_layernorm(int dtype, const float* in, int ld_in, const float* gamma, const float* beta, float eps,
                      void* out_t, float* out_f, int M, int D, hipStream_t s) {
-    if (D % 4 != 0 || D > 256 * LN_MAXV || (ld_in % 4) != 0) {
+    if (D % 4 != 0 || D > 256 * LN_MAXV || (ld_in % 4) != 0 || (dtype == CAP_DT_G8 && D % 8 != 0)) {
         cap_set_error("layernorm: unsupported width %d (ld %d)", D, ld_in);
         return -1;
     }
@@ -494,7 +485,7 @@ int launch_layernorm(int dtype, const float* in, int ld_in, const float* gamma, 
     hipLaunchKernelGGL((layernorm_kernel<TT, MV>), dim3((M + 3) / 4), dim3(256), 0, s, in, ld_in, gamma, beta, eps,    \
                        (TT*)out_t, out_f, M, D)
 #define CAP_LN_T(TT) do { if (D <= 1024) CAP_LN(TT, 4); else if (D <= 2048) CAP_LN(TT, 8); else CAP_LN(TT, LN_MAXV); } while (0)
-    if (dtype == CAP_DT_BF16) CAP_LN_T(bf16_t); else CAP_LN_T(float);
+    CAP_DISPATCH_T(dtype, CAP_LN_T);
 #undef CAP_LN_T
 #undef CAP_LN
     CAP_HIP_CHECK(hipGetLastError());
@@ -505,27 +496,21 @@ int launch_reduce_layernorm(int dtype, const void* part, int S, const float* bia
                             const float* gamma, const float* beta, float eps, void* out_t, float* out_f, float* y_out,
                             int M, int D, hipStream_t s, bool per_row_block, bool part_in_t) {
     if (per_row_block && part_in_t) { cap_set_error("reduce_layernorm: the per-row-block kernel takes fp32 partial sums"); return -1; }
-    if (D % 4 != 0 || D > 256 * LN_MAXV || S < 1) { cap_set_error("reduce_layernorm: unsupported width %d / slices %d", D, S); return -1; }
+    if (D % 4 != 0 || D > 256 * LN_MAXV || S < 1 || (dtype == CAP_DT_G8 && D % 8 != 0)) { cap_set_error("reduce_layernorm: unsupported width %d / slices %d", D, S); return -1; }
     // per_row_block: the decoder's choice (a few hundred rows, latency-bound).  The two kernels round differently in the
     // last bit, so the choice is the CALLER's (by path), never the row count's: a frame's result must not depend on the
     // batch it rides in.
     if (per_row_block && D <= 1024) {
-        if (dtype == CAP_DT_BF16)
-            hipLaunchKernelGGL(reduce_layernorm_row_kernel<bf16_t>, dim3(M), dim3(256), 0, s, (const float*)part, S, bias, resid, gamma,
-                               beta, eps, (bf16_t*)out_t, out_f, y_out, M, D);
-        else
-            hipLaunchKernelGGL(reduce_layernorm_row_kernel<float>, dim3(M), dim3(256), 0, s, (const float*)part, S, bias, resid, gamma,
-                               beta, eps, (float*)out_t, out_f, y_out, M, D);
+#define CAP_RR(TT) hipLaunchKernelGGL(reduce_layernorm_row_kernel<TT>, dim3(M), dim3(256), 0, s, (const float*)part, S, bias, resid, gamma, beta, eps, (TT*)out_t, out_f, y_out, M, D)
+        CAP_DISPATCH_T(dtype, CAP_RR);
+#undef CAP_RR
         CAP_HIP_CHECK(hipGetLastError());
         return 0;
     }
     if (per_row_block && D <= 3072) {     // wide rows, decode-sized row count (the caller's choice, as above)
-        if (dtype == CAP_DT_BF16)
-            hipLaunchKernelGGL(reduce_layernorm_wide_kernel<bf16_t>, dim3(M), dim3(256), 0, s, (const float*)part, S, bias, resid, gamma,
-                               beta, eps, (bf16_t*)out_t, out_f, y_out, M, D);
-        else
-            hipLaunchKernelGGL(reduce_layernorm_wide_kernel<float>, dim3(M), dim3(256), 0, s, (const float*)part, S, bias, resid, gamma,
-                               beta, eps, (float*)out_t, out_f, y_out, M, D);
+#define CAP_RW(TT) hipLaunchKernelGGL(reduce_layernorm_wide_kernel<TT>, dim3(M), dim3(256), 0, s, (const float*)part, S, bias, resid, gamma, beta, eps, (TT*)out_t, out_f, y_out, M, D)
+        CAP_DISPATCH_T(dtype, CAP_RW);
+#undef CAP_RW
         CAP_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -537,6 +522,7 @@ int launch_reduce_layernorm(int dtype, const void* part, int S, const float* bia
 #define CAP_RLN_T(TT, PP) do { if (D <= 1024) CAP_RLN(TT, PP, 4); else if (D <= 2048) CAP_RLN(TT, PP, 8); else CAP_RLN(TT, PP, LN_MAXV); } while (0)
     if (dtype == CAP_DT_BF16 && part_in_t) CAP_RLN_T(bf16_t, bf16_t);
     else if (dtype == CAP_DT_BF16) CAP_RLN_T(bf16_t, float);
+    else if (dtype == CAP_DT_G8) CAP_RLN_T(g8_t, float);
     else CAP_RLN_T(float, float);
 #undef CAP_RLN_T
 #undef CAP_RLN
@@ -560,17 +546,16 @@ __global__ __launch_bounds__(256) void reduce_bias_act_kernel(const float* __res
         }
         if (bias) { const float4 b = *(const float4*)(bias + c); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
         if (act == 2) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-        out[e] = from_f32<T>(a.x); out[e + 1] = from_f32<T>(a.y); out[e + 2] = from_f32<T>(a.z); out[e + 3] = from_f32<T>(a.w);
+        store4(out + (e - c), c, a);
     }
 }
 
 int launch_reduce_bias_act(int dtype, const float* part, int S, const float* bias, void* out, int M, int N, int act, hipStream_t s) {
     if (N % 4 != 0) { cap_set_error("reduce_bias_act: N must be a multiple of 4"); return -1; }
     const int grid = (int)std::min<size_t>(((size_t)M * N / 4 + 255) / 256, 2048);
-    if (dtype == CAP_DT_BF16)
-        hipLaunchKernelGGL(reduce_bias_act_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, part, S, bias, (bf16_t*)out, M, N, act);
-    else
-        hipLaunchKernelGGL(reduce_bias_act_kernel<float>, dim3(grid), dim3(256), 0, s, part, S, bias, (float*)out, M, N, act);
+#define CAP_RB(TT) hipLaunchKernelGGL(reduce_bias_act_kernel<TT>, dim3(grid), dim3(256), 0, s, part, S, bias, (TT*)out, M, N, act)
+    CAP_DISPATCH_T(dtype, CAP_RB);
+#undef CAP_RB
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -579,12 +564,9 @@ int launch_embed_tokens(int dtype, const int* ids, int L, const float* word, con
                         const float* gamma, const float* beta, float eps, void* out_t, float* out_f, int R, int D,
                         hipStream_t s) {
     if (D % 4 != 0 || D > 256 * LN_MAXV) { cap_set_error("embed_tokens: unsupported width %d", D); return -1; }
-    if (dtype == CAP_DT_BF16)
-        hipLaunchKernelGGL(embed_tokens_kernel<bf16_t>, dim3((R + 3) / 4), dim3(256), 0, s, ids, L, word, pos, type0, gamma,
-                           beta, eps, (bf16_t*)out_t, out_f, R, D);
-    else
-        hipLaunchKernelGGL(embed_tokens_kernel<float>, dim3((R + 3) / 4), dim3(256), 0, s, ids, L, word, pos, type0, gamma,
-                           beta, eps, (float*)out_t, out_f, R, D);
+#define CAP_ET(TT) hipLaunchKernelGGL(embed_tokens_kernel<TT>, dim3((R + 3) / 4), dim3(256), 0, s, ids, L, word, pos, type0, gamma, beta, eps, (TT*)out_t, out_f, R, D)
+    CAP_DISPATCH_T(dtype, CAP_ET);
+#undef CAP_ET
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -600,12 +582,9 @@ int launch_embed(int dtype, const int* seq, int seq_ld, int t, const float* word
                  const float* gamma, const float* beta, float eps, void* out_t, float* out_f, int R, int D,
                  hipStream_t s, float* y_out) {
     if (D % 4 != 0 || D > 256 * LN_MAXV) { cap_set_error("embed: unsupported width %d", D); return -1; }
-    if (dtype == CAP_DT_BF16)
-        hipLaunchKernelGGL(embed_kernel<bf16_t>, dim3((R + 3) / 4), dim3(256), 0, s, seq, seq_ld, t, word, pos, gamma,
-                           beta, eps, (bf16_t*)out_t, out_f, y_out, R, D);
-    else
-        hipLaunchKernelGGL(embed_kernel<float>, dim3((R + 3) / 4), dim3(256), 0, s, seq, seq_ld, t, word, pos, gamma,
-                           beta, eps, (float*)out_t, out_f, y_out, R, D);
+#define CAP_EM(TT) hipLaunchKernelGGL(embed_kernel<TT>, dim3((R + 3) / 4), dim3(256), 0, s, seq, seq_ld, t, word, pos, gamma, beta, eps, (TT*)out_t, out_f, y_out, R, D)
+    CAP_DISPATCH_T(dtype, CAP_EM);
+#undef CAP_EM
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -19,6 +19,8 @@
 //   gemm_big2_kernel  bf16 256x256 persistent, second generation (the encoder GEMMs): see its header.
 // Edge tiles clamp their load rows and guard their stores.  Workgroup ids are remapped so each XCD (blockIdx % 8) walks
 // a contiguous run of tiles that share A panels in its L2.
+#include <type_traits>
+
 #include "gemm.h"
 #include "ln.h"
 
@@ -47,6 +49,20 @@ template <> struct Mma<float> {
     }
 };
 
+// G8 (split fp16, common.h): a 128-byte slab row holds 32 k values as chunks [H0 L0 H1 L1 H2 L2 H3 L3]; lane (r16, kg)
+// of a 16x16x32 MFMA takes the hi chunk 2 kg and the lo chunk 2 kg + 1 of its row, and every product is three MFMAs in
+// THIS order (all kernels, so a row of C has the same bits whichever tile shape its batch size selects):
+//   acc += a_hi.w_lo;  acc += a_lo.w_hi;  acc += a_hi.w_hi
+template <> struct Mma<g8_t> {
+    using vec = f16x8;
+    static constexpr int EPC = 4;
+    __device__ static __forceinline__ void run(f32x16&, const vec&, const vec&) {}     // (32x32 path unused)
+    __device__ static __forceinline__ void run16(f32x4& acc, const vec& a, const vec& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+    }
+};
+template <typename T> constexpr bool is_g8 = std::is_same<T, g8_t>::value;
+
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // NOT HIP's uint4: its union members defeat SROA and
@@ -56,6 +72,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // NOT HIP's u
 template <typename T, bool OUT_F32, int EPI, bool RESID = true>
 __device__ __forceinline__ void epi_store4(const GemmParams& p, int row, int col, f32x4 v, f32x4 biasv) {
     // bias is loaded once per lane by the caller (it depends on the column only); residual rows are loaded here
+    if constexpr (is_g8<T>) v *= (1.0f / G8_WSCALE);      // weights are stored scaled (common.h): exact power of two
     if (EPI != EPI_PARTIAL) v += biasv;
     if (EPI != EPI_PARTIAL && p.gelu == 1) {   // p.gelu: 1 = exact-erf GELU, 2 = ReLU (OPT).  Two uniform branches: a
 #pragma unroll                                 // per-element select computes the GELU polynomial for ReLU launches too
@@ -101,6 +118,9 @@ __device__ __forceinline__ void epi_store4(const GemmParams& p, int row, int col
     }
     if constexpr (OUT_F32) {
         *(f32x4*)((float*)base + o) = v;
+    } else if constexpr (is_g8<T>) {
+        static_assert(!is_g8<T> || EPI == EPI_STORE || EPI == EPI_PARTIAL, "G8 output exists for plain row-major stores only");
+        store4((g8_t*)base + (o - col), col, make_float4(v[0], v[1], v[2], v[3]));
     } else if constexpr (sizeof(T) == 4) {
         *(f32x4*)((float*)base + o) = v;
     } else {
@@ -165,7 +185,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(G
         db[i] = BM * 128 + swz_off(row, ch);
     }
 
-    constexpr bool B16 = sizeof(T) == 2;                  // bf16: 16x16x32 blocks (see Mma<bf16_t>::run16)
+    constexpr bool G8 = is_g8<T>;
+    constexpr bool B16 = sizeof(T) == 2 || G8;            // bf16 / split fp16: 16x16x32 blocks (see Mma<bf16_t>::run16)
     constexpr int MI16 = WM / 16, NI16 = WN / 16;
     const int r16 = lane & 15, kg = lane >> 4;
     f32x16 acc[B16 ? 1 : MI][B16 ? 1 : NI];
@@ -214,7 +235,27 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(G
             __syncthreads();
             const char* a_s = buf;
             const char* b_s = buf + BM * 128;
-            if constexpr (B16) {
+            if constexpr (G8) {
+                vec ah[MI16], al[MI16], bh[NI16], bl[NI16];
+#pragma unroll
+                for (int i = 0; i < MI16; ++i) {
+                    ah[i] = *(const vec*)(a_s + swz_off(wm0 + i * 16 + r16, 2 * kg));
+                    al[i] = *(const vec*)(a_s + swz_off(wm0 + i * 16 + r16, 2 * kg + 1));
+                }
+#pragma unroll
+                for (int j = 0; j < NI16; ++j) {
+                    bh[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, 2 * kg));
+                    bl[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, 2 * kg + 1));
+                }
+#pragma unroll
+                for (int i = 0; i < MI16; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI16; ++j) {
+                        Mma<g8_t>::run16(acc16[i][j], ah[i], bl[j]);
+                        Mma<g8_t>::run16(acc16[i][j], al[i], bh[j]);
+                        Mma<g8_t>::run16(acc16[i][j], ah[i], bh[j]);
+                    }
+            } else if constexpr (B16) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     vec af[MI16], bf[NI16];
@@ -528,10 +569,9 @@ __device__ __forceinline__ void epi_store_f32(const GemmParams& p, int row, int 
 // consecutive columns per lane" into "16 consecutive bytes per lane, 8 lanes per 128-byte row": every global store
 // instruction writes 8 whole cache lines.  The strip is outside the stage buffers, so no barrier is involved.
 // bias_w: LDS address of the fp32 bias of this wave's first column (nullptr: none).
-template <bool OUT_F32, int EPI, int MI, int NI>
+template <typename T, bool OUT_F32, int EPI, int MI, int NI>
 __device__ __forceinline__ void big2_epilogue(const GemmParams& p, const f32x4 (&acc)[MI][NI], char* strip,
                                               const char* bias_w, int row0, int col0, int lane) {
-    using T = bf16_t;
     const int r16 = lane & 15, kg = lane >> 4;
     const int act = EPI != EPI_PARTIAL ? p.gelu : 0;     // uniform: 1 = exact-erf GELU, 2 = ReLU
     f32x4 biasv[NI];
@@ -539,7 +579,9 @@ __device__ __forceinline__ void big2_epilogue(const GemmParams& p, const f32x4 (
     for (int j = 0; j < NI; ++j) biasv[j] = bias_w ? *(const f32x4*)(bias_w + (j * 16 + 4 * kg) * 4) : f32x4(0.f);
     const int srow = lane >> 3, spiece = lane & 7;
     constexpr bool F32OUT = OUT_F32 || EPI == EPI_PARTIAL || EPI == EPI_PATCH;
-    constexpr int NPB = F32OUT ? 2 : 4;                 // 16-column blocks per 128-byte strip row
+    constexpr bool G8OUT = !F32OUT && is_g8<T>;         // 4 bytes per element like fp32: 32 columns = four [hi | lo] groups
+    static_assert(!G8OUT || EPI == EPI_STORE, "G8 output exists for plain row-major stores only");
+    constexpr int NPB = (F32OUT || G8OUT) ? 2 : 4;      // 16-column blocks per 128-byte strip row
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -548,6 +590,7 @@ __device__ __forceinline__ void big2_epilogue(const GemmParams& p, const f32x4 (
             for (int jj = 0; jj < NPB; ++jj) {
                 const int j = jp * NPB + jj;
                 f32x4 v = acc[i][j];
+                if constexpr (is_g8<T>) v *= (1.0f / G8_WSCALE);
                 if (EPI != EPI_PARTIAL) v += biasv[j];
                 if (act == 1) {
 #pragma unroll
@@ -558,6 +601,8 @@ __device__ __forceinline__ void big2_epilogue(const GemmParams& p, const f32x4 (
                 }
                 if constexpr (F32OUT) {
                     *(f32x4*)(strip + r16 * 144 + (jj * 16 + 4 * kg) * 4) = v;
+                } else if constexpr (G8OUT) {
+                    store4((g8_t*)(strip + r16 * 144), jj * 16 + 4 * kg, make_float4(v[0], v[1], v[2], v[3]));
                 } else {
                     bf16x4 w;
 #pragma unroll
@@ -572,6 +617,12 @@ __device__ __forceinline__ void big2_epilogue(const GemmParams& p, const f32x4 (
                     const f32x4 v = *(const f32x4*)(strip + (rr * 8 + srow) * 144 + spiece * 16);
                     const int col = col0 + jp * 32 + spiece * 4;
                     if (row < p.M && col < p.N) epi_store_f32<EPI>(p, row, col, v);
+                } else if constexpr (G8OUT) {
+                    // the strip row is the 128-byte image of 32 G8 elements: copy it out as it is (N % 8 == 0: a group's
+                    // two 16-byte pieces are inside or outside together)
+                    const u32x4 raw = *(const u32x4*)(strip + (rr * 8 + srow) * 144 + spiece * 16);
+                    const int col = col0 + jp * 32 + spiece * 4;
+                    if (row < p.M && col < p.N) epi_store_raw<T, EPI>(p, row, col, raw, true);
                 } else {
                     const u32x4 raw = *(const u32x4*)(strip + (rr * 8 + srow) * 144 + spiece * 16);
                     const int col = col0 + jp * 64 + spiece * 8;
@@ -598,16 +649,17 @@ __device__ __forceinline__ void big2_epilogue(const GemmParams& p, const f32x4 (
 //     does not wait for those stores.
 // VAR: 0 compiler schedule, 1 iglp_opt(0), 2 iglp_opt(1); PROF: cycle stamps to p.aux (diagnostic build only).
 // (Cache-policy A/B on MI355X: non-temporal A loads -5..-20 %, non-temporal C stores within noise - neither kept.)
-template <bool OUT_F32, int EPI, int VAR, bool PROF, int NWM = 2, int NWN = 4>
+// T = g8_t (split fp16): the same pipeline with 32 k values per 64 KiB stage ([hi | lo] chunk pairs) and three MFMAs per
+// product (see Mma<g8_t>); per stage and wave 96 MFMAs against 24 ds_read_b128.
+template <typename T, bool OUT_F32, int EPI, int VAR, bool PROF, int NWM = 2, int NWN = 4>
 __global__ __launch_bounds__(NWM * NWN * 64, NWM * NWN == 8 ? 2 : 1) void gemm_big2_kernel(GemmParams p) {
-    using T = bf16_t;
-    using vec = bf16x8;
+    using vec = typename Mma<T>::vec;
     // wave grid NWM x NWN over the 256x256 tile: 2x4 = two waves per SIMD, 128x64 each (shipped).  2x2 = one wave per
     // SIMD with 128x128 each (256 accumulator registers, a third less LDS read traffic per flop) measured 7-25 % SLOWER
     // with the compiler's schedule (212 B/lane of scratch at 512 registers), so it is not instantiated.
     constexpr int BM = 256, BN = 256, NW = NWM * NWN, WM = BM / NWM, WN = BN / NWN, MI = WM / 16, NI = WN / 16;
     constexpr int PPW = 32 / NW;                         // 8-row DMA pieces of A (and of W) per wave per slab
-    constexpr int EPC = 8, STAGE = (BM + BN) * 128;      // 64 KiB
+    constexpr int EPC = Mma<T>::EPC, STAGE = (BM + BN) * 128;      // 64 KiB
     constexpr int SCHED = VAR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -616,7 +668,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, NWM * NWN == 8 ? 2 : 1) void gemm_b
     const int wm0 = (wave / NWN) * WM, wn0 = (wave % NWN) * WN;
     const int r16 = lane & 15, kg = lane >> 4;
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
-    const int nk = p.K >> 6;
+    const int nk = p.K / (8 * EPC);
 
     const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
     const int nl = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
@@ -705,25 +757,45 @@ __global__ __launch_bounds__(NWM * NWN * 64, NWM * NWN == 8 ? 2 : 1) void gemm_b
             const char* b_s = a_s + BM * 128;
             if constexpr (SCHED == 1) __builtin_amdgcn_iglp_opt(0);
             if constexpr (SCHED == 2) __builtin_amdgcn_iglp_opt(1);
+            if constexpr (is_g8<T>) {
+                vec bh[NI], bl[NI];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                vec af[MI], bf[NI];
+                for (int j = 0; j < NI; ++j) {
+                    bh[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, 2 * kg));
+                    bl[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, 2 * kg + 1));
+                }
 #pragma unroll
-                for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, ks * 4 + kg));
+                for (int i = 0; i < MI; ++i) {
+                    const vec ah = *(const vec*)(a_s + swz_off(wm0 + i * 16 + r16, 2 * kg));
+                    const vec al = *(const vec*)(a_s + swz_off(wm0 + i * 16 + r16, 2 * kg + 1));
 #pragma unroll
-                for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz_off(wm0 + i * 16 + r16, ks * 4 + kg));
+                    for (int j = 0; j < NI; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah, acc[i][j], 0, 0, 0);
+                    }
+                }
+            } else {
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                for (int ks = 0; ks < 2; ++ks) {
+                    vec af[MI], bf[NI];
 #pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, ks * 4 + kg));
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz_off(wm0 + i * 16 + r16, ks * 4 + kg));
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                }
             }
         }
         // This wave's pieces of the next tile's first slab (issued one slab ago) have landed - checked now, before the
         // epilogue stores enter the same in-order counter.
         const long long prof_e0 = PROF ? clock64() : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        big2_epilogue<OUT_F32, EPI, MI, NI>(p, acc, smem + 2 * STAGE + 2048 + wave * (16 * 144),
+        big2_epilogue<T, OUT_F32, EPI, MI, NI>(p, acc, smem + 2 * STAGE + 2048 + wave * (16 * 144),
                                             has_bias ? bias_lds + (tcount & 1) * 1024 + wn0 * 4 : nullptr, m0 + wm0, n0 + wn0, lane);
         if (tile + nl < c1) {
             // every wave is done reading the last slab's stage buffer and the bias slot, and has seen its own pieces of
@@ -889,7 +961,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big3_kernel(GemmParams p) {
         // bias goes to the other slot now (one operation per wave, see issue_bias)
         if (tile + nl < c1) issue_bias(tile + nl, (tcount + 1) & 1);
         else issue_bias(tile, (tcount + 1) & 1);
-        big2_epilogue<OUT_F32, EPI, MI, NI>(p, acc, smem + 4 * HSTAGE + 2048 + 8 * 1024 + 2048 + wave * (16 * 144),
+        big2_epilogue<bf16_t, OUT_F32, EPI, MI, NI>(p, acc, smem + 4 * HSTAGE + 2048 + 8 * 1024 + 2048 + wave * (16 * 144),
                                             has_bias ? bias_lds + (tcount & 1) * 1024 + wn0 * 4 : nullptr, m0 + wm0, n0 + wn0, lane);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the dummy groups before the LDS goes away
@@ -909,10 +981,10 @@ int launch_big3(const GemmParams& p, hipStream_t stream) {
     return 0;
 }
 
-template <bool OUT_F32, int EPI, int VAR, bool PROF, int NWM = 2, int NWN = 4>
+template <typename T, bool OUT_F32, int EPI, int VAR, bool PROF, int NWM = 2, int NWN = 4>
 int launch_big2(const GemmParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 512 * 128 + 2 * 1024 + 8 * 16 * 144;   // two stages + bias ping-pong + epilogue strips
-    auto kern = gemm_big2_kernel<OUT_F32, EPI, VAR, PROF, NWM, NWN>;
+    auto kern = gemm_big2_kernel<T, OUT_F32, EPI, VAR, PROF, NWM, NWN>;
     int n_cu = 0;
     if (cap_kernel_setup((const void*)kern, LDS, &n_cu) != 0) return -1;
     const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
@@ -951,21 +1023,30 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
 
 template <typename T, bool OUT_F32, int EPI>
 int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
+    if (tile >= 10 && tile <= 12) {
+        if constexpr (is_g8<T>) {
+            if (p.K >= 64 && !p.resid) {
+                if (tile == 10) return launch_big2<T, OUT_F32, EPI, 0, false>(p, stream);
+                if (tile == 11) return launch_big2<T, OUT_F32, EPI, 1, false>(p, stream);
+                return launch_big2<T, OUT_F32, EPI, 2, false>(p, stream);
+            }
+        }
+    }
     if (tile >= 10 && tile <= 15) {                     // second-generation kernel (bf16): A/B ids, 13 = instrumented
         if constexpr (sizeof(T) == 2) {
             if (p.K >= 128 && !p.resid) {
-                if (tile == 10) return launch_big2<OUT_F32, EPI, 0, false>(p, stream);
-                if (tile == 11) return launch_big2<OUT_F32, EPI, 1, false>(p, stream);
-                if (tile == 12) return launch_big2<OUT_F32, EPI, 2, false>(p, stream);
+                if (tile == 10) return launch_big2<T, OUT_F32, EPI, 0, false>(p, stream);
+                if (tile == 11) return launch_big2<T, OUT_F32, EPI, 1, false>(p, stream);
+                if (tile == 12) return launch_big2<T, OUT_F32, EPI, 2, false>(p, stream);
                 if (tile == 14) return launch_big3<OUT_F32, EPI>(p, stream);
                 if (tile == 15) return launch_big3<OUT_F32, EPI, 1>(p, stream);
-                if constexpr (!OUT_F32 && EPI == EPI_STORE) return launch_big2<OUT_F32, EPI, 2, true>(p, stream);
+                if constexpr (!OUT_F32 && EPI == EPI_STORE) return launch_big2<T, OUT_F32, EPI, 2, true>(p, stream);
             }
         }
         tile = 3;
     }
     if (tile == 9) {                                    // instrumented main loop: per-wave cycle counts to p.aux
-        if constexpr (sizeof(T) == 2 && !OUT_F32 && EPI == EPI_STORE) return launch_big<T, OUT_F32, EPI, 4>(p, stream);
+        if constexpr (sizeof(T) == 2 && !is_g8<T> && !OUT_F32 && EPI == EPI_STORE) return launch_big<T, OUT_F32, EPI, 4>(p, stream);
         tile = 3;
     }
     if ((tile == 3 || tile == 5) && p.resid) tile = 4;  // the LDS-DMA kernels have no residual operand
@@ -974,14 +1055,19 @@ int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
         // with the MFMAs (A/B: tools/gemm_cycles.py, profiles/)
         if constexpr (sizeof(T) == 2) {
             if (p.K >= 128 && p.K <= 1024) return launch_big3<OUT_F32, EPI>(p, stream);   // short K: see gemm_big3_kernel
-            if (p.K >= 128) return launch_big2<OUT_F32, EPI, 2, false>(p, stream);
+            if (p.K >= 128) return launch_big2<T, OUT_F32, EPI, 2, false>(p, stream);
             return launch_big<T, OUT_F32, EPI, 3>(p, stream);
+        } else if constexpr (is_g8<T>) {
+            // split fp16: the second-generation pipeline with 32 k per stage.  10 / 11 / 12 pick the schedule for A/B runs.
+            if (p.K >= 64) return launch_big2<T, OUT_F32, EPI, 0, false>(p, stream);
+            return launch_cfg<T, 256, 256, 128, 64, 1, 2, OUT_F32, EPI>(p, stream);
         } else {
             return launch_big<T, OUT_F32, EPI, 0>(p, stream);
         }
     }
     if (tile == 5) {                                    // first-generation kernel, kept for A/B
         if constexpr (sizeof(T) == 2) return launch_big<T, OUT_F32, EPI, 3>(p, stream);
+        else if constexpr (is_g8<T>) return launch_big2<T, OUT_F32, EPI, 0, false>(p, stream);
         else return launch_big<T, OUT_F32, EPI, 0>(p, stream);
     }
     if (tile == 4) return launch_cfg<T, 256, 256, 128, 64, 1, 2, OUT_F32, EPI>(p, stream);
@@ -1006,8 +1092,8 @@ int launch_t(const GemmParams& p, int tile, hipStream_t stream) {
             return p.out_f32 ? launch_tile<T, true, EPI_STORE>(p, tile, nk, stream)
                              : launch_tile<T, false, EPI_STORE>(p, tile, nk, stream);
         case EPI_PATCH: return launch_tile<T, true, EPI_PATCH>(p, tile, nk, stream);
-        case EPI_CROSSKV: return launch_tile<T, false, EPI_CROSSKV>(p, tile, nk, stream);
-        case EPI_QKVCACHE: return launch_tile<T, false, EPI_QKVCACHE>(p, tile, nk, stream);
+        case EPI_CROSSKV: return launch_tile<T, is_g8<T>, EPI_CROSSKV>(p, tile, nk, stream);     // split mode: the K/V caches
+        case EPI_QKVCACHE: return launch_tile<T, is_g8<T>, EPI_QKVCACHE>(p, tile, nk, stream);   // are fp32
     }
     cap_set_error("launch_gemm: unknown epilogue %d", p.epi);
     return -1;
@@ -1018,6 +1104,11 @@ int launch_t(const GemmParams& p, int tile, hipStream_t stream) {
 int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream) {
     const int slab = dtype == CAP_DT_BF16 ? 64 : 32;
     const int esz = dtype == CAP_DT_BF16 ? 2 : 4;
+    if (dtype == CAP_DT_G8 && (p.lda % 8 != 0 || p.ldw % 8 != 0 || (p.epi == EPI_STORE && !p.out_f32 && (p.N % 8 != 0 || p.ldc % 8 != 0)))) {
+        cap_set_error("launch_gemm: G8 operands need lda / ldw (and N / ldc of a G8 output) to be multiples of 8 (lda=%d ldw=%d N=%d ldc=%d)",
+                      p.lda, p.ldw, p.N, p.ldc);
+        return -1;
+    }
     if (p.epi == EPI_PARTIAL && (p.splitk < 1 || p.K % (slab * p.splitk) != 0)) {
         cap_set_error("launch_gemm: split-K %d does not divide K=%d into whole %d-element slabs", p.splitk, p.K, slab);
         return -1;
@@ -1056,6 +1147,7 @@ int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream) {
     }
     if (dtype == CAP_DT_BF16) return launch_t<bf16_t>(p, tile, stream);
     if (dtype == CAP_DT_F32) return launch_t<float>(p, tile, stream);
+    if (dtype == CAP_DT_G8) return launch_t<g8_t>(p, tile, stream);
     cap_set_error("launch_gemm: unknown dtype %d", dtype);
     return -1;
 }

@@ -33,10 +33,7 @@ __device__ __forceinline__ void ln_row(const float4 (&v)[MAXV], int nv, int lane
             o.x = (v[i].x - mean) * rstd * g.x + bb.x; o.y = (v[i].y - mean) * rstd * g.y + bb.y;
             o.z = (v[i].z - mean) * rstd * g.z + bb.z; o.w = (v[i].w - mean) * rstd * g.w + bb.w;
             if (out_f) *(float4*)(out_f + c) = o;
-            if (out_t) {
-                out_t[c] = from_f32<T>(o.x); out_t[c + 1] = from_f32<T>(o.y);
-                out_t[c + 2] = from_f32<T>(o.z); out_t[c + 3] = from_f32<T>(o.w);
-            }
+            if (out_t) store4(out_t, c, o);
         }
     }
 }

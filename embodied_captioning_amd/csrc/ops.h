@@ -6,9 +6,9 @@
 // ---- elementwise.hip -------------------------------------------------------------------------
 // fp32 -> T copy (weight upload / activation cast); dst rows may be padded: dst[r*dst_ld + c] = src[r*cols + c]
 int launch_convert(int dtype, const float* src, void* dst, size_t n, hipStream_t s);
-int launch_convert2d(int dtype, const float* src, void* dst, int rows, int cols, int dst_ld, hipStream_t s);
+int launch_convert2d(int dtype, const float* src, void* dst, int rows, int cols, int dst_ld, hipStream_t s, float scale = 1.0f);
 // dst[cols][rows] = src[rows][cols]^T
-int launch_convert2d_t(int dtype, const float* src, void* dst, int rows, int cols, hipStream_t s);
+int launch_convert2d_t(int dtype, const float* src, void* dst, int rows, int cols, hipStream_t s, float scale = 1.0f);
 // im2col-free patch gather: pixels -> A[B*P, Kpad] (T).  fmt 0: fp32 NCHW normalised; fmt 1: u8 NHWC raw RGB,
 // normalised on the fly with (x/255 - mean[c]) / std[c].
 int launch_patchify(int dtype, const void* pixels, int fmt, int B, int img, int ps, int Kpad, void* out,
@@ -45,7 +45,8 @@ int launch_copy_f32(const float* src, float* dst, size_t n, hipStream_t s);
 // ViT self-attention over a fused qkv buffer [B*N, 3*H*64] (T) -> ctx [B*N, H*64] (T); scale = 1/8.
 // impl 0 = auto (MFMA for bf16 when N <= 256, scalar otherwise), 1 = scalar, 2 = MFMA.
 int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s, int head_dim = 64,
-                         int causal = 0);   // causal: query i sees keys 0..i (decoder prefill over fused q|k|v rows)
+                         int causal = 0,    // causal: query i sees keys 0..i (decoder prefill over fused q|k|v rows)
+                         int out_dtype = -1);   // type of ctx when it differs from qkv's (split mode: fp32 in, G8 out)
 int launch_generic_attention(int dtype, const void* q, long ldq, long qbs, const void* k, long ldk, long kbs, const void* v,
                              long ldv, long vbs, void* out, long ldo, long obs, int B, int Lq, int Lk, int H, int hd,
                              int causal_off, hipStream_t s);
@@ -68,7 +69,7 @@ int launch_rows_broadcast(int dtype, const float* src, float* dst_f, void* dst_t
 int launch_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             hipStream_t s, const float* q_part = nullptr, int q_S = 0, const float* q_bias = nullptr,
-                            int q_ld = 0, int q_col0 = 0, int append_kv = 0);
+                            int q_ld = 0, int q_col0 = 0, int append_kv = 0, int out_dtype = -1);   // out_dtype: see launch_vit_attention
 
 // attentional pooler (CoCa): fixed projected queries qp fp32 [Q, E] shared by every image; kv (T) [B*N, 2E] with K in
 // columns [0,E) and V in [E,2E); heads of E/heads dims (64 or 96); out (T) [B*Q, E].  scale = 1/sqrt(head_dim).

@@ -39,14 +39,22 @@ extern "C" {
 typedef struct CapHandle_s* CapHandle;
 
 enum { CAP_ARCH_BLIP = 0, CAP_ARCH_COCA = 1, CAP_ARCH_MINILM = 2, CAP_ARCH_BLIP2 = 3 };
-enum { CAP_F32 = 0, CAP_BF16 = 1 };              /* arithmetic type of the GEMM/attention operands (accumulate: fp32) */
+/* Arithmetic of the GEMM / attention operands (accumulation is fp32 in every mode):
+ *   CAP_F32        fp32 operands, exact fp32 products on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32)
+ *   CAP_BF16       bf16 operands on the bf16 MFMA pipe - fastest, but not token-identical to an fp32 reference
+ *   CAP_F32_SPLIT  fp32 values carried into every GEMM as two fp16 halves (hi + lo = x to 2^-23), each product formed as
+ *                  hi.hi + hi.lo + lo.hi on the fp16 MFMA pipe: products good to ~2^-21 (fp32: 2^-24, bf16: 2^-9) at 3/16
+ *                  of the fp32 pipe's cost; LayerNorm, softmax, attention, residual stream and K/V caches are fp32 as in
+ *                  CAP_F32.  Token-identical to the fp32 reference on every golden fixture; the default of the plugin and
+ *                  of bench.py.  CAP_ARCH_BLIP only. */
+enum { CAP_F32 = 0, CAP_BF16 = 1, CAP_F32_SPLIT = 2 };
 enum { CAP_PIX_F32_NCHW = 0, CAP_PIX_U8_NHWC = 1 }; /* normalised fp32 [B,3,H,W] | raw RGB uint8 [B,H,W,3] */
 
 typedef struct CapConfig {
     int32_t struct_size;          /* sizeof(CapConfig), for ABI checking */
     int32_t arch;                 /* CAP_ARCH_BLIP | CAP_ARCH_COCA | CAP_ARCH_MINILM (sentence encoder: only the t_* / vocab /
                                      max_pos / max_batch / max_len fields are read; max_len = tokens per sentence) */
-    int32_t compute_dtype;        /* CAP_F32 (strict parity) | CAP_BF16 (MFMA bf16 in, fp32 accumulate) */
+    int32_t compute_dtype;        /* CAP_F32 | CAP_BF16 | CAP_F32_SPLIT (see the enum) */
     /* vision tower */
     int32_t image_size, patch_size, v_hidden, v_layers, v_heads, v_mlp;
     float v_eps;
@@ -150,7 +158,10 @@ size_t cap_device_bytes(CapHandle h);
 int cap_profile_enable(CapHandle h, int on);
 int cap_profile_report(CapHandle h, char* buf, size_t buf_bytes);
 
-/* ---- single-kernel entry points (used by tests/ to check each kernel against a plain reference) ---- */
+/* ---- single-kernel entry points (used by tests/ to check each kernel against a plain reference) ----
+ * dtype CAP_F32_SPLIT follows the mode's convention: GEMM operands (A, W, and a non-fp32 C) and the outputs of kernels that
+ * feed a GEMM (layernorm out_t, attention ctx / out) are G8 = 4 bytes per element, every 8 consecutive elements of a row
+ * stored as [8 fp16 hi | 8 fp16 lo]; q|k|v, caches and partial sums are fp32. */
 int cap_op_gemm(int dtype, const void* A, const void* W, const float* bias, const float* resid, void* C, int M, int N,
                 int K, int gelu, int out_f32, int tile, void* stream);
 int cap_op_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps, void* out_t,
@@ -175,6 +186,9 @@ int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const v
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             void* stream);
 int cap_op_convert(int dtype, const float* src, void* dst, size_t n, void* stream);
+/* Weight upload as cap_load_weight does it: dst [rows, cols] in the GEMM-operand type of `dtype` (CAP_F32_SPLIT: G8 halves of
+ * 4096 * w - the split GEMM's epilogue divides by 4096; a G8 buffer is 4 bytes per element, cols % 8 == 0). */
+int cap_op_convert_weight(int dtype, const float* src, void* dst, int rows, int cols, void* stream);
 
 #ifdef __cplusplus
 }

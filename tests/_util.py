@@ -64,3 +64,25 @@ def token_parity(ours, ref, margins, tau):
         exact += row_ok
         diverged += (not row_ok)
     return exact, diverged, first_bad
+
+
+# ---- G8: the GEMM-operand layout of the split-fp16 mode (embodied_captioning_amd/csrc/common.h) ----------------------
+G8_WSCALE = 4096.0
+
+
+def g8_encode(x, scale=1.0):
+    """fp32 [..., K] (K % 8 == 0) -> float32-typed container of the same shape whose bytes are the G8 image: every 8
+    consecutive elements of a row = [8 fp16 hi | 8 fp16 lo], hi = rn16(s x), lo = rn16(s x - hi)."""
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float32)) * np.float32(scale)
+    assert x.shape[-1] % 8 == 0
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    g = np.stack([hi.reshape(*x.shape[:-1], -1, 8), lo.reshape(*x.shape[:-1], -1, 8)], axis=-2)   # [..., K/8, 2, 8]
+    return np.ascontiguousarray(g).view(np.float32).reshape(x.shape)
+
+
+def g8_decode(c, scale=1.0):
+    """Inverse of g8_encode: container (float32-typed, [..., K]) -> the fp32 values hi + lo (divided by scale)."""
+    c = np.ascontiguousarray(np.asarray(c, dtype=np.float32))
+    h = c.view(np.float16).reshape(*c.shape[:-1], -1, 2, 8).astype(np.float32)
+    return ((h[..., 0, :] + h[..., 1, :]) / np.float32(scale)).reshape(c.shape)

@@ -1,0 +1,194 @@
+"""GPU: the split-fp16 mode (CAP_F32_SPLIT, dtype "f32s") kernel by kernel, through the C ABI.
+
+Every GEMM operand is G8 (two fp16 halves per fp32 value, tests/_util.g8_encode); a product is hi.hi + hi.lo + lo.hi on
+the fp16 MFMA pipe with fp32 accumulation.  The claims checked here: (1) the GEMM is as accurate as the fp32-MFMA GEMM
+against an fp64 reference of the ORIGINAL fp32 operands (tolerance 1e-5 on O(1) outputs - bf16 misses it by 3 orders);
+(2) every tile shape gives the same bits (batch invariance); (3) the kernels that feed a GEMM write correct G8."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from _util import G8_WSCALE, g8_decode, g8_encode
+
+SPLIT = 2
+gpu = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from embodied_captioning_amd import _native
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _native.load_library()
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check(lib, rc):
+    assert rc == 0, lib.cap_last_error().decode()
+
+
+def _g8(x, scale=1.0):
+    return torch.from_numpy(g8_encode(x.numpy(), scale)).cuda()
+
+
+def test_g8_container_round_trips_on_the_host():
+    x = (np.random.default_rng(0).standard_normal((5, 64)) * np.logspace(-6, 3, 64)).astype(np.float32)
+    back = g8_decode(g8_encode(x))
+    # 2^-22 relative while the lo half is a normal fp16 number; below that the absolute error is half an fp16 subnormal step
+    assert np.all(np.abs(back - x) <= np.maximum(np.abs(x) * 2.0 ** -22, 2.0 ** -25))
+    wb = g8_decode(g8_encode(x * 1e-3, G8_WSCALE), G8_WSCALE)         # weights travel scaled by 4096
+    assert np.all(np.abs(wb - x * 1e-3) <= np.maximum(np.abs(x * 1e-3) * 2.0 ** -22, 2.0 ** -25 / G8_WSCALE))
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("shape", [(256, 256, 128), (197, 768, 768), (300, 200, 192), (33, 7632, 64), (1, 64, 64), (520, 516, 3072),
+                                   (2000, 2304, 768)])
+@gpu
+def test_split_gemm_is_fp32_grade(lib, tile, shape):
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    Ad, Wd, bd = _g8(A), _g8(W, G8_WSCALE), bias.cuda()
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    _check(lib, lib.cap_op_gemm(SPLIT, _p(Ad), _p(Wd), _p(bd), _p(None), _p(out), M, N, K, 0, 1, tile, _stream()))
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double().T + bias.double()          # the ORIGINAL fp32 operands, not their split images
+    assert torch.isfinite(out).all()
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 1e-5 * math.sqrt(max(K, 256) / 256), err
+    # the exact-product fp32 MFMA kernel on the same operands is no closer than a factor of a few
+    o32 = torch.empty_like(out)
+    _check(lib, lib.cap_op_gemm(0, _p(A.cuda()), _p(W.cuda()), _p(bd), _p(None), _p(o32), M, N, K, 0, 1, 0, _stream()))
+    torch.cuda.synchronize()
+    e32 = (o32.cpu().double() - ref).abs().max().item()
+    assert err < 8 * e32 + 2e-6, (err, e32)
+
+
+@gpu
+def test_split_gemm_tiles_are_bit_identical(lib):
+    """Batch invariance: the tile shape follows the row count, so every tile shape must produce the same bits."""
+    M, N, K = 520, 768, 768
+    g = torch.Generator().manual_seed(3)
+    Ad, Wd = _g8(torch.randn(M, K, generator=g)), _g8(torch.randn(N, K, generator=g) / math.sqrt(K), G8_WSCALE)
+    bd = torch.randn(N, generator=g).cuda()
+    outs = []
+    for tile in (1, 2, 3, 4, 10, 11, 12):
+        o = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        _check(lib, lib.cap_op_gemm(SPLIT, _p(Ad), _p(Wd), _p(bd), _p(None), _p(o), M, N, K, 0, 1, tile, _stream()))
+        outs.append(o)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+
+
+@gpu
+@pytest.mark.parametrize("tile", [0, 2, 3])
+def test_split_gemm_gelu_into_g8_output(lib, tile):
+    M, N, K = 600, 3072, 256
+    g = torch.Generator().manual_seed(11)
+    A, W, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    Ad, Wd, bd = _g8(A), _g8(W, G8_WSCALE), bias.cuda()
+    out = torch.zeros(M, N, dtype=torch.float32, device="cuda")          # G8 container
+    _check(lib, lib.cap_op_gemm(SPLIT, _p(Ad), _p(Wd), _p(bd), _p(None), _p(out), M, N, K, 1, 0, tile, _stream()))
+    torch.cuda.synchronize()
+    want = torch.nn.functional.gelu(A.double() @ W.double().T + bias.double())
+    got = torch.from_numpy(g8_decode(out.cpu().numpy())).double()
+    assert (got - want).abs().max().item() < 1e-5
+
+
+@gpu
+def test_split_gemm_rejects_rows_that_break_groups(lib):
+    """A G8 row is whole groups of 8 elements: a G8 output 68 columns wide cannot exist (an fp32 output can)."""
+    a = torch.zeros(68, 96, device="cuda")
+    c = torch.zeros(68, 68, device="cuda")
+    assert lib.cap_op_gemm(SPLIT, _p(a), _p(a), _p(None), _p(None), _p(c), 68, 68, 96, 0, 1, 0, _stream()) == 0
+    rc = lib.cap_op_gemm(SPLIT, _p(a), _p(a), _p(None), _p(None), _p(c), 68, 68, 96, 0, 0, 0, _stream())
+    assert rc != 0 and b"multiples of 8" in lib.cap_last_error()
+    torch.cuda.synchronize()
+
+
+@gpu
+def test_device_converts_equal_the_host_encoding(lib):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(37, 200, generator=g) * torch.logspace(-5, 2, 200)
+    d = torch.zeros(37, 200, dtype=torch.float32, device="cuda")
+    _check(lib, lib.cap_op_convert(SPLIT, _p(x.cuda()), _p(d), x.numel(), _stream()))
+    w = torch.zeros(37, 200, dtype=torch.float32, device="cuda")
+    _check(lib, lib.cap_op_convert_weight(SPLIT, _p(x.cuda()), _p(w), 37, 200, _stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), g8_encode(x.numpy()).view(np.uint32))
+    assert np.array_equal(w.cpu().numpy().view(np.uint32), g8_encode(x.numpy(), G8_WSCALE).view(np.uint32))
+
+
+@gpu
+@pytest.mark.parametrize("D", [128, 768, 1024])
+def test_layernorm_writes_g8(lib, D):
+    M = 131
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(M, D, generator=g) * 3 + 1
+    gamma, beta = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    xd, gd, bd = x.cuda(), gamma.cuda(), beta.cuda()
+    out_t = torch.zeros(M, D, dtype=torch.float32, device="cuda")
+    out_f = torch.zeros(M, D, dtype=torch.float32, device="cuda")
+    _check(lib, lib.cap_op_layernorm(SPLIT, _p(xd), _p(gd), _p(bd), C.c_float(1e-5), _p(out_t), _p(out_f), M, D, _stream()))
+    torch.cuda.synchronize()
+    # the G8 image holds exactly the fp32 output to 2^-23
+    got = g8_decode(out_t.cpu().numpy())
+    f = out_f.cpu().numpy()
+    assert np.max(np.abs(got - f)) <= np.max(np.abs(f)) * 2.0 ** -21
+    assert (out_f.cpu() - torch.nn.functional.layer_norm(x, (D,), gamma, beta, 1e-5)).abs().max().item() < 2e-5
+
+
+def _attn_ref(qkv, B, N, H):
+    D = H * 64
+    x = qkv.double().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (x[0] @ x[1].transpose(-1, -2)) * 0.125
+    return (torch.softmax(s, -1) @ x[2]).permute(0, 2, 1, 3).reshape(B * N, D)
+
+
+@gpu
+@pytest.mark.parametrize("N", [17, 197, 257, 577])
+@pytest.mark.parametrize("mode", ["f32", "split"])
+def test_vit_attention_fp32_mfma(lib, N, mode):
+    """fp32 q|k|v in; dtype 0: fp32 context (the fp32 MFMA kernel for 1 / 7 / 9 key blocks, the scalar one otherwise),
+    dtype 2: G8 context."""
+    B, H = 3, 4
+    g = torch.Generator().manual_seed(N)
+    qkv = torch.randn(B * N, 3 * H * 64, generator=g) * 1.5
+    ctx = torch.full((B * N, H * 64), float("nan"), dtype=torch.float32, device="cuda")
+    qd = qkv.cuda()
+    _check(lib, lib.cap_op_vit_attention(SPLIT if mode == "split" else 0, _p(qd), _p(ctx), B, N, H, 0, _stream()))
+    torch.cuda.synchronize()
+    got = ctx.cpu().numpy()
+    if mode == "split":
+        got = g8_decode(got)
+    err = np.abs(got.astype(np.float64) - _attn_ref(qkv, B, N, H).numpy()).max()
+    assert err < 1e-5, err
+
+
+@gpu
+def test_decode_attention_writes_g8(lib):
+    R, H, n_keys, kv_ld = 24, 12, 197, 197
+    g = torch.Generator().manual_seed(9)
+    q = torch.randn(R, H * 64, generator=g)
+    k = torch.randn(R, H, kv_ld, 64, generator=g)
+    v = torch.randn(R, H, kv_ld, 64, generator=g)
+    out = torch.zeros(R, H * 64, dtype=torch.float32, device="cuda")
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    _check(lib, lib.cap_op_decode_attention(SPLIT, _p(qd), _p(kd), _p(vd), _p(None), 0, 1, kv_ld, n_keys, _p(out), R, H, 0, _stream()))
+    torch.cuda.synchronize()
+    s = torch.einsum("rhd,rhkd->rhk", q.view(R, H, 64).double(), k.double()) * 0.125
+    want = torch.einsum("rhk,rhkd->rhd", torch.softmax(s, -1), v.double()).reshape(R, H * 64)
+    got = torch.from_numpy(g8_decode(out.cpu().numpy())).double()
+    assert (got - want).abs().max().item() < 1e-5
