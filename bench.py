@@ -409,6 +409,8 @@ def main():
                 "config": {"workload": f"BLIP-base ViT-B/16 encoder + {'greedy' if a.beams == 1 else f'beam-{a.beams}'} decode, {B} frames/GPU {S}x{S}, "
                                        f"max_length={L}, caption all-gather", "global_batch": world * B,
                            "parallelism": f"dp{world}", "streams": a.streams}}
+        ln = lens[:B].float()
+        line["caption_tokens"] = {"mean": round(float(ln.mean()), 2), "max": int(ln.max()), "of": L}
         if a.early_exit or a.eos_boost != 9.0:
             line["config"]["early_exit_poll"] = a.early_exit
             line["config"]["eos_boost"] = a.eos_boost

@@ -728,10 +728,12 @@ __global__ __launch_bounds__(256, 3) void decode_attention_wave_kernel(const T* 
                                                                     T* __restrict__ vbase,
                                                                     const int* __restrict__ anc, int anc_ld,
                                                                     int rows_per_kv, int kv_ld, int n_keys,
-                                                                    TO* __restrict__ out, int R, int H, QSource qs) {
+                                                                    TO* __restrict__ out, int R, int H, QSource qs,
+                                                                    const int* __restrict__ skip) {
     const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (unit >= R * H) return;
     const int row = unit / H, h = unit - row * H, Dh = H * 64;
+    if (skip && skip[row]) return;          // caption already ended: its logits are never looked at again
     const int lane = threadIdx.x & 63, ksub = lane >> 3, dch = lane & 7;
     const bool fused_kv = qs.part != nullptr && qs.append_kv;
     // program order = issue order: ancestry indices, then the split-K partials, then the history (which waits on the
@@ -825,13 +827,17 @@ __global__ __launch_bounds__(256, 3) void decode_attention_online_kernel(const T
                                                                       const T* __restrict__ vbase,
                                                                       const int* __restrict__ anc, int anc_ld,
                                                                       int rows_per_kv, int kv_ld, int n_keys,
-                                                                      TO* __restrict__ out, int R, int H, QSource qs) {
+                                                                      TO* __restrict__ out, int R, int H, QSource qs,
+                                                                      const int* __restrict__ skip) {
     // G = key groups (of 8 keys) per chunk, chosen by the launcher so the chunks are balanced (197 keys -> 4 x 56).
     // DB: two register buffers, the next chunk's loads are in flight while the current one is consumed.
     constexpr int CH = 8 * G;
     const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (unit >= R * H) return;
     const int row = unit / H, h = unit - row * H, Dh = H * 64;
+    // a caption that has ended keeps its row, but nothing reads the row's logits any more (the selection kernels emit pad):
+    // its 100-200 KB of K/V per layer are not streamed.  On the bench workload the mean caption is ~11 of 19 steps long.
+    if (skip && skip[row]) return;
     const int lane = threadIdx.x & 63, ksub = lane >> 3, dch = lane & 7;
     const int src0 = row / rows_per_kv;
     float m = -INFINITY, l = 0.f, o[8], qv[8];
@@ -1336,7 +1342,7 @@ int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
 int launch_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             hipStream_t s, const float* q_part, int q_S, const float* q_bias, int q_ld, int q_col0,
-                            int append_kv, int out_dtype) {
+                            int append_kv, int out_dtype, const int* skip_rows) {
     if (out_dtype < 0) out_dtype = dtype;
     if (out_dtype != dtype && !(dtype == CAP_DT_F32 && out_dtype == CAP_DT_G8 && impl == 0)) {
         cap_set_error("decode_attention: output type %d for input type %d is not supported here", out_dtype, dtype);
@@ -1351,7 +1357,7 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
     if (n_keys <= 0 || n_keys > 8192) { cap_set_error("decode_attention: bad key count %d", n_keys); return -1; }
 #define CAP_DA_WAVE_O(TT, NI, TOO)                                                                                     \
     hipLaunchKernelGGL((decode_attention_wave_kernel<TT, NI, TOO>), dim3((R * H + 3) / 4), dim3(256), 0, s, (const TT*)q,  \
-                       (TT*)kbase, (TT*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, (TOO*)out, R, H, qs)
+                       (TT*)kbase, (TT*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, (TOO*)out, R, H, qs, skip_rows)
 #define CAP_DA_WAVE(TT, NI) CAP_DA_WAVE_O(TT, NI, TT)
     // bf16: chunks of 40 keys, double-buffered (168 VGPRs -> 3 waves/SIMD, all of a 256-row launch resident at once;
     // 197 image tokens = 5 chunks).  fp32: chunks of 56 keys, single buffer (same register budget).
@@ -1361,7 +1367,7 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
 #define CAP_DA_ONLINE_NT(TT, DBB, NTT)                                                                                 \
     hipLaunchKernelGGL((decode_attention_online_kernel<TT, (DBB ? 5 : 7), DBB, NTT>), dim3((R * H + 3) / 4), dim3(256), 0, \
                        s, (const TT*)q, (const TT*)kbase, (const TT*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys,      \
-                       (TT*)out, R, H, qs)
+                       (TT*)out, R, H, qs, skip_rows)
 #define CAP_DA_ONLINE(TT, DBB)                                                                                         \
     do {                                                                                                               \
         if (DBB && rows_per_kv == 1 && !anc) CAP_DA_ONLINE_NT(TT, DBB, DBB); else CAP_DA_ONLINE_NT(TT, DBB, false);    \
@@ -1381,7 +1387,7 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
             else
                 hipLaunchKernelGGL((decode_attention_online_kernel<float, 7, false, false, g8_t>), dim3((R * H + 3) / 4), dim3(256), 0,
                                    s, (const float*)q, (const float*)kbase, (const float*)vbase, anc, anc_ld, rows_per_kv, kv_ld,
-                                   n_keys, (g8_t*)out, R, H, qs);
+                                   n_keys, (g8_t*)out, R, H, qs, skip_rows);
         } else {
             if (ng8 <= 1) CAP_DA_WAVE(float, 1); else if (ng8 <= 2) CAP_DA_WAVE(float, 2);
             else if (ng8 <= 4) CAP_DA_WAVE(float, 4); else CAP_DA_ONLINE(float, false);

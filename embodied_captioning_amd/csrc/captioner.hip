@@ -1034,6 +1034,9 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
     const CapConfig& c = m->c;
     const int T = c.t_hidden, F = c.t_ffn, H = c.t_heads, R = d.R, NT = m->NT;
     const size_t e = m->esz;
+    // greedy: the attention kernels leave the rows of ended captions alone (d.finished is set by greedy_select one step
+    // before); the GEMMs still cover every row - they are bound by the weight stream, not by the row count
+    const int* skip = K == 1 ? d.finished : nullptr;
     TRY(launch_embed(m->gdt, tokens, tok_ld, t, m->word_f32, m->tpos, m->emb_g, m->emb_b, c.t_eps, d.dx_t, d.dx, R, T, s));
     for (int i = 0; i < c.t_layers; ++i) {
         const TLayer& L = m->tl[i];
@@ -1046,12 +1049,12 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
             TRY(gemm_partial(m, s, "dec_gemm_qkv", d.dx_t, L.w_qkv, d.dpart, R, 3 * T, T, 4, &S));
             ProfScope ps(m, s, "dec_self_attn", 4.0 * R * H * (t + 1) * 64, 2.0 * R * H * (t + 1) * 64 * e + (double)S * R * 3 * T * 4);
             TRY(launch_decode_attention(m->dt, nullptr, kc, vc, anc, Lm, 1, Lm, t + 1, d.dctx, R, H, 0, s, d.dpart, S,
-                                        L.b_qkv, 3 * T, 0, 1, m->gdt));
+                                        L.b_qkv, 3 * T, 0, 1, m->gdt, skip));
         } else {
             TRY(gemm(m, s, "dec_gemm_qkv", d.dx_t, T, L.w_qkv, T, d.dq, T, L.b_qkv, nullptr, R, 3 * T, T, 0, 0, EPI_QKVCACHE,
                      R, H, Lm, t, nullptr, kc));
             ProfScope ps(m, s, "dec_self_attn", 4.0 * R * H * (t + 1) * 64, 2.0 * R * H * (t + 1) * 64 * e);
-            TRY(launch_decode_attention(m->dt, d.dq, kc, vc, anc, Lm, 1, Lm, t + 1, d.dctx, R, H, 0, s, nullptr, 0, nullptr, 0, 0, 0, m->gdt));
+            TRY(launch_decode_attention(m->dt, d.dq, kc, vc, anc, Lm, 1, Lm, t + 1, d.dctx, R, H, 0, s, nullptr, 0, nullptr, 0, 0, 0, m->gdt, skip));
         }
         TRY(gemm_splitk_ln(m, s, d, "dec_gemm_so", d.dctx, L.w_so, L.b_so, L.so_g, L.so_b, T, T));
         {
@@ -1062,7 +1065,7 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
             const char* cv = (char*)m->cross + (((size_t)i * 2 + 1) * d.Btot + d.b0) * H * NT * 64 * e;
             ProfScope ps(m, s, "dec_cross_attn", 4.0 * R * H * NT * 64, 2.0 * d.B * H * NT * 64 * e);
             TRY(launch_decode_attention(m->dt, nullptr, ck, cv, nullptr, 0, K, NT, NT, d.dctx, R, H, 0, s, d.dpart, S, L.b_cq,
-                                        T, 0, 0, m->gdt));
+                                        T, 0, 0, m->gdt, skip));
         }
         TRY(gemm_splitk_ln(m, s, d, "dec_gemm_co", d.dctx, L.w_co, L.b_co, L.co_g, L.co_b, T, T));
         TRY(gemm(m, s, "dec_gemm_f1", d.dx_t, T, L.w_f1, T, d.dh, F, L.b_f1, nullptr, R, F, T, 1, 0));

@@ -69,7 +69,8 @@ int launch_rows_broadcast(int dtype, const float* src, float* dst_f, void* dst_t
 int launch_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             hipStream_t s, const float* q_part = nullptr, int q_S = 0, const float* q_bias = nullptr,
-                            int q_ld = 0, int q_col0 = 0, int append_kv = 0, int out_dtype = -1);   // out_dtype: see launch_vit_attention
+                            int q_ld = 0, int q_col0 = 0, int append_kv = 0, int out_dtype = -1,   // out_dtype: see launch_vit_attention
+                            const int* skip_rows = nullptr);   // int32 [R] or null: rows with a non-zero flag are left untouched
 
 // attentional pooler (CoCa): fixed projected queries qp fp32 [Q, E] shared by every image; kv (T) [B*N, 2E] with K in
 // columns [0,E) and V in [E,2E); heads of E/heads dims (64 or 96); out (T) [B*Q, E].  scale = 1/sqrt(head_dim).

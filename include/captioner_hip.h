@@ -137,7 +137,9 @@ int cap_encode(CapHandle h, const void* pixels, int pixel_fmt, int B, float* out
  *   out_ids     int32 [B, max_len]   token ids incl. BOS; rows are padded after their end
  *   out_len     int32 [B]            tokens in each row incl. BOS and EOS (may be NULL)
  *   out_scores  fp32  [B]            beam `sequences_scores`; untouched for greedy (may be NULL)
- *   out_step_logits fp32 [max_len-1, B*num_beams, vocab]  raw per-step logits (may be NULL)
+ *   out_step_logits fp32 [max_len-1, B*num_beams, vocab]  raw per-step logits (may be NULL).  Greedy: a caption's rows
+ *               are meaningful up to and including the step that produced its EOS; later steps of that row are
+ *               unspecified (the attention kernels skip ended captions; HF feeds them pad and ignores the result)
  * max_len <= cfg.max_len, B <= cfg.max_batch, num_beams <= cfg.max_beams. */
 int cap_generate(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_beams, int max_len,
                  float length_penalty, int32_t* out_ids, int32_t* out_len, float* out_scores,

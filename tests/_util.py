@@ -74,6 +74,7 @@ def g8_encode(x, scale=1.0):
     """fp32 [..., K] (K % 8 == 0) -> float32-typed container of the same shape whose bytes are the G8 image: every 8
     consecutive elements of a row = [8 fp16 hi | 8 fp16 lo], hi = rn16(s x), lo = rn16(s x - hi)."""
     x = np.ascontiguousarray(np.asarray(x, dtype=np.float32)) * np.float32(scale)
+    x = np.clip(x, -65000.0, 65000.0).astype(np.float32)     # G8_AMAX: the device clamps to fp16's range the same way
     assert x.shape[-1] % 8 == 0
     hi = x.astype(np.float16)
     lo = (x - hi.astype(np.float32)).astype(np.float16)
