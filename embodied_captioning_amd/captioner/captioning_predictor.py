@@ -22,6 +22,21 @@ class CaptioningPredictor(_Base):
         if cfg is not None:
             self.input_height, self.input_width = cfg.height, cfg.width
 
+    def load_checkpoint_state_dict(self, sd, strict: bool = False):
+        """What `Captioner(load_checkpoint=True)` does with `checkpoint['model']` (reference predictor_utils.py:182-185:
+        `self.model.load_state_dict(checkpoint['model'], strict=False)` on the wrapper): wrapper / DDP key prefixes are
+        dropped, tied heads filled in, and the tensors go to the engine AND to every replica of its pool.  Raises when no
+        tensor of the dict belongs to the architecture."""
+        from ..weights import BLIP_TIED, strip_wrapper_prefixes
+        sd = strip_wrapper_prefixes(dict(sd))
+        for dst, src in BLIP_TIED.items():
+            if dst not in sd and src in sd:
+                sd[dst] = sd[src]
+        res = self.engine.load_state_dict(sd, strict=strict)
+        if getattr(self, "pool", None) is not None:
+            self.pool.load_state_dict(sd, strict=strict)
+        return res
+
     def pre_process_input(self, inputs):
         pass
 

@@ -91,7 +91,9 @@ class BLIP2(BLIP):
         CaptioningPredictor.__init__(self, cfg)
         self.num_beams = 1
         self.batch_size = int(getattr(cfg, "batch_size", 8) or 8)
-        dtype = getattr(cfg, "dtype", "bf16") or "bf16"
+        dtype = getattr(cfg, "dtype", None) or "bf16"
+        if int(getattr(cfg, "streams", 1) or 1) > 1:
+            logger.warning("captioner.streams > 1 is implemented for arch_name 'blip' only: running one engine")
         self._device = torch.device(getattr(cfg, "device", "cuda:0") or "cuda:0")
         self.tokenizer = None
         if model_dir is None:
@@ -106,7 +108,8 @@ class BLIP2(BLIP):
                 self.tokenizer = AutoTokenizer.from_pretrained(model_dir)
             except Exception as e:  # noqa: BLE001
                 logger.warning("no tokenizer under %s (%s): captions are returned as space-separated token ids", model_dir, e)
-        # the reference passes no length: HF then generates 20 new tokens; `max_length` in the config overrides that
+        # the reference passes no length: HF then generates 20 new tokens; the optional config key `max_new_tokens` (HF's
+        # name) overrides that.  The plugin's `max_length` key is BLIP's / CoCa's TOTAL length and is not read here.
         self.max_length = int(getattr(cfg, "max_new_tokens", 0) or self.arch.max_new_tokens)
         self.engine = CaptionerEngine(self.arch, dtype=dtype, max_batch=self.batch_size, max_beams=1, max_len=self.max_length,
                                       device=self._device)

@@ -32,7 +32,9 @@ class CoCa(CaptioningPredictor):
         super().__init__(cfg)
         name = cfg.model_name or "coca_ViT-L-14"
         self.batch_size = int(getattr(cfg, "batch_size", 8) or 8)
-        dtype = getattr(cfg, "dtype", "bf16") or "bf16"
+        dtype = getattr(cfg, "dtype", None) or "bf16"
+        if int(getattr(cfg, "streams", 1) or 1) > 1:
+            logger.warning("captioner.streams > 1 is implemented for arch_name 'blip' only: running one engine")
         self._device = torch.device(getattr(cfg, "device", "cuda:0") or "cuda:0")
         self.tokenizer = None
         # optional config key `image_size` = open_clip's force_image_size (factory.py:243-245): 224 (pretrained) or e.g. 336;

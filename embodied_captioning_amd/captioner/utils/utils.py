@@ -1,7 +1,11 @@
 """Plugin configuration objects - same fields as the reference's ``experimenting_env/captioner/utils/utils.py:2-12``
 plus optional keys (defaults keep existing yamls working): num_beams, max_length, dtype, batch_size, device,
-image_size (CoCa: open_clip's force_image_size), streams (engines / HIP streams the micro-batches of one call rotate over,
-engine.EnginePool; 1 = one engine), early_exit_poll (look for "every caption finished" every n decode steps; None = 4)."""
+image_size (CoCa: open_clip's force_image_size), streams (BLIP: engines / HIP streams the micro-batches of one call rotate
+over, engine.EnginePool; 1 = one engine; the BLIP-2 / CoCa wrappers run one engine and warn when asked for more),
+early_exit_poll (look for "every caption finished" every n decode steps; None = 4), max_new_tokens (BLIP-2: tokens to
+generate, HF's name; None = 20 as HF's generate default - `max_length` is BLIP's / CoCa's total length and is not read by
+BLIP-2).  dtype: "f32s" (default for BLIP: fp32-grade split-fp16 GEMMs, token-identical to the fp32 reference), "bf16",
+"f32"; None = the architecture's default."""
 
 
 class Configuration:
@@ -12,8 +16,8 @@ class Configuration:
 
 class CaptionerField:
     def __init__(self, arch_name=None, model_name=None, checkpoint_name=None, height=None, width=None,
-                 num_beams=1, max_length=20, dtype="bf16", batch_size=8, device="cuda:0", image_size=None, streams=1,
-                 early_exit_poll=None):
+                 num_beams=1, max_length=20, dtype=None, batch_size=8, device="cuda:0", image_size=None, streams=1,
+                 early_exit_poll=None, max_new_tokens=None):
         self.arch_name = arch_name
         self.model_name = model_name
         self.checkpoint_name = checkpoint_name
@@ -27,3 +31,4 @@ class CaptionerField:
         self.image_size = image_size
         self.streams = streams
         self.early_exit_poll = early_exit_poll
+        self.max_new_tokens = max_new_tokens

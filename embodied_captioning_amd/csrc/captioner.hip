@@ -854,7 +854,7 @@ int run_text_encoder(Captioner* m, const int* ids, const int* lens, int B, int L
     {
         ProfScope ps(m, s, "te_embed", 0, (double)M * T * (12 + m->esz));
         TRY(launch_embed_tokens(m->dt, ids, L, m->word_f32, m->tpos, m->tok_type, m->emb_g, m->emb_b, c.t_eps, m->te_xt,
-                                m->te_x, M, T, s));
+                                m->te_x, M, T, s, c.vocab));
     }
     for (int i = 0; i < c.t_layers; ++i) {
         const TLayer& Ly = m->tl[i];
@@ -1161,11 +1161,15 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
     if (ns > B) ns = B;
     if (ns > 1) CAP_HIP_CHECK(hipEventRecord(m->ev_fork, s));
     const int per = (B + ns - 1) / ns;
+    int rc = 0;
     for (int si = 0; si < ns; ++si) {
         const int b0 = si * per, Bs = (b0 + per <= B ? per : B - b0);
         if (Bs <= 0) continue;
         hipStream_t st = si == 0 ? s : m->aux[si - 1];
         if (si > 0) CAP_HIP_CHECK(hipStreamWaitEvent(st, m->ev_fork, 0));
+        // the slice's launches; a failure stops the slice but NOT the joins below: the caller's stream must stay ordered
+        // after whatever the aux streams were given, or the shared arena is reused under them
+        auto slice = [&]() -> int {
         const Dec d = make_slice(m, b0, Bs, B, K, Lm, si);
         const int Rs = d.R;
         if (K == 1) {
@@ -1207,15 +1211,34 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
             TRY(launch_beam_finalize(d.beam, Bs, K, Lm, out_ids + (size_t)b0 * Lm, out_len ? out_len + b0 : nullptr,
                                      out_scores ? out_scores + b0 : nullptr, st));
         }
+        return 0;
+        };
+        if (rc == 0) rc = slice();
         if (si > 0) {
-            CAP_HIP_CHECK(hipEventRecord(m->ev_join[si - 1], st));
-            CAP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_join[si - 1], 0));
+            if (hipEventRecord(m->ev_join[si - 1], st) != hipSuccess || hipStreamWaitEvent(s, m->ev_join[si - 1], 0) != hipSuccess) {
+                (void)hipStreamSynchronize(st);
+                if (rc == 0) { cap_set_error("cap_generate: cannot join a decode stream"); rc = -1; }
+            }
         }
     }
-    return 0;
+    return rc;
 }
 
 }  // namespace
+
+// Everything a handle owns - also the exit of every failed cap_create (streams and events included).
+static void release_captioner(Captioner* m) {
+    for (auto& r : m->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (void* p : m->allocs) (void)hipFree(p);
+    if (m->stage) (void)hipFree(m->stage);
+    if (m->host_flag) (void)hipHostFree(m->host_flag);
+    for (int i = 0; i < 3; ++i) {
+        if (m->aux[i]) (void)hipStreamDestroy(m->aux[i]);
+        if (m->ev_join[i]) (void)hipEventDestroy(m->ev_join[i]);
+    }
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    delete m;
+}
 
 // ================================================================================================ C ABI
 extern "C" {
@@ -1304,14 +1327,13 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
         for (int i = 0; ok && i + 1 < m->nslices; ++i)
             ok = hipStreamCreateWithFlags(&m->aux[i], hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { cap_set_error("cap_create: cannot create decode streams/events"); delete m; return -1; }
+        if (!ok) { cap_set_error("cap_create: cannot create decode streams/events"); release_captioner(m); return -1; }
         const char* fl = getenv("CAP_FUSE_LN");
         m->fuse_ln = fl && atoi(fl) != 0;
         for (int i = 0; i < m->nslices && !text_only; ++i) {
             if (dev_alloc(m, (void**)&m->ln_cnt[i], 64 * sizeof(int)) != 0 || hipMemset(m->ln_cnt[i], 0, 64 * sizeof(int)) != hipSuccess) {
                 cap_set_error("cap_create: cannot allocate the split-K arrival counters");
-                for (void* q : m->allocs) (void)hipFree(q);
-                delete m;
+                release_captioner(m);
                 return -1;
             }
         }
@@ -1321,8 +1343,7 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
                       : cfg->arch == CAP_ARCH_COCA ? (build_coca(m) != 0 || build_arena_coca(m) != 0)
                                                    : (build_blip(m) != 0 || build_arena(m) != 0);
     if (built) {
-        for (void* p : m->allocs) (void)hipFree(p);
-        delete m;
+        release_captioner(m);       // the message of the failing step is kept
         return -1;
     }
     *out = (CapHandle)m;
@@ -1331,18 +1352,8 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
 
 int cap_destroy(CapHandle h) {
     if (!h) return 0;
-    Captioner* m = (Captioner*)h;
     (void)hipDeviceSynchronize();
-    for (auto& r : m->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
-    for (void* p : m->allocs) (void)hipFree(p);
-    if (m->stage) (void)hipFree(m->stage);
-    if (m->host_flag) (void)hipHostFree(m->host_flag);
-    for (int i = 0; i < 3; ++i) {
-        if (m->aux[i]) (void)hipStreamDestroy(m->aux[i]);
-        if (m->ev_join[i]) (void)hipEventDestroy(m->ev_join[i]);
-    }
-    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-    delete m;
+    release_captioner((Captioner*)h);
     return 0;
 }
 

@@ -295,10 +295,10 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int* __restrict
                                                            const float* __restrict__ word, const float* __restrict__ pos,
                                                            const float* __restrict__ type0,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float eps, T* out_t, float* out_f, int R, int D) {
+                                                           float eps, T* out_t, float* out_f, int R, int D, int V) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= R) return;
-    const int tok = ids[row], l = row % L;
+    const int tok = min(max(ids[row], 0), V - 1), l = row % L;      // ids are caller data: never index outside the table
     const int nv = (D + 255) / 256;
     float4 v[LN_MAXV];
     const float* w = word + (size_t)tok * D;
@@ -562,9 +562,9 @@ int launch_reduce_bias_act(int dtype, const float* part, int S, const float* bia
 
 int launch_embed_tokens(int dtype, const int* ids, int L, const float* word, const float* pos, const float* type0,
                         const float* gamma, const float* beta, float eps, void* out_t, float* out_f, int R, int D,
-                        hipStream_t s) {
-    if (D % 4 != 0 || D > 256 * LN_MAXV) { cap_set_error("embed_tokens: unsupported width %d", D); return -1; }
-#define CAP_ET(TT) hipLaunchKernelGGL(embed_tokens_kernel<TT>, dim3((R + 3) / 4), dim3(256), 0, s, ids, L, word, pos, type0, gamma, beta, eps, (TT*)out_t, out_f, R, D)
+                        hipStream_t s, int V) {
+    if (D % 4 != 0 || D > 256 * LN_MAXV || V < 1) { cap_set_error("embed_tokens: unsupported width %d / vocabulary %d", D, V); return -1; }
+#define CAP_ET(TT) hipLaunchKernelGGL(embed_tokens_kernel<TT>, dim3((R + 3) / 4), dim3(256), 0, s, ids, L, word, pos, type0, gamma, beta, eps, (TT*)out_t, out_f, R, D, V)
     CAP_DISPATCH_T(dtype, CAP_ET);
 #undef CAP_ET
     CAP_HIP_CHECK(hipGetLastError());

@@ -1125,6 +1125,13 @@ int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream) {
         cap_set_error("launch_gemm: N / ldc / ldr must be multiples of 4 (N=%d ldc=%d ldr=%d)", p.N, p.ldc, p.ldr);
         return -1;
     }
+    // The LDS-DMA kernels fetch a tile's bias with 16-byte DMA reads from bias + min(col, N - 4): N % 4 == 0 (above) keeps
+    // the clamped address inside the vector and 16-byte aligned - provided the vector itself is.  The epilogues read bias
+    // and residual rows as 16-byte vectors too.
+    if (((uintptr_t)p.bias & 15) || ((uintptr_t)p.resid & 15) || ((uintptr_t)p.C & 15)) {
+        cap_set_error("launch_gemm: bias / resid / C must be 16-byte aligned");
+        return -1;
+    }
     if (p.epi == EPI_PARTIAL && p.ln_counter) {
         const int nb = ((p.N + 63) / 64) * p.splitk, grid = ((p.M + 63) / 64) * nb;
         if (tile != 2 || nb < 16 || p.ldc != p.N || p.N > 256 * LN_MAXV || grid > 512) {

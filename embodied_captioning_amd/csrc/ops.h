@@ -27,7 +27,7 @@ int launch_reduce_layernorm(int dtype, const void* part, int S, const float* bia
 int launch_reduce_bias_act(int dtype, const float* part, int S, const float* bias, void* out, int M, int N, int act, hipStream_t s);
 int launch_embed_tokens(int dtype, const int* ids, int L, const float* word, const float* pos, const float* type0,
                         const float* gamma, const float* beta, float eps, void* out_t, float* out_f, int R, int D,
-                        hipStream_t s);
+                        hipStream_t s, int V);   // ids outside [0, V) are clamped
 int launch_mean_pool_normalize(const float* x, const int* lens, int B, int L, int D, float* out, hipStream_t s);
 int launch_text_attention(int dtype, const void* qkv, const int* lens, void* ctx, int B, int L, int H, int head_dim,
                           hipStream_t s);

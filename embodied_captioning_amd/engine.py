@@ -82,7 +82,8 @@ class CaptionerEngine:
     # ------------------------------------------------------------------------------------------ lifetime
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:
-            self.lib.cap_destroy(self._h)
+            with torch.cuda.device(self.device):          # cap_destroy synchronises and frees on the CURRENT device
+                self.lib.cap_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -105,18 +106,26 @@ class CaptionerEngine:
         return int(self.lib.cap_last_decode_steps(self._h))
 
     # ------------------------------------------------------------------------------------------ weights
-    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> Dict[str, object]:
         """HF BLIP key names or an open_clip CoCa state dict (derived tensors are added here).
-        Tied / unknown tensors are skipped; missing ones raise."""
-        if self.is_coca and "derived.pool_q" not in sd:
-            from .coca_weights import coca_library_state_dict
-            sd = coca_library_state_dict(sd, self.arch)
-        if getattr(self, "is_blip2", False) and "derived.qformer_x0" not in sd:
-            # the Q-Former's input = LayerNorm(query_tokens) is a constant of the checkpoint: computed once here
-            sd = dict(sd)
-            q = sd["query_tokens"].float()[0]
-            sd["derived.qformer_x0"] = torch.nn.functional.layer_norm(
-                q, (q.shape[-1],), sd["qformer.layernorm.weight"].float(), sd["qformer.layernorm.bias"].float(), self.arch.q_eps)
+        Tensors the architecture does not store (tied heads, buffers) are skipped and reported; with strict=True missing
+        ones raise.  A dict in which NOTHING matches always raises - it is a wrong checkpoint or wrong key prefixes, never a
+        successful load.  Returns {"matched": n, "unknown": [names]}."""
+        try:
+            if self.is_coca and "derived.pool_q" not in sd:
+                from .coca_weights import coca_library_state_dict
+                sd = coca_library_state_dict(sd, self.arch)
+            if getattr(self, "is_blip2", False) and "derived.qformer_x0" not in sd:
+                # the Q-Former's input = LayerNorm(query_tokens) is a constant of the checkpoint: computed once here
+                sd = dict(sd)
+                q = sd["query_tokens"].float()[0]
+                sd["derived.qformer_x0"] = torch.nn.functional.layer_norm(
+                    q, (q.shape[-1],), sd["qformer.layernorm.weight"].float(), sd["qformer.layernorm.bias"].float(), self.arch.q_eps)
+        except KeyError as e:
+            raise N.CaptionerHipError(f"state dict lacks {e}: this architecture derives tensors from the checkpoint at load "
+                                      f"and needs the complete dict (keys with a 'model.' / 'module.' prefix? see "
+                                      f"weights.strip_wrapper_prefixes)") from e
+        matched, unknown = 0, []
         with torch.cuda.device(self.device):
             s = _stream_ptr(self.device)
             for name, t in sd.items():
@@ -129,9 +138,17 @@ class CaptionerEngine:
                                               max(t.dim(), 1), shape, C.c_void_p(s))
                 if rc < 0:
                     raise N.CaptionerHipError(f"cap_load_weight({name}): {N.last_error()}")
+                if rc == 0:
+                    matched += 1
+                else:
+                    unknown.append(name)
+            if len(sd) and not matched:
+                raise N.CaptionerHipError(f"none of the {len(sd)} tensors is one this architecture stores "
+                                          f"(first keys: {list(sd)[:3]}): wrong checkpoint or key prefix")
             missing = self.lib.cap_finalize_weights(self._h)
             if missing and strict:
                 raise N.CaptionerHipError(f"checkpoint incomplete: {N.last_error()}")
+        return {"matched": matched, "unknown": unknown}
 
     # ------------------------------------------------------------------------------------------ forward
     def _pixels(self, pixels: torch.Tensor):
@@ -174,7 +191,9 @@ class CaptionerEngine:
         logits = None
         if output_logits:
             steps = L if getattr(self, "is_blip2", False) else L - 1
-            logits = torch.empty((steps, B * num_beams, self.arch.vocab), dtype=torch.float32, device=self.device)
+            # zeros, not empty: with early exit the steps after the last executed one are never written (callers see 0, not
+            # stale memory); `last_decode_steps` tells how many steps ran
+            logits = torch.zeros((steps, B * num_beams, self.arch.vocab), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             N.check(self.lib.cap_generate(self._h, C.c_void_p(pixels.data_ptr()), fmt, B, num_beams, L,
                                           C.c_float(length_penalty), C.c_void_p(ids.data_ptr()),
@@ -226,9 +245,11 @@ class EnginePool:
     def __len__(self) -> int:
         return len(self.engines)
 
-    def load_state_dict(self, sd, strict: bool = True) -> None:
+    def load_state_dict(self, sd, strict: bool = True):
+        res = None
         for e in self.engines:
-            e.load_state_dict(sd, strict=strict)
+            res = e.load_state_dict(sd, strict=strict)
+        return res
 
     def set_early_exit(self, poll_steps: int) -> None:
         for e in self.engines:
@@ -354,10 +375,11 @@ class TextEncoderEngine:
         if ids.dim() != 2 or lens.shape != (ids.shape[0],):
             raise ValueError(f"ids must be [B, L] and lens [B], got {tuple(ids.shape)} / {tuple(lens.shape)}")
         B, L = ids.shape
-        if int(lens.max()) > L or int(lens.min()) < 1:
-            raise ValueError("lens must be within 1..L")
-        if int(ids.max()) >= self.arch.vocab or int(ids.min()) < 0:
-            raise ValueError("token id outside the vocabulary")
+        if not ids.is_cuda and not lens.is_cuda:      # host tensors: validate here for free; device tensors are clamped by the
+            if int(lens.max()) > L or int(lens.min()) < 1:                      # kernels (no host synchronisation per call)
+                raise ValueError("lens must be within 1..L")
+            if int(ids.max()) >= self.arch.vocab or int(ids.min()) < 0:
+                raise ValueError("token id outside the vocabulary")
         ids = ids.to(self.device, torch.int32).contiguous()
         lens = lens.to(self.device, torch.int32).contiguous()
         out = torch.empty((B, self.arch.hidden), dtype=torch.float32, device=self.device)

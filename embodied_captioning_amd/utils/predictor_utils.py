@@ -27,13 +27,14 @@ class Captioner(_Base):
         logger.info("Captioner model loaded successfully")
         if load_checkpoint and checkpoint_path is not None:
             checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
-            self.model.engine.load_state_dict(checkpoint["model"], strict=False)
-            logger.info(f"Captioner model checkpoint loaded successfully from {checkpoint_path}")
+            res = self.model.load_checkpoint_state_dict(checkpoint["model"], strict=False)
+            logger.info(f"Captioner model checkpoint loaded successfully from {checkpoint_path} "
+                        f"({res['matched']} tensors, {len(res['unknown'])} not stored by this architecture)")
 
     def get_captioner(self, cfg):
         """Get the captioner model based on the configuration settings (reference :190-202)."""
-        extra = {k: getattr(cfg, k) for k in ("num_beams", "max_length", "dtype", "batch_size", "device", "streams",
-                                              "early_exit_poll", "image_size")
+        extra = {k: getattr(cfg, k) for k in ("num_beams", "max_length", "max_new_tokens", "dtype", "batch_size", "device",
+                                              "streams", "early_exit_poll", "image_size")
                  if hasattr(cfg, k)}
         captioner_cfg = Configuration(arch_name=cfg.arch_name, model_name=cfg.model_name,
                                       checkpoint_name=getattr(cfg, "checkpoint_name", None), height=cfg.height,

@@ -320,6 +320,18 @@ def _strip_prefixes(sd: Dict[str, torch.Tensor], prefixes: Iterable[str] = ("mod
     return out
 
 
+def strip_wrapper_prefixes(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Keys of a checkpoint saved from the reference's WRAPPER module (`torch.save({'model': captioner.state_dict()})`,
+    loaded back by predictor_utils.py:182-185 into the wrapper): the wrapped network is the attribute `model`, DDP adds
+    `module.` - both are dropped, repeatedly, from the front of every key."""
+    out = {}
+    for k, v in sd.items():
+        while k.startswith("module.") or k.startswith("model."):
+            k = k.split(".", 1)[1]
+        out[k] = v
+    return out
+
+
 def load_state_dict_file(path: str) -> Dict[str, torch.Tensor]:
     """Read one weight file. Accepts .safetensors, or a torch pickle that is a state dict or wraps one
     under 'model' / 'state_dict' (reference: predictor_utils.py:182-185, evaluate_finetuned_model.py:139-146,

@@ -76,6 +76,40 @@ def test_gemm_epilogues_gelu_residual_and_typed_output(lib, dtype):
     assert (x.cpu().double() - (ref + resid.double())).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("tile", [3, 4, 5, 10, 12, 14])
+@pytest.mark.parametrize("N", [4, 8, 68, 200, 260, 516])
+def test_gemm_bias_at_edge_widths_on_the_lds_dma_tiles(lib, dtype, tile, N):
+    """Round-1 fault fence ("The 22:40 GEMM fault"): the 256x256 LDS-DMA kernels fetch the bias of a tile by
+    16-byte DMA from bias + min(col, N - 4).  Widths that are not multiples of the 256-wide tile, down to N = 4, with the
+    bias vector placed at the END of its allocation (any read past it leaves the buffer), edge rows (M = 197 / 300)."""
+    tag, tdt = DT[dtype]
+    for M, K in ((197, 768), (300, 192)):
+        g = torch.Generator().manual_seed(N * 31 + M)
+        A = torch.randn(M, K, generator=g).to(tdt)
+        W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(tdt)
+        pool = torch.zeros(4096, dtype=torch.float32, device="cuda")
+        bias = pool[4096 - N:]                                    # 16-byte aligned: N % 4 == 0
+        bias.copy_(torch.randn(N, generator=g))
+        Ad, Wd = A.cuda(), W.cuda()
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        _check(lib, lib.cap_op_gemm(tag, _p(Ad), _p(Wd), _p(bias), _p(None), _p(out), M, N, K, 0, 1, tile, _stream()))
+        torch.cuda.synchronize()
+        ref = A.double() @ W.double().T + bias.cpu().double()
+        assert (out.cpu().double() - ref).abs().max().item() < 2e-4 * math.sqrt(K / 64)
+
+
+def test_gemm_rejects_widths_and_pointers_the_dma_path_cannot_take(lib):
+    a = torch.zeros(64, 64, device="cuda")
+    b = torch.zeros(80, device="cuda")
+    # N % 4 != 0: the clamped bias DMA address would be 4-byte aligned only
+    rc = lib.cap_op_gemm(0, _p(a), _p(a), _p(b), _p(None), _p(a), 64, 62, 64, 0, 1, 3, _stream())
+    assert rc != 0 and b"multiples of 4" in lib.cap_last_error()
+    # a bias vector that is not 16-byte aligned
+    rc = lib.cap_op_gemm(0, _p(a), _p(a), _p(b[1:]), _p(None), _p(a), 64, 64, 64, 0, 1, 3, _stream())
+    assert rc != 0 and b"16-byte aligned" in lib.cap_last_error()
+
+
 def test_gemm_rejects_bad_shapes(lib):
     a = torch.zeros(64, 48, device="cuda")
     rc = lib.cap_op_gemm(0, _p(a), _p(a), _p(None), _p(None), _p(a), 64, 64, 48, 0, 1, 0, _stream())

@@ -94,3 +94,51 @@ def test_plugin_streams_option_gives_the_same_captions():
     one, three = build(1), build(3)
     assert three.model.pool is not None and len(three.model.pool) == 3 and one.model.pool is None
     assert three.caption_batch(crops) == one.caption_batch(crops)
+
+
+def test_captioner_load_checkpoint_reaches_engine_and_pool(tmp_path):
+    """`Captioner(load_checkpoint=True, checkpoint_path=...)` - reference predictor_utils.py:182-185 loads
+    `checkpoint['model']` into the WRAPPER, so its keys carry a `model.` prefix (DDP: `module.model.`).  The weights must
+    reach the engine and every replica of the stream pool; a dict with no tensor of the architecture must raise, not log
+    success over the base weights."""
+    import types
+    from embodied_captioning_amd._native import CaptionerHipError
+    from embodied_captioning_amd.config import BlipArch
+    from embodied_captioning_amd.utils.predictor_utils import Captioner
+    from embodied_captioning_amd.weights import procedural_blip_state_dict
+    arch = BlipArch.tiny()
+    new = procedural_blip_state_dict(arch, 11, eos_boost=2.0)
+    path = str(tmp_path / "finetuned.pt")
+    torch.save({"model": {"module.model." + k: v for k, v in new.items()}}, path)
+
+    def plugin(model_name, **kw):
+        cap_cfg = types.SimpleNamespace(arch_name="blip", model_name=model_name, checkpoint_name=None, height=224, width=224,
+                                        dtype="f32s", max_length=12, batch_size=2, streams=2)
+        return Captioner(types.SimpleNamespace(captioner=cap_cfg), **kw)
+
+    crops = [_pil(i) for i in range(20, 26)]
+    want = plugin("procedural-tiny:11:2.0").caption_batch(crops)            # built directly from the new weights
+    base = plugin("procedural-tiny:4:2.0")
+    assert base.caption_batch(crops) != want
+    cap = plugin("procedural-tiny:4:2.0", load_checkpoint=True, checkpoint_path=path)
+    assert cap.caption_batch(crops) == want                                 # 3 micro-batches over the 2 pool engines
+    assert [cap(c) for c in crops[:2]] == want[:2]                          # forward() runs on the wrapper's own engine
+    bad = str(tmp_path / "other.pt")
+    torch.save({"model": {"backbone.layer.weight": torch.zeros(3, 3)}}, bad)
+    with pytest.raises(CaptionerHipError):
+        plugin("procedural-tiny:4:2.0", load_checkpoint=True, checkpoint_path=bad)
+
+
+def test_generate_logits_tail_is_zero_after_early_exit():
+    """With early exit the steps after the last executed one are never written: callers must see zeros, not stale memory."""
+    from embodied_captioning_amd.config import BlipArch
+    from embodied_captioning_amd.engine import CaptionerEngine
+    from embodied_captioning_amd.weights import procedural_blip_state_dict, synthetic_pixels
+    arch = BlipArch.tiny()
+    eng = CaptionerEngine(arch, dtype="f32s", max_batch=3, max_beams=1, max_len=20)
+    eng.load_state_dict(procedural_blip_state_dict(arch, seed=5, eos_boost=12.0))
+    eng.set_early_exit(2)
+    out = eng.generate(synthetic_pixels(3, arch.image_size, seed=9).cuda(), max_length=20, output_logits=True)
+    n = eng.last_decode_steps
+    assert n < 19 and float(out["logits"][n:].abs().max()) == 0.0 and float(out["logits"][0].abs().max()) > 0.0
+    eng.close()
