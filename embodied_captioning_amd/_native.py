@@ -37,6 +37,7 @@ _SIGNATURES = {
     "cap_last_error": (C.c_char_p, []),
     "cap_version": (C.c_int, []),
     "cap_create": (C.c_int, [C.POINTER(CapConfig), C.POINTER(C.c_void_p)]),
+    "cap_create_shared": (C.c_int, [C.POINTER(CapConfig), C.c_void_p, C.POINTER(C.c_void_p)]),
     "cap_destroy": (C.c_int, [C.c_void_p]),
     "cap_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p]),
     "cap_finalize_weights": (C.c_int, [C.c_void_p]),

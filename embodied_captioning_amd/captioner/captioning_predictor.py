@@ -25,17 +25,15 @@ class CaptioningPredictor(_Base):
     def load_checkpoint_state_dict(self, sd, strict: bool = False):
         """What `Captioner(load_checkpoint=True)` does with `checkpoint['model']` (reference predictor_utils.py:182-185:
         `self.model.load_state_dict(checkpoint['model'], strict=False)` on the wrapper): wrapper / DDP key prefixes are
-        dropped, tied heads filled in, and the tensors go to the engine AND to every replica of its pool.  Raises when no
-        tensor of the dict belongs to the architecture."""
+        dropped, tied heads filled in, and the tensors go to the weight store that the engine and every replica of its
+        stream pool share.  Raises when no tensor of the dict belongs to the architecture."""
         from ..weights import BLIP_TIED, strip_wrapper_prefixes
         sd = strip_wrapper_prefixes(dict(sd))
         for dst, src in BLIP_TIED.items():
             if dst not in sd and src in sd:
                 sd[dst] = sd[src]
-        res = self.engine.load_state_dict(sd, strict=strict)
-        if getattr(self, "pool", None) is not None:
-            self.pool.load_state_dict(sd, strict=strict)
-        return res
+        # the pool of a wrapper (cfg.streams > 1) is attached to the engine's weight store: one load serves every replica
+        return self.engine.load_state_dict(sd, strict=strict)
 
     def pre_process_input(self, inputs):
         pass

@@ -74,14 +74,14 @@ class BLIP(CaptioningPredictor):
         self.engine.set_early_exit(poll)
         self.engine.load_state_dict(sd)
         # cfg.streams > 1: micro-batches of one generate_batch call rotate over that many engines / HIP streams and overlap
-        # (engine.EnginePool; same captions, more memory: one arena and one weight copy per engine)
+        # (engine.EnginePool; same captions; one arena per engine, ONE copy of the weights: the pool's engines attach to
+        # this engine's weight store)
         self.pool = None
         n_streams = int(getattr(cfg, "streams", 1) or 1)
         if n_streams > 1:
             from ....engine import EnginePool
             self.pool = EnginePool(self.arch, n=n_streams, device=self._device, dtype=dtype, max_batch=self.batch_size,
-                                   max_beams=getattr(self, "num_beams", 1), max_len=self.engine.max_len)
-            self.pool.load_state_dict(sd)
+                                   max_beams=getattr(self, "num_beams", 1), max_len=self.engine.max_len, weights_of=self.engine)
             self.pool.set_early_exit(poll)
 
     # nn.Module surface the callers use; weights live in the engine, so .to() only re-targets host-side tensors

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <string>
 #include <set>
@@ -62,6 +63,18 @@ struct Slot {            // where one checkpoint tensor (or a row range of a fus
 
 struct ProfTag { std::string tag; double flops, bytes; hipEvent_t e0, e1; };
 
+// The weights of one model on one GPU: device buffers in allocation order + the name -> buffer registry.  Read-only once
+// loaded, so every handle of an EnginePool points at the same store (cap_create_shared): a pool of n engines costs one copy
+// of the weights plus n arenas.  Freed when the last handle that references it is destroyed.
+struct WeightStore {
+    std::vector<void*> ptrs;
+    std::vector<size_t> sizes;
+    std::multimap<std::string, Slot> slots;
+    size_t bytes = 0;
+    std::atomic<int> refs{1};
+    int device = 0;
+};
+
 struct VLayer {
     void *w_qkv, *w_proj, *w_fc1, *w_fc2;
     float *b_qkv, *b_proj, *b_fc1, *b_fc2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
@@ -99,9 +112,11 @@ struct Captioner {
     int gdt;                     // type of every GEMM operand (A and W): == dt, except CAP_F32_SPLIT: dt = fp32, gdt = G8
                                  // (split fp16, common.h) - there every kernel whose output feeds a GEMM writes G8
     int NT, P, Kpatch, Kpad;
-    size_t dev_bytes = 0;
-    std::vector<void*> allocs;
-    std::multimap<std::string, Slot> slots;
+    size_t dev_bytes = 0;        // arena (+ the weights when this handle created the store)
+    std::vector<void*> allocs;   // arena: owned by this handle
+    WeightStore* ws = nullptr;   // weights: shared
+    bool replay = false;         // building a handle on an existing store: walloc hands out the store's buffers in order
+    size_t wcur = 0;
     float* stage = nullptr; size_t stage_elems = 0;
     // early exit of the decode loop (cap_set_early_exit): poll every `poll` steps through a host-mapped word
     int poll = 0; int* host_flag = nullptr; int* host_flag_dev = nullptr;
@@ -175,22 +190,46 @@ int dev_alloc(Captioner* m, void** p, size_t bytes) {
 
 #define TRY(x) do { if ((x) != 0) return -1; } while (0)
 
+// weight buffer: a new allocation recorded in the store, or (replay) the store's next buffer - the build_* functions run
+// the same sequence of calls for the same architecture, which the size check enforces
+int walloc(Captioner* m, void** p, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    WeightStore* ws = m->ws;
+    if (m->replay) {
+        if (m->wcur >= ws->ptrs.size() || ws->sizes[m->wcur] != bytes) {
+            cap_set_error("cap_create_shared: the configuration does not describe the model whose weights are shared "
+                          "(buffer %zu: %zu bytes wanted)", m->wcur, bytes);
+            return -1;
+        }
+        *p = ws->ptrs[m->wcur++];
+        return 0;
+    }
+    CAP_HIP_CHECK(hipMalloc(p, bytes));
+    ws->ptrs.push_back(*p);
+    ws->sizes.push_back(bytes);
+    ws->bytes += bytes;
+    m->dev_bytes += bytes;
+    return 0;
+}
+
 int add_slot(Captioner* m, const std::string& name, void* dst, int dtype, int64_t rows, int64_t cols, int dst_ld = 0) {
+    if (m->replay) return 0;
     Slot s; s.dst = dst; s.dtype = dtype; s.rows = rows; s.cols = cols; s.dst_ld = dst_ld ? dst_ld : (int)cols;
-    m->slots.insert({name, s});
+    m->ws->slots.insert({name, s});
     return 0;
 }
 
 // allocate a fp32 vector and register it
 int reg_f32(Captioner* m, const std::string& name, float** p, int64_t n) {
-    TRY(dev_alloc(m, (void**)p, n * 4));
+    TRY(walloc(m, (void**)p, n * 4));
     return add_slot(m, name, *p, CAP_DT_F32, 1, n);
 }
 // allocate a compute-dtype matrix [rows, ld] and register it
 int reg_mat(Captioner* m, const std::string& name, void** p, int64_t rows, int64_t cols, int ld = 0) {
     if (!ld) ld = (int)cols;
-    TRY(dev_alloc(m, p, (size_t)rows * ld * m->esz));
-    if (ld != cols) CAP_HIP_CHECK(hipMemset(*p, 0, (size_t)rows * ld * m->esz));
+    TRY(walloc(m, p, (size_t)rows * ld * m->esz));
+    if (ld != cols && !m->replay) CAP_HIP_CHECK(hipMemset(*p, 0, (size_t)rows * ld * m->esz));
     return add_slot(m, name, *p, m->gdt, rows, cols, ld);
 }
 
@@ -224,26 +263,26 @@ int build_blip(Captioner* m) {
 
     const std::string tb = "text_decoder.bert.";
     // the embedding table is read twice: fp32 rows for the lookup, compute-dtype [V,T] as the (tied) LM-head weight
-    TRY(dev_alloc(m, (void**)&m->word_f32, (size_t)V * T * 4));
+    TRY(walloc(m, (void**)&m->word_f32, (size_t)V * T * 4));
     add_slot(m, tb + "embeddings.word_embeddings.weight", m->word_f32, CAP_DT_F32, V, T);
     if (m->gdt == CAP_DT_F32) {
         m->word_t = m->word_f32;
     } else {
-        TRY(dev_alloc(m, &m->word_t, (size_t)V * T * m->esz));
+        TRY(walloc(m, &m->word_t, (size_t)V * T * m->esz));
         add_slot(m, tb + "embeddings.word_embeddings.weight", m->word_t, m->gdt, V, T);
     }
     TRY(reg_f32(m, tb + "embeddings.position_embeddings.weight", &m->tpos, (int64_t)c.max_pos * T));
     TRY(reg_f32(m, tb + "embeddings.LayerNorm.weight", &m->emb_g, T));
     TRY(reg_f32(m, tb + "embeddings.LayerNorm.bias", &m->emb_b, T));
     // cross-attention K/V projections of all layers fused into one [L*2*T, D] weight (one GEMM per image batch)
-    TRY(dev_alloc(m, &m->w_ckv, (size_t)c.t_layers * 2 * T * D * m->esz));
-    TRY(dev_alloc(m, (void**)&m->b_ckv, (size_t)c.t_layers * 2 * T * 4));
+    TRY(walloc(m, &m->w_ckv, (size_t)c.t_layers * 2 * T * D * m->esz));
+    TRY(walloc(m, (void**)&m->b_ckv, (size_t)c.t_layers * 2 * T * 4));
     m->tl.resize(c.t_layers);
     for (int i = 0; i < c.t_layers; ++i) {
         TLayer& L = m->tl[i];
         const std::string p = tb + "encoder.layer." + std::to_string(i) + ".";
-        TRY(dev_alloc(m, &L.w_qkv, (size_t)3 * T * T * m->esz));
-        TRY(dev_alloc(m, (void**)&L.b_qkv, (size_t)3 * T * 4));
+        TRY(walloc(m, &L.w_qkv, (size_t)3 * T * T * m->esz));
+        TRY(walloc(m, (void**)&L.b_qkv, (size_t)3 * T * 4));
         const char* nm[3] = {"query", "key", "value"};
         for (int j = 0; j < 3; ++j) {
             add_slot(m, p + "attention.self." + nm[j] + ".weight", (char*)L.w_qkv + (size_t)j * T * T * m->esz, m->gdt, T, T);
@@ -364,11 +403,13 @@ int build_coca(Captioner* m) {
     TRY(reg_f32(m, "text_decoder.ln_final.bias", &m->lnf_b, E));
     TRY(reg_mat(m, "derived.vocab.weight", &m->w_cvocab, V, E));
     // constant vectors for the affine-free LayerNorm that feeds the folded cross-K/V projection
-    TRY(dev_alloc(m, (void**)&m->ones, (size_t)E * 4));
-    TRY(dev_alloc(m, (void**)&m->zeros, (size_t)E * 4));
-    TRY(launch_fill_f32(m->ones, 1.0f, E, nullptr));
-    TRY(launch_fill_f32(m->zeros, 0.0f, E, nullptr));
-    CAP_HIP_CHECK(hipDeviceSynchronize());
+    TRY(walloc(m, (void**)&m->ones, (size_t)E * 4));
+    TRY(walloc(m, (void**)&m->zeros, (size_t)E * 4));
+    if (!m->replay) {
+        TRY(launch_fill_f32(m->ones, 1.0f, E, nullptr));
+        TRY(launch_fill_f32(m->zeros, 0.0f, E, nullptr));
+        CAP_HIP_CHECK(hipDeviceSynchronize());
+    }
     return 0;
 }
 
@@ -545,8 +586,8 @@ int build_blip2(Captioner* m) {
         QLayer& L = m->ql[i];
         L.cross = i % c.q_cross_freq == 0;
         const std::string p = "qformer.encoder.layer." + std::to_string(i) + ".";
-        TRY(dev_alloc(m, &L.w_qkv, (size_t)3 * Q * Q * m->esz));
-        TRY(dev_alloc(m, (void**)&L.b_qkv, (size_t)3 * Q * 4));
+        TRY(walloc(m, &L.w_qkv, (size_t)3 * Q * Q * m->esz));
+        TRY(walloc(m, (void**)&L.b_qkv, (size_t)3 * Q * 4));
         for (int j = 0; j < 3; ++j) {
             add_slot(m, p + "attention.attention." + nm[j] + ".weight", (char*)L.w_qkv + (size_t)j * Q * Q * m->esz, m->dt, Q, Q);
             add_slot(m, p + "attention.attention." + nm[j] + ".bias", L.b_qkv + (size_t)j * Q, CAP_DT_F32, 1, Q);
@@ -558,8 +599,8 @@ int build_blip2(Captioner* m) {
         if (L.cross) {
             TRY(reg_mat(m, p + "crossattention.attention.query.weight", &L.w_cq, Q, Q));
             TRY(reg_f32(m, p + "crossattention.attention.query.bias", &L.b_cq, Q));
-            TRY(dev_alloc(m, &L.w_ckv, (size_t)2 * Q * D * m->esz));
-            TRY(dev_alloc(m, (void**)&L.b_ckv, (size_t)2 * Q * 4));
+            TRY(walloc(m, &L.w_ckv, (size_t)2 * Q * D * m->esz));
+            TRY(walloc(m, (void**)&L.b_ckv, (size_t)2 * Q * 4));
             for (int j = 0; j < 2; ++j) {
                 add_slot(m, p + "crossattention.attention." + nm[j + 1] + ".weight", (char*)L.w_ckv + (size_t)j * Q * D * m->esz, m->dt, Q, D);
                 add_slot(m, p + "crossattention.attention." + nm[j + 1] + ".bias", L.b_ckv + (size_t)j * Q, CAP_DT_F32, 1, Q);
@@ -581,10 +622,10 @@ int build_blip2(Captioner* m) {
 
     const std::string lm = "language_model.model.decoder.";
     // token table twice: fp32 rows for the lookup, compute dtype as the tied LM head
-    TRY(dev_alloc(m, (void**)&m->o_tok, (size_t)V * T * 4));
+    TRY(walloc(m, (void**)&m->o_tok, (size_t)V * T * 4));
     add_slot(m, lm + "embed_tokens.weight", m->o_tok, CAP_DT_F32, V, T);
     if (m->dt == CAP_DT_F32) m->o_tok_t = m->o_tok;
-    else { TRY(dev_alloc(m, &m->o_tok_t, (size_t)V * T * m->esz)); add_slot(m, lm + "embed_tokens.weight", m->o_tok_t, m->dt, V, T); }
+    else { TRY(walloc(m, &m->o_tok_t, (size_t)V * T * m->esz)); add_slot(m, lm + "embed_tokens.weight", m->o_tok_t, m->dt, V, T); }
     TRY(reg_f32(m, lm + "embed_positions.weight", &m->o_pos, (int64_t)(c.max_pos + 2) * T));
     const size_t Bm = c.max_batch, Lmax = nq + 1 + c.max_len;
     m->ol.resize(c.t_layers);
@@ -592,8 +633,8 @@ int build_blip2(Captioner* m) {
     for (int i = 0; i < c.t_layers; ++i) {
         OLayer& L = m->ol[i];
         const std::string p = lm + "layers." + std::to_string(i) + ".";
-        TRY(dev_alloc(m, &L.w_qkv, (size_t)3 * T * T * m->esz));
-        TRY(dev_alloc(m, (void**)&L.b_qkv, (size_t)3 * T * 4));
+        TRY(walloc(m, &L.w_qkv, (size_t)3 * T * T * m->esz));
+        TRY(walloc(m, (void**)&L.b_qkv, (size_t)3 * T * 4));
         for (int j = 0; j < 3; ++j) {
             add_slot(m, p + "self_attn." + pn[j] + ".weight", (char*)L.w_qkv + (size_t)j * T * T * m->esz, m->dt, T, T);
             add_slot(m, p + "self_attn." + pn[j] + ".bias", L.b_qkv + (size_t)j * T, CAP_DT_F32, 1, T);
@@ -810,7 +851,7 @@ int build_minilm(Captioner* m) {
     const int T = c.t_hidden, F = c.t_ffn, V = c.vocab;
     TRY(reg_f32(m, "embeddings.word_embeddings.weight", &m->word_f32, (int64_t)V * T));
     TRY(reg_f32(m, "embeddings.position_embeddings.weight", &m->tpos, (int64_t)c.max_pos * T));
-    TRY(dev_alloc(m, (void**)&m->tok_type, (size_t)2 * T * 4));
+    TRY(walloc(m, (void**)&m->tok_type, (size_t)2 * T * 4));
     add_slot(m, "embeddings.token_type_embeddings.weight", m->tok_type, CAP_DT_F32, 2, T);
     TRY(reg_f32(m, "embeddings.LayerNorm.weight", &m->emb_g, T));
     TRY(reg_f32(m, "embeddings.LayerNorm.bias", &m->emb_b, T));
@@ -818,8 +859,8 @@ int build_minilm(Captioner* m) {
     for (int i = 0; i < c.t_layers; ++i) {
         TLayer& L = m->tl[i];
         const std::string p = "encoder.layer." + std::to_string(i) + ".";
-        TRY(dev_alloc(m, &L.w_qkv, (size_t)3 * T * T * m->esz));
-        TRY(dev_alloc(m, (void**)&L.b_qkv, (size_t)3 * T * 4));
+        TRY(walloc(m, &L.w_qkv, (size_t)3 * T * T * m->esz));
+        TRY(walloc(m, (void**)&L.b_qkv, (size_t)3 * T * 4));
         const char* nm[3] = {"query", "key", "value"};
         for (int j = 0; j < 3; ++j) {
             add_slot(m, p + "attention.self." + nm[j] + ".weight", (char*)L.w_qkv + (size_t)j * T * T * m->esz, m->dt, T, T);
@@ -1230,6 +1271,10 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
 static void release_captioner(Captioner* m) {
     for (auto& r : m->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (void* p : m->allocs) (void)hipFree(p);
+    if (m->ws && m->ws->refs.fetch_sub(1) == 1) {        // last handle on these weights
+        for (void* p : m->ws->ptrs) (void)hipFree(p);
+        delete m->ws;
+    }
     if (m->stage) (void)hipFree(m->stage);
     if (m->host_flag) (void)hipHostFree(m->host_flag);
     for (int i = 0; i < 3; ++i) {
@@ -1246,7 +1291,7 @@ extern "C" {
 const char* cap_last_error(void) { return g_err; }
 int cap_version(void) { return 1; }
 
-int cap_create(const CapConfig* cfg, CapHandle* out) {
+static int create_impl(const CapConfig* cfg, Captioner* share, CapHandle* out) {
     if (!cfg || !out) { cap_set_error("cap_create: null argument"); return -1; }
     if (cfg->struct_size != (int)sizeof(CapConfig)) {
         cap_set_error("cap_create: CapConfig size mismatch (caller %d, library %d)", cfg->struct_size, (int)sizeof(CapConfig));
@@ -1305,8 +1350,22 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
         }
         if (cfg->v_hidden % 64 || cfg->v_mlp % 64 || cfg->t_ffn % 64) { cap_set_error("cap_create: widths must be multiples of 64"); return -1; }
     }
+    int dev = 0;
+    CAP_HIP_CHECK(hipGetDevice(&dev));
+    if (share) {
+        // same model, same arithmetic, same GPU; only the capacity of the arena may differ
+        CapConfig a = *cfg, b = share->c;
+        a.max_batch = b.max_batch = 0; a.max_beams = b.max_beams = 0; a.max_len = b.max_len = 0;
+        if (memcmp(&a, &b, sizeof(a)) != 0 || share->ws->device != dev) {
+            cap_set_error("cap_create_shared: the new handle must describe the same model, compute dtype and GPU as the handle "
+                          "whose weights it shares");
+            return -1;
+        }
+    }
     Captioner* m = new Captioner();
     m->c = *cfg;
+    if (share) { m->ws = share->ws; m->ws->refs.fetch_add(1); m->replay = true; }
+    else { m->ws = new WeightStore(); m->ws->device = dev; }
     m->dt = cfg->compute_dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32;
     m->gdt = cfg->compute_dtype == CAP_F32_SPLIT ? CAP_DT_G8 : m->dt;
     m->esz = m->dt == CAP_DT_BF16 ? 2 : 4;            // a G8 element is 4 bytes like fp32
@@ -1346,8 +1405,20 @@ int cap_create(const CapConfig* cfg, CapHandle* out) {
         release_captioner(m);       // the message of the failing step is kept
         return -1;
     }
+    if (m->replay && m->wcur != m->ws->ptrs.size()) {
+        cap_set_error("cap_create_shared: the shared store holds %zu buffers, this configuration uses %zu", m->ws->ptrs.size(), m->wcur);
+        release_captioner(m);
+        return -1;
+    }
     *out = (CapHandle)m;
     return 0;
+}
+
+int cap_create(const CapConfig* cfg, CapHandle* out) { return create_impl(cfg, nullptr, out); }
+
+int cap_create_shared(const CapConfig* cfg, CapHandle weights_of, CapHandle* out) {
+    if (!weights_of) { cap_set_error("cap_create_shared: null handle"); return -1; }
+    return create_impl(cfg, (Captioner*)weights_of, out);
 }
 
 int cap_destroy(CapHandle h) {
@@ -1380,7 +1451,7 @@ int cap_load_weight(CapHandle h, const char* name, const float* data, int on_dev
     hipStream_t s = (hipStream_t)stream;
     int64_t n = 1;
     for (int i = 0; i < ndim; ++i) n *= shape[i];
-    auto range = m->slots.equal_range(name);
+    auto range = m->ws->slots.equal_range(name);
     if (range.first == range.second) return 1;   // not a tensor this architecture stores (e.g. tied decoder.weight)
     const float* src = data;
     if (!on_device) {
@@ -1411,7 +1482,7 @@ int cap_finalize_weights(CapHandle h) {
     if (!m) { cap_set_error("null handle"); return -1; }
     int missing = 0;
     std::string names;
-    for (auto& kv : m->slots)
+    for (auto& kv : m->ws->slots)
         if (!kv.second.loaded) {
             if (missing < 8) names += (missing ? ", " : "") + kv.first;
             ++missing;

@@ -31,7 +31,9 @@ class CaptionerEngine:
     """One handle = one model replica on one GPU, bound to torch's current stream of `device` at each call."""
 
     def __init__(self, arch: BlipArch, dtype: str = "bf16", max_batch: int = 8, max_beams: int = 1,
-                 max_len: int = 20, device: str | torch.device = "cuda:0"):
+                 max_len: int = 20, device: str | torch.device = "cuda:0", share_weights_with: "CaptionerEngine | None" = None):
+        """share_weights_with: an engine of the same model / dtype / GPU whose (read-only) weights this one uses instead of
+        holding a copy - it gets its own arena only (cap_create_shared); load_state_dict through either is seen by both."""
         if not torch.cuda.is_available():
             raise N.CaptionerHipError("CaptionerEngine needs a GPU (torch.cuda.is_available() is False); "
                                       "there is no CPU fallback in the product path")
@@ -76,8 +78,12 @@ class CaptionerEngine:
             cfg.pix_mean[i] = OPENAI_CLIP_MEAN[i]
             cfg.pix_std[i] = OPENAI_CLIP_STD[i]
         self._h = C.c_void_p()
+        self.shares_weights = share_weights_with is not None
         with torch.cuda.device(self.device):
-            N.check(self.lib.cap_create(C.byref(cfg), C.byref(self._h)), "cap_create")
+            if share_weights_with is not None:
+                N.check(self.lib.cap_create_shared(C.byref(cfg), share_weights_with._h, C.byref(self._h)), "cap_create_shared")
+            else:
+                N.check(self.lib.cap_create(C.byref(cfg), C.byref(self._h)), "cap_create")
 
     # ------------------------------------------------------------------------------------------ lifetime
     def close(self) -> None:
@@ -218,7 +224,8 @@ class CaptionerEngine:
 
 
 class EnginePool:
-    """Several CaptionerEngines (own arenas, same weights) on their own streams: consecutive batches overlap.
+    """Several CaptionerEngines on their own streams: consecutive batches overlap.  Every engine has its own arena (activations,
+    K/V caches); the weights exist ONCE - engines 1.. are created on engine 0's weight store (cap_create_shared).
 
     One `cap_generate` is a chain of ~2 800 dependent kernels; between two dependent kernels of one HIP queue the GPU
     idles for the dispatch hand-over.  Independent batches do not depend on each other, so another
@@ -232,12 +239,14 @@ class EnginePool:
         outs = pool.generate_many(batches)            # or: out = pool.submit(px) ... pool.join()
     """
 
-    def __init__(self, arch, n: int = 2, device: str | torch.device = "cuda:0", engine_cls=None, **engine_kw):
+    def __init__(self, arch, n: int = 2, device: str | torch.device = "cuda:0", engine_cls=None, weights_of=None, **engine_kw):
+        """weights_of: an existing engine whose weight store ALL n engines of the pool attach to (nothing to load then)."""
         if n < 1:
             raise ValueError("EnginePool needs at least one engine")
         self.device = torch.device(device)
         engine_cls = engine_cls or CaptionerEngine           # TextEncoderEngine: submit(ids, lens, method="embed")
-        self.engines = [engine_cls(arch, device=device, **engine_kw) for _ in range(n)]
+        first = engine_cls(arch, device=device, share_weights_with=weights_of, **engine_kw)
+        self.engines = [first] + [engine_cls(arch, device=device, share_weights_with=first, **engine_kw) for _ in range(n - 1)]
         with torch.cuda.device(self.device):
             self.streams = [torch.cuda.Stream(self.device) for _ in range(n)]
         self.arch, self._next = arch, 0
@@ -246,10 +255,7 @@ class EnginePool:
         return len(self.engines)
 
     def load_state_dict(self, sd, strict: bool = True):
-        res = None
-        for e in self.engines:
-            res = e.load_state_dict(sd, strict=strict)
-        return res
+        return self.engines[0].load_state_dict(sd, strict=strict)      # one weight store behind every engine of the pool
 
     def set_early_exit(self, poll_steps: int) -> None:
         for e in self.engines:
@@ -336,7 +342,7 @@ class TextEncoderEngine:
     pseudolabeler.py:568,677); tokenisation stays on the host (captioner/sentence_encoder.py)."""
 
     def __init__(self, arch: MiniLMArch, dtype: str = "bf16", max_batch: int = 64, max_len: int = 32,
-                 device: str | torch.device = "cuda:0"):
+                 device: str | torch.device = "cuda:0", share_weights_with: "TextEncoderEngine | None" = None):
         if not torch.cuda.is_available():
             raise N.CaptionerHipError("TextEncoderEngine needs a GPU; there is no CPU fallback in the product path")
         self.lib = N.load_library()
@@ -350,8 +356,12 @@ class TextEncoderEngine:
         cfg.vocab, cfg.max_pos, cfg.t_eps = arch.vocab, arch.max_pos, arch.eps
         cfg.max_batch, cfg.max_beams, cfg.max_len = max_batch, 1, max_len
         self._h = C.c_void_p()
+        self.shares_weights = share_weights_with is not None
         with torch.cuda.device(self.device):
-            N.check(self.lib.cap_create(C.byref(cfg), C.byref(self._h)), "cap_create")
+            if share_weights_with is not None:
+                N.check(self.lib.cap_create_shared(C.byref(cfg), share_weights_with._h, C.byref(self._h)), "cap_create_shared")
+            else:
+                N.check(self.lib.cap_create(C.byref(cfg), C.byref(self._h)), "cap_create")
 
     close = CaptionerEngine.close
     __del__ = CaptionerEngine.__del__

@@ -82,6 +82,12 @@ const char* cap_last_error(void);
 int cap_version(void);
 
 int cap_create(const CapConfig* cfg, CapHandle* out);
+/* A further handle on the SAME weights (read-only once loaded): own arena / KV caches / workspace, sized by cfg's max_batch,
+ * max_beams, max_len; everything else in cfg must equal the configuration of `weights_of` (same model, compute dtype, GPU).
+ * What a pool of engines on several streams uses: n handles cost one copy of the weights + n arenas.  Tensors loaded through
+ * any of the handles are seen by all.  The weights are freed when the last handle referencing them is destroyed (any order).
+ * Replaces: one `model.to(device)` copy per worker (reference utils/predictor_utils.py:187). */
+int cap_create_shared(const CapConfig* cfg, CapHandle weights_of, CapHandle* out);
 int cap_destroy(CapHandle h);
 
 /* Stream one fp32 tensor of the checkpoint into the library.  Names: HuggingFace BLIP state-dict keys for CAP_ARCH_BLIP;
@@ -151,7 +157,8 @@ int cap_generate(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_
  * (sentence-transformers Pooling(mean) + Normalize).  All pointers are device pointers. */
 int cap_embed_text(CapHandle h, const int32_t* ids, const int32_t* lens, int B, int L, float* out, void* stream);
 
-/* Bytes of device memory held by the handle (weights + arena). */
+/* Bytes of device memory this handle allocated: its arena, plus the weights if it is the handle that created them
+ * (cap_create); a cap_create_shared handle reports its arena only. */
 size_t cap_device_bytes(CapHandle h);
 
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  While enabled every launch of the

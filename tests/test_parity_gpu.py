@@ -361,3 +361,37 @@ def test_engine_pool_gives_single_engine_results():
                     assert torch.equal(w["sequences_scores"], o["sequences_scores"])
         pool.close()
     single.close()
+
+
+def test_pool_engines_share_one_copy_of_the_weights():
+    """cap_create_shared: engines 1.. of a pool hold an arena only; results are those of a private copy; the store outlives
+    the engine that created it (any destroy order); a handle for another model / dtype cannot attach."""
+    from embodied_captioning_amd._native import CaptionerHipError
+    from embodied_captioning_amd.config import BlipArch
+    from embodied_captioning_amd.engine import CaptionerEngine, EnginePool
+    g, meta, arch, sd, px = golden_inputs("blip_tiny")
+    B, L = meta["batch"], meta["max_length"]
+    own = CaptionerEngine(arch, dtype="f32s", max_batch=B, max_beams=1, max_len=L)
+    own.load_state_dict(sd)
+    want = own.generate(px.cuda(), max_length=L)["sequences"].cpu()
+    pool = EnginePool(arch, n=3, dtype="f32s", max_batch=B, max_beams=1, max_len=L)
+    pool.load_state_dict(sd)
+    b0, b1, b2 = (e.device_bytes for e in pool.engines)
+    assert b0 == own.device_bytes and b1 == b2 and b1 < b0
+    weights = b0 - b1
+    assert weights > 4 * sum(v.numel() for k, v in sd.items() if "weight" in k and v.dim() == 2) * 0.9
+    for o in pool.generate_many([px.cuda()] * 4, max_length=L):
+        assert torch.equal(o["sequences"].cpu(), want)
+    # the creator goes first: the others keep working on the store
+    pool.engines[0].close()
+    with torch.cuda.stream(pool.streams[1]):
+        again = pool.engines[1].generate(px.cuda(), max_length=L)["sequences"]
+    torch.cuda.synchronize()
+    assert torch.equal(again.cpu(), want)
+    with pytest.raises(CaptionerHipError):
+        CaptionerEngine(arch, dtype="bf16", max_batch=B, max_beams=1, max_len=L, share_weights_with=pool.engines[1])
+    import dataclasses
+    with pytest.raises(CaptionerHipError):
+        CaptionerEngine(dataclasses.replace(arch, t_layers=arch.t_layers + 1), dtype="f32s", max_batch=B, max_beams=1, max_len=L,
+                        share_weights_with=pool.engines[1])
+    pool.engines[1].close(); pool.engines[2].close(); own.close()
