@@ -68,28 +68,58 @@ def gather_caption_records(ids: torch.Tensor, lens: torch.Tensor, n_pad: int, pa
 
 
 def caption_shard(generate: Callable[[torch.Tensor], Dict[str, torch.Tensor]], frames_of: Callable[[int, int], torch.Tensor],
-                  n_frames: int, micro_batch: int, max_len: int, pad_id: int = 0, join: Callable[[], None] | None = None):
+                  n_frames: int, micro_batch: int, max_len: int, pad_id: int = 0, join: Callable[[], None] | None = None,
+                  resume_dir: str | None = None, record_every: int = 16):
     """Caption frames [first, last) of this rank in micro-batches and gather everything.
     `frames_of(first, count)` returns the device tensor of frames; `generate(frames)` returns {"sequences","lengths"}.
-    `join`: called once after the last micro-batch was issued - for a `generate` that only starts the work on another stream
-    (engine.EnginePool.submit / .join: consecutive micro-batches overlap).
+    `join`: called after the last micro-batch (of a record, see below) was issued - for a `generate` that only starts the work
+    on another stream (engine.EnginePool.submit / .join: consecutive micro-batches overlap).
+    `resume_dir`: failure handling for long jobs.  After every `record_every` micro-batches the finished caption records of
+    that span are written to `resume_dir/records_<first>_<last>_L<max_len>.npz` (temporary name + rename: a file is whole
+    or absent); a rerun with the same arguments loads the spans whose file exists instead of captioning them again, so a
+    job killed at frame k restarts at the span that contains k.  The file name carries the span, which is a function of
+    (n_frames, world, rank, micro_batch, record_every): runs with another sharding simply do not find each other's files.
+    (The reference's driver has no resume: `detector/pseudolabeler.py:835-843` rewrites every episode_<e>_step_<s>.npz.)
     Returns (ids_all, lens_all) trimmed to n_frames rows, in global frame order."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     first, last, per = shard_range(n_frames, rank, world)
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    if resume_dir is not None:
+        os.makedirs(resume_dir, exist_ok=True)
+    span = micro_batch * max(int(record_every), 1) if resume_dir is not None else max(last - first, 1)
     ids_parts, len_parts = [], []
-    for i in range(first, last, micro_batch):
-        n = min(micro_batch, last - i)
-        out = generate(frames_of(i, n))
-        ids_parts.append(out["sequences"][:, :max_len])
-        len_parts.append(out["lengths"])
-    if join is not None:
-        join()
+    for s0 in range(first, last, span):
+        s1 = min(s0 + span, last)
+        path = os.path.join(resume_dir, f"records_{s0:010d}_{s1:010d}_L{max_len}.npz") if resume_dir is not None else None
+        if path is not None and os.path.exists(path):
+            import numpy as np
+            with np.load(path) as rec:
+                ids_parts.append(torch.from_numpy(rec["ids"]).to(dev))
+                len_parts.append(torch.from_numpy(rec["lens"]).to(dev))
+            continue
+        span_ids, span_lens = [], []
+        for i in range(s0, s1, micro_batch):
+            n = min(micro_batch, s1 - i)
+            out = generate(frames_of(i, n))
+            span_ids.append(out["sequences"][:, :max_len])
+            span_lens.append(out["lengths"])
+        if join is not None:
+            join()
+        ids_s, lens_s = torch.cat(span_ids), torch.cat(span_lens)
+        if path is not None:
+            import numpy as np
+            tmp = f"{path}.tmp{os.getpid()}.npz"
+            np.savez(tmp, ids=ids_s.cpu().numpy(), lens=lens_s.cpu().numpy())      # .cpu() waits for the span's work
+            os.replace(tmp, path)
+        ids_parts.append(ids_s.to(dev))
+        len_parts.append(lens_s.to(dev))
     if ids_parts:
         ids = torch.cat(ids_parts)
         lens = torch.cat(len_parts)
-    else:   # a rank beyond the end of a short job still takes part in the collective
-        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    else:   # a rank beyond the end of a short job still takes part in the collective (and still joins its streams once)
+        if join is not None:
+            join()
         ids = torch.full((0, max_len), pad_id, dtype=torch.int32, device=dev)
         lens = torch.zeros((0,), dtype=torch.int32, device=dev)
     ids_all, lens_all = gather_caption_records(ids, lens, per, pad_id)

@@ -70,3 +70,35 @@ def test_sharded_caption_gather_world2(n_frames):
     want_len = (frames % 6 + 1).int()
     for _, ids, lens in res:                      # every rank holds the full table in global frame order
         assert torch.equal(ids, want_ids) and torch.equal(lens, want_len)
+
+
+def test_caption_shard_resume_skips_finished_spans(tmp_path):
+    """Failure handling of the shard driver: records of finished spans are files; a rerun captions
+    only the spans whose file is missing and returns the same table."""
+    from embodied_captioning_amd import distributed as D
+    L, calls = 5, []
+
+    def frames_of(first, n):
+        return torch.arange(first, first + n, dtype=torch.int32)
+
+    def generate(frames):
+        calls.append(int(frames[0]))
+        ids = torch.stack([(frames * 3 + j) % 97 for j in range(L)], dim=1).int()
+        return {"sequences": ids, "lengths": (frames % L + 1).int()}
+
+    d = str(tmp_path / "records")
+    want = D.caption_shard(generate, frames_of, 23, micro_batch=4, max_len=L)
+    calls.clear()
+    a = D.caption_shard(generate, frames_of, 23, micro_batch=4, max_len=L, resume_dir=d, record_every=2)
+    assert calls == [0, 4, 8, 12, 16, 20] and torch.equal(a[0], want[0]) and torch.equal(a[1], want[1])
+    files = sorted(os.listdir(d))
+    assert files == ["records_0000000000_0000000008_L5.npz", "records_0000000008_0000000016_L5.npz",
+                     "records_0000000016_0000000023_L5.npz"]
+    calls.clear()
+    b = D.caption_shard(generate, frames_of, 23, micro_batch=4, max_len=L, resume_dir=d, record_every=2)
+    assert calls == [] and torch.equal(b[0], want[0]) and torch.equal(b[1], want[1])
+    os.remove(os.path.join(d, files[1]))                   # the job died while this span was in flight
+    calls.clear()
+    c = D.caption_shard(generate, frames_of, 23, micro_batch=4, max_len=L, resume_dir=d, record_every=2)
+    assert calls == [8, 12] and torch.equal(c[0], want[0]) and torch.equal(c[1], want[1])
+    assert not [f for f in os.listdir(d) if "tmp" in f]

@@ -67,3 +67,15 @@ def test_product_package_never_imports_oracle():
             if fn.endswith(".py"):
                 src = open(os.path.join(dp, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, fn)
+
+
+@pytest.mark.skipif(os.environ.get("CAP_RUN_ASAN") != "1", reason="rebuilds every .hip file with -fsanitize=address (~2 min): "
+                    "set CAP_RUN_ASAN=1; the committed run is profiles/r02_asan_host.txt")
+def test_host_side_asan_run_of_the_abi_argument_handling(tmp_path):
+    """SURVEY.md section 5 (sanitizers): the host half of the library under AddressSanitizer + LeakSanitizer - every failing
+    cap_create / cap_load_weight / launcher argument check returns an error code with nothing leaked or overrun."""
+    import subprocess
+    log = tmp_path / "asan.log"
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "asan_host_check.sh"), str(log)], capture_output=True, text=True)
+    text = log.read_text() if log.exists() else ""
+    assert r.returncode == 0 and "0 failures" in text and "ERROR: AddressSanitizer" not in text, r.stderr + text

@@ -28,12 +28,16 @@ def main():
     ap.add_argument("--frames", type=int, default=50000)
     ap.add_argument("--micro-batch", type=int, default=256)
     ap.add_argument("--max-length", type=int, default=20)
-    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--dtype", default="f32s", help="f32s (token-identical to the fp32 reference, default) | bf16 | f32")
     ap.add_argument("--streams", type=int, default=3, help="engines / HIP streams the micro-batches rotate over (engine.EnginePool)")
     ap.add_argument("--boxes", type=int, default=0, help="> 0: every unit is an object crop - raw 512x512 BGR frames made on "
                     "the device, this many boxes per frame (host RNG, seed = frame index), the reference's expand_box, crop + "
                     "Pillow-exact bicubic resize on the device (preprocess.crop_resize_u8), then the captioner; --frames "
                     "counts crops")
+    ap.add_argument("--resume", default=None, metavar="DIR", help="write the finished caption records of every --record-every "
+                    "micro-batches to DIR and, on a rerun with the same arguments, skip the spans whose record exists "
+                    "(distributed.caption_shard)")
+    ap.add_argument("--record-every", type=int, default=16)
     a = ap.parse_args()
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
     torch.cuda.set_device(local)
@@ -82,7 +86,7 @@ def main():
     t0 = time.perf_counter()
     first, last, _ = shard_range(a.frames, rank, world)
     ids, lens = caption_shard(lambda f: eng.submit(f, max_length=a.max_length), frames_of, a.frames, a.micro_batch,
-                              a.max_length, arch.pad, join=eng.join)
+                              a.max_length, arch.pad, join=eng.join, resume_dir=a.resume, record_every=a.record_every)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     ids_h, lens_h = ids.cpu().numpy(), lens.cpu().numpy()
