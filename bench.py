@@ -243,23 +243,30 @@ def main_coca(a):
     B = a.batch if a.batch != 256 else 128
     sd = procedural_coca_state_dict(arch, 0)
     px = synthetic_pixels(B, arch.image_size, seed=0).cuda()
-    eng = CaptionerEngine(arch, dtype=a.dtype, max_batch=B, max_beams=1, max_len=arch.seq_len)
+    K = a.beams
+    eng = CaptionerEngine(arch, dtype=a.dtype, max_batch=B, max_beams=K, max_len=arch.seq_len)
     eng.load_state_dict(sd)
-    pool = pooled(a, arch, sd, max_batch=B, max_beams=1, max_len=arch.seq_len)
-    dt, _ = timed_steps(pool or eng, px, arch.seq_len, a.steps, a.warmup, 1, lambda i, l: (i, l))
+    pool = None
+    if a.streams > 1:
+        from embodied_captioning_amd.engine import EnginePool
+        pool = EnginePool(arch, n=a.streams, dtype=a.dtype, max_batch=B, max_beams=K, max_len=arch.seq_len, weights_of=eng)
+    dt, _ = timed_steps(pool or eng, px, arch.seq_len, a.steps, a.warmup, 1, lambda i, l: (i, l), K)
     if pool is not None:
         pool.close()
     eng.profile(True)
-    eng.generate(px, max_length=arch.seq_len)
+    eng.generate(px, num_beams=K, max_length=arch.seq_len)
     rep = eng.profile_report()
     eng.profile(False)
     tags = [t for t in ENC_GEMM_TAGS if t in rep]
     fl = sum(rep[t]["flops"] for t in tags); ms = sum(rep[t]["ms"] for t in tags)
     S = a.image_size
-    line = {"metric": f"captions/sec (CoCa ViT-L/14 {S}x{S}, top_k=1, seq_len=30)", "value": round(B * a.steps / dt, 2),
+    how = "top_k=1" if K == 1 else f"beam={K} (reference _generate_beamsearch, one beam group)"
+    line = {"metric": f"captions/sec (CoCa ViT-L/14 {S}x{S}, {how}, seq_len=30)", "value": round(B * a.steps / dt, 2),
             "unit": "captions/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "dtype": a.dtype, "data": "synthetic frames, procedural weights",
-            "config": {"workload": f"CoCa ViT-L/14 encoder + attentional pooler + 29 KV-cached decode steps, {B} frames", "streams": a.streams},
+            "config": {"workload": f"CoCa ViT-L/14 encoder + attentional pooler + 29 KV-cached decode steps x {K} beam(s), {B} frames "
+                                   "(SURVEY config 5's model and decode on ONE GPU; parity of this path is unpinned - DESIGN.md section 2)",
+                       "streams": a.streams, "beams": K},
             "roofline": {"bound": "mfma", "kernel": "gemm_big3_kernel / gemm_big2_kernel (ViT-L qkv/proj/fc1/fc2)",
                          "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
                          "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_TFLOPS[a.dtype], 4), "traffic": None},

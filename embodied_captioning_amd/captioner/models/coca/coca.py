@@ -32,6 +32,9 @@ class CoCa(CaptioningPredictor):
         super().__init__(cfg)
         name = cfg.model_name or "coca_ViT-L-14"
         self.batch_size = int(getattr(cfg, "batch_size", 8) or 8)
+        # num_beams 1 (default) = the wrapper's call in the reference, generate(generation_type="top_k", top_k=1) (coca.py:29);
+        # > 1 = the model's `_generate_beamsearch` with one beam group (coca_model.py:335-482; SURVEY config 5 asks beam 5)
+        self.num_beams = int(getattr(cfg, "num_beams", 1) or 1)
         dtype = getattr(cfg, "dtype", None) or "bf16"
         if int(getattr(cfg, "streams", 1) or 1) > 1:
             logger.warning("captioner.streams > 1 is implemented for arch_name 'blip' only: running one engine")
@@ -61,7 +64,7 @@ class CoCa(CaptioningPredictor):
                 self.tokenizer = open_clip
             except Exception:  # noqa: BLE001
                 logger.warning("open_clip is not installed: captions are returned as space-separated token ids")
-        self.engine = CaptionerEngine(self.arch, dtype=dtype, max_batch=self.batch_size, max_beams=1,
+        self.engine = CaptionerEngine(self.arch, dtype=dtype, max_batch=self.batch_size, max_beams=self.num_beams,
                                       max_len=self.arch.seq_len, device=self._device)
         # HF generate stops once every caption has its EOS; look every few steps (cfg early_exit_poll, 0 = never)
         poll = getattr(cfg, "early_exit_poll", None)
@@ -112,7 +115,7 @@ class CoCa(CaptioningPredictor):
         px = self.preprocess(images)
         seqs, lens = [], []
         for i in range(0, px.shape[0], self.batch_size):
-            out = self.engine.generate(px[i:i + self.batch_size].to(self._device), max_length=self.arch.seq_len)
+            out = self.engine.generate(px[i:i + self.batch_size].to(self._device), num_beams=self.num_beams, max_length=self.arch.seq_len)
             seqs.append(out["sequences"]); lens.append(out["lengths"])
         seq, ln = torch.cat(seqs).cpu(), torch.cat(lens).cpu()
         return {"texts": [self.decode(r[:n]) for r, n in zip(seq.tolist(), ln.tolist())], "sequences": seq, "lengths": ln}

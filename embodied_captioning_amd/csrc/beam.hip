@@ -1,6 +1,13 @@
 // Device-side beam search bookkeeping with HuggingFace v5 semantics (HF:generation/utils.py:3010-3204, 3316-3523):
 // 2*K candidates per item, -1e9 masking arithmetic in fp32, finished pool with the length penalty
-// (cur_len+1-prompt)^lp, early-stop heuristic on cur_len-prompt.  The self-attention KV cache is never copied on a
+// (cur_len+1-prompt)^lp, early-stop heuristic on cur_len-prompt.
+// BEAM_LEGACY_RAW: the reference's CoCa loop instead (coca_model.py:335-482: HF's pre-5.x BeamSearchScorer, one beam group) -
+// the same 2K-candidate step with three differences: (1) candidates are scored with RAW logits + the running score (no
+// log-softmax; MinLength's -inf on EOS) - coca_model.py:418-425; (2) the start token counts in every length denominator
+// (decoder_prompt_len is never passed): finished score = sum / (cur_len + 1)^lp; (3) `BeamHypotheses.is_done` compares the
+// pool's worst score with the step's best CANDIDATE (EOS ones included) / (cur_len + 1)^lp, not with the best running beam.
+// `finalize` adding the open beams at seq_len is the max-length rule of the last step here (every top-K candidate finishes),
+// which selects the same best hypothesis.  The self-attention KV cache is never copied on a
 // beam reorder: each row carries a table anc[row][pos] = physical row that wrote position `pos` of its history.
 //
 //   beam_rows_kernel   one block per (item, beam) row: log-softmax statistics + the row's top-2K candidates
@@ -67,7 +74,7 @@ __device__ __forceinline__ bool after(float v, int i, float pv, int pi) { return
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
 __global__ __launch_bounds__(256) void beam_rows_kernel(char* st, BeamLayout lo, const float* __restrict__ logits,
-                                                        int ld, int V, int K, int par) {
+                                                        int ld, int V, int K, int par, int raw, int eos_mask) {
     if (*(const int*)(st + lo.active) == 0) return;
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* x = logits + (size_t)row * ld;
@@ -96,7 +103,8 @@ __global__ __launch_bounds__(256) void beam_rows_kernel(char* st, BeamLayout lo,
     for (int c = 0; c < 2 * K; ++c) {
         float bv = -INFINITY; int bi = 0x7fffffff;
         for (int i = tid; i < V; i += 256) {
-            const float v = ((x[i] - m) - lsum) + run;
+            float v = raw ? x[i] + run : ((x[i] - m) - lsum) + run;
+            if (i == eos_mask) v = -INFINITY;
             if (after(v, i, pv, pi) && better(v, i, bv, bi)) { bv = v; bi = i; }
         }
 #pragma unroll
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(256) void beam_rows_kernel(char* st, BeamLayout lo,
 // that do not fit in LDS.
 template <int CT>
 __global__ __launch_bounds__(256) void beam_rows_lds_kernel(char* st, BeamLayout lo, const float* __restrict__ logits,
-                                                            int ld, int V, int K, int par) {
+                                                            int ld, int V, int K, int par, int raw, int eos_mask) {
     if (*(const int*)(st + lo.active) == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int V4 = (V + 3) >> 2, C = 2 * K;
@@ -175,7 +183,8 @@ __global__ __launch_bounds__(256) void beam_rows_lds_kernel(char* st, BeamLayout
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = 4 * j + u;
-            const float v = ((e[u] - m) - lsum) + run;
+            float v = raw ? e[u] + run : ((e[u] - m) - lsum) + run;
+            if (i == eos_mask) v = -INFINITY;
             if (i < V && better(v, i, tv[CT - 1], ti[CT - 1])) {
                 tv[CT - 1] = v; ti[CT - 1] = i;
 #pragma unroll
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(256) void beam_rows_lds_kernel(char* st, BeamLayout
 __global__ __launch_bounds__(64) void beam_merge_kernel(char* st, BeamLayout lo, int B, int K, int L, int V,
                                                         int cur_len, int eos, float denom_fin, float denom_run,
                                                         const int* __restrict__ anc_old, int* __restrict__ anc_new,
-                                                        int anc_ld) {
+                                                        int anc_ld, int legacy) {
     int* flags = (int*)(st + lo.active);          // [0] active, [1] parity of the final state, [2] any_open, [3] some_miss, [4] done
     if (flags[0] == 0) return;
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(char* st, BeamLayout lo,
         // ---- g. early-stop heuristic (cur_len already advanced by one)
         float mn = new_sc[0];
         for (int k = 1; k < K; ++k) mn = fminf(mn, new_sc[k]);
-        const float best_run = run_lp[run_pick[0]] / denom_run;
+        const float best_run = (legacy ? val[0] : run_lp[run_pick[0]]) / denom_run;
         bool any = false, all_hits = true;
         for (int k = 0; k < K; ++k) {
             const float worst = new_fin[k] ? mn : -1.0e9f;
@@ -355,10 +364,11 @@ __global__ void beam_finalize_kernel(char* st, BeamLayout lo, int B, int K, int 
 
 size_t beam_state_bytes(int B, int K, int max_len) { return beam_layout(B, K, max_len).total; }
 
-int launch_beam_init(void* state, int B, int K, int max_len, int bos, int pad, int eos, hipStream_t s) {
+int launch_beam_init(void* state, int B, int K, int max_len, int bos, int pad, int eos, hipStream_t s, int mode) {
     if (K < 1 || K > MAXK) { cap_set_error("beam search supports 1..%d beams (got %d)", MAXK, K); return -1; }
-    // HF: `output_fill_value = pad_token_id or eos_token_id[0]` - pad id 0 falls through to EOS.
-    const int fill = pad ? pad : eos;
+    // HF v5: `output_fill_value = pad_token_id or eos_token_id[0]` - pad id 0 falls through to EOS.  The legacy scorer's
+    // finalize fills with pad_token_id as it is (CoCa: 0).
+    const int fill = mode == BEAM_LEGACY_RAW ? pad : (pad ? pad : eos);
     hipLaunchKernelGGL(beam_init_kernel, dim3(64), dim3(256), 0, s, (char*)state, beam_layout(B, K, max_len), B, K,
                        max_len, bos, fill);
     CAP_HIP_CHECK(hipGetLastError());
@@ -366,9 +376,11 @@ int launch_beam_init(void* state, int B, int K, int max_len, int bos, int pad, i
 }
 
 int launch_beam_step(void* state, const float* logits, int ld, int V, int B, int K, int max_len, int cur_len,
-                     int eos, float length_penalty, int* anc, int anc_ld, hipStream_t s) {
+                     int eos, float length_penalty, int* anc, int anc_ld, hipStream_t s, int mode, int min_len) {
     const BeamLayout lo = beam_layout(B, K, max_len);
     const int par = cur_len & 1;
+    const int raw = mode == BEAM_LEGACY_RAW ? 1 : 0;
+    const int eos_mask = (raw && cur_len < min_len) ? eos : -1;       // MinLengthLogitsProcessor(min_len, eos)
     const size_t lds = (size_t)((V + 3) / 4) * 16 + (size_t)2 * K * 256 * 8;
     if (lds <= 150 * 1024 && (ld & 3) == 0 && V > 2 * K) {
         if (cap_kernel_setup((const void*)beam_rows_lds_kernel<4>, 150 * 1024, nullptr) != 0 ||
@@ -376,22 +388,24 @@ int launch_beam_step(void* state, const float* logits, int ld, int V, int B, int
             cap_kernel_setup((const void*)beam_rows_lds_kernel<16>, 150 * 1024, nullptr) != 0)
             return -1;
         if (2 * K <= 4)
-            hipLaunchKernelGGL(beam_rows_lds_kernel<4>, dim3(B * K), dim3(256), lds, s, (char*)state, lo, logits, ld, V, K, par);
+            hipLaunchKernelGGL(beam_rows_lds_kernel<4>, dim3(B * K), dim3(256), lds, s, (char*)state, lo, logits, ld, V, K, par, raw, eos_mask);
         else if (2 * K <= 8)
-            hipLaunchKernelGGL(beam_rows_lds_kernel<8>, dim3(B * K), dim3(256), lds, s, (char*)state, lo, logits, ld, V, K, par);
+            hipLaunchKernelGGL(beam_rows_lds_kernel<8>, dim3(B * K), dim3(256), lds, s, (char*)state, lo, logits, ld, V, K, par, raw, eos_mask);
         else
-            hipLaunchKernelGGL(beam_rows_lds_kernel<16>, dim3(B * K), dim3(256), lds, s, (char*)state, lo, logits, ld, V, K, par);
+            hipLaunchKernelGGL(beam_rows_lds_kernel<16>, dim3(B * K), dim3(256), lds, s, (char*)state, lo, logits, ld, V, K, par, raw, eos_mask);
     } else {
-        hipLaunchKernelGGL(beam_rows_kernel, dim3(B * K), dim3(256), 0, s, (char*)state, lo, logits, ld, V, K, par);
+        hipLaunchKernelGGL(beam_rows_kernel, dim3(B * K), dim3(256), 0, s, (char*)state, lo, logits, ld, V, K, par, raw, eos_mask);
     }
     CAP_HIP_CHECK(hipGetLastError());
-    // prompt length is 1 ([BOS]); python computes the float power in double, torch divides in fp32
-    const float denom_fin = (float)pow((double)(cur_len + 1 - 1), (double)length_penalty);
-    const float denom_run = (float)pow((double)(cur_len + 1 - 1), (double)length_penalty);
+    // v5: prompt length is 1 ([BOS]); python computes the float power in double, torch divides in fp32.  Legacy scorer: the
+    // prompt is not subtracted (generated_len = cur_len + 1 with decoder_prompt_len = 0)
+    const int glen = raw ? cur_len + 1 : cur_len + 1 - 1;
+    const float denom_fin = (float)pow((double)glen, (double)length_penalty);
+    const float denom_run = (float)pow((double)glen, (double)length_penalty);
     const int* anc_old = anc ? anc + (size_t)par * B * K * anc_ld : nullptr;
     int* anc_new = anc ? anc + (size_t)(par ^ 1) * B * K * anc_ld : nullptr;
     hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, s, (char*)state, lo, B, K, max_len, V, cur_len, eos,
-                       denom_fin, denom_run, anc_old, anc_new, anc_ld);
+                       denom_fin, denom_run, anc_old, anc_new, anc_ld, raw);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }

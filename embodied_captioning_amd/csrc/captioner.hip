@@ -416,7 +416,7 @@ int build_coca(Captioner* m) {
 int build_arena_coca(Captioner* m) {
     const CapConfig& c = m->c;
     const size_t Bm = c.max_batch, NT = m->NT, D = c.v_hidden, E = c.embed_dim, e = m->esz, Q = c.pool_queries;
-    const size_t M = Bm * NT, R = Bm, Lm = c.max_len, H = c.t_heads;
+    const size_t M = Bm * NT, R = Bm * c.max_beams, Lm = c.max_len, H = c.t_heads;     // R: decode rows (image x beam)
     TRY(dev_alloc(m, &m->patches, Bm * m->P * m->Kpad * e));
     CAP_HIP_CHECK(hipMemset(m->patches, 0, Bm * m->P * m->Kpad * e));
     TRY(dev_alloc(m, (void**)&m->X, M * D * 4));
@@ -436,7 +436,7 @@ int build_arena_coca(Captioner* m) {
     TRY(dev_alloc(m, (void**)&m->seq, R * Lm * 4));
     TRY(dev_alloc(m, (void**)&m->finished, R * 4));
     TRY(dev_alloc(m, (void**)&m->lens, R * 4));
-    TRY(dev_alloc(m, (void**)&m->anc, 256));
+    TRY(dev_alloc(m, (void**)&m->anc, 2 * R * Lm * 4 + 256));    // beam ancestry of the self-attention caches (beam.hip)
     TRY(dev_alloc(m, (void**)&m->dx, R * E * 4));
     TRY(dev_alloc(m, (void**)&m->dy, R * E * 4));
     TRY(dev_alloc(m, (void**)&m->dpart, 12 * R * E * 4));
@@ -448,6 +448,8 @@ int build_arena_coca(Captioner* m) {
     TRY(dev_alloc(m, (void**)&m->logits, R * (size_t)m->ldl * 4));
     m->ccache.resize(c.t_layers + c.mm_layers);
     for (auto& p : m->ccache) TRY(dev_alloc(m, &p, 2 * R * H * Lm * 64 * e));
+    if (c.max_beams > 1)
+        for (int i = 0; i < 4; ++i) TRY(dev_alloc(m, &m->beam[i], beam_state_bytes((int)Bm, c.max_beams, (int)Lm)));
     return 0;
 }
 
@@ -1126,13 +1128,15 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
 // [causal self-attention block, cross-attention block]).  Every block is pre-LN: the residual stream x stays fp32 in
 // d.dx and each split-K consumer kernel both adds the branch to x and emits LayerNorm_next(x) as the next GEMM operand.
 // The reference recomputes the whole prefix through both towers every step (coca_model.py:294-303).
-int run_coca_step(Captioner* m, const Dec& d, int t, int Lm, hipStream_t s) {
+// tokens [R, tok_ld]: newest token of every row at column t; K rows per image share the image's cross K/V; anc (beams): the
+// ancestry table of the self-attention caches (row r's history position j was written by physical row anc[r][j]).
+int run_coca_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, int t, int K, const int* anc, int Lm, hipStream_t s) {
     const CapConfig& c = m->c;
     const int E = m->E, F = c.t_ffn, H = c.t_heads, R = d.R, Q = m->Q;
     const size_t e = m->esz;
     const int nb = (int)m->cb.size();
     // x = tok_emb[token] + pos[t]  (raw sum to d.dx), ln = LayerNorm_{block0.ln_1}(x)
-    TRY(launch_embed(m->dt, d.seq, Lm, t, m->tok_emb, m->tpos, m->cb[0].ln1_g, m->cb[0].ln1_b, c.t_eps, d.dx_t, nullptr, R, E, s,
+    TRY(launch_embed(m->dt, tokens, tok_ld, t, m->tok_emb, m->tpos, m->cb[0].ln1_g, m->cb[0].ln1_b, c.t_eps, d.dx_t, nullptr, R, E, s,
                      d.dx));
     for (int bi = 0; bi < nb; ++bi) {
         const CBlock& b = m->cb[bi];
@@ -1144,7 +1148,7 @@ int run_coca_step(Captioner* m, const Dec& d, int t, int Lm, hipStream_t s) {
             char* vc = kc + (size_t)R * H * Lm * 64 * e;
             TRY(gemm_partial(m, s, "coca_gemm_qkv", d.dx_t, b.w_in, d.dpart, R, 3 * E, E, 4, &S));
             ProfScope ps(m, s, "coca_self_attn", 4.0 * R * H * (t + 1) * 64, 2.0 * R * H * (t + 1) * 64 * e);
-            TRY(launch_decode_attention(m->dt, nullptr, kc, vc, nullptr, 0, 1, Lm, t + 1, d.dctx, R, H, 0, s, d.dpart, S, b.b_in,
+            TRY(launch_decode_attention(m->dt, nullptr, kc, vc, anc, Lm, 1, Lm, t + 1, d.dctx, R, H, 0, s, d.dpart, S, b.b_in,
                                         3 * E, 0, 1));
         } else {
             TRY(gemm_partial(m, s, "coca_gemm_cq", d.dx_t, b.w_in, d.dpart, R, E, E, 4, &S));
@@ -1152,7 +1156,7 @@ int run_coca_step(Captioner* m, const Dec& d, int t, int Lm, hipStream_t s) {
             const char* ck = (char*)m->cross + ((((size_t)b.cross_idx * 2 + 0) * d.Btot + d.b0) * H * Q + 1) * 64 * e;
             const char* cv = (char*)m->cross + ((((size_t)b.cross_idx * 2 + 1) * d.Btot + d.b0) * H * Q + 1) * 64 * e;
             ProfScope ps(m, s, "coca_cross_attn", 4.0 * R * H * (Q - 1) * 64, 2.0 * d.B * H * (Q - 1) * 64 * e);
-            TRY(launch_decode_attention(m->dt, nullptr, ck, cv, nullptr, 0, 1, Q, Q - 1, d.dctx, R, H, 0, s, d.dpart, S, b.b_in, E,
+            TRY(launch_decode_attention(m->dt, nullptr, ck, cv, nullptr, 0, K, Q, Q - 1, d.dctx, R, H, 0, s, d.dpart, S, b.b_in, E,
                                         0, 0));
         }
         // x += out_proj(ctx) ; ln = LayerNorm_2(x)
@@ -1216,7 +1220,7 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
         if (K == 1) {
             hipLaunchKernelGGL(init_seq_kernel, dim3(64), dim3(256), 0, st, d.seq, d.finished, d.lens, Rs, Lm, c.bos, c.pad);
         } else {
-            TRY(launch_beam_init(d.beam, Bs, K, Lm, c.bos, c.pad, c.eos, st));
+            TRY(launch_beam_init(d.beam, Bs, K, Lm, c.bos, c.pad, c.eos, st, coca ? BEAM_LEGACY_RAW : BEAM_HF_V5));
             hipLaunchKernelGGL(iota_rows_kernel, dim3(64), dim3(256), 0, st, d.anc, Rs, Lm);
         }
         CAP_HIP_CHECK(hipGetLastError());
@@ -1225,7 +1229,7 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
             if (si == 0) m->last_steps = t + 1;
             const int* tokens = K == 1 ? d.seq : beam_running_tokens_p(d.beam, Bs, K, Lm, cur_len & 1);
             const int* anc = K == 1 ? nullptr : d.anc + (size_t)(cur_len & 1) * Rs * Lm;
-            if (coca) TRY(run_coca_step(m, d, t, Lm, st));
+            if (coca) TRY(run_coca_step(m, d, tokens, Lm, t, K, anc, Lm, st));
             else TRY(run_decoder_step(m, d, tokens, Lm, t, K, anc, Lm, st));
             if (out_step_logits) {
                 hipLaunchKernelGGL(copy_logits_kernel, dim3(1024), dim3(256), 0, st, d.logits, m->ldl,
@@ -1237,7 +1241,8 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
                 TRY(launch_greedy_select(d.logits, m->ldl, c.vocab, d.seq, Lm, t, Lm, c.eos, c.pad, d.finished, d.lens, Rs, st,
                                          coca ? c.min_len : 0, coca ? 1 : 0));
             else
-                TRY(launch_beam_step(d.beam, d.logits, m->ldl, c.vocab, Bs, K, Lm, cur_len, c.eos, lp, d.anc, Lm, st));
+                TRY(launch_beam_step(d.beam, d.logits, m->ldl, c.vocab, Bs, K, Lm, cur_len, c.eos, lp, d.anc, Lm, st,
+                                     coca ? BEAM_LEGACY_RAW : BEAM_HF_V5, coca ? c.min_len : 0));
             if (ns == 1) {
                 bool done;
                 TRY(poll_all_finished(m, t, Lm - 1, d.finished, Rs, K == 1 ? nullptr : beam_active_flag_p(d.beam, Bs, K, Lm), st, &done));
@@ -1334,8 +1339,8 @@ static int create_impl(const CapConfig* cfg, Captioner* share, CapHandle* out) {
         if (cfg->arch == CAP_ARCH_COCA) {
             const int hd = cfg->pool_heads > 0 ? cfg->embed_dim / cfg->pool_heads : 0;
             if (cfg->embed_dim != cfg->t_hidden || cfg->pool_queries < 2 || cfg->mm_layers < 1 || (hd != 64 && hd != 96) ||
-                hd * cfg->pool_heads != cfg->embed_dim || cfg->max_beams != 1) {
-                cap_set_error("cap_create: CoCa needs embed_dim == t_hidden, pooler head_dim 64 or 96, mm_layers >= 1, max_beams 1");
+                hd * cfg->pool_heads != cfg->embed_dim) {
+                cap_set_error("cap_create: CoCa needs embed_dim == t_hidden, pooler head_dim 64 or 96, mm_layers >= 1");
                 return -1;
             }
         }
@@ -1537,10 +1542,8 @@ int cap_generate(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_
         if (num_beams != 1) { cap_set_error("cap_generate: BLIP-2 supports greedy decoding (num_beams = 1)"); return -1; }
         return run_generate_blip2(m, pixels, pixel_fmt, B, max_len, out_ids, out_len, out_step_logits, (hipStream_t)stream);
     }
-    if (m->c.arch == CAP_ARCH_COCA && num_beams != 1) {
-        cap_set_error("cap_generate: CoCa supports the reference's top-k(1) loop only (num_beams = 1)");
-        return -1;
-    }
+    // CoCa: num_beams == 1 is the reference's top-k(1) loop (coca.py:29), num_beams > 1 its `_generate_beamsearch` with one
+    // beam group (coca_model.py:335-482; length_penalty is the scorer's: pass 1.0 for the reference's default)
     return run_generate(m, pixels, pixel_fmt, B, num_beams, max_len, length_penalty, out_ids, out_len, out_scores,
                         out_step_logits, (hipStream_t)stream);
 }

@@ -347,7 +347,8 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const float* __restr
                                                             int eos, int pad, int* __restrict__ finished,
                                                             int* __restrict__ out_len, int min_len, int force_eos) {
     // min_len > 0: EOS cannot win while the row has fewer than min_len tokens (HF MinLengthLogitsProcessor, used by the
-    // reference's CoCa loop coca_model.py:235-240); force_eos: the last position is EOS (coca_model.py:317-318)
+    // reference's CoCa loop coca_model.py:235-240); force_eos (= "this is the CoCa loop"): the last position is EOS
+    // (coca_model.py:317-318) and a sampled pad id ends the row (:305)
     const int row = blockIdx.x, tid = threadIdx.x;
     const bool mask_eos = min_len > 0 && t + 1 < min_len;
     const float* x = logits + (size_t)row * ld;
@@ -400,6 +401,10 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const float* __restr
         seq[(size_t)row * seq_ld + t + 1] = tok;
         if (!fin) {
             if (tok == eos || t + 2 >= max_len) { finished[row] = 1; out_len[row] = t + 2; }
+            // the reference's CoCa loop also stops a row whose newest token IS the pad id (coca_model.py:305: `mask =
+            // last == eos | last == pad`; pad id 0 is an ordinary vocabulary entry there): it emits pad from then on and
+            // gets no EOS.  The row's length then excludes that pad.
+            else if (force_eos && tok == pad) { finished[row] = 1; out_len[row] = t + 1; }
         }
     }
 }

@@ -99,9 +99,12 @@ int launch_crop_resize_u8(const uint8_t* frame, int H, int W, int bgr, const int
 
 // ---- beam.hip --------------------------------------------------------------------------------
 size_t beam_state_bytes(int B, int K, int max_len);
-int launch_beam_init(void* state, int B, int K, int max_len, int bos, int pad, int eos, hipStream_t s);
+// mode: BEAM_HF_V5 (log-softmax scores, HF 5.x `_beam_search`) or BEAM_LEGACY_RAW (the reference's CoCa loop: raw-logit
+// scores, HF's pre-5.x BeamSearchScorer with one group, MinLength(min_len) on EOS) - see beam.hip
+enum { BEAM_HF_V5 = 0, BEAM_LEGACY_RAW = 1 };
+int launch_beam_init(void* state, int B, int K, int max_len, int bos, int pad, int eos, hipStream_t s, int mode = BEAM_HF_V5);
 int launch_beam_step(void* state, const float* logits, int ld, int V, int B, int K, int max_len, int cur_len,
-                     int eos, float length_penalty, int* anc, int anc_ld, hipStream_t s);
+                     int eos, float length_penalty, int* anc, int anc_ld, hipStream_t s, int mode = BEAM_HF_V5, int min_len = 0);
 int launch_beam_finalize(void* state, int B, int K, int max_len, int* out_ids, int* out_len, float* out_scores,
                          hipStream_t s);
 // device pointer: int32, 1 while the beam loop of this state is still running (HF `is_done.all()` not yet true)

@@ -193,3 +193,109 @@ def generate_top1(sd, a, pixels: Tensor, seq_len: Optional[int] = None, min_seq_
         if text.shape[1] >= seq_len:                          # MaxLengthCriteria(seq_len)
             break
     return {"text": text, "logits": out_logits, "image_embs": image_embs}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Beam search: the reference's `_generate_beamsearch` (coca_model.py:335-482) with HF's legacy `BeamSearchScorer`
+# (coca_model.py:20-46 imports it, :353-358 builds it with the scorer's defaults: length_penalty 1.0,
+# do_early_stopping False, num_beam_hyps_to_keep 1).  **PARITY UNPINNED**, doubly: `BeamSearchScorer` left transformers in
+# 5.x, so the scorer below is restated from the published 4.4x source (transformers/generation/beam_search.py:
+# `BeamSearchScorer.process` / `.finalize`, `BeamHypotheses.add` / `.is_done`), not imported.
+# Things that are specific to the reference's loop and easy to get wrong:
+#   * the scores are RAW logits (+ MinLength's -inf on EOS), not log-probabilities: coca_model.py:418-425 adds
+#     `beam_scores` to `next_token_logits` after the processors, there is no log_softmax;
+#   * `decoder_prompt_len` is never passed, so the start-of-text token counts in every length-penalty denominator;
+#   * no forced EOS at seq_len (that is the sampling loop's, :317-318): MaxLengthCriteria(seq_len) just ends the loop and
+#     `finalize` adds the open beams;
+#   * num_beam_groups must divide num_beams (:370); the reference's defaults 6 / 3 do, config 5's beam=5 runs with one group.
+class _BeamHyps:
+    def __init__(self, num_beams, length_penalty=1.0):
+        self.k, self.lp, self.beams, self.worst = num_beams, length_penalty, [], 1e9
+
+    def add(self, hyp, sum_logprobs, generated_len):
+        score = sum_logprobs / (generated_len ** self.lp)
+        if len(self.beams) < self.k or score > self.worst:
+            self.beams.append((score, hyp))
+            if len(self.beams) > self.k:
+                order = sorted((s, i) for i, (s, _) in enumerate(self.beams))
+                del self.beams[order[0][1]]
+                self.worst = order[1][0]
+            else:
+                self.worst = min(score, self.worst)
+
+    def is_done(self, best_sum_logprobs, cur_len):             # early_stopping False: the heuristic
+        if len(self.beams) < self.k:
+            return False
+        return self.worst >= best_sum_logprobs / cur_len ** self.lp
+
+
+@torch.no_grad()
+def generate_beamsearch(sd, a, pixels: Tensor, num_beams: int = 5, seq_len: Optional[int] = None,
+                        min_seq_len: Optional[int] = None, image_embs: Optional[Tensor] = None):
+    """coca_model.py:335-482 with num_beam_groups = 1.  Returns {"sequences": int64 [B, <= seq_len] (EOS appended where it
+    fits, pad after), "scores": the winning hypotheses' length-normalised scores, "image_embs"}."""
+    seq_len = seq_len or a.seq_len
+    min_seq_len = a.min_seq_len if min_seq_len is None else min_seq_len
+    assert seq_len > min_seq_len
+    if image_embs is None:
+        _, image_embs = encode_image(sd, a, pixels)
+    B, K = image_embs.shape[0], num_beams
+    embs = torch.repeat_interleave(image_embs, K, dim=0)                      # :350 (the reference re-encodes K copies)
+    input_ids = torch.full((B * K, 1), a.sot, dtype=torch.int64)
+    hyps = [_BeamHyps(K) for _ in range(B)]
+    done = [False] * B
+    beam_scores = torch.full((B, K), -1e9, dtype=torch.float32)
+    beam_scores[:, 0] = 0                                                     # :383 with num_sub_beams == num_beams
+    beam_scores = beam_scores.view(B * K)
+    while True:
+        logits = last_logits_full(sd, a, embs, input_ids)                     # whole prefix, as the reference does (:394-401)
+        V = logits.shape[-1]
+        if input_ids.shape[1] < min_seq_len:
+            logits = logits.clone()
+            logits[:, a.eos] = float("-inf")                                  # MinLengthLogitsProcessor
+        scores = (logits + beam_scores[:, None]).view(B, K * V)               # :418-425
+        top_v, top_i = torch.topk(scores, 2 * K, dim=1, largest=True, sorted=True)
+        next_idx, next_tok = top_i // V, top_i % V
+        # ---- BeamSearchScorer.process
+        cur_len = input_ids.shape[-1] + 1
+        nb_scores = torch.zeros(B, K); nb_tok = torch.full((B, K), a.pad, dtype=torch.int64); nb_idx = torch.zeros(B, K, dtype=torch.int64)
+        for b in range(B):
+            if done[b]:
+                continue                                                      # zeros / pad / index 0
+            slot = 0
+            for rank in range(2 * K):
+                tok, sc, bi = int(next_tok[b, rank]), float(top_v[b, rank]), b * K + int(next_idx[b, rank])
+                if tok == a.eos:
+                    if rank >= K:
+                        continue
+                    hyps[b].add(input_ids[bi].clone(), sc, generated_len=cur_len)
+                else:
+                    nb_scores[b, slot], nb_tok[b, slot], nb_idx[b, slot] = sc, tok, bi
+                    slot += 1
+                if slot == K:
+                    break
+            done[b] = done[b] or hyps[b].is_done(float(top_v[b].max()), cur_len)
+        beam_scores = nb_scores.view(B * K)
+        beam_idx = nb_idx.view(B * K)
+        input_ids = torch.cat([input_ids[beam_idx], nb_tok.view(B * K, 1)], dim=-1)          # :455-457, :468
+        if all(done) or input_ids.shape[1] >= seq_len:                        # :472
+            break
+    # ---- BeamSearchScorer.finalize(max_length = seq_len)
+    for b in range(B):
+        if done[b]:
+            continue
+        for k in range(K):
+            row = b * K + k
+            hyps[b].add(input_ids[row], float(beam_scores[row]), generated_len=input_ids.shape[-1])
+    best, best_scores = [], []
+    for b in range(B):
+        s, h = sorted(hyps[b].beams, key=lambda x: x[0])[-1]
+        best.append(h); best_scores.append(s)
+    lens = [len(h) for h in best]
+    width = min(max(lens) + 1, seq_len)
+    out = torch.full((B, width), a.pad, dtype=torch.int64)
+    for b, h in enumerate(best):
+        out[b, : lens[b]] = h
+        if lens[b] < width:
+            out[b, lens[b]] = a.eos
+    return {"sequences": out, "scores": torch.tensor(best_scores), "image_embs": image_embs}

@@ -135,3 +135,27 @@ def test_attention_and_block_equal_the_torch_modules_open_clip_composes():
             want = blk(x, kv, None if cross else mask)
         got = R._block(x, bsd, "b", H, 1e-5, causal=not cross, kv=kv)
         assert (got - want).abs().max().item() < 5e-6
+
+
+def test_beam_search_restatement_unpinned_properties():
+    """oracle/coca_ref.generate_beamsearch (coca_model.py:335-482 + HF's legacy BeamSearchScorer, restated): with one beam it
+    walks the arg-max path of the top-k(1) loop; with more beams the returned hypothesis scores at least as well under the
+    scorer's own measure (sum of raw logits / length incl. start token and EOS); MinLength holds; rows are EOS-terminated
+    and padded."""
+    from embodied_captioning_amd.config import CocaArch
+    from embodied_captioning_amd.weights import procedural_coca_state_dict, synthetic_pixels
+    from oracle import coca_ref as R
+    a = CocaArch.tiny()
+    sd = procedural_coca_state_dict(a, 3, eos_boost=2.0)
+    px = synthetic_pixels(4, a.image_size, seed=3)
+    g = R.generate_top1(sd, a, px)
+    b1 = R.generate_beamsearch(sd, a, px, num_beams=1, image_embs=g["image_embs"])
+    n = min(g["text"].shape[1], b1["sequences"].shape[1])
+    assert torch.equal(g["text"][:, :n], b1["sequences"][:, :n])
+    b5 = R.generate_beamsearch(sd, a, px, num_beams=5, image_embs=g["image_embs"])
+    assert (b5["scores"] >= b1["scores"] - 1e-5).all()
+    for row in b5["sequences"].tolist():
+        assert row[0] == a.sot
+        body = [t for t in row if t != a.pad]
+        assert len(body) >= a.min_seq_len and (body[-1] == a.eos or len(body) == a.seq_len)
+        assert a.eos not in body[:-1]

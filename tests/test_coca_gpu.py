@@ -134,3 +134,76 @@ def test_coca_wrapper_dict_api():
     assert torch.isinf(out["logits"][0][0, model.arch.eos])        # MinLength mask visible in the recorded logits
     ppl = model.compute_perplexity()
     assert torch.isfinite(ppl)
+
+
+def _beam_expected(ref, L, pad):
+    """The reference returns [B, <= seq_len] (EOS appended where it fits, pad after); the ABI returns [B, max_len] + lengths."""
+    seq = ref["sequences"]
+    want = _padded(seq, L, pad)
+    lens = []
+    for r in seq.tolist():
+        n = len(r)
+        while n > 1 and r[n - 1] == pad:
+            n -= 1
+        lens.append(n)
+    return want, np.array(lens)
+
+
+@pytest.mark.parametrize("boost,K", [(0.0, 5), (4.0, 5), (2.0, 3), (2.0, 1 + 5)])
+def test_coca_beam_search_unpinned_tiny_fp32_matches_restatement(boost, K):
+    """Config 5's decode: the reference's `_generate_beamsearch` (coca_model.py:335-482, raw-logit scores, HF's legacy
+    BeamSearchScorer, one beam group) on the device against its restatement oracle/coca_ref.generate_beamsearch - UNPINNED:
+    neither open_clip nor the scorer (gone from transformers 5) can be run here."""
+    from embodied_captioning_amd.config import CocaArch
+    from embodied_captioning_amd.engine import CaptionerEngine
+    from embodied_captioning_amd.weights import procedural_coca_state_dict, synthetic_pixels
+    from oracle import coca_ref as R
+    a = CocaArch.tiny()
+    B = 5
+    sd = procedural_coca_state_dict(a, 3, eos_boost=boost)
+    px = synthetic_pixels(B, a.image_size, seed=3)
+    eng = CaptionerEngine(a, dtype="f32", max_batch=B, max_beams=K, max_len=a.seq_len)
+    eng.load_state_dict(sd)
+    _, embs = R.encode_image(sd, a, px)
+    ref = R.generate_beamsearch(sd, a, px, num_beams=K, image_embs=embs)
+    out = eng.generate(px.cuda(), num_beams=K, max_length=a.seq_len, length_penalty=1.0)
+    want, lens = _beam_expected(ref, a.seq_len, a.pad)
+    assert np.array_equal(out["sequences"].cpu().numpy(), want), (out["sequences"].cpu().numpy(), want)
+    assert np.array_equal(out["lengths"].cpu().numpy(), lens)
+    np.testing.assert_allclose(out["sequences_scores"].cpu().numpy(), ref["scores"].numpy(), rtol=0, atol=1e-3)
+    # greedy on the same handle still is the reference's top-k(1) loop
+    g = R.generate_top1(sd, a, px, image_embs=embs)
+    assert np.array_equal(eng.generate(px.cuda(), max_length=a.seq_len)["sequences"].cpu().numpy(), _padded(g["text"], a.seq_len, a.pad))
+    eng.close()
+
+
+def test_coca_beam_search_unpinned_vit_l14_336_first_steps():
+    """The production geometry of config 5 (ViT-L/14 at 336x336, 577 image tokens, 12 + 12 text layers, vocabulary 49408,
+    beam 5): fp32 beams identical to the restatement over the first steps (seq_len 7: the restatement recomputes the whole
+    prefix on the host, as the reference does), bf16 beams well-formed."""
+    import dataclasses
+    from embodied_captioning_amd.config import CocaArch
+    from embodied_captioning_amd.engine import CaptionerEngine
+    from embodied_captioning_amd.weights import procedural_coca_state_dict, synthetic_pixels
+    from oracle import coca_ref as R
+    a = dataclasses.replace(CocaArch(), image_size=336)
+    sd = procedural_coca_state_dict(a, 0, eos_boost=3.0)
+    B, K, L, MIN = 2, 5, 7, 3
+    px = synthetic_pixels(B, 336, seed=1)
+    eng = CaptionerEngine(dataclasses.replace(a, min_seq_len=MIN), dtype="f32", max_batch=B, max_beams=K, max_len=L)
+    eng.load_state_dict(sd)
+    tok = eng.encode(px.cuda()).cpu()
+    ref = R.generate_beamsearch(sd, a, px, num_beams=K, seq_len=L, min_seq_len=MIN, image_embs=tok[:, 1:].contiguous())
+    out = eng.generate(px.cuda(), num_beams=K, max_length=L, length_penalty=1.0)
+    want, lens = _beam_expected(ref, L, a.pad)
+    assert np.array_equal(out["sequences"].cpu().numpy(), want), (out["sequences"].cpu().numpy(), want)
+    np.testing.assert_allclose(out["sequences_scores"].cpu().numpy(), ref["scores"].numpy(), rtol=0, atol=2e-3)
+    eng.close()
+    eng = CaptionerEngine(a, dtype="bf16", max_batch=B, max_beams=K, max_len=a.seq_len)
+    eng.load_state_dict(sd)
+    o = eng.generate(px.cuda(), num_beams=K, max_length=a.seq_len, length_penalty=1.0)
+    seq, ln = o["sequences"].cpu().numpy(), o["lengths"].cpu().numpy()
+    assert (seq[:, 0] == a.sot).all() and (ln >= a.min_seq_len).all() and (ln <= a.seq_len).all()
+    for r, n in zip(seq, ln):
+        assert (r[n:] == a.pad).all() and (n == a.seq_len or r[n - 1] == a.eos)
+    eng.close()
