@@ -953,11 +953,14 @@ int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_emb
     for (int i = 0; i < c.v_layers; ++i) {
         const VLayer& L = m->vl[i];
         TRY(add_ln(L.ln1_g, L.ln1_b, m->ln, nullptr));
-        // (split mode: the attention kernel is not a GEMM - it reads q|k|v as fp32 and writes the context as G8)
-        TRY(gemm(m, s, "gemm_qkv", m->ln, D, L.w_qkv, D, m->qkv, 3 * D, L.b_qkv, nullptr, M, 3 * D, D, 0, m->gdt == CAP_DT_G8 ? 1 : 0));
+        // split mode: q|k|v stay G8 when the split-fp16 MFMA attention kernel covers this token count, else the GEMM writes
+        // fp32 for the fp32 attention kernels; either way the context comes out as G8 (the proj GEMM's operand)
+        const bool g8_attn = m->gdt == CAP_DT_G8 && D / H == 64 && vit_attention_takes_g8(NT);
+        TRY(gemm(m, s, "gemm_qkv", m->ln, D, L.w_qkv, D, m->qkv, 3 * D, L.b_qkv, nullptr, M, 3 * D, D, 0,
+                 (m->gdt == CAP_DT_G8 && !g8_attn) ? 1 : 0));
         {
             ProfScope ps(m, s, "vit_attention", 4.0 * B * H * (double)NT * NT * 64, (double)M * 4 * D * m->esz);
-            TRY(launch_vit_attention(m->dt, m->qkv, m->ctx, B, NT, H, 0, s, D / H, 0, m->gdt));
+            TRY(launch_vit_attention(g8_attn ? CAP_DT_G8 : m->dt, m->qkv, m->ctx, B, NT, H, 0, s, D / H, 0, m->gdt));
         }
         TRY(gemm(m, s, "gemm_proj", m->ctx, D, L.w_proj, D, m->delta, D, L.b_proj, nullptr, M, D, D, 0, kDeltaInT ? 0 : 1));
         pending = true;
@@ -1602,6 +1605,10 @@ int cap_op_layernorm(int dtype, const float* in, const float* gamma, const float
     return launch_layernorm(dt_of(dtype), in, D, gamma, beta, eps, out_t, out_f, M, D, (hipStream_t)stream);
 }
 int cap_op_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, void* stream) {
+    // dtype CAP_F32_SPLIT: impl 3 = G8 q|k|v in (what the split mode's qkv GEMM writes; the split-fp16 MFMA kernel), any other
+    // impl = fp32 q|k|v in; the context is G8 either way
+    if (dtype == CAP_F32_SPLIT && impl == 3)
+        return launch_vit_attention(CAP_DT_G8, qkv, ctx, B, N, H, 0, (hipStream_t)stream, 64, 0, CAP_DT_G8);
     return launch_vit_attention(in_dt_of(dtype), qkv, ctx, B, N, H, impl, (hipStream_t)stream, 64, 0, dt_of(dtype));
 }
 int cap_op_vit_attention_hd(int dtype, const void* qkv, void* ctx, int B, int N, int H, int head_dim, int impl, void* stream) {

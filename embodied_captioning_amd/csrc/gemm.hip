@@ -770,6 +770,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, NWM * NWN == 8 ? 2 : 1) void gemm_b
                     const vec al = *(const vec*)(a_s + swz_off(wm0 + i * 16 + r16, 2 * kg + 1));
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
+                        // three dependent MFMAs in a row on one accumulator: measured FASTER than three passes over j (the
+                        // matrix pipe forwards the accumulator; tools/bench_gemm_split.py: 458 vs 478 us on the qkv shape)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah, acc[i][j], 0, 0, 0);
@@ -1059,7 +1061,8 @@ int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
             return launch_big<T, OUT_F32, EPI, 3>(p, stream);
         } else if constexpr (is_g8<T>) {
             // split fp16: the second-generation pipeline with 32 k per stage.  10 / 11 / 12 pick the schedule for A/B runs.
-            if (p.K >= 64) return launch_big2<T, OUT_F32, EPI, 0, false>(p, stream);
+            // iglp_opt(0) measured +2..3 % over the compiler's schedule on every encoder shape (tools/bench_gemm_split.py)
+            if (p.K >= 64) return launch_big2<T, OUT_F32, EPI, 1, false>(p, stream);
             return launch_cfg<T, 256, 256, 128, 64, 1, 2, OUT_F32, EPI>(p, stream);
         } else {
             return launch_big<T, OUT_F32, EPI, 0>(p, stream);

@@ -192,3 +192,23 @@ def test_decode_attention_writes_g8(lib):
     want = torch.einsum("rhk,rhkd->rhd", torch.softmax(s, -1), v.double()).reshape(R, H * 64)
     got = torch.from_numpy(g8_decode(out.cpu().numpy())).double()
     assert (got - want).abs().max().item() < 1e-5
+
+
+@gpu
+@pytest.mark.parametrize("N", [17, 197, 224, 257])
+def test_vit_attention_split_mfma_on_g8_qkv(lib, N):
+    """The split-fp16 MFMA attention kernel (impl 3): G8 q|k|v as the split mode's qkv GEMM writes them, G8 context out;
+    both products as hi.lo + lo.hi + hi.hi on the fp16 pipe - fp32-grade against an fp64 reference of the fp32 values."""
+    B, H = 3, 4
+    g = torch.Generator().manual_seed(N)
+    qkv = torch.randn(B * N, 3 * H * 64, generator=g) * 1.5
+    qd = _g8(qkv)
+    ctx = torch.full((B * N, H * 64), float("nan"), dtype=torch.float32, device="cuda")
+    _check(lib, lib.cap_op_vit_attention(SPLIT, _p(qd), _p(ctx), B, N, H, 3, _stream()))
+    torch.cuda.synchronize()
+    got = g8_decode(ctx.cpu().numpy())
+    assert np.isfinite(got).all()
+    err = np.abs(got.astype(np.float64) - _attn_ref(qkv, B, N, H).numpy()).max()
+    assert err < 1e-5, err
+    # unsupported token counts are refused (the engine then keeps q|k|v in fp32 for the fp32 kernels)
+    assert lib.cap_op_vit_attention(SPLIT, _p(qd), _p(ctx), 1, 577, H, 3, _stream()) != 0

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the split-fp16 (G8) GEMM over the captioner's shapes (GPU box only).
+    python tools/bench_gemm_split.py            # encoder shapes x schedule variants, decode shapes x tiles
+Prints 2MNK/t (the Linear layer's rate) and 3x that (MFMA flops executed) per variant."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from embodied_captioning_amd import _native  # noqa: E402
+
+lib = _native.load_library()
+s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+SPLIT = 2
+
+
+def g8(x, scale=1.0):
+    d = torch.empty_like(x)
+    if scale == 1.0:
+        assert lib.cap_op_convert(SPLIT, C.c_void_p(x.data_ptr()), C.c_void_p(d.data_ptr()), x.numel(), s) == 0
+    else:
+        assert lib.cap_op_convert_weight(SPLIT, C.c_void_p(x.data_ptr()), C.c_void_p(d.data_ptr()), x.shape[0], x.shape[1], s) == 0
+    return d
+
+
+SHAPES = [("qkv", 50432, 2304, 768, 0, 0, (3, 11, 12)), ("proj", 50432, 768, 768, 0, 1, (3, 11, 12)),
+          ("fc1", 50432, 3072, 768, 1, 0, (3, 11, 12)), ("fc2", 50432, 768, 3072, 0, 1, (3, 11, 12)),
+          ("crosskv", 50432, 18432, 768, 0, 1, (3,)),
+          ("vocab", 256, 30524, 768, 0, 1, (1, 2, 3)), ("dec768", 256, 768, 768, 0, 1, (1, 2)),
+          ("dec_f1", 256, 3072, 768, 1, 0, (1, 2)), ("dec_qkv", 256, 2304, 768, 0, 1, (1, 2))]
+for name, M, N, K, gelu, f32out, tiles in SHAPES:
+    A = g8(torch.randn(M, K, device="cuda"))
+    W = g8(torch.randn(N, K, device="cuda") / K ** 0.5, 4096.0)
+    bias = torch.randn(N, device="cuda")
+    out = torch.zeros(M, N, device="cuda", dtype=torch.float32)
+    line = f"{name:8s} M={M} N={N} K={K}:"
+    for rep in range(2):
+        for tile in tiles:
+            def run():
+                rc = lib.cap_op_gemm(SPLIT, C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(bias.data_ptr()),
+                                     C.c_void_p(0), C.c_void_p(out.data_ptr()), M, N, K, gelu, f32out, tile, s)
+                assert rc == 0, lib.cap_last_error()
+            for _ in range(3):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 20
+            e0.record()
+            for _ in range(n):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / n
+            tf = 2.0 * M * N * K / us / 1e6
+            line += f"  tile{tile}: {us:8.1f} us {tf:6.1f} TF ({3 * tf:6.0f} exec)"
+    print(line, flush=True)
