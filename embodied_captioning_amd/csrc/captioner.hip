@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/captioner_hip.h"
+#include "decode_xcd.h"
 #include "gemm.h"
 #include "ops.h"
 
@@ -163,6 +164,16 @@ struct Captioner {
     int* ln_cnt[4] = {nullptr, nullptr, nullptr, nullptr};
     int ln_total[4] = {0, 0, 0, 0};
     bool fuse_ln = false;
+    // ---- persistent decode-step kernel (decode_xcd.hip): XCD barrier counters + the values they hold after the launches
+    // issued so far, error word (host-mapped), one event per handle for the cross-stream launch chain
+    bool use_xcd = false;
+    int n_cu = 0;
+    int* xcd_bar = nullptr;        // [2][8][64]: barrier counters, then registration counters
+    unsigned xcd_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned xcd_reg_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long* xcd_dbg = nullptr;  // CAP_XCD_DBG=1: per-barrier timestamps of the last launch (tools/xcd_phase_times.py)
+    int* xcd_err_host = nullptr; int* xcd_err_dev = nullptr;
+    hipEvent_t xcd_ev = nullptr;
     // ---- BLIP-2 (CAP_ARCH_BLIP2)
     std::vector<QLayer> ql;
     std::vector<OLayer> ol;
@@ -1075,6 +1086,76 @@ int gemm_splitk_ln(Captioner* m, hipStream_t s, const Dec& d, const char* tag, c
     return gemm_splitk_reduce_ln(m, s, d, tag, A, W, bias, g, b, m->c.t_eps, N, K, d.dx_t, d.dx, nullptr);
 }
 
+// Two persistent decode kernels resident at once (two streams) could each hold part of the GPU and spin on barriers that
+// need the rest - forever.  They are therefore chained on the GPU, across every stream and handle of the process on a device:
+// a launch first waits for the event recorded behind the previous one.  (A stream that is being captured into a graph cannot
+// wait on outside work: the chain is skipped there - graphs of generate are for single-stream use.)
+struct XcdChain { std::mutex mu; std::map<int, hipEvent_t> tail; };
+static XcdChain g_xcd_chain;
+
+int launch_xcd_chained(Captioner* m, const XParams& p, hipStream_t s) {
+    int dev = 0;
+    CAP_HIP_CHECK(hipGetDevice(&dev));
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cs);
+    std::lock_guard<std::mutex> lock(g_xcd_chain.mu);
+    if (cs == hipStreamCaptureStatusNone) {
+        auto it = g_xcd_chain.tail.find(dev);
+        if (it != g_xcd_chain.tail.end() && it->second && it->second != m->xcd_ev) CAP_HIP_CHECK(hipStreamWaitEvent(s, it->second, 0));
+    }
+    TRY(launch_decode_step_xcd(m->gdt, p, m->n_cu, s));
+    if (cs == hipStreamCaptureStatusNone) {
+        CAP_HIP_CHECK(hipEventRecord(m->xcd_ev, s));
+        g_xcd_chain.tail[dev] = m->xcd_ev;
+    }
+    return 0;
+}
+
+void xcd_chain_forget(Captioner* m) {          // a handle goes away: nobody may wait on its event any more
+    if (!m->xcd_ev) return;
+    std::lock_guard<std::mutex> lock(g_xcd_chain.mu);
+    for (auto& kv : g_xcd_chain.tail)
+        if (kv.second == m->xcd_ev) kv.second = nullptr;      // (cap_destroy has synchronised the device: nothing is pending)
+}
+
+// All layers of one decode step in one launch (decode_xcd.hip) -> d.dx (fp32) / d.dx_t (operand) hold the last layer's output.
+int run_decoder_layers_xcd(Captioner* m, const Dec& d, const int* tokens, int tok_ld, int t, int K, const int* anc, int Lm,
+                           const int* skip, hipStream_t s) {
+    const CapConfig& c = m->c;
+    const int T = c.t_hidden, F = c.t_ffn, H = c.t_heads, R = d.R, NT = m->NT;
+    const size_t e = m->esz;
+    XParams p;
+    memset(&p, 0, sizeof(p));
+    p.n_layers = c.t_layers;
+    for (int i = 0; i < c.t_layers; ++i) {
+        const TLayer& L = m->tl[i];
+        XLayer& x = p.layers[i];
+        x.w_qkv = L.w_qkv; x.w_so = L.w_so; x.w_cq = L.w_cq; x.w_co = L.w_co; x.w_f1 = L.w_f1; x.w_f2 = L.w_f2;
+        x.b_qkv = L.b_qkv; x.b_so = L.b_so; x.so_g = L.so_g; x.so_b = L.so_b; x.b_cq = L.b_cq; x.b_co = L.b_co;
+        x.co_g = L.co_g; x.co_b = L.co_b; x.b_f1 = L.b_f1; x.b_f2 = L.b_f2; x.f_g = L.f_g; x.f_b = L.f_b;
+        char* kc = (char*)L.self_cache + d.cache_off;
+        x.kc = kc; x.vc = kc + (size_t)R * H * Lm * 64 * e;
+        x.ck = (char*)m->cross + (((size_t)i * 2 + 0) * d.Btot + d.b0) * H * NT * 64 * e;
+        x.cv = (char*)m->cross + (((size_t)i * 2 + 1) * d.Btot + d.b0) * H * NT * 64 * e;
+    }
+    p.R = R; p.T = T; p.F = F; p.H = H; p.NT = NT; p.Lm = Lm; p.t = t; p.K = K; p.eps = c.t_eps;
+    p.x = d.dx; p.xt = d.dx_t; p.qkv = d.dpart; p.q = d.dpart + (size_t)3 * R * T; p.tmp = d.dy; p.ctx = d.dctx; p.h = d.dh;
+    p.anc = anc; p.anc_ld = Lm; p.skip = skip; p.tokens = tokens; p.tok_ld = tok_ld;
+    p.word = m->word_f32; p.pos = m->tpos; p.emb_g = m->emb_g; p.emb_b = m->emb_b;
+    p.bar = m->xcd_bar; p.reg = m->xcd_bar + 8 * 64; p.err = m->xcd_err_dev; p.dbg = m->xcd_dbg;
+    const int nl = m->n_cu / 8, RX = (R + 7) / 8, nbar = xcd_barriers_per_launch(c.t_layers);
+    for (int x = 0; x < 8; ++x) {
+        p.bar_base[x] = m->xcd_base[x];
+        if (R - x * RX > 0) m->xcd_base[x] += (unsigned)(nbar * nl);
+        p.reg_base[x] = m->xcd_reg_base[x];
+        m->xcd_reg_base[x] += (unsigned)nl;             // every XCD receives n_cu / 8 workgroups of every launch
+    }
+    const double wbytes = ((double)T * T * 6 + 2.0 * T * F) * c.t_layers * e;
+    ProfScope ps(m, s, "dec_layers_xcd", 2.0 * R * ((double)T * T * 6 + 2.0 * T * F) * c.t_layers + 4.0 * R * H * (NT + t + 1) * 64 * c.t_layers,
+                 8.0 * wbytes + 2.0 * d.B * H * NT * 64 * e * c.t_layers);
+    return launch_xcd_chained(m, p, s);
+}
+
 int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, int t, int K, const int* anc, int Lm,
                      hipStream_t s) {
     const CapConfig& c = m->c;
@@ -1083,6 +1164,9 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
     // greedy: the attention kernels leave the rows of ended captions alone (d.finished is set by greedy_select one step
     // before); the GEMMs still cover every row - they are bound by the weight stream, not by the row count
     const int* skip = K == 1 ? d.finished : nullptr;
+    if (m->use_xcd && m->nslices == 1) {
+        TRY(run_decoder_layers_xcd(m, d, tokens, tok_ld, t, K, anc, Lm, skip, s));
+    } else {
     TRY(launch_embed(m->gdt, tokens, tok_ld, t, m->word_f32, m->tpos, m->emb_g, m->emb_b, c.t_eps, d.dx_t, d.dx, R, T, s));
     for (int i = 0; i < c.t_layers; ++i) {
         const TLayer& L = m->tl[i];
@@ -1116,6 +1200,7 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
         TRY(gemm_splitk_ln(m, s, d, "dec_gemm_co", d.dctx, L.w_co, L.b_co, L.co_g, L.co_b, T, T));
         TRY(gemm(m, s, "dec_gemm_f1", d.dx_t, T, L.w_f1, T, d.dh, F, L.b_f1, nullptr, R, F, T, 1, 0));
         TRY(gemm_splitk_ln(m, s, d, "dec_gemm_f2", d.dh, L.w_f2, L.b_f2, L.f_g, L.f_b, T, F));
+    }
     }
     TRY(gemm(m, s, "dec_gemm_tr", d.dx_t, T, m->w_tr, T, d.dy, T, m->b_tr, nullptr, R, T, T, 1, 1));
     {
@@ -1290,6 +1375,12 @@ static void release_captioner(Captioner* m) {
         if (m->ev_join[i]) (void)hipEventDestroy(m->ev_join[i]);
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    xcd_chain_forget(m);
+    if (m->xcd_ev) (void)hipEventDestroy(m->xcd_ev);
+    if (m->xcd_err_host) {
+        if (*m->xcd_err_host) fprintf(stderr, "libcaptioner_hip: persistent decode kernel reported error bits %d on a destroyed handle\n", *m->xcd_err_host);
+        (void)hipHostFree(m->xcd_err_host);
+    }
     delete m;
 }
 
@@ -1412,6 +1503,32 @@ static int create_impl(const CapConfig* cfg, Captioner* share, CapHandle* out) {
     if (built) {
         release_captioner(m);       // the message of the failing step is kept
         return -1;
+    }
+    if (cfg->arch == CAP_ARCH_BLIP) {
+        // persistent decode-step kernel (decode_xcd.hip): OFF by default, CAP_DECODE_XCD=1 enables it for A/B runs.  Measured on
+        // MI355X at 256 rows (tools/xcd_phase_times.py): correct (every parity test passes on it), one launch per step instead
+        // of ~140, XCD-local barriers at 0.9 us - and still slower than the launch-per-kernel path: 200 us against 170 us per
+        // layer in split mode (135 against 120 in bf16), because partitioning the ROWS by XCD makes every XCD stream all the
+        // weights (8 x 33 MB per layer) and every workgroup re-read its XCD's whole activation block; DESIGN.md section 4.
+        const char* env = getenv("CAP_DECODE_XCD");
+        int n_cu = 0;
+        bool ok = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess;
+        m->n_cu = n_cu;
+        if (ok && env && atoi(env) != 0 && cfg->t_layers <= XCD_MAX_LAYERS &&
+            xcd_decode_supported(m->gdt, m->dt, cfg->t_hidden, cfg->t_ffn, cfg->t_heads, n_cu)) {
+            ok = dev_alloc(m, (void**)&m->xcd_bar, 2 * 8 * 64 * sizeof(int)) == 0 && hipMemset(m->xcd_bar, 0, 2 * 8 * 64 * sizeof(int)) == hipSuccess &&
+                 hipHostMalloc((void**)&m->xcd_err_host, sizeof(int), hipHostMallocMapped) == hipSuccess &&
+                 hipHostGetDevicePointer((void**)&m->xcd_err_dev, m->xcd_err_host, 0) == hipSuccess &&
+                 hipEventCreateWithFlags(&m->xcd_ev, hipEventDisableTiming) == hipSuccess;
+            if (!ok) { cap_set_error("cap_create: cannot set up the persistent decode kernel"); release_captioner(m); return -1; }
+            *m->xcd_err_host = 0;
+            m->use_xcd = true;
+            const char* dbg = getenv("CAP_XCD_DBG");
+            if (dbg && atoi(dbg) != 0 && (dev_alloc(m, (void**)&m->xcd_dbg, 4096 * 8) != 0 || hipMemset(m->xcd_dbg, 0, 4096 * 8) != hipSuccess)) {
+                release_captioner(m);
+                return -1;
+            }
+        }
     }
     if (m->replay && m->wcur != m->ws->ptrs.size()) {
         cap_set_error("cap_create_shared: the shared store holds %zu buffers, this configuration uses %zu", m->ws->ptrs.size(), m->wcur);
@@ -1541,6 +1658,15 @@ int cap_generate(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_
     Captioner* m = (Captioner*)h;
     TRY(check_call(m, B, num_beams, max_len, pixel_fmt));
     if (!pixels || !out_ids) { cap_set_error("cap_generate: null buffer"); return -1; }
+    if (m->xcd_err_host && *(volatile int*)m->xcd_err_host) {
+        // an earlier generate on this handle: a barrier of the persistent decode kernel timed out (1) or a workgroup was not on
+        // the XCD its index implies (2) - its captions were wrong.  The handle falls back to the launch-per-kernel path.
+        cap_set_error("cap_generate: the persistent decode kernel reported error bits %d in an earlier call on this handle; "
+                      "that call's captions are invalid (set CAP_DECODE_XCD=0 to avoid the kernel)", *m->xcd_err_host);
+        *m->xcd_err_host = 0;
+        m->use_xcd = false;
+        return -1;
+    }
     if (m->c.arch == CAP_ARCH_BLIP2) {
         if (num_beams != 1) { cap_set_error("cap_generate: BLIP-2 supports greedy decoding (num_beams = 1)"); return -1; }
         return run_generate_blip2(m, pixels, pixel_fmt, B, max_len, out_ids, out_len, out_step_logits, (hipStream_t)stream);
@@ -1549,6 +1675,16 @@ int cap_generate(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_
     // beam group (coca_model.py:335-482; length_penalty is the scorer's: pass 1.0 for the reference's default)
     return run_generate(m, pixels, pixel_fmt, B, num_beams, max_len, length_penalty, out_ids, out_len, out_scores,
                         out_step_logits, (hipStream_t)stream);
+}
+
+/* diagnostics: the persistent decode kernel's per-barrier timestamps (100 MHz ticks) of the last launch, when the handle was
+ * created under CAP_XCD_DBG=1; returns the number of values copied (0: not enabled). */
+int cap_debug_xcd_times(CapHandle h, long long* out, int n) {
+    Captioner* m = (Captioner*)h;
+    if (!m || !m->xcd_dbg || !out || n < 1) return 0;
+    n = n < 4096 ? n : 4096;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, m->xcd_dbg, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
 }
 
 int cap_profile_enable(CapHandle h, int on) {

@@ -164,6 +164,9 @@ size_t cap_device_bytes(CapHandle h);
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  While enabled every launch of the
  * tagged kernels is bracketed by an event pair; cap_profile_report synchronises the stream and writes a JSON object
  * {"tag": {"launches": n, "ms": total, "flops": f, "bytes": b}, ...} into buf. */
+/* Diagnostics of the persistent decode-step kernel (handles created under CAP_XCD_DBG=1): 100 MHz timestamps taken after
+ * every XCD-local barrier of the last launch by one workgroup; returns the number of values copied (0: not enabled). */
+int cap_debug_xcd_times(CapHandle h, long long* out, int n);
 int cap_profile_enable(CapHandle h, int on);
 int cap_profile_report(CapHandle h, char* buf, size_t buf_bytes);
 
