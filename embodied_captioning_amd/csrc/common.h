@@ -113,7 +113,10 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 template <typename T> __device__ __forceinline__ float gelu_for(float x);
 template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
 template <> __device__ __forceinline__ float gelu_for<__bf16>(float x) { return gelu_erf_fast(x); }
-template <> __device__ __forceinline__ float gelu_for<g8_t>(float x) { return gelu_erf(x); }
+// split mode: the A&S 7.1.26 form (|erf error| <= 1.5e-7, i.e. a few fp32 ulps - the same order as the split product's own
+// 2^-21) instead of libm's branchy erff: the fc1 epilogue covers 155 M elements per layer at batch 256 and measured 1.4 ms
+// per batch slower with erff; every golden stays token-identical (tests/test_parity_gpu.py)
+template <> __device__ __forceinline__ float gelu_for<g8_t>(float x) { return gelu_erf_fast(x); }
 
 // One-time per (kernel, device) setup shared by the launchers: raises the kernel's dynamic-LDS limit when `lds_bytes`
 // exceeds the 64 KiB default and returns the device's CU count in *n_cu (may be null).  Thread-safe; a handle per GPU in

@@ -49,9 +49,9 @@ def test_g8_container_round_trips_on_the_host():
     assert np.all(np.abs(wb - x * 1e-3) <= np.maximum(np.abs(x * 1e-3) * 2.0 ** -22, 2.0 ** -25 / G8_WSCALE))
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 16])
 @pytest.mark.parametrize("shape", [(256, 256, 128), (197, 768, 768), (300, 200, 192), (33, 7632, 64), (1, 64, 64), (520, 516, 3072),
-                                   (2000, 2304, 768)])
+                                   (2000, 2304, 768), (70000, 768, 96)])
 @gpu
 def test_split_gemm_is_fp32_grade(lib, tile, shape):
     M, N, K = shape
@@ -83,7 +83,7 @@ def test_split_gemm_tiles_are_bit_identical(lib):
     Ad, Wd = _g8(torch.randn(M, K, generator=g)), _g8(torch.randn(N, K, generator=g) / math.sqrt(K), G8_WSCALE)
     bd = torch.randn(N, generator=g).cuda()
     outs = []
-    for tile in (1, 2, 3, 4, 10, 11, 12):
+    for tile in (1, 2, 3, 4, 10, 11, 12, 16):
         o = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
         _check(lib, lib.cap_op_gemm(SPLIT, _p(Ad), _p(Wd), _p(bd), _p(None), _p(o), M, N, K, 0, 1, tile, _stream()))
         outs.append(o)
@@ -93,7 +93,7 @@ def test_split_gemm_tiles_are_bit_identical(lib):
 
 
 @gpu
-@pytest.mark.parametrize("tile", [0, 2, 3])
+@pytest.mark.parametrize("tile", [0, 2, 3, 16])
 def test_split_gemm_gelu_into_g8_output(lib, tile):
     M, N, K = 600, 3072, 256
     g = torch.Generator().manual_seed(11)

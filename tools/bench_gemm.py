@@ -25,8 +25,8 @@ for name, M, N, K, gelu, f32out in SHAPES:
     out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if f32out else tdt)
     resid = None   # the branch GEMMs write a delta; the residual add lives in the add+LayerNorm kernel
     line = f"{name:8s} M={M} N={N} K={K}:"
-    for tile in (1, 2, 3, 4):
-        if (tile == 2 and M > 1000) or (tile == 4 and M < 1000):
+    for tile in (1, 2, 3, 4, 16):
+        if (tile == 2 and M > 1000) or (tile in (4, 16) and M < 1000):
             continue
         def run():
             rc = lib.cap_op_gemm(tag, C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(bias.data_ptr()),

@@ -28,9 +28,9 @@ def g8(x, scale=1.0):
     return d
 
 
-SHAPES = [("qkv", 50432, 2304, 768, 0, 0, (3, 11, 12)), ("proj", 50432, 768, 768, 0, 1, (3, 11, 12)),
-          ("fc1", 50432, 3072, 768, 1, 0, (3, 11, 12)), ("fc2", 50432, 768, 3072, 0, 1, (3, 11, 12)),
-          ("crosskv", 50432, 18432, 768, 0, 1, (3,)),
+SHAPES = [("qkv", 50432, 2304, 768, 0, 0, (3, 16)), ("proj", 50432, 768, 768, 0, 1, (3, 16)),
+          ("fc1", 50432, 3072, 768, 1, 0, (3, 16)), ("fc2", 50432, 768, 3072, 0, 1, (3, 16)),
+          ("crosskv", 50432, 18432, 768, 0, 1, (3, 16)), ("sq8k", 8192, 8192, 8192, 0, 1, (3, 16)),
           ("vocab", 256, 30524, 768, 0, 1, (1, 2, 3)), ("dec768", 256, 768, 768, 0, 1, (1, 2)),
           ("dec_f1", 256, 3072, 768, 1, 0, (1, 2)), ("dec_qkv", 256, 2304, 768, 0, 1, (1, 2))]
 for name, M, N, K, gelu, f32out, tiles in SHAPES:
