@@ -130,30 +130,39 @@ __global__ __launch_bounds__(256) void beam_rows_kernel(char* st, BeamLayout lo,
 // (unrolled insertion, static indices), and the block then merges the 256 sorted lists by 2K rounds of block arg-max.
 // Same arithmetic and the same (value desc, index asc) order as beam_rows_kernel, which stays as the fallback for rows
 // that do not fit in LDS.
-template <int CT>
+// STAGE = false: vocabularies whose row does not fit in LDS next to the candidate lists (CoCa: 49408 x 4 B = 193 KiB): the
+// same single-scan candidate selection reading the row from global memory (twice more for the log-softmax statistics; not at
+// all for raw-logit scores) - the 2K-pass fallback kernel took 874 us per step at 128 x 5 rows there.
+template <int CT, bool STAGE = true>
 __global__ __launch_bounds__(256) void beam_rows_lds_kernel(char* st, BeamLayout lo, const float* __restrict__ logits,
                                                             int ld, int V, int K, int par, int raw, int eos_mask) {
     if (*(const int*)(st + lo.active) == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int V4 = (V + 3) >> 2, C = 2 * K;
-    float* xs = (float*)smem;                                  // [V4 * 4], tail padded with -inf
-    float* lv = xs + (size_t)V4 * 4;                           // [C][256] candidate values, c-major
+    float* xs = (float*)smem;                                  // STAGE: [V4 * 4], tail padded with -inf
+    float* lv = xs + (STAGE ? (size_t)V4 * 4 : 0);             // [C][256] candidate values, c-major
     int* li = (int*)(lv + (size_t)C * 256);                    // [C][256] candidate indices
     __shared__ float redf[4];
     __shared__ int redi[4];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* x = logits + (size_t)row * ld;
-    float m = -INFINITY;
-    for (int j = tid; j < V4; j += 256) {
+    auto ldg = [&](int j) {                                     // 4 logits of the row, -inf beyond V
         float4 v;
         if (4 * j + 3 < V) v = *(const float4*)(x + 4 * j);
         else {
             v.x = 4 * j < V ? x[4 * j] : -INFINITY; v.y = 4 * j + 1 < V ? x[4 * j + 1] : -INFINITY;
             v.z = 4 * j + 2 < V ? x[4 * j + 2] : -INFINITY; v.w = -INFINITY;
         }
-        *(float4*)(xs + 4 * j) = v;
-        m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
-    }
+        return v;
+    };
+    auto ld4 = [&](int j) { return STAGE ? *(const float4*)(xs + 4 * j) : ldg(j); };
+    float m = -INFINITY;
+    if (STAGE || !raw)
+        for (int j = tid; j < V4; j += 256) {
+            const float4 v = ldg(j);
+            if (STAGE) *(float4*)(xs + 4 * j) = v;
+            m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+        }
     m = wave_max(m);
     if (lane == 0) redf[wave] = m;
     __syncthreads();
@@ -164,10 +173,11 @@ __global__ __launch_bounds__(256) void beam_rows_lds_kernel(char* st, BeamLayout
     // sum may differ from it in the last bits - as it does between any two reduction orders; both are tested against
     // the oracle's beam scores.
     float sum = 0.f;
-    for (int j = tid; j < V4; j += 256) {
-        const float4 v = *(const float4*)(xs + 4 * j);
-        sum += expf(v.x - m); sum += expf(v.y - m); sum += expf(v.z - m); sum += expf(v.w - m);   // exp(-inf) = 0 on the pad
-    }
+    if (!raw)
+        for (int j = tid; j < V4; j += 256) {
+            const float4 v = ld4(j);
+            sum += expf(v.x - m); sum += expf(v.y - m); sum += expf(v.z - m); sum += expf(v.w - m);   // exp(-inf) = 0 on the pad
+        }
     sum = wave_sum(sum);
     if (lane == 0) redf[wave] = sum;
     __syncthreads();
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(256) void beam_rows_lds_kernel(char* st, BeamLayout
 #pragma unroll
     for (int c = 0; c < CT; ++c) { tv[c] = -INFINITY; ti[c] = 0x7fffffff; }
     for (int j = tid; j < V4; j += 256) {
-        const float4 q = *(const float4*)(xs + 4 * j);
+        const float4 q = ld4(j);
         const float e[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -393,6 +403,14 @@ int launch_beam_step(void* state, const float* logits, int ld, int V, int B, int
             hipLaunchKernelGGL(beam_rows_lds_kernel<8>, dim3(B * K), dim3(256), lds, s, (char*)state, lo, logits, ld, V, K, par, raw, eos_mask);
         else
             hipLaunchKernelGGL(beam_rows_lds_kernel<16>, dim3(B * K), dim3(256), lds, s, (char*)state, lo, logits, ld, V, K, par, raw, eos_mask);
+    } else if ((ld & 3) == 0 && V > 2 * K) {
+        const size_t lds2 = (size_t)2 * K * 256 * 8;                 // candidate lists only
+        if (2 * K <= 4)
+            hipLaunchKernelGGL((beam_rows_lds_kernel<4, false>), dim3(B * K), dim3(256), lds2, s, (char*)state, lo, logits, ld, V, K, par, raw, eos_mask);
+        else if (2 * K <= 8)
+            hipLaunchKernelGGL((beam_rows_lds_kernel<8, false>), dim3(B * K), dim3(256), lds2, s, (char*)state, lo, logits, ld, V, K, par, raw, eos_mask);
+        else
+            hipLaunchKernelGGL((beam_rows_lds_kernel<16, false>), dim3(B * K), dim3(256), lds2, s, (char*)state, lo, logits, ld, V, K, par, raw, eos_mask);
     } else {
         hipLaunchKernelGGL(beam_rows_kernel, dim3(B * K), dim3(256), 0, s, (char*)state, lo, logits, ld, V, K, par, raw, eos_mask);
     }
