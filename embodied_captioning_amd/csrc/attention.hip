@@ -586,98 +586,114 @@ __global__ __launch_bounds__(256, 1) void vit_attention_f32_mfma(const float* __
 //     source address) so the 16 lanes of a ds_read_b128 phase - 16 consecutive keys, same chunk - hit 16 different slots;
 //   * lane (r32, hh) of a 32x32x16 MFMA supplies 8 consecutive d = group 2 ks + hh: hi chunk 2 (2 ks + hh), lo chunk + 1;
 //   * P.V: V^T fragments through ds_read_b64_tr_b16 from the hi and the lo chunks; P (fp32, in (0, 1]) is split in registers.
-// 1 / 7 / 9 key blocks (N <= 32, 193..224, 257..288); one workgroup per (image, head), 112 / 144 KiB of LDS, EIGHT waves: the
-// 7 (9) query tiles of 197 (257) tokens go to different waves, two per SIMD, so one wave's softmax / P-split VALU work runs
-// under the other's MFMAs (four waves took 2 rounds of tiles: 268 us per layer at batch 256 against 1xx with eight).
-template <int KB>
-__global__ __launch_bounds__(512, 1) void vit_attention_split(const g8_t* __restrict__ qkv, g8_t* __restrict__ ctx, int N, int H) {
+// Any token count: a workgroup = one (image, head, group of 8 query tiles), EIGHT waves = one 32-query tile each (two per
+// SIMD, so one wave's softmax / P-split VALU work runs under the other's MFMAs); the keys are walked in chunks of KC key
+// blocks (KC = 7: 224 keys, 112 KiB of LDS) with an online softmax across chunks - 197 tokens are one chunk and one group
+// (the arithmetic of a single-pass softmax), 577 tokens (384-pixel checkpoints) three chunks x three groups.
+// ONE: the caller guarantees a single chunk (nkb <= KC): no rescaling state, the single-pass arithmetic.
+template <int KC, bool ONE>
+__global__ __launch_bounds__(512, 1) void vit_attention_split(const g8_t* __restrict__ qkv, g8_t* __restrict__ ctx, int N, int H, int QG) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NP = KB * 32;
+    constexpr int NP = KC * 32;
     char* Ks = smem;                                   // [NP] rows of 256 B
     char* Vs = smem + NP * 256;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int qg = blockIdx.x % QG, bh = blockIdx.x / QG, b = bh / H, h = bh % H;
     const int D = H * 64, ld = 3 * D;
     const int tid = threadIdx.x, lane = tid & 63, r32 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const char* base = (const char*)(qkv + (size_t)b * N * ld + h * 64);      // byte address of (token 0, q dims of head h)
     const size_t rowb = (size_t)ld * 4;
-
-    // 1 KiB pieces of 4 rows; piece p of K and of V go to wave p % 8
-    for (int p = wave; p < NP / 4; p += 8) {
-        const int row = p * 4 + (lane >> 4);
-        const int c = (lane & 15) ^ (row & 15);
-        const char* src = base + (size_t)min(row, N - 1) * rowb + c * 16;
-        __builtin_amdgcn_global_load_lds(CAP_GPTR(src + (size_t)D * 4), CAP_LPTR(Ks + p * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(CAP_GPTR(src + (size_t)2 * D * 4), CAP_LPTR(Vs + p * 1024), 16, 0, 0);
-    }
-    __syncthreads();   // vmcnt(0) + barrier: every piece has landed
-
     auto koff = [](int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); };
     const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
-    const int nqt = (N + 31) / 32;
+    const int nqt = (N + 31) / 32, nkb = nqt;
     const float c1 = 0.125f * LOG2E;
-    for (int qt = wave; qt < nqt; qt += 8) {
-        const int q = qt * 32 + r32, qc = min(q, N - 1);
-        f16x8 qh[4], ql[4];
+
+    const int qt = qg * 8 + wave;                      // this wave's query tile (may be past the end: it still helps with the DMA)
+    const bool live = qt < nqt;
+    const int q = qt * 32 + r32, qc = min(q, N - 1);
+    f16x8 qh[4], ql[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const char* qp = base + (size_t)qc * rowb + (2 * ks + hh) * 32;
-            qh[ks] = *(const f16x8*)qp;
-            ql[ks] = *(const f16x8*)(qp + 16);
+    for (int ks = 0; ks < 4; ++ks) {
+        const char* qp = base + (size_t)qc * rowb + (2 * ks + hh) * 32;
+        qh[ks] = *(const f16x8*)qp;
+        ql[ks] = *(const f16x8*)(qp + 16);
+    }
+    float m = -INFINITY, l = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
+
+    for (int c0 = 0; c0 < (ONE ? 1 : nkb); c0 += KC) {
+        if (c0 > 0) __syncthreads();                   // every wave is done with the previous chunk's K / V
+        // 1 KiB pieces of 4 rows; piece p of K and of V go to wave p % 8
+        for (int p = wave; p < NP / 4; p += 8) {
+            const int row = p * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (row & 15);
+            const char* src = base + (size_t)min(c0 * 32 + row, N - 1) * rowb + c * 16;
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(src + (size_t)D * 4), CAP_LPTR(Ks + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(src + (size_t)2 * D * 4), CAP_LPTR(Vs + p * 1024), 16, 0, 0);
         }
-        f32x16 s[KB];
+        __syncthreads();                               // vmcnt(0) + barrier: every piece has landed
+        if (!live) continue;
+        f32x16 s[KC];
+        float cm = -INFINITY;
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
+        for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+            for (int e = 0; e < 16; ++e) s[kc][e] = 0.f;
+            if (c0 + kc < nkb) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const f16x8 kh = *(const f16x8*)(Ks + koff(kb * 32 + r32, 2 * (2 * ks + hh)));
-                const f16x8 kl = *(const f16x8*)(Ks + koff(kb * 32 + r32, 2 * (2 * ks + hh) + 1));
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s[kb], 0, 0, 0);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s[kb], 0, 0, 0);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s[kb], 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) {
+                    const f16x8 kh = *(const f16x8*)(Ks + koff(kc * 32 + r32, 2 * (2 * ks + hh)));
+                    const f16x8 kl = *(const f16x8*)(Ks + koff(kc * 32 + r32, 2 * (2 * ks + hh) + 1));
+                    s[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s[kc], 0, 0, 0);
+                    s[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s[kc], 0, 0, 0);
+                    s[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s[kc], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);      // keep later K reads from piling up over this chain (spills at 256 VGPRs)
         }
-        // softmax over keys for query column r32: key(kb, e) = kb*32 + (e&3) + 8*(e>>2) + 4*hh
-        float m = -INFINITY;
+        // scores of this chunk for query column r32: key(kc, e) = (c0 + kc)*32 + (e&3) + 8*(e>>2) + 4*hh
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+        for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                if (kb == KB - 1) {
-                    const int key = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    if (key >= N) s[kb][e] = -INFINITY;
-                }
-                m = fmaxf(m, s[kb][e]);
+                const int key = (c0 + kc) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (key >= N) s[kc][e] = -INFINITY;     // padding keys and key blocks past the end
+                cm = fmaxf(cm, s[kc][e]);
             }
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float l = 0.f;
+        cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+        float mn = cm;
+        if constexpr (!ONE) {
+            mn = fmaxf(m, cm);
+            const float alpha = __builtin_amdgcn_exp2f((m - mn) * c1);      // first chunk: exp2(-inf) = 0 and l, o are 0
+            l *= alpha;
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+            m = mn;
+        }
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float p = __builtin_amdgcn_exp2f((s[kb][e] - m) * c1);
-                s[kb][e] = p;
+                const float p = __builtin_amdgcn_exp2f((s[kc][e] - mn) * c1);
+                s[kc][e] = p;
                 l += p;
             }
-        l += __shfl_xor(l, 32, 64);
-
-        f32x16 o[2];
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+        for (int kc = 0; kc < KC; ++kc) {
+            if (c0 + kc >= nkb) continue;               // (its probabilities are all zero)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 // B operand: element j of lane half hh is P^T[key = kb*32 + 16*s2 + 8*(j>>2) + 4*hh + (j&3)][q]
                 f16x8 ph, pl;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float pv = s[kb][8 * s2 + j];
+                    const float pv = s[kc][8 * s2 + j];
                     const f16_t hv = (f16_t)pv;
                     ph[j] = hv;
                     pl[j] = (f16_t)(pv - (float)hv);
@@ -687,7 +703,7 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split(const g8_t* __rest
                     // A operand (see vit_attention_mfma): this lane ADDRESSES row key0 (+8), dims dcol..dcol+3 and RECEIVES
                     // column (lane & 15) of the 4 rows of its 16-lane group; once from the hi chunk, once from the lo chunk
                     const int dcol = db * 32 + (tg & 1) * 16 + tp * 4;
-                    const int key0 = kb * 32 + 16 * s2 + 4 * (tg >> 1) + tq;
+                    const int key0 = kc * 32 + 16 * s2 + 4 * (tg >> 1) + tq;
                     const int ch = 2 * (dcol >> 3), sub = (dcol & 7) * 2;
                     const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + koff(key0, ch) + sub));
                     const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + koff(key0 + 8, ch) + sub));
@@ -701,16 +717,18 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split(const g8_t* __rest
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-        if (q < N) {
-            const float inv = 1.0f / l;
-            g8_t* op = ctx + ((size_t)b * N + q) * D;
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    store4(op, h * 64 + db * 32 + 8 * g + 4 * hh,
-                           make_float4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
         }
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (live && q < N) {
+        const float inv = 1.0f / l;
+        g8_t* op = ctx + ((size_t)b * N + q) * D;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                store4(op, h * 64 + db * 32 + 8 * g + 4 * hh,
+                       make_float4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
     }
 }
 
@@ -1417,12 +1435,13 @@ int launch_flash_wide(const void* qkv, void* ctx, int B, int N, int H, int hd, i
     return 0;
 }
 
-template <int KB>
-int launch_split_kb(const void* qkv, void* ctx, int B, int N, int H, hipStream_t s) {
-    const int lds = 2 * KB * 32 * 256;
-    auto kern = vit_attention_split<KB>;
+template <int KC, bool ONE>
+int launch_split_kc(const void* qkv, void* ctx, int B, int N, int H, hipStream_t s) {
+    const int lds = 2 * KC * 32 * 256;
+    auto kern = vit_attention_split<KC, ONE>;
     if (cap_kernel_setup((const void*)kern, lds, nullptr) != 0) return -1;
-    hipLaunchKernelGGL(kern, dim3(B * H), dim3(512), lds, s, (const g8_t*)qkv, (g8_t*)ctx, N, H);
+    const int QG = ((N + 31) / 32 + 7) / 8;               // groups of 8 query tiles
+    hipLaunchKernelGGL(kern, dim3(B * H * QG), dim3(512), lds, s, (const g8_t*)qkv, (g8_t*)ctx, N, H, QG);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1439,23 +1458,19 @@ int launch_f32_mfma_kb(const void* qkv, void* ctx, int B, int N, int H, hipStrea
 
 }  // namespace
 
-bool vit_attention_takes_g8(int N) {
-    const int kb = (N + 31) / 32;
-    return kb == 1 || kb == 7 || kb == 9;
-}
+bool vit_attention_takes_g8(int N) { return N >= 1; }     // any token count: the keys are walked in chunks
 
 int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s, int head_dim, int causal,
                          int out_dtype) {
     if (out_dtype < 0) out_dtype = dtype;
     if (dtype == CAP_DT_G8) {              // G8 q|k|v (the split mode's qkv GEMM output): the split-fp16 MFMA kernel
-        const int kbs = (N + 31) / 32;
         if (out_dtype != CAP_DT_G8 || head_dim != 64 || causal || !vit_attention_takes_g8(N)) {
-            cap_set_error("vit_attention: G8 q|k|v need head_dim 64, no mask and 1 / 7 / 9 key blocks (N=%d)", N);
+            cap_set_error("vit_attention: G8 q|k|v need head_dim 64 and no mask (N=%d)", N);
             return -1;
         }
-        if (kbs == 1) return launch_split_kb<1>(qkv, ctx, B, N, H, s);
-        if (kbs == 7) return launch_split_kb<7>(qkv, ctx, B, N, H, s);
-        return launch_split_kb<9>(qkv, ctx, B, N, H, s);
+        if (N <= 64) return launch_split_kc<2, true>(qkv, ctx, B, N, H, s);       // fixture-sized inputs
+        if (N <= 224) return launch_split_kc<7, true>(qkv, ctx, B, N, H, s);     // 197 tokens: one pass over all keys
+        return launch_split_kc<4, false>(qkv, ctx, B, N, H, s);                  // chunks of 128 keys, online softmax
     }
     if (out_dtype != dtype && !(dtype == CAP_DT_F32 && out_dtype == CAP_DT_G8 && head_dim == 64 && !causal)) {
         cap_set_error("vit_attention: output type %d for input type %d is not supported here", out_dtype, dtype);

@@ -19,6 +19,7 @@
 //   gemm_big2_kernel  bf16 256x256 persistent, second generation (the encoder GEMMs): see its header.
 // Edge tiles clamp their load rows and guard their stores.  Workgroup ids are remapped so each XCD (blockIdx % 8) walks
 // a contiguous run of tiles that share A panels in its L2.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "gemm.h"
@@ -1215,12 +1216,19 @@ int launch_big3(const GemmParams& p, hipStream_t stream) {
     return 0;
 }
 
+// CAP_GEMM_CUS=n (A/B knob): the persistent 256x256 kernels take at most n CUs, leaving the rest to kernels of other streams
+static int gemm_cu_cap() {
+    static const int cap = [] { const char* e = getenv("CAP_GEMM_CUS"); return e ? atoi(e) : 0; }();
+    return cap;
+}
+
 template <typename T, bool OUT_F32, int EPI, int VAR, bool PROF, int NWM = 2, int NWN = 4>
 int launch_big2(const GemmParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 512 * 128 + 2 * 1024 + 8 * 16 * 144;   // two stages + bias ping-pong + epilogue strips
     auto kern = gemm_big2_kernel<T, OUT_F32, EPI, VAR, PROF, NWM, NWN>;
     int n_cu = 0;
     if (cap_kernel_setup((const void*)kern, LDS, &n_cu) != 0) return -1;
+    if (gemm_cu_cap() > 0 && gemm_cu_cap() < n_cu) n_cu = gemm_cu_cap();
     const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int grid = ntiles < n_cu ? ntiles : n_cu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWM * NWN * 64), LDS, stream, p);

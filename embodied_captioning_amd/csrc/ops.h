@@ -48,7 +48,7 @@ int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
                          int causal = 0,    // causal: query i sees keys 0..i (decoder prefill over fused q|k|v rows)
                          int out_dtype = -1);   // type of ctx when it differs from qkv's (split mode: fp32 in, G8 out)
 // split mode: can the q|k|v buffer be G8 (launch_vit_attention(CAP_DT_G8, ...): the split-fp16 MFMA kernel) for N tokens?
-// Otherwise the qkv GEMM writes fp32 and the fp32 kernels run (fp32 in, G8 out).
+// (Yes for every N since the kernel walks the keys in chunks; kept as the switch to the fp32 kernels: fp32 in, G8 out.)
 bool vit_attention_takes_g8(int N);
 int launch_generic_attention(int dtype, const void* q, long ldq, long qbs, const void* k, long ldk, long kbs, const void* v,
                              long ldv, long vbs, void* out, long ldo, long obs, int B, int Lq, int Lk, int H, int hd,
