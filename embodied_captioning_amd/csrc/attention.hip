@@ -1084,6 +1084,107 @@ __global__ __launch_bounds__(256, 3) void decode_attention_online_kernel(const T
     }
 }
 
+// ---- decode attention over a K/V block SHARED by the NB beams of an image (cross-attention under beam search, no ancestry):
+// one wave per (image, head) streams the block once and serves all NB query rows from the same registers - with one wave per
+// (row, head) the NB rows each pull the block through L2 (CoCa 336, 5 beams: 500 MB of L2 traffic per launch, 81 us).  Chunking
+// (G) and the per-row operation order are those of decode_attention_online_kernel: a row's result has the same bits.
+template <typename T, int G, int NB, typename TO = T>
+__global__ __launch_bounds__(256, 2) void decode_attention_shared_kernel(const T* __restrict__ q, const T* __restrict__ kbase,
+                                                                      const T* __restrict__ vbase, int kv_ld, int n_keys,
+                                                                      TO* __restrict__ out, int n_img, int H, QSource qs,
+                                                                      const int* __restrict__ skip) {
+    constexpr int CH = 8 * G;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= n_img * H) return;
+    const int img = unit / H, h = unit - img * H, Dh = H * 64, R = n_img * NB;
+    const int lane = threadIdx.x & 63, ksub = lane >> 3, dch = lane & 7;
+    bool live[NB], any = false;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { live[b] = !(skip && skip[img * NB + b]); any |= live[b]; }
+    if (!any) return;
+    float m[NB], l[NB], o[NB][8], qv[NB][8];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        m[b] = -INFINITY; l[b] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[b][e] = 0.f;
+    }
+    Raw8<T> kr[G], vr[G];
+    auto issue = [&](int k0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int key = k0 + g * 8 + ksub;
+            if (key < n_keys) {
+                const size_t off = (((size_t)img * H + h) * kv_ld + key) * 64 + dch * 8;
+                kr[g].load(kbase + off); vr[g].load(vbase + off);
+            } else {
+                kr[g].zero(); vr[g].zero();
+            }
+        }
+    };
+    issue(0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int row = img * NB + b;
+        if (qs.part) {
+            Part8 pq;
+            pq.issue(qs, R, row, qs.col0 + h * 64 + dch * 8);
+            pq.finish<T>(qs, qv[b]);
+        } else {
+            load8<T>(q + (size_t)row * Dh + h * 64 + dch * 8, qv[b]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[b][e] *= 0.125f;
+    }
+    for (int k0 = 0;;) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float sc[G], cm = -INFINITY;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float sv = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sv = fmaf(qv[b][e], kr[g].get(e), sv);
+                sv += __shfl_xor(sv, 1, 64); sv += __shfl_xor(sv, 2, 64); sv += __shfl_xor(sv, 4, 64);
+                sc[g] = (k0 + g * 8 + ksub < n_keys) ? sv : -INFINITY;
+                cm = fmaxf(cm, sc[g]);
+            }
+            cm = fmaxf(cm, __shfl_xor(cm, 8, 64)); cm = fmaxf(cm, __shfl_xor(cm, 16, 64)); cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+            const float mn = fmaxf(m[b], cm);
+            const float c = expf(m[b] - mn);
+            l[b] *= c;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[b][e] *= c;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float pj = expf(sc[g] - mn);
+                l[b] += pj;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[b][e] = fmaf(pj, vr[g].get(e), o[b][e]);
+            }
+            m[b] = mn;
+        }
+        k0 += CH;
+        if (k0 >= n_keys) break;
+        issue(k0);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float lb = l[b];
+        lb += __shfl_xor(lb, 8, 64); lb += __shfl_xor(lb, 16, 64); lb += __shfl_xor(lb, 32, 64);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[b][e] += __shfl_xor(o[b][e], 8, 64); o[b][e] += __shfl_xor(o[b][e], 16, 64); o[b][e] += __shfl_xor(o[b][e], 32, 64);
+        }
+        if (ksub == 0 && live[b]) {
+            const float inv = 1.0f / lb;
+            TO* op = out + (size_t)(img * NB + b) * Dh;
+            store4(op, h * 64 + dch * 8, make_float4(o[b][0] * inv, o[b][1] * inv, o[b][2] * inv, o[b][3] * inv));
+            store4(op, h * 64 + dch * 8 + 4, make_float4(o[b][4] * inv, o[b][5] * inv, o[b][6] * inv, o[b][7] * inv));
+        }
+    }
+}
+
 // ---- attentional pooler: Q learned queries (already layer-normed and projected on the host, identical for every
 // image) attend over the N image tokens.  One thread per query, K/V tiles broadcast from LDS, online softmax; head_dim is
 // a template parameter (CoCa ViT-L/14: 768 / 8 heads = 96).  ~1 % of the CoCa encoder's flops.
@@ -1554,6 +1655,27 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
     if (append_kv && ng8 > 4 && q_part) {
         cap_set_error("decode_attention: fused k/v append supports up to 32 positions (got %d)", n_keys);
         return -1;
+    }
+    // beams of an image over its shared block (cross-attention, no ancestry): one wave per (image, head) for all beams
+    if (impl == 0 && !anc && ng8 > 4 && rows_per_kv >= 2 && rows_per_kv <= 5 && R % rows_per_kv == 0 && !append_kv) {
+        const int n_img = R / rows_per_kv;
+#define CAP_DA_SHARED(TT, GG, NBB, TOO)                                                                                 \
+    hipLaunchKernelGGL((decode_attention_shared_kernel<TT, GG, NBB, TOO>), dim3((n_img * H + 3) / 4), dim3(256), 0, s,     \
+                       (const TT*)q, (const TT*)kbase, (const TT*)vbase, kv_ld, n_keys, (TOO*)out, n_img, H, qs, skip_rows)
+#define CAP_DA_SHARED_NB(TT, GG, TOO)                                                                                   \
+    switch (rows_per_kv) {                                                                                             \
+        case 2: CAP_DA_SHARED(TT, GG, 2, TOO); break;                                                                  \
+        case 3: CAP_DA_SHARED(TT, GG, 3, TOO); break;                                                                  \
+        case 4: CAP_DA_SHARED(TT, GG, 4, TOO); break;                                                                  \
+        default: CAP_DA_SHARED(TT, GG, 5, TOO); break;                                                                 \
+    }
+        if (dtype == CAP_DT_BF16) CAP_DA_SHARED_NB(bf16_t, 5, bf16_t)
+        else if (out_dtype == CAP_DT_G8) CAP_DA_SHARED_NB(float, 7, g8_t)
+        else CAP_DA_SHARED_NB(float, 7, float)
+#undef CAP_DA_SHARED_NB
+#undef CAP_DA_SHARED
+        CAP_HIP_CHECK(hipGetLastError());
+        return 0;
     }
     if (impl == 0) {
         if (dtype == CAP_DT_BF16) {

@@ -184,33 +184,125 @@ __global__ __launch_bounds__(256) void beam_rows_lds_kernel(char* st, BeamLayout
     const float lsum = logf(redf[0] + redf[1] + redf[2] + redf[3]);
     const float run = ((const float*)(st + lo.run_score[par]))[row];
     __syncthreads();
+    float* cv = (float*)(st + lo.cand_val) + (size_t)row * C;
+    int* ci = (int*)(st + lo.cand_idx) + (size_t)row * C;
+    auto score = [&](float e, int i) {
+        const float v = raw ? e + run : ((e - m) - lsum) + run;
+        return i == eos_mask ? -INFINITY : v;
+    };
+    // streaming from global memory (vocabulary larger than the LDS): 8 loads of 16 bytes per thread are in flight at a time
+    constexpr int U = STAGE ? 1 : 8;
+    // Selection by threshold.  (A) every thread finds the best element of its slice; the C-th best of those 256 is a bound tau
+    // that at least C elements of the row reach, so the row's best C all lie at or above it.  (B) a second scan appends what
+    // reaches tau to a list in LDS (typically C .. 3C entries), which is ranked directly.  A per-thread sorted list of C
+    // instead (the fallback below) makes every lane of a wave walk the insertion whenever ONE lane inserts: 500 us per step
+    // at 640 rows x 49408 (CoCa, 5 beams).
+    constexpr int CAP = 1024;
+    __shared__ float sbv[256];
+    __shared__ int sbi[256];
+    __shared__ float listv[CAP];
+    __shared__ int listi[CAP];
+    __shared__ int cnt, taui;
+    __shared__ float tauv;
+    {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int j0 = tid; j0 < V4; j0 += 256 * U) {
+            float4 qq[U];
+#pragma unroll
+            for (int w = 0; w < U; ++w) {
+                const int j = j0 + w * 256;
+                qq[w] = j < V4 ? ld4(j) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            }
+#pragma unroll
+            for (int w = 0; w < U; ++w) {
+                const int j = j0 + w * 256;
+                const float e[4] = {qq[w].x, qq[w].y, qq[w].z, qq[w].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = 4 * j + u;
+                    const float v = score(e[u], i);
+                    if (i < V && better(v, i, bv, bi)) { bv = v; bi = i; }
+                }
+            }
+        }
+        sbv[tid] = bv; sbi[tid] = bi;
+        if (tid == 0) { cnt = 0; tauv = -INFINITY; taui = 0x7fffffff; }      // fewer than C slices with data: everything passes
+        __syncthreads();
+        int rank = 0;
+        for (int t = 0; t < 256; ++t) rank += better(sbv[t], sbi[t], bv, bi) ? 1 : 0;
+        if (rank == C - 1 && bi != 0x7fffffff) { tauv = bv; taui = bi; }    // indices are unique: exactly one such thread
+        __syncthreads();
+        const float tv0 = tauv; const int ti0 = taui;
+        for (int j0 = tid; j0 < V4; j0 += 256 * U) {
+            float4 qq[U];
+#pragma unroll
+            for (int w = 0; w < U; ++w) {
+                const int j = j0 + w * 256;
+                qq[w] = j < V4 ? ld4(j) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            }
+#pragma unroll
+            for (int w = 0; w < U; ++w) {
+                const int j = j0 + w * 256;
+                const float e[4] = {qq[w].x, qq[w].y, qq[w].z, qq[w].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = 4 * j + u;
+                    const float v = score(e[u], i);
+                    if (i < V && !better(tv0, ti0, v, i)) {                   // at or above tau
+                        const int pos = atomicAdd(&cnt, 1);
+                        if (pos < CAP) { listv[pos] = v; listi[pos] = i; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int n = cnt;
+        if (n <= CAP) {
+            for (int e = tid; e < n; e += 256) {
+                const float v = listv[e]; const int i = listi[e];
+                int r = 0;
+                for (int t = 0; t < n; ++t) r += better(listv[t], listi[t], v, i) ? 1 : 0;
+                if (r < C) { cv[r] = v; ci[r] = i; }
+            }
+            return;
+        }
+        __syncthreads();
+    }
+    // fallback (more than CAP elements at or above tau: long runs of equal logits): per-thread sorted lists, merged by the block
     float tv[CT]; int ti[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) { tv[c] = -INFINITY; ti[c] = 0x7fffffff; }
-    for (int j = tid; j < V4; j += 256) {
-        const float4 q = ld4(j);
-        const float e[4] = {q.x, q.y, q.z, q.w};
+    for (int j0 = tid; j0 < V4; j0 += 256 * U) {
+        float4 qq[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = 4 * j + u;
-            float v = raw ? e[u] + run : ((e[u] - m) - lsum) + run;
-            if (i == eos_mask) v = -INFINITY;
-            if (i < V && better(v, i, tv[CT - 1], ti[CT - 1])) {
-                tv[CT - 1] = v; ti[CT - 1] = i;
+        for (int w = 0; w < U; ++w) {
+            const int j = j0 + w * 256;
+            qq[w] = j < V4 ? ld4(j) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        }
 #pragma unroll
-                for (int c = CT - 1; c > 0; --c)
-                    if (better(tv[c], ti[c], tv[c - 1], ti[c - 1])) {
-                        const float fv = tv[c]; tv[c] = tv[c - 1]; tv[c - 1] = fv;
-                        const int fi = ti[c]; ti[c] = ti[c - 1]; ti[c - 1] = fi;
-                    }
+        for (int w = 0; w < U; ++w) {
+            const int j = j0 + w * 256;
+            const float e[4] = {qq[w].x, qq[w].y, qq[w].z, qq[w].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = 4 * j + u;
+                float v = raw ? e[u] + run : ((e[u] - m) - lsum) + run;
+                if (i == eos_mask) v = -INFINITY;
+                if (i < V && better(v, i, tv[CT - 1], ti[CT - 1])) {
+                    tv[CT - 1] = v; ti[CT - 1] = i;
+#pragma unroll
+                    for (int c = CT - 1; c > 0; --c)
+                        if (better(tv[c], ti[c], tv[c - 1], ti[c - 1])) {
+                            const float fv = tv[c]; tv[c] = tv[c - 1]; tv[c - 1] = fv;
+                            const int fi = ti[c]; ti[c] = ti[c - 1]; ti[c - 1] = fi;
+                        }
+                }
             }
         }
     }
 #pragma unroll
     for (int c = 0; c < CT; ++c)
         if (c < C) { lv[c * 256 + tid] = tv[c]; li[c * 256 + tid] = ti[c]; }
-    float* cv = (float*)(st + lo.cand_val) + (size_t)row * C;
-    int* ci = (int*)(st + lo.cand_idx) + (size_t)row * C;
     int h = 0;                                                  // head of this thread's list
     for (int c = 0; c < C; ++c) {
         float bv = h < C ? lv[h * 256 + tid] : -INFINITY;
@@ -385,17 +477,14 @@ int launch_beam_init(void* state, int B, int K, int max_len, int bos, int pad, i
     return 0;
 }
 
-int launch_beam_step(void* state, const float* logits, int ld, int V, int B, int K, int max_len, int cur_len,
-                     int eos, float length_penalty, int* anc, int anc_ld, hipStream_t s, int mode, int min_len) {
-    const BeamLayout lo = beam_layout(B, K, max_len);
-    const int par = cur_len & 1;
-    const int raw = mode == BEAM_LEGACY_RAW ? 1 : 0;
-    const int eos_mask = (raw && cur_len < min_len) ? eos : -1;       // MinLengthLogitsProcessor(min_len, eos)
+// The 2K best continuations of every running beam -> cand_val / cand_idx of the state block.
+static int launch_beam_rows(void* state, const BeamLayout& lo, const float* logits, int ld, int V, int B, int K, int par, int raw,
+                            int eos_mask, hipStream_t s) {
     const size_t lds = (size_t)((V + 3) / 4) * 16 + (size_t)2 * K * 256 * 8;
-    if (lds <= 150 * 1024 && (ld & 3) == 0 && V > 2 * K) {
-        if (cap_kernel_setup((const void*)beam_rows_lds_kernel<4>, 150 * 1024, nullptr) != 0 ||
-            cap_kernel_setup((const void*)beam_rows_lds_kernel<8>, 150 * 1024, nullptr) != 0 ||
-            cap_kernel_setup((const void*)beam_rows_lds_kernel<16>, 150 * 1024, nullptr) != 0)
+    if (lds <= 148 * 1024 && (ld & 3) == 0 && V > 2 * K) {
+        if (cap_kernel_setup((const void*)beam_rows_lds_kernel<4>, 148 * 1024, nullptr) != 0 ||
+            cap_kernel_setup((const void*)beam_rows_lds_kernel<8>, 148 * 1024, nullptr) != 0 ||
+            cap_kernel_setup((const void*)beam_rows_lds_kernel<16>, 148 * 1024, nullptr) != 0)
             return -1;
         if (2 * K <= 4)
             hipLaunchKernelGGL(beam_rows_lds_kernel<4>, dim3(B * K), dim3(256), lds, s, (char*)state, lo, logits, ld, V, K, par, raw, eos_mask);
@@ -415,6 +504,16 @@ int launch_beam_step(void* state, const float* logits, int ld, int V, int B, int
         hipLaunchKernelGGL(beam_rows_kernel, dim3(B * K), dim3(256), 0, s, (char*)state, lo, logits, ld, V, K, par, raw, eos_mask);
     }
     CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_beam_step(void* state, const float* logits, int ld, int V, int B, int K, int max_len, int cur_len,
+                     int eos, float length_penalty, int* anc, int anc_ld, hipStream_t s, int mode, int min_len) {
+    const BeamLayout lo = beam_layout(B, K, max_len);
+    const int par = cur_len & 1;
+    const int raw = mode == BEAM_LEGACY_RAW ? 1 : 0;
+    const int eos_mask = (raw && cur_len < min_len) ? eos : -1;       // MinLengthLogitsProcessor(min_len, eos)
+    if (launch_beam_rows(state, lo, logits, ld, V, B, K, par, raw, eos_mask, s) != 0) return -1;
     // v5: prompt length is 1 ([BOS]); python computes the float power in double, torch divides in fp32.  Legacy scorer: the
     // prompt is not subtracted (generated_len = cur_len + 1 with decoder_prompt_len = 0)
     const int glen = raw ? cur_len + 1 : cur_len + 1 - 1;
@@ -441,4 +540,16 @@ const int* beam_active_flag_p(void* state, int B, int K, int max_len) {
 }
 const int* beam_running_tokens_p(void* state, int B, int K, int max_len, int parity) {
     return (const int*)((char*)state + beam_layout(B, K, max_len).run_seq[parity]);
+}
+
+// test hook (cap_op_beam_candidates): the candidate selection alone on a freshly initialised state (running scores 0 for beam
+// 0, -1e9 for the others); the lists land in out_val / out_idx [B*K][2K], best first
+int beam_candidates_only(void* state, const float* logits, int ld, int V, int B, int K, int mode, int eos_mask, float* out_val,
+                         int* out_idx, hipStream_t s) {
+    const BeamLayout lo = beam_layout(B, K, 4);
+    if (launch_beam_init(state, B, K, 4, 1, 0, 2, s, mode) != 0) return -1;
+    if (launch_beam_rows(state, lo, logits, ld, V, B, K, 0, mode == BEAM_LEGACY_RAW ? 1 : 0, eos_mask, s) != 0) return -1;
+    CAP_HIP_CHECK(hipMemcpyAsync(out_val, (char*)state + lo.cand_val, (size_t)B * K * 2 * K * 4, hipMemcpyDeviceToDevice, s));
+    CAP_HIP_CHECK(hipMemcpyAsync(out_idx, (char*)state + lo.cand_idx, (size_t)B * K * 2 * K * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
 }

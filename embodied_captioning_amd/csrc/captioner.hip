@@ -174,6 +174,7 @@ struct Captioner {
     long long* xcd_dbg = nullptr;  // CAP_XCD_DBG=1: per-barrier timestamps of the last launch (tools/xcd_phase_times.py)
     int* xcd_err_host = nullptr; int* xcd_err_dev = nullptr;
     hipEvent_t xcd_ev = nullptr;
+    hipEvent_t enc_ev = nullptr;           // image side of the last generate is done (encoder chain)
     // ---- BLIP-2 (CAP_ARCH_BLIP2)
     std::vector<QLayer> ql;
     std::vector<OLayer> ol;
@@ -1275,19 +1276,58 @@ __global__ void copy_i32_kernel(const int* s, int* d, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
 }
 
-int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm, float lp, int32_t* out_ids,
-                 int32_t* out_len, float* out_scores, float* out_step_logits, hipStream_t s) {
+// CAP_ENCODER_CHAIN=1: the image sides (encoder + cross-K/V GEMM: MFMA-bound, every CU) of the generates of ALL handles and
+// streams of the process on a device run one after the other - a generate's image side waits for the event behind the previous
+// one's.  Two image sides at once only slow each other; what a stream pool can hide under one is another batch's decode chain.
+struct EncChain { std::mutex mu; std::map<int, hipEvent_t> tail; };
+static EncChain g_enc_chain;
+static bool enc_chain_on() {
+    static const bool on = [] { const char* e = getenv("CAP_ENCODER_CHAIN"); return e && atoi(e) != 0; }();
+    return on;
+}
+void enc_chain_forget(Captioner* m) {
+    if (!m->enc_ev) return;
+    std::lock_guard<std::mutex> lock(g_enc_chain.mu);
+    for (auto& kv : g_enc_chain.tail)
+        if (kv.second == m->enc_ev) kv.second = nullptr;
+}
+
+static int run_image_side(Captioner* m, const void* pixels, int fmt, int B, hipStream_t s) {
     const CapConfig& c = m->c;
-    const int R = B * K, NT = m->NT, D = c.v_hidden, T = c.t_hidden, H = c.t_heads;
-    const bool coca = c.arch == CAP_ARCH_COCA;
+    const int NT = m->NT, D = c.v_hidden, T = c.t_hidden, H = c.t_heads;
     TRY(run_encoder(m, pixels, fmt, B, nullptr, s));
-    if (coca) {
+    if (c.arch == CAP_ARCH_COCA) {
         TRY(run_coca_pool(m, B, nullptr, s));
         TRY(gemm(m, s, "gemm_crosskv", m->xhat, m->E, m->w_ckv, m->E, m->cross, 0, m->b_ckv, nullptr, B * m->Q,
                  c.mm_layers * 2 * m->E, m->E, 0, 0, EPI_CROSSKV, m->Q, H, B));
     } else {
         TRY(gemm(m, s, "gemm_crosskv", m->emb_t, D, m->w_ckv, D, m->cross, 0, m->b_ckv, nullptr, B * NT, c.t_layers * 2 * T, D,
                  0, 0, EPI_CROSSKV, NT, H, B));
+    }
+    return 0;
+}
+
+int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm, float lp, int32_t* out_ids,
+                 int32_t* out_len, float* out_scores, float* out_step_logits, hipStream_t s) {
+    const CapConfig& c = m->c;
+    const int R = B * K;
+    const bool coca = c.arch == CAP_ARCH_COCA;
+    hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cs0);
+    if (enc_chain_on() && cs0 == hipStreamCaptureStatusNone) {
+        int dev = 0;
+        CAP_HIP_CHECK(hipGetDevice(&dev));
+        if (!m->enc_ev) CAP_HIP_CHECK(hipEventCreateWithFlags(&m->enc_ev, hipEventDisableTiming));
+        // the lock covers the enqueue: the event must be recorded before another thread may wait on it
+        std::lock_guard<std::mutex> lock(g_enc_chain.mu);
+        auto it = g_enc_chain.tail.find(dev);
+        if (it != g_enc_chain.tail.end() && it->second && it->second != m->enc_ev) CAP_HIP_CHECK(hipStreamWaitEvent(s, it->second, 0));
+        const int rc_img = run_image_side(m, pixels, fmt, B, s);
+        CAP_HIP_CHECK(hipEventRecord(m->enc_ev, s));
+        g_enc_chain.tail[dev] = m->enc_ev;
+        if (rc_img != 0) return rc_img;
+    } else {
+        TRY(run_image_side(m, pixels, fmt, B, s));
     }
     // decode: independent row slices, one per stream (slice 0 stays on the caller's stream)
     int ns = m->nslices;
@@ -1377,6 +1417,8 @@ static void release_captioner(Captioner* m) {
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     xcd_chain_forget(m);
     if (m->xcd_ev) (void)hipEventDestroy(m->xcd_ev);
+    enc_chain_forget(m);
+    if (m->enc_ev) (void)hipEventDestroy(m->enc_ev);
     if (m->xcd_err_host) {
         if (*m->xcd_err_host) fprintf(stderr, "libcaptioner_hip: persistent decode kernel reported error bits %d on a destroyed handle\n", *m->xcd_err_host);
         (void)hipHostFree(m->xcd_err_host);
@@ -1776,6 +1818,17 @@ int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const v
                             void* stream) {
     return launch_decode_attention(in_dt_of(dtype), q, kbase, vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, out, R, H, impl,
                                    (hipStream_t)stream, nullptr, 0, nullptr, 0, 0, 0, dt_of(dtype));
+}
+int cap_op_beam_candidates(const float* logits, int ld, int V, int B, int K, int legacy_raw, int masked_id, float* out_val,
+                           int32_t* out_idx, void* stream) {
+    if (!logits || !out_val || !out_idx || B < 1 || K < 1 || V < 1 || ld < V) { cap_set_error("cap_op_beam_candidates: bad arguments"); return -1; }
+    void* st = nullptr;
+    CAP_HIP_CHECK(hipMalloc(&st, beam_state_bytes(B, K, 4)));
+    int rc = beam_candidates_only(st, logits, ld, V, B, K, legacy_raw ? BEAM_LEGACY_RAW : BEAM_HF_V5, masked_id, out_val, out_idx,
+                                  (hipStream_t)stream);
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = -1;
+    (void)hipFree(st);
+    return rc;
 }
 int cap_op_convert(int dtype, const float* src, void* dst, size_t n, void* stream) {
     return launch_convert(dt_of(dtype), src, dst, n, (hipStream_t)stream);

@@ -102,6 +102,8 @@ int launch_crop_resize_u8(const uint8_t* frame, int H, int W, int bgr, const int
 
 // ---- beam.hip --------------------------------------------------------------------------------
 size_t beam_state_bytes(int B, int K, int max_len);
+int beam_candidates_only(void* state, const float* logits, int ld, int V, int B, int K, int mode, int eos_mask, float* out_val,
+                         int* out_idx, hipStream_t s);     // test hook: candidate selection of the first step alone
 // mode: BEAM_HF_V5 (log-softmax scores, HF 5.x `_beam_search`) or BEAM_LEGACY_RAW (the reference's CoCa loop: raw-logit
 // scores, HF's pre-5.x BeamSearchScorer with one group, MinLength(min_len) on EOS) - see beam.hip
 enum { BEAM_HF_V5 = 0, BEAM_LEGACY_RAW = 1 };

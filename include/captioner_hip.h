@@ -197,6 +197,12 @@ int cap_op_gemm_skinny_slices(int N, int K, int finished);
 int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int32_t* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             void* stream);
+/* The candidate selection of a beam step alone (first step: running score 0 for beam 0 of an item, -1e9 for the others):
+ * logits fp32 [B*K][ld] -> the 2K best (score, token) per row, best first, ties to the lower token id; legacy_raw: scores are
+ * raw logits + running score (CoCa), else log-softmax + running score (HF v5); masked_id >= 0: that token scores -inf (legacy
+ * MinLength).  Synchronises the stream. */
+int cap_op_beam_candidates(const float* logits, int ld, int V, int B, int K, int legacy_raw, int masked_id, float* out_val,
+                           int32_t* out_idx, void* stream);
 int cap_op_convert(int dtype, const float* src, void* dst, size_t n, void* stream);
 /* Weight upload as cap_load_weight does it: dst [rows, cols] in the GEMM-operand type of `dtype` (CAP_F32_SPLIT: G8 halves of
  * 4096 * w - the split GEMM's epilogue divides by 4096; a G8 buffer is 4 bytes per element, cols % 8 == 0). */

@@ -270,7 +270,8 @@ def test_causal_prefill_attention(lib, N, hd):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("impl", [0, 1])
-@pytest.mark.parametrize("n_keys,beams", [(1, 1), (7, 1), (20, 3), (33, 2), (197, 3), (255, 1)])
+@pytest.mark.parametrize("n_keys,beams", [(1, 1), (7, 1), (20, 3), (33, 2), (197, 3), (255, 1), (197, 5), (255, 2), (577, 4),
+                                          (197, 6)])
 def test_decode_attention_with_ancestry_and_shared_kv(lib, dtype, n_keys, beams, impl):
     tag, tdt = DT[dtype]
     Bimg, H, kv_ld = 4, 3, max(n_keys, 20)
@@ -299,6 +300,47 @@ def test_decode_attention_with_ancestry_and_shared_kv(lib, dtype, n_keys, beams,
             ref[r, h * 64:(h + 1) * 64] = p @ v
     err = (out.float().cpu().double() - ref).abs().max().item()
     assert err < (1e-5 if dtype == "f32" else 2e-2), err
+    if shared and beams > 1 and impl == 0:
+        # the kernel that serves all beams of an image from one pass over the shared block (2-5 beams) gives every row the bits
+        # of the one-wave-per-row kernel (here: each row with its own copy of the block)
+        Kr, Vr = Kd.repeat_interleave(beams, 0).contiguous(), Vd.repeat_interleave(beams, 0).contiguous()
+        out1 = torch.zeros_like(out)
+        _check(lib, lib.cap_op_decode_attention(tag, _p(qd), _p(Kr), _p(Vr), None, kv_ld, 1, kv_ld, n_keys, _p(out1), R, H, 0,
+                                                _stream()))
+        assert torch.equal(out, out1)
+
+
+@pytest.mark.parametrize("V,K", [(30524, 3), (49408, 5), (49408, 2), (1000, 8), (64, 3), (30524, 7)])
+@pytest.mark.parametrize("kind", ["random", "quantised", "constant", "ramp"])
+def test_beam_candidate_selection_exact_with_ties(lib, V, K, kind):
+    """2K best (raw logit + running score, token) per row, ties to the lower token id: the threshold selection, its fallback
+    (more than 1024 elements at the bound: constant / coarsely quantised rows) and both vocabulary paths (row staged in LDS /
+    streamed from global memory) against a host sort.  Raw-score mode: one fp32 add per element, so the comparison is exact."""
+    B = 3
+    R, C = B * K, 2 * K
+    ld = (V + 3) // 4 * 4 + 8
+    g = torch.Generator().manual_seed(V + K)
+    if kind == "random":
+        x = torch.randn(R, ld, generator=g)
+    elif kind == "quantised":
+        x = torch.randint(0, 4, (R, ld), generator=g).float()
+    elif kind == "constant":
+        x = torch.full((R, ld), 1.5)
+    else:
+        x = torch.arange(ld).float().repeat(R, 1) * 0.25           # the best are the last columns of the row
+    masked = 7 if V > 7 else -1
+    xd = x.cuda()
+    val = torch.zeros(R, C, device="cuda")
+    idx = torch.zeros(R, C, dtype=torch.int32, device="cuda")
+    _check(lib, lib.cap_op_beam_candidates(_p(xd), ld, V, B, K, 1, masked, _p(val), _p(idx), _stream()))
+    run = np.where(np.arange(R) % K == 0, np.float32(0), np.float32(-1e9)).astype(np.float32)
+    sc = x[:, :V].numpy() + run[:, None]
+    if masked >= 0:
+        sc[:, masked] = -np.inf
+    for r in range(R):
+        order = np.lexsort((np.arange(V), -sc[r].astype(np.float64)))[:C]
+        assert np.array_equal(idx[r].cpu().numpy(), order), (r, idx[r].cpu().numpy(), order)
+        assert np.array_equal(val[r].cpu().numpy(), sc[r][order])
 
 
 def test_lds_dma_gemm_kernels_match_generic_kernel_bitwise(lib):
