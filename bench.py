@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Captioner throughput bench (BASELINE.json metric: captions/sec, 224x224, beam=1, + greedy token parity).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -48,8 +48,8 @@ ENC_GEMM_TAGS = ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2")
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--max-length", type=int, default=20)
     ap.add_argument("--dtype", default="f32s", choices=["bf16", "f32", "f32s"],
@@ -167,6 +167,7 @@ def roofline_pass(eng, px, L, dtype, arch, batch):
             "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
             "flops_per_launch": k * fl / n, "avg_launch_us": round(1e3 * ms / n, 2), "launches_per_step": n // reps,
             "mfma_products_per_mac": k, "linear_layer_tflops": round(alg, 2), "linear_layer_flops_per_launch": fl / n,
+            "frac_linear_layer": round(alg / peak, 4),
             "note": "achieved = MFMA flops the kernel executes per second (mfma_products_per_mac x 2MNK / t) against the dense "
                     "peak of the MFMA pipe it runs on (MI355X_MICROARCH.md); linear_layer_tflops = 2MNK / t.  "
                     + ("The same Linear layers on the exact-product fp32 MFMA pipe (peak 157.3) are the f32_exact leg."

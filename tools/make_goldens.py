@@ -126,23 +126,41 @@ def main():
     print("blip_base")
     np.savez_compressed(os.path.join(gold, "blip_base.npz"), **run(BlipArch(), seed=0, batch=8,
                                                                      max_length=20, beams=3, full=False, eos_boost=9.0))
-    # the three known-answer tests of the reference (captioning_predictor.py:66-98): inputs are the literals
-    # there; expected = torcheval Perplexity of (input, target=argmax) == exp(-mean(log max softmax)).
-    kats = []
-    for inp in ([[[0.3659, 0.7025, 0.3104]], [[0.0097, 0.6577, 0.1947]], [[0.5659, 0.0025, 0.0104]],
-                 [[0.9097, 0.0577, 0.7947]]],
-                [[[0.5659, 0.0025, 0.0104]], [[0.9097, 0.0577, 0.7947]]],
-                [[[0.3659, 0.7025, 0.3104]], [[0.0097, 0.6577, 0.1947]]]):
-        x = torch.tensor(inp, dtype=torch.float64)                      # [n, 1, V]; target = argmax token
-        lp = torch.log_softmax(x, dim=-1).max(dim=-1).values
-        kats.append({"input": inp, "expected": float(torch.exp(-lp.mean()))})
-    with open(os.path.join(gold, "perplexity_kat.json"), "w") as f:
-        json.dump(kats, f, indent=1)
+    write_perplexity_kats(gold)
     print("blip_base64")
     np.savez_compressed(os.path.join(gold, "blip_base64.npz"), **run_greedy_only(BlipArch(), seed=0, batch=64,
                                                                                     max_length=20, eos_boost=9.0))
     print("done")
 
 
+def write_perplexity_kats(gold):
+    """The three known-answer tests of the reference (captioning_predictor.py:66-98): inputs AND targets are the literals
+    there; expected = what the reference compares against, torcheval's Perplexity(input, target) = exp(mean cross-entropy of
+    the target tokens) - computed here from that definition (F.cross_entropy on the literal targets, float64), NOT from the
+    max-softmax formula under test.  The definition itself is anchored on the value torcheval's documentation publishes for
+    its first example (targets [[2], [1]] -> 2.7593), kept as a fourth entry."""
+    cases = [([[[0.3659, 0.7025, 0.3104]], [[0.0097, 0.6577, 0.1947]], [[0.5659, 0.0025, 0.0104]], [[0.9097, 0.0577, 0.7947]]],
+              [[1], [1], [0], [0]]),
+             ([[[0.5659, 0.0025, 0.0104]], [[0.9097, 0.0577, 0.7947]]], [[0], [0]]),
+             ([[[0.3659, 0.7025, 0.3104]], [[0.0097, 0.6577, 0.1947]]], [[1], [1]])]
+    kats = []
+    for inp, tgt in cases:
+        x = torch.tensor(inp, dtype=torch.float64)                      # [n, 1, V]
+        t = torch.tensor(tgt)
+        ce = torch.nn.functional.cross_entropy(x.reshape(-1, x.shape[-1]), t.reshape(-1), reduction="mean")
+        kats.append({"input": inp, "target": tgt, "expected": float(torch.exp(ce)), "target_is_argmax": True})
+    doc_in, doc_t = [[[0.3659, 0.7025, 0.3104]], [[0.0097, 0.6577, 0.1947]]], [[2], [1]]
+    x = torch.tensor(doc_in, dtype=torch.float64)
+    ce = torch.nn.functional.cross_entropy(x.reshape(-1, 3), torch.tensor(doc_t).reshape(-1), reduction="mean")
+    assert abs(float(torch.exp(ce)) - 2.7593) < 1e-4
+    kats.append({"input": doc_in, "target": doc_t, "expected": float(torch.exp(ce)), "published": 2.7593,
+                 "target_is_argmax": False})
+    with open(os.path.join(gold, "perplexity_kat.json"), "w") as f:
+        json.dump(kats, f, indent=1)
+
+
 if __name__ == "__main__":
-    main()
+    if "--only-perplexity" in sys.argv:
+        write_perplexity_kats(os.path.join(ROOT, "tests", "golden"))
+    else:
+        main()
