@@ -590,8 +590,10 @@ __global__ __launch_bounds__(256, 1) void vit_attention_f32_mfma(const float* __
 // SIMD, so one wave's softmax / P-split VALU work runs under the other's MFMAs); the keys are walked in chunks of KC key
 // blocks (KC = 7: 224 keys, 112 KiB of LDS) with an online softmax across chunks - 197 tokens are one chunk and one group
 // (the arithmetic of a single-pass softmax), 577 tokens (384-pixel checkpoints) three chunks x three groups.
-// ONE: the caller guarantees a single chunk (nkb <= KC): no rescaling state, the single-pass arithmetic.
-template <int KC, bool ONE>
+// ONE: the caller guarantees a single chunk (nkb <= KC): no rescaling state, the single-pass arithmetic.  EXACT (with ONE):
+// nkb == KC, every key block exists and only the last one has padding keys - no per-block guards in the MFMA chains (197
+// tokens: 218 us per launch at 256 x 12 heads, 255 us with the guards).
+template <int KC, bool ONE, bool EXACT = false>
 __global__ __launch_bounds__(512, 1) void vit_attention_split(const g8_t* __restrict__ qkv, g8_t* __restrict__ ctx, int N, int H, int QG) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP = KC * 32;
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split(const g8_t* __rest
         for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[kc][e] = 0.f;
-            if (c0 + kc < nkb) {
+            if (EXACT || c0 + kc < nkb) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const f16x8 kh = *(const f16x8*)(Ks + koff(kc * 32 + r32, 2 * (2 * ks + hh)));
@@ -660,8 +662,10 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split(const g8_t* __rest
         for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int key = (c0 + kc) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                if (key >= N) s[kc][e] = -INFINITY;     // padding keys and key blocks past the end
+                if (!EXACT || kc == KC - 1) {
+                    const int key = (c0 + kc) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (key >= N) s[kc][e] = -INFINITY;     // padding keys and key blocks past the end
+                }
                 cm = fmaxf(cm, s[kc][e]);
             }
         cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split(const g8_t* __rest
             }
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
-            if (c0 + kc >= nkb) continue;               // (its probabilities are all zero)
+            if (!EXACT && c0 + kc >= nkb) continue;     // (its probabilities are all zero)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 // B operand: element j of lane half hh is P^T[key = kb*32 + 16*s2 + 8*(j>>2) + 4*hh + (j&3)][q]
@@ -1536,10 +1540,10 @@ int launch_flash_wide(const void* qkv, void* ctx, int B, int N, int H, int hd, i
     return 0;
 }
 
-template <int KC, bool ONE>
+template <int KC, bool ONE, bool EXACT = false>
 int launch_split_kc(const void* qkv, void* ctx, int B, int N, int H, hipStream_t s) {
     const int lds = 2 * KC * 32 * 256;
-    auto kern = vit_attention_split<KC, ONE>;
+    auto kern = vit_attention_split<KC, ONE, EXACT>;
     if (cap_kernel_setup((const void*)kern, lds, nullptr) != 0) return -1;
     const int QG = ((N + 31) / 32 + 7) / 8;               // groups of 8 query tiles
     hipLaunchKernelGGL(kern, dim3(B * H * QG), dim3(512), lds, s, (const g8_t*)qkv, (g8_t*)ctx, N, H, QG);
@@ -1570,7 +1574,8 @@ int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
             return -1;
         }
         if (N <= 64) return launch_split_kc<2, true>(qkv, ctx, B, N, H, s);       // fixture-sized inputs
-        if (N <= 224) return launch_split_kc<7, true>(qkv, ctx, B, N, H, s);     // 197 tokens: one pass over all keys
+        if (N > 192 && N <= 224) return launch_split_kc<7, true, true>(qkv, ctx, B, N, H, s);     // 197 tokens: one pass, 7 key blocks
+        if (N <= 224) return launch_split_kc<7, true>(qkv, ctx, B, N, H, s);
         return launch_split_kc<4, false>(qkv, ctx, B, N, H, s);                  // chunks of 128 keys, online softmax
     }
     if (out_dtype != dtype && !(dtype == CAP_DT_F32 && out_dtype == CAP_DT_G8 && head_dim == 64 && !causal)) {
