@@ -12,7 +12,7 @@ records (ids int32 [256,20] + lengths) that feeds the consensus step.  Frames an
 
 The headline (`value`, `dtype`, `roofline`, `kernels`, `parity`) is the mode that holds the metric's parity clause: "f32s" =
 CAP_F32_SPLIT, fp32 values carried into every GEMM as two fp16 halves with three fp16 MFMAs per product (DESIGN.md section
-2): greedy tokens identical to the fp32 reference on all 64 golden rows.  The faster bf16 mode, which is NOT token-identical,
+2): greedy tokens identical to the fp32 reference on all 256 golden rows (one whole batch).  The faster bf16 mode, which is NOT token-identical,
 is reported under the extra key `bf16`; the exact-product fp32-MFMA mode under `f32_exact`.
 
     python bench.py --gpus N --strong --frames 50000      # strong scaling (SURVEY config 4): a FIXED total of frames,
@@ -405,7 +405,8 @@ def extra_mode(arch, sd, px, L, B, dev, dtype, streams, ref_ids, golden):
 
 
 def golden_parity(ids, g, arch, L, B, tau):
-    """Greedy tokens of rows 0..63 against the committed HF greedy loop (tests/golden/blip_base64.npz, same seeds).  tau = 0:
+    """Greedy tokens against the committed HF greedy loop (tests/golden/blip_base256.npz: the whole 256-frame batch, same
+    seeds).  tau = 0:
     every differing row counts as a mismatch (the bar of the fp32-grade modes); bf16 is judged with the near-tie rule."""
     from tests._util import pad_to, token_parity
     ref = pad_to(g["greedy_sequences"], L, arch.pad)
@@ -413,7 +414,7 @@ def golden_parity(ids, g, arch, L, B, tau):
     exact, div, bad = token_parity(ids[:n].cpu().numpy(), ref[:n], g["greedy_margin"][:, :n], tau)
     return {"rows": int(n), "token_identical_rows": int(exact), "diverged_at_near_tie": int(div) if tau > 0 else 0,
             "mismatched_rows": int(div) if tau == 0 else (0 if bad is None else 1), "near_tie_margin": tau,
-            "reference": "HF transformers 5.15 BlipForConditionalGeneration greedy, fp32 CPU (tests/golden/blip_base64.npz)"}
+            "reference": "HF transformers 5.15 BlipForConditionalGeneration greedy, fp32 CPU (tests/golden/blip_base256.npz)"}
 
 
 def main_strong(a, arch, sd, dev, rank, world):
@@ -567,7 +568,7 @@ def main():
         golden = None
         try:
             from tests._util import load_golden
-            golden, _, _ = load_golden("blip_base64")               # 64 rows of the real HF greedy loop, same seeds
+            golden, _, _ = load_golden("blip_base256")              # 256 rows of the real HF greedy loop, same seeds
             line["parity"] = golden_parity(ids, golden, arch, L, B, 0.3 if a.dtype == "bf16" else 0.0)
         except Exception as e:  # noqa: BLE001
             line["parity"] = {"error": repr(e)}

@@ -77,6 +77,31 @@ def test_wide_golden_64_rows(dtype):
     eng.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32s", "f32"])
+def test_wide_golden_256_rows_one_whole_headline_batch(dtype):
+    """256 frames = the bench's batch through the real HF greedy loop (tests/golden/blip_base256.npz, tools/make_goldens.py
+    --wide256-only): the fp32-grade modes are token-identical on every row, no tolerance rule.  Also through the stream pool's
+    path for the default mode: the same frames as four micro-batches of 64 on three engines that share the weights."""
+    g, meta, arch, sd, px = golden_inputs("blip_base256")
+    B, L = meta["batch"], meta["max_length"]
+    assert B == 256
+    eng = _engine(arch, dtype, B, 1, L)
+    eng.load_state_dict(sd)
+    pxd = px.cuda()
+    seq = eng.generate(pxd, num_beams=1, max_length=L)["sequences"].cpu().numpy()
+    ref = g["greedy_sequences"]
+    same = (seq == ref).all(axis=1)
+    assert same.all(), (int(same.sum()), np.nonzero(~same)[0][:8])
+    if dtype == "f32s":
+        from embodied_captioning_amd.engine import EnginePool
+        pool = EnginePool(arch, n=3, dtype=dtype, max_batch=64, max_beams=1, max_len=L, weights_of=eng)
+        outs = pool.generate_many([pxd[i:i + 64] for i in range(0, B, 64)], threads=True, num_beams=1, max_length=L)
+        seq2 = torch.cat([o["sequences"] for o in outs]).cpu().numpy()
+        assert np.array_equal(seq2, ref)
+        pool.close()
+    eng.close()
+
+
 @pytest.mark.parametrize("name", ["blip_tiny", "blip_base"])
 def test_bf16_matches_golden_within_tolerance(name):
     g, meta, arch, sd, px = golden_inputs(name)

@@ -112,6 +112,12 @@ def main():
     torch.manual_seed(0)
     gold = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
+    if "--wide256-only" in sys.argv:
+        # 256 frames = one whole headline batch through the real HF greedy loop (rows 0..63 are blip_base64's)
+        print("blip_base256")
+        np.savez_compressed(os.path.join(gold, "blip_base256.npz"), **run_greedy_only(BlipArch(), seed=0, batch=256,
+                                                                                         max_length=20, eos_boost=9.0))
+        return
     if "--wide-only" in sys.argv:
         print("blip_base64")
         np.savez_compressed(os.path.join(gold, "blip_base64.npz"), **run_greedy_only(BlipArch(), seed=0, batch=64,
