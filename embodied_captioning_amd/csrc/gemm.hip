@@ -1272,12 +1272,15 @@ int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
         }
         tile = 3;
     }
-    if (tile >= 10 && tile <= 12) {
+    if (tile >= 10 && tile <= 13) {
         if constexpr (is_g8<T>) {
             if (p.K >= 64 && !p.resid) {
                 if (tile == 10) return launch_big2<T, OUT_F32, EPI, 0, false>(p, stream);
                 if (tile == 11) return launch_big2<T, OUT_F32, EPI, 1, false>(p, stream);
-                return launch_big2<T, OUT_F32, EPI, 2, false>(p, stream);
+                if (tile == 12) return launch_big2<T, OUT_F32, EPI, 2, false>(p, stream);
+                // 13: the shipped schedule with cycle stamps to p.aux (tools/bench_gemm_split.py --cycles)
+                if constexpr (!OUT_F32 && EPI == EPI_STORE) return launch_big2<T, OUT_F32, EPI, 1, true>(p, stream);
+                return launch_big2<T, OUT_F32, EPI, 1, false>(p, stream);
             }
         }
     }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Micro-benchmark of the split-fp16 (G8) GEMM over the captioner's shapes (GPU box only).
     python tools/bench_gemm_split.py            # encoder shapes x schedule variants, decode shapes x tiles
+    python tools/bench_gemm_split.py --cycles   # in-kernel cycle accounting of the shipped schedule instead
 Prints 2MNK/t (the Linear layer's rate) and 3x that (MFMA flops executed) per variant."""
 import ctypes as C
 import os
@@ -33,7 +34,7 @@ SHAPES = [("qkv", 50432, 2304, 768, 0, 0, (3, 16)), ("proj", 50432, 768, 768, 0,
           ("crosskv", 50432, 18432, 768, 0, 1, (3, 16)), ("sq8k", 8192, 8192, 8192, 0, 1, (3, 16)),
           ("vocab", 256, 30524, 768, 0, 1, (1, 2, 3)), ("dec768", 256, 768, 768, 0, 1, (1, 2)),
           ("dec_f1", 256, 3072, 768, 1, 0, (1, 2)), ("dec_qkv", 256, 2304, 768, 0, 1, (1, 2))]
-for name, M, N, K, gelu, f32out, tiles in SHAPES:
+for name, M, N, K, gelu, f32out, tiles in ([] if "--cycles" in sys.argv else SHAPES):
     A = g8(torch.randn(M, K, device="cuda"))
     W = g8(torch.randn(N, K, device="cuda") / K ** 0.5, 4096.0)
     bias = torch.randn(N, device="cuda")
@@ -58,3 +59,25 @@ for name, M, N, K, gelu, f32out, tiles in SHAPES:
             tf = 2.0 * M * N * K / us / 1e6
             line += f"  tile{tile}: {us:8.1f} us {tf:6.1f} TF ({3 * tf:6.0f} exec)"
     print(line, flush=True)
+
+if "--cycles" in sys.argv:
+    # in-kernel cycle accounting of the shipped schedule (tile 13 = instrumented build, G8 output): per wave, shader cycles in
+    # total / waiting for its own DMA (vmcnt) / waiting at the stage barrier / in the epilogue; a stage = 32 k values (64 KiB)
+    for name, M, N, K in [("sq8k", 8192, 8192, 8192), ("qkv", 50432, 2304, 768), ("fc1", 50432, 3072, 768), ("k3072", 50432, 768, 3072)]:
+        A = g8(torch.randn(M, K, device="cuda"))
+        W = g8(torch.randn(N, K, device="cuda") / K ** 0.5, 4096.0)
+        out = torch.zeros(M, N, device="cuda", dtype=torch.float32)          # G8 output: 4 bytes per element
+        dbg = torch.zeros(256 * 8 * 6, device="cuda", dtype=torch.int64)
+        for _ in range(3):
+            rc = lib.cap_op_gemm(SPLIT, C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(0), C.c_void_p(dbg.data_ptr()),
+                                 C.c_void_p(out.data_ptr()), M, N, K, 0, 0, 13, s)
+            assert rc == 0, lib.cap_last_error()
+        torch.cuda.synchronize()
+        d = dbg.view(256, 8, 6).double().cpu()
+        d = d[d[:, 0, 0] > 0]
+        cyc, wall, dma, bar, epi, tc = [d[:, :, i] for i in range(6)]
+        mhz = (cyc / (wall / 100.0)).mean().item()
+        nst = (tc * (K // 32)).mean().item()
+        print(f"cycles {name:6s} M={M} N={N} K={K}: clock {mhz:7.1f} MHz  tiles/block {tc.mean().item():.2f}  per stage: total "
+              f"{(cyc.mean().item() - epi.mean().item()) / nst:.0f} (MFMA issue alone: 3072)  dma-wait {dma.mean().item() / nst:.0f}  barrier-wait "
+              f"{bar.mean().item() / nst:.0f}  | epilogue/tile {(epi / tc).mean().item():.0f} cycles", flush=True)
