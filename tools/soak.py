@@ -11,14 +11,14 @@ from embodied_captioning_amd.engine import CaptionerEngine, EnginePool  # noqa: 
 from embodied_captioning_amd.weights import procedural_blip_state_dict, synthetic_pixels  # noqa: E402
 
 B, L, N = 256, 20, int(os.environ.get("N", 120))
+DTYPE = os.environ.get("DTYPE", "f32s")            # the default mode; DTYPE=bf16 for the bf16 kernels
 arch = BlipArch()
 sd = procedural_blip_state_dict(arch, 0, eos_boost=9.0)
-one = CaptionerEngine(arch, dtype="bf16", max_batch=B, max_beams=1, max_len=L)
+one = CaptionerEngine(arch, dtype=DTYPE, max_batch=B, max_beams=1, max_len=L)
 one.load_state_dict(sd)
 frames = [synthetic_pixels(B, arch.image_size, seed=5, first=i * B).cuda() for i in range(4)]
 want = [{k: v.clone() for k, v in one.generate(f, max_length=L).items()} for f in frames]
-pool = EnginePool(arch, n=3, dtype="bf16", max_batch=B, max_beams=1, max_len=L)
-pool.load_state_dict(sd)
+pool = EnginePool(arch, n=3, dtype=DTYPE, max_batch=B, max_beams=1, max_len=L, weights_of=one)
 bad = 0
 for threads, poll in ((False, 0), (True, 0), (True, 4)):
     pool.set_early_exit(poll)
