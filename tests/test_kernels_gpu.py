@@ -343,6 +343,27 @@ def test_beam_candidate_selection_exact_with_ties(lib, V, K, kind):
         assert np.array_equal(val[r].cpu().numpy(), sc[r][order])
 
 
+@pytest.mark.parametrize("V,K", [(30524, 3), (49408, 3), (512, 2)])
+def test_beam_candidate_selection_log_softmax_scores(lib, V, K):
+    """HF-v5 scoring (log-softmax + running score) through both vocabulary paths (row staged in LDS / streamed from global
+    memory): tokens equal torch's top-2K of the fp32 log-softmax, scores within 1e-5."""
+    B = 2
+    R, C = B * K, 2 * K
+    ld = (V + 3) // 4 * 4
+    g = torch.Generator().manual_seed(V * 7 + K)
+    x = torch.randn(R, ld, generator=g) * 3.0
+    xd = x.cuda()
+    val = torch.zeros(R, C, device="cuda")
+    idx = torch.zeros(R, C, dtype=torch.int32, device="cuda")
+    _check(lib, lib.cap_op_beam_candidates(_p(xd), ld, V, B, K, 0, -1, _p(val), _p(idx), _stream()))
+    run = torch.where(torch.arange(R) % K == 0, 0.0, -1.0e9).double()
+    sc = torch.log_softmax(x[:, :V].double(), -1) + run[:, None]
+    for r in range(0, R, K):                       # rows with running score 0: fp32 resolves the scores
+        top = torch.topk(sc[r], C)
+        assert torch.equal(idx[r].cpu().long(), top.indices), r
+        assert (val[r].cpu().double() - top.values).abs().max().item() < 1e-5
+
+
 def test_lds_dma_gemm_kernels_match_generic_kernel_bitwise(lib):
     """The persistent LDS-DMA kernels (raw barriers, counted vmcnt) share the generic kernel's accumulation order: any repeat
     that differs from it bit for bit would be an LDS read overtaking its DMA (tools/gemm_race_screen.py is the long form)."""
