@@ -79,6 +79,58 @@ def parse():
     return ap.parse_args()
 
 
+class PowerSampler:
+    """Socket power of THIS process's GPU from the amdgpu hwmon node (power1_input, microwatts), sampled every 50 ms by a
+    host thread while the timed steps run - a reading, never part of the metric.  The card is found through the device's PCI
+    bus id; any failure (no sysfs access, no node) leaves `result()` as None."""
+
+    def __init__(self, device_index: int):
+        import glob
+        import threading
+        self.path, self.samples, self._stop, self._t = None, [], threading.Event(), None
+        try:
+            bus = torch.cuda.get_device_properties(device_index).pci_bus_id
+            want = f"{bus:02x}:" if isinstance(bus, int) else str(bus).lower()
+            dom = getattr(torch.cuda.get_device_properties(device_index), "pci_domain_id", 0)
+            dev = getattr(torch.cuda.get_device_properties(device_index), "pci_device_id", 0)
+            addr = f"{dom:04x}:{bus:02x}:{dev:02x}" if isinstance(bus, int) else want
+            for card in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.realpath(card).lower().rsplit("/", 1)[-1].startswith(addr):
+                    nodes = glob.glob(os.path.join(card, "hwmon", "hwmon*", "power1_input"))
+                    if nodes:
+                        self.path = nodes[0]
+        except Exception:  # noqa: BLE001
+            self.path = None
+        self._threading = threading
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append(int(open(self.path).read()) * 1e-6)
+            except Exception:  # noqa: BLE001
+                return
+            self._stop.wait(0.05)
+
+    def __enter__(self):
+        if self.path:
+            self._t = self._threading.Thread(target=self._run, daemon=True)
+            self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._t:
+            self._t.join()
+
+    def result(self, captions: float, seconds: float):
+        if len(self.samples) < 4:
+            return None
+        w = float(np.mean(self.samples[1:]))
+        return {"watts_mean": round(w, 1), "watts_max": round(float(np.max(self.samples)), 1), "samples": len(self.samples),
+                "joules_per_caption": round(w * seconds / captions, 4),
+                "source": "amdgpu hwmon power1_input of this GPU, 50 ms samples over the timed region (informational)"}
+
+
 def timed_steps(eng, px, L, steps, warmup, world, gather, beams=1):
     """`eng`: a CaptionerEngine, or an EnginePool - consecutive steps then run on the pool's engines / streams and overlap
     (each step is still one whole batch through encoder + decode + gather; all of them finish inside the timed region)."""
@@ -100,12 +152,14 @@ def timed_steps(eng, px, L, steps, warmup, world, gather, beams=1):
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    res = run(steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
+    with PowerSampler(torch.cuda.current_device()) as ps:
+        t0 = time.perf_counter()
+        res = run(steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        dt = time.perf_counter() - t0
+    timed_steps.power = ps
     return dt, res
 
 
@@ -541,6 +595,10 @@ def main():
                            "parallelism": f"dp{world}", "streams": a.streams, "compute_mode": a.dtype}}
         ln = lens[:B].float()
         line["caption_tokens"] = {"mean": round(float(ln.mean()), 2), "max": int(ln.max()), "of": L}
+        pw = getattr(timed_steps, "power", None)
+        pw = pw.result(B * a.steps, dt) if pw is not None else None      # rank 0's GPU, its own captions
+        if pw:
+            line["power"] = pw
         if a.early_exit or a.eos_boost != 9.0:
             line["config"]["early_exit_poll"] = a.early_exit
             line["config"]["eos_boost"] = a.eos_boost
