@@ -102,6 +102,28 @@ def test_wide_golden_256_rows_one_whole_headline_batch(dtype):
     eng.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32s", "f32"])
+def test_beam3_golden_64_rows_config3(dtype):
+    """SURVEY config 3's batch (64 frames, beam 3, max_length 20) against the real HF beam search
+    (tests/golden/blip_base64_beam3.npz, tools/make_goldens.py --beam64-only): sequences identical, scores within 1e-3."""
+    g, meta, arch, sd, px = golden_inputs("blip_base64_beam3")
+    B, L, K = meta["batch"], meta["max_length"], meta["beams"]
+    assert (B, K) == (64, 3)
+    eng = _engine(arch, dtype, B, K, L)
+    eng.load_state_dict(sd)
+    out = eng.generate(px.cuda(), num_beams=K, max_length=L)
+    seq = out["sequences"].cpu().numpy()
+    ref = g["beam_sequences"]
+    fill = arch.pad or arch.eos
+    for r in range(B):
+        row = list(ref[r])
+        n = (row.index(arch.eos, 1) + 1) if arch.eos in row[1:] else L       # HF's rows end with EOS, then its fill / our padding
+        assert np.array_equal(seq[r, :n], ref[r, :n]), (r, seq[r], ref[r])
+        assert (seq[r, n:] == fill).all(), (r, seq[r])
+    np.testing.assert_allclose(out["sequences_scores"].cpu().numpy(), g["beam_scores"], rtol=0, atol=1e-3)
+    eng.close()
+
+
 @pytest.mark.parametrize("name", ["blip_tiny", "blip_base"])
 def test_bf16_matches_golden_within_tolerance(name):
     g, meta, arch, sd, px = golden_inputs(name)

@@ -108,10 +108,33 @@ def run_greedy_only(arch: BlipArch, seed: int, batch: int, max_length: int, eos_
                                              arch=arch.__dict__, transformers="5.15.0", torch=torch.__version__)))}
 
 
+def run_beam_only(arch: BlipArch, seed: int, batch: int, max_length: int, beams: int, eos_boost: float):
+    """Config 3's batch (64 frames, beam 3) through the real HF beam search: sequences + sequences_scores only."""
+    sd = procedural_blip_state_dict(arch, seed, eos_boost=eos_boost)
+    model = build_hf(arch, sd)
+    pixels = synthetic_pixels(batch, arch.image_size, seed=seed)
+    seqs, scores = [], []
+    with torch.no_grad():
+        for i in range(0, batch, 16):
+            b = model.generate(pixel_values=pixels[i:i + 16], max_length=max_length, num_beams=beams, do_sample=False,
+                               length_penalty=1.0, early_stopping=False, output_scores=True, return_dict_in_generate=True)
+            seq = torch.full((b.sequences.shape[0], max_length), arch.pad, dtype=torch.long)
+            seq[:, : b.sequences.shape[1]] = b.sequences
+            seqs.append(seq); scores.append(b.sequences_scores)
+    return {"beam_sequences": torch.cat(seqs).numpy().astype(np.int32), "beam_scores": torch.cat(scores).numpy(),
+            "meta": np.array(json.dumps(dict(seed=seed, eos_boost=eos_boost, batch=batch, max_length=max_length, beams=beams,
+                                             arch=arch.__dict__, transformers="5.15.0", torch=torch.__version__)))}
+
+
 def main():
     torch.manual_seed(0)
     gold = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
+    if "--beam64-only" in sys.argv:
+        print("blip_base64_beam3")
+        np.savez_compressed(os.path.join(gold, "blip_base64_beam3.npz"), **run_beam_only(BlipArch(), seed=0, batch=64,
+                                                                                           max_length=20, beams=3, eos_boost=9.0))
+        return
     if "--wide256-only" in sys.argv:
         # 256 frames = one whole headline batch through the real HF greedy loop (rows 0..63 are blip_base64's)
         print("blip_base256")
