@@ -58,6 +58,22 @@ def test_oracle_matches_wide_hf_golden_slice(golden_dir):
     assert np.array_equal(seq, ref[:, : seq.shape[1]]) and (ref[:, seq.shape[1]:] == arch.pad).all()
 
 
+def test_oracle_beam_search_matches_config3_hf_golden_slice(golden_dir):
+    """tests/golden/blip_base64_beam3.npz: config 3's 64 frames through HF's beam search; the oracle's beam search on rows 16..31
+    (one of the generator's chunks of 16, so HF's fill column count is known): sequences identical, scores within 1e-4."""
+    g, meta, arch, sd, px = _load(golden_dir, "blip_base64_beam3")
+    b = R.beam_search_generate(sd, arch, px[16:32], meta["beams"], meta["max_length"])
+    seq = b["sequences"].numpy()
+    ref = g["beam_sequences"][16:32]
+    fill = arch.pad or arch.eos
+    for r in range(16):
+        row = list(ref[r])
+        n = (row.index(arch.eos, 1) + 1) if arch.eos in row[1:] else len(row)
+        assert np.array_equal(seq[r, : min(n, seq.shape[1])], ref[r, : min(n, seq.shape[1])])
+        assert (seq[r, n:] == fill).all()
+    np.testing.assert_allclose(b["sequences_scores"].numpy(), g["beam_scores"][16:32], rtol=0, atol=1e-4)
+
+
 def test_perplexity_known_answers(golden_dir):
     with open(os.path.join(golden_dir, "perplexity_kat.json")) as f:
         kats = json.load(f)
