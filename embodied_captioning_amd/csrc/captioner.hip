@@ -1057,10 +1057,10 @@ int gemm_splitk_reduce_ln(Captioner* m, hipStream_t s, const Dec& d, const char*
     const int slab = m->dt == CAP_DT_BF16 ? 64 : 32;
     const int nk = K / slab;
     int S = 1;
-    // 32-wide slabs (fp32 / split): at most 4 slices - 8 slices of 3 slabs each write and re-read twice the partial sums for
-    // nothing (pooled headline +2 %, -1.6 % joules per caption; CAP_SPLITK_MAX overrides for A/B runs)
+    // at most 4 slices: 8 slices write and re-read twice the partial sums for nothing (pooled: split mode +2 % and -1.6 %
+    // joules per caption, bf16 +3 %, CoCa beam-5 +1 %; CAP_SPLITK_MAX overrides for A/B runs)
     static const int senv = [] { const char* e = getenv("CAP_SPLITK_MAX"); return e ? atoi(e) : 0; }();
-    const int smax = senv > 0 ? senv : (slab == 32 ? 4 : 8);
+    const int smax = senv > 0 ? senv : 4;
     for (int cand : {8, 4, 2})
         if (cand <= smax && nk % cand == 0 && nk / cand >= 3) { S = cand; break; }
     GemmParams p;
