@@ -67,9 +67,20 @@ def gather_caption_records(ids: torch.Tensor, lens: torch.Tensor, n_pad: int, pa
     return ids_all, lens_all
 
 
+def _fp_hash(fingerprint: str) -> str:
+    import hashlib
+    return hashlib.sha256(fingerprint.encode()).hexdigest()[:12]
+
+
+def job_fingerprint(**parts) -> str:
+    """A readable, order-independent identity of a captioning job for `caption_shard(fingerprint=...)`, e.g.
+    job_fingerprint(weights="blip-base@sha256:...", dtype="f32s", beams=1, frames="synthetic:seed=17")."""
+    return ";".join(f"{k}={parts[k]}" for k in sorted(parts))
+
+
 def caption_shard(generate: Callable[[torch.Tensor], Dict[str, torch.Tensor]], frames_of: Callable[[int, int], torch.Tensor],
                   n_frames: int, micro_batch: int, max_len: int, pad_id: int = 0, join: Callable[[], None] | None = None,
-                  resume_dir: str | None = None, record_every: int = 16):
+                  resume_dir: str | None = None, record_every: int = 16, fingerprint: str | None = None):
     """Caption frames [first, last) of this rank in micro-batches and gather everything.
     `frames_of(first, count)` returns the device tensor of frames; `generate(frames)` returns {"sequences","lengths"}.
     `join`: called after the last micro-batch (of a record, see below) was issued - for a `generate` that only starts the work
@@ -79,6 +90,10 @@ def caption_shard(generate: Callable[[torch.Tensor], Dict[str, torch.Tensor]], f
     or absent); a rerun with the same arguments loads the spans whose file exists instead of captioning them again, so a
     job killed at frame k restarts at the span that contains k.  The file name carries the span, which is a function of
     (n_frames, world, rank, micro_batch, record_every): runs with another sharding simply do not find each other's files.
+    `fingerprint`: what produced the records - any string that identifies the job (`job_fingerprint(...)`: checkpoint, dtype,
+    beams, frame source).  Its hash is part of the file name and the string itself is stored in the file: records written under
+    another fingerprint are never loaded (a warning names them), and a file whose stored string differs from its name's hash
+    is refused.  Without a fingerprint (None) every record of the span is trusted, as before.
     (The reference's driver has no resume: `detector/pseudolabeler.py:835-843` rewrites every episode_<e>_step_<s>.npz.)
     Returns (ids_all, lens_all) trimmed to n_frames rows, in global frame order."""
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -91,10 +106,21 @@ def caption_shard(generate: Callable[[torch.Tensor], Dict[str, torch.Tensor]], f
     ids_parts, len_parts = [], []
     for s0 in range(first, last, span):
         s1 = min(s0 + span, last)
-        path = os.path.join(resume_dir, f"records_{s0:010d}_{s1:010d}_L{max_len}.npz") if resume_dir is not None else None
+        stem = f"records_{s0:010d}_{s1:010d}_L{max_len}"
+        path = os.path.join(resume_dir, stem + (f"_{_fp_hash(fingerprint)}" if fingerprint is not None else "") + ".npz") \
+            if resume_dir is not None else None
+        if path is not None and fingerprint is not None and not os.path.exists(path):
+            other = [f for f in os.listdir(resume_dir) if f.startswith(stem) and f.endswith(".npz") and ".tmp" not in f]
+            if other:
+                import warnings
+                warnings.warn(f"caption_shard: {resume_dir} holds records of this span from another job ({other[0]}); "
+                              f"they are ignored and the span is captioned again under fingerprint {fingerprint!r}")
         if path is not None and os.path.exists(path):
             import numpy as np
             with np.load(path) as rec:
+                if fingerprint is not None and ("fingerprint" not in rec or str(rec["fingerprint"]) != fingerprint):
+                    raise RuntimeError(f"caption_shard: {path} was not written by this job (stored fingerprint "
+                                       f"{str(rec['fingerprint']) if 'fingerprint' in rec else None!r}, expected {fingerprint!r})")
                 ids_parts.append(torch.from_numpy(rec["ids"]).to(dev))
                 len_parts.append(torch.from_numpy(rec["lens"]).to(dev))
             continue
@@ -110,7 +136,8 @@ def caption_shard(generate: Callable[[torch.Tensor], Dict[str, torch.Tensor]], f
         if path is not None:
             import numpy as np
             tmp = f"{path}.tmp{os.getpid()}.npz"
-            np.savez(tmp, ids=ids_s.cpu().numpy(), lens=lens_s.cpu().numpy())      # .cpu() waits for the span's work
+            extra = {"fingerprint": np.array(fingerprint)} if fingerprint is not None else {}
+            np.savez(tmp, ids=ids_s.cpu().numpy(), lens=lens_s.cpu().numpy(), **extra)      # .cpu() waits for the span's work
             os.replace(tmp, path)
         ids_parts.append(ids_s.to(dev))
         len_parts.append(lens_s.to(dev))

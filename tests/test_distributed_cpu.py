@@ -102,3 +102,40 @@ def test_caption_shard_resume_skips_finished_spans(tmp_path):
     c = D.caption_shard(generate, frames_of, 23, micro_batch=4, max_len=L, resume_dir=d, record_every=2)
     assert calls == [8, 12] and torch.equal(c[0], want[0]) and torch.equal(c[1], want[1])
     assert not [f for f in os.listdir(d) if "tmp" in f]
+
+
+def test_caption_shard_resume_ignores_records_of_another_job(tmp_path):
+    """A rerun in the same directory with another checkpoint / dtype / beam count must not pick up the old spans: the job
+    fingerprint is part of the record's name and content."""
+    import numpy as np
+    from embodied_captioning_amd import distributed as D
+    L, calls = 4, []
+
+    def frames_of(first, n):
+        return torch.arange(first, first + n, dtype=torch.int32)
+
+    def make(mult):
+        def generate(frames):
+            calls.append(int(frames[0]))
+            return {"sequences": torch.stack([(frames * mult + j) % 89 for j in range(L)], dim=1).int(), "lengths": (frames % L + 1).int()}
+        return generate
+
+    d = str(tmp_path / "records")
+    fa = D.job_fingerprint(weights="A", dtype="f32s", beams=1)
+    fb = D.job_fingerprint(dtype="f32s", beams=1, weights="B")
+    assert fa == D.job_fingerprint(beams=1, dtype="f32s", weights="A") and fa != fb
+    a = D.caption_shard(make(3), frames_of, 10, micro_batch=4, max_len=L, resume_dir=d, record_every=1, fingerprint=fa)
+    calls.clear()
+    with pytest.warns(UserWarning, match="another job"):
+        b = D.caption_shard(make(5), frames_of, 10, micro_batch=4, max_len=L, resume_dir=d, record_every=1, fingerprint=fb)
+    assert calls == [0, 4, 8] and not torch.equal(a[0], b[0])            # job B captioned everything itself
+    calls.clear()
+    a2 = D.caption_shard(make(3), frames_of, 10, micro_batch=4, max_len=L, resume_dir=d, record_every=1, fingerprint=fa)
+    assert calls == [] and torch.equal(a2[0], a[0])                      # job A still finds its own records
+    # a file renamed into another job's slot is refused, not loaded
+    name_a = [f for f in sorted(os.listdir(d)) if D._fp_hash(fa) in f][0]
+    name_b = name_a.replace(D._fp_hash(fa), D._fp_hash(fb))
+    os.replace(os.path.join(d, name_a), os.path.join(d, name_b))
+    with pytest.raises(RuntimeError, match="not written by this job"):
+        D.caption_shard(make(5), frames_of, 10, micro_batch=4, max_len=L, resume_dir=d, record_every=1, fingerprint=fb)
+    assert np.load(os.path.join(d, name_b))["fingerprint"] == fa
