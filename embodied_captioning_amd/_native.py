@@ -52,7 +52,7 @@ _SIGNATURES = {
     "cap_set_early_exit": (C.c_int, [C.c_void_p, C.c_int]),
     "cap_last_decode_steps": (C.c_int, [C.c_void_p]),
     "cap_device_bytes": (C.c_size_t, [C.c_void_p]),
-    "cap_debug_xcd_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "cap_g8_saturations": (C.c_longlong, [C.c_int]),
     "cap_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "cap_profile_report": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "cap_op_gemm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

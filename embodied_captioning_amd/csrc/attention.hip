@@ -1829,3 +1829,5 @@ int launch_pool_attention(int dtype, const float* qp, const void* kv, void* out,
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+CAP_DEFINE_G8_CLAMP_READER(cap_g8_clamped_attention)

@@ -15,7 +15,6 @@
 #include <vector>
 
 #include "../../include/captioner_hip.h"
-#include "decode_xcd.h"
 #include "gemm.h"
 #include "ops.h"
 
@@ -119,6 +118,7 @@ struct Captioner {
     bool replay = false;         // building a handle on an existing store: walloc hands out the store's buffers in order
     size_t wcur = 0;
     float* stage = nullptr; size_t stage_elems = 0;
+    unsigned int* absmax_dev = nullptr;   // cap_load_weight: max |w| of a tensor bound for a G8 slot (range check)
     // early exit of the decode loop (cap_set_early_exit): poll every `poll` steps through a host-mapped word
     int poll = 0; int* host_flag = nullptr; int* host_flag_dev = nullptr;
     int last_steps = 0;          // decode steps the last cap_generate ran (cap_last_decode_steps)
@@ -139,11 +139,7 @@ struct Captioner {
     int *seq, *finished, *lens, *anc;
     float *dx, *dy, *logits, *dpart;
     void *dx_t, *dq, *dctx, *dh;
-    // decode runs as up to 4 independent row slices on separate HIP streams (latency-bound kernels overlap)
-    int nslices = 1;
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-    void* beam[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* beam = nullptr;
     size_t cache_layer_bytes = 0;
     // ---- CoCa (CAP_ARCH_COCA)
     int Q = 0, E = 0;
@@ -156,25 +152,6 @@ struct Captioner {
     std::vector<CBlock> cb;
     std::vector<void*> ccache;
     int ldl;
-    // fused split-K consumer (GemmParams::ln_counter): per-slice arrival counters (one int per 64-row tile, only ever
-    // incremented) and the value they reach after the launches issued so far.  OFF by default: measured on MI355X the
-    // in-kernel hand-over between blocks of different XCDs costs MORE than the ~5 us launch it removes (agent-scope
-    // fences: +35 us per GEMM; fence-free agent-scope stores/loads + counter: +6..11 us; batch 256: 46.7 vs 39.0 ms per
-    // generate, results identical run to run).  CAP_FUSE_LN=1 enables it for A/B runs (tools/fused_ln_stress.py).
-    int* ln_cnt[4] = {nullptr, nullptr, nullptr, nullptr};
-    int ln_total[4] = {0, 0, 0, 0};
-    bool fuse_ln = false;
-    // ---- persistent decode-step kernel (decode_xcd.hip): XCD barrier counters + the values they hold after the launches
-    // issued so far, error word (host-mapped), one event per handle for the cross-stream launch chain
-    bool use_xcd = false;
-    int n_cu = 0;
-    int* xcd_bar = nullptr;        // [2][8][64]: barrier counters, then registration counters
-    unsigned xcd_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned xcd_reg_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long* xcd_dbg = nullptr;  // CAP_XCD_DBG=1: per-barrier timestamps of the last launch (tools/xcd_phase_times.py)
-    int* xcd_err_host = nullptr; int* xcd_err_dev = nullptr;
-    hipEvent_t xcd_ev = nullptr;
-    hipEvent_t enc_ev = nullptr;           // image side of the last generate is done (encoder chain)
     // ---- BLIP-2 (CAP_ARCH_BLIP2)
     std::vector<QLayer> ql;
     std::vector<OLayer> ol;
@@ -461,7 +438,7 @@ int build_arena_coca(Captioner* m) {
     m->ccache.resize(c.t_layers + c.mm_layers);
     for (auto& p : m->ccache) TRY(dev_alloc(m, &p, 2 * R * H * Lm * 64 * e));
     if (c.max_beams > 1)
-        for (int i = 0; i < 4; ++i) TRY(dev_alloc(m, &m->beam[i], beam_state_bytes((int)Bm, c.max_beams, (int)Lm)));
+        TRY(dev_alloc(m, &m->beam, beam_state_bytes((int)Bm, c.max_beams, (int)Lm)));
     return 0;
 }
 
@@ -494,7 +471,7 @@ int build_arena(Captioner* m) {
     m->ldl = (c.vocab + 3) & ~3;
     TRY(dev_alloc(m, (void**)&m->logits, R * (size_t)m->ldl * 4));
     for (int i = 0; i < c.t_layers; ++i) TRY(dev_alloc(m, &m->tl[i].self_cache, 2 * R * H * Lm * 64 * e));
-    for (int i = 0; i < 4; ++i) TRY(dev_alloc(m, &m->beam[i], beam_state_bytes((int)Bm, c.max_beams, (int)Lm)));
+    TRY(dev_alloc(m, &m->beam, beam_state_bytes((int)Bm, c.max_beams, (int)Lm)));
     return 0;
 }
 
@@ -1004,11 +981,12 @@ int run_coca_pool(Captioner* m, int B, float* tokens_out, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------- decoder
-// One decode slice = a contiguous range of images [b0, b0+B) with R = B*K rows; all pointers are pre-offset, row
-// indices inside the kernels are slice-local.  Slices are independent (no shared mutable state), so they can run on
-// different streams.
+// The decode state of a contiguous range of images [b0, b0+B) with R = B*K rows; all pointers are pre-offset, row indices
+// inside the kernels are range-local.  (cap_generate decodes the whole batch as one range: row slices of ONE batch on their own
+// streams measured level at 2 and slower at 3-4 - DESIGN.md section 4 - and were removed; whole batches overlap through
+// engine.EnginePool instead.)
 struct Dec {
-    int b0, B, R, Btot, idx;
+    int b0, B, R, Btot;
     float *dx, *dy, *logits, *dpart;
     char *dx_t, *dq, *dctx, *dh;
     int *seq, *finished, *lens, *anc;
@@ -1016,17 +994,17 @@ struct Dec {
     size_t cache_off;     // byte offset of this slice's [k|v][R][H][Lm][64] block inside every layer's self cache
 };
 
-Dec make_slice(Captioner* m, int b0, int B, int Btot, int K, int Lm, int idx) {
+Dec make_slice(Captioner* m, int b0, int B, int Btot, int K, int Lm) {
     const CapConfig& c = m->c;
     const size_t T = c.t_hidden, F = c.t_ffn, H = c.t_heads, e = m->esz;
     const size_t r0 = (size_t)b0 * K;
     Dec d;
-    d.b0 = b0; d.B = B; d.R = B * K; d.Btot = Btot; d.idx = idx;
+    d.b0 = b0; d.B = B; d.R = B * K; d.Btot = Btot;
     d.dx = m->dx + r0 * T; d.dy = m->dy + r0 * T; d.logits = m->logits + r0 * m->ldl; d.dpart = m->dpart + 12 * r0 * T;
     d.dx_t = (char*)m->dx_t + r0 * T * e; d.dq = (char*)m->dq + r0 * T * e; d.dctx = (char*)m->dctx + r0 * T * e;
     d.dh = (char*)m->dh + r0 * F * e;
     d.seq = m->seq + r0 * Lm; d.finished = m->finished + r0; d.lens = m->lens + r0; d.anc = m->anc + 2 * r0 * Lm;
-    d.beam = m->beam[idx];
+    d.beam = m->beam;
     d.cache_off = 2 * r0 * H * Lm * 64 * e;
     return d;
 }
@@ -1048,9 +1026,9 @@ int gemm_partial(Captioner* m, hipStream_t s, const char* tag, const void* A, co
 }
 
 // Decode-sized GEMM whose consumer is a LayerNorm: split K over S blocks per tile (every block's slabs are all in flight
-// at once -> one memory round trip), partial sums to dpart, then y = sum + bias + resid (-> y_out) and LayerNorm(y) ->
-// out_t / out_f.  The consumer runs inside the GEMM kernel when the launch qualifies (GemmParams::ln_counter), else as the
-// block-per-row kernel.
+// at once -> one memory round trip), partial sums to dpart, then the block-per-row kernel: y = sum + bias + resid (-> y_out)
+// and LayerNorm(y) -> out_t / out_f.  (Running the consumer inside the GEMM kernel behind arrival counters cost more than the
+// launch it saves - cross-XCD hand-over, DESIGN.md section 4 - and was removed.)
 int gemm_splitk_reduce_ln(Captioner* m, hipStream_t s, const Dec& d, const char* tag, const void* A, const void* W,
                           const float* bias, const float* g, const float* b, float eps, int N, int K, void* out_t,
                           float* out_f, float* y_out) {
@@ -1058,26 +1036,13 @@ int gemm_splitk_reduce_ln(Captioner* m, hipStream_t s, const Dec& d, const char*
     const int nk = K / slab;
     int S = 1;
     // at most 4 slices: 8 slices write and re-read twice the partial sums for nothing (pooled: split mode +2 % and -1.6 %
-    // joules per caption, bf16 +3 %, CoCa beam-5 +1 %; CAP_SPLITK_MAX overrides for A/B runs)
-    static const int senv = [] { const char* e = getenv("CAP_SPLITK_MAX"); return e ? atoi(e) : 0; }();
-    const int smax = senv > 0 ? senv : 4;
-    for (int cand : {8, 4, 2})
-        if (cand <= smax && nk % cand == 0 && nk / cand >= 3) { S = cand; break; }
+    // joules per caption, bf16 +3 %, CoCa beam-5 +1 %)
+    for (int cand : {4, 2})
+        if (nk % cand == 0 && nk / cand >= 3) { S = cand; break; }
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = d.dpart; p.ldc = N; p.M = d.R; p.N = N; p.K = K;
     p.out_f32 = 1; p.epi = EPI_PARTIAL; p.splitk = S;
-    const int nb = ((N + 63) / 64) * S, grid = ((d.R + 63) / 64) * nb;
-    const bool fused = m->fuse_ln && m->ln_cnt[d.idx] && nb >= 16 && grid <= 512 && N <= 2048 && (d.R + 63) / 64 <= 64;
-    if (fused) {
-        m->ln_total[d.idx] = (int)((unsigned)m->ln_total[d.idx] + (unsigned)nb);
-        p.ln_counter = m->ln_cnt[d.idx]; p.ln_target = m->ln_total[d.idx];
-        p.bias = bias; p.resid = d.dx; p.ln_gamma = g; p.ln_beta = b; p.ln_eps = eps;
-        p.ln_out_t = out_t; p.ln_out_f = out_f; p.ln_y_out = y_out;
-        ProfScope ps(m, s, tag, 2.0 * d.R * N * K,
-                     ((double)d.R * K + (double)N * K) * m->esz + (double)(2 * S + 2) * d.R * N * 4 + (double)d.R * N * m->esz);
-        return launch_gemm(m->gdt, p, 2, s);
-    }
     {
         ProfScope ps(m, s, tag, 2.0 * d.R * N * K, ((double)d.R * K + (double)N * K) * m->esz + (double)S * d.R * N * 4);
         TRY(launch_gemm(m->gdt, p, 2, s));
@@ -1091,76 +1056,6 @@ int gemm_splitk_ln(Captioner* m, hipStream_t s, const Dec& d, const char* tag, c
     return gemm_splitk_reduce_ln(m, s, d, tag, A, W, bias, g, b, m->c.t_eps, N, K, d.dx_t, d.dx, nullptr);
 }
 
-// Two persistent decode kernels resident at once (two streams) could each hold part of the GPU and spin on barriers that
-// need the rest - forever.  They are therefore chained on the GPU, across every stream and handle of the process on a device:
-// a launch first waits for the event recorded behind the previous one.  (A stream that is being captured into a graph cannot
-// wait on outside work: the chain is skipped there - graphs of generate are for single-stream use.)
-struct XcdChain { std::mutex mu; std::map<int, hipEvent_t> tail; };
-static XcdChain g_xcd_chain;
-
-int launch_xcd_chained(Captioner* m, const XParams& p, hipStream_t s) {
-    int dev = 0;
-    CAP_HIP_CHECK(hipGetDevice(&dev));
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(s, &cs);
-    std::lock_guard<std::mutex> lock(g_xcd_chain.mu);
-    if (cs == hipStreamCaptureStatusNone) {
-        auto it = g_xcd_chain.tail.find(dev);
-        if (it != g_xcd_chain.tail.end() && it->second && it->second != m->xcd_ev) CAP_HIP_CHECK(hipStreamWaitEvent(s, it->second, 0));
-    }
-    TRY(launch_decode_step_xcd(m->gdt, p, m->n_cu, s));
-    if (cs == hipStreamCaptureStatusNone) {
-        CAP_HIP_CHECK(hipEventRecord(m->xcd_ev, s));
-        g_xcd_chain.tail[dev] = m->xcd_ev;
-    }
-    return 0;
-}
-
-void xcd_chain_forget(Captioner* m) {          // a handle goes away: nobody may wait on its event any more
-    if (!m->xcd_ev) return;
-    std::lock_guard<std::mutex> lock(g_xcd_chain.mu);
-    for (auto& kv : g_xcd_chain.tail)
-        if (kv.second == m->xcd_ev) kv.second = nullptr;      // (cap_destroy has synchronised the device: nothing is pending)
-}
-
-// All layers of one decode step in one launch (decode_xcd.hip) -> d.dx (fp32) / d.dx_t (operand) hold the last layer's output.
-int run_decoder_layers_xcd(Captioner* m, const Dec& d, const int* tokens, int tok_ld, int t, int K, const int* anc, int Lm,
-                           const int* skip, hipStream_t s) {
-    const CapConfig& c = m->c;
-    const int T = c.t_hidden, F = c.t_ffn, H = c.t_heads, R = d.R, NT = m->NT;
-    const size_t e = m->esz;
-    XParams p;
-    memset(&p, 0, sizeof(p));
-    p.n_layers = c.t_layers;
-    for (int i = 0; i < c.t_layers; ++i) {
-        const TLayer& L = m->tl[i];
-        XLayer& x = p.layers[i];
-        x.w_qkv = L.w_qkv; x.w_so = L.w_so; x.w_cq = L.w_cq; x.w_co = L.w_co; x.w_f1 = L.w_f1; x.w_f2 = L.w_f2;
-        x.b_qkv = L.b_qkv; x.b_so = L.b_so; x.so_g = L.so_g; x.so_b = L.so_b; x.b_cq = L.b_cq; x.b_co = L.b_co;
-        x.co_g = L.co_g; x.co_b = L.co_b; x.b_f1 = L.b_f1; x.b_f2 = L.b_f2; x.f_g = L.f_g; x.f_b = L.f_b;
-        char* kc = (char*)L.self_cache + d.cache_off;
-        x.kc = kc; x.vc = kc + (size_t)R * H * Lm * 64 * e;
-        x.ck = (char*)m->cross + (((size_t)i * 2 + 0) * d.Btot + d.b0) * H * NT * 64 * e;
-        x.cv = (char*)m->cross + (((size_t)i * 2 + 1) * d.Btot + d.b0) * H * NT * 64 * e;
-    }
-    p.R = R; p.T = T; p.F = F; p.H = H; p.NT = NT; p.Lm = Lm; p.t = t; p.K = K; p.eps = c.t_eps;
-    p.x = d.dx; p.xt = d.dx_t; p.qkv = d.dpart; p.q = d.dpart + (size_t)3 * R * T; p.tmp = d.dy; p.ctx = d.dctx; p.h = d.dh;
-    p.anc = anc; p.anc_ld = Lm; p.skip = skip; p.tokens = tokens; p.tok_ld = tok_ld;
-    p.word = m->word_f32; p.pos = m->tpos; p.emb_g = m->emb_g; p.emb_b = m->emb_b;
-    p.bar = m->xcd_bar; p.reg = m->xcd_bar + 8 * 64; p.err = m->xcd_err_dev; p.dbg = m->xcd_dbg;
-    const int nl = m->n_cu / 8, RX = (R + 7) / 8, nbar = xcd_barriers_per_launch(c.t_layers);
-    for (int x = 0; x < 8; ++x) {
-        p.bar_base[x] = m->xcd_base[x];
-        if (R - x * RX > 0) m->xcd_base[x] += (unsigned)(nbar * nl);
-        p.reg_base[x] = m->xcd_reg_base[x];
-        m->xcd_reg_base[x] += (unsigned)nl;             // every XCD receives n_cu / 8 workgroups of every launch
-    }
-    const double wbytes = ((double)T * T * 6 + 2.0 * T * F) * c.t_layers * e;
-    ProfScope ps(m, s, "dec_layers_xcd", 2.0 * R * ((double)T * T * 6 + 2.0 * T * F) * c.t_layers + 4.0 * R * H * (NT + t + 1) * 64 * c.t_layers,
-                 8.0 * wbytes + 2.0 * d.B * H * NT * 64 * e * c.t_layers);
-    return launch_xcd_chained(m, p, s);
-}
-
 int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, int t, int K, const int* anc, int Lm,
                      hipStream_t s) {
     const CapConfig& c = m->c;
@@ -1169,9 +1064,6 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
     // greedy: the attention kernels leave the rows of ended captions alone (d.finished is set by greedy_select one step
     // before); the GEMMs still cover every row - they are bound by the weight stream, not by the row count
     const int* skip = K == 1 ? d.finished : nullptr;
-    if (m->use_xcd && m->nslices == 1) {
-        TRY(run_decoder_layers_xcd(m, d, tokens, tok_ld, t, K, anc, Lm, skip, s));
-    } else {
     TRY(launch_embed(m->gdt, tokens, tok_ld, t, m->word_f32, m->tpos, m->emb_g, m->emb_b, c.t_eps, d.dx_t, d.dx, R, T, s));
     for (int i = 0; i < c.t_layers; ++i) {
         const TLayer& L = m->tl[i];
@@ -1205,7 +1097,6 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
         TRY(gemm_splitk_ln(m, s, d, "dec_gemm_co", d.dctx, L.w_co, L.b_co, L.co_g, L.co_b, T, T));
         TRY(gemm(m, s, "dec_gemm_f1", d.dx_t, T, L.w_f1, T, d.dh, F, L.b_f1, nullptr, R, F, T, 1, 0));
         TRY(gemm_splitk_ln(m, s, d, "dec_gemm_f2", d.dh, L.w_f2, L.b_f2, L.f_g, L.f_b, T, F));
-    }
     }
     TRY(gemm(m, s, "dec_gemm_tr", d.dx_t, T, m->w_tr, T, d.dy, T, m->b_tr, nullptr, R, T, T, 1, 1));
     {
@@ -1280,22 +1171,6 @@ __global__ void copy_i32_kernel(const int* s, int* d, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
 }
 
-// CAP_ENCODER_CHAIN=1: the image sides (encoder + cross-K/V GEMM: MFMA-bound, every CU) of the generates of ALL handles and
-// streams of the process on a device run one after the other - a generate's image side waits for the event behind the previous
-// one's.  Two image sides at once only slow each other; what a stream pool can hide under one is another batch's decode chain.
-struct EncChain { std::mutex mu; std::map<int, hipEvent_t> tail; };
-static EncChain g_enc_chain;
-static bool enc_chain_on() {
-    static const bool on = [] { const char* e = getenv("CAP_ENCODER_CHAIN"); return e && atoi(e) != 0; }();
-    return on;
-}
-void enc_chain_forget(Captioner* m) {
-    if (!m->enc_ev) return;
-    std::lock_guard<std::mutex> lock(g_enc_chain.mu);
-    for (auto& kv : g_enc_chain.tail)
-        if (kv.second == m->enc_ev) kv.second = nullptr;
-}
-
 static int run_image_side(Captioner* m, const void* pixels, int fmt, int B, hipStream_t s) {
     const CapConfig& c = m->c;
     const int NT = m->NT, D = c.v_hidden, T = c.t_hidden, H = c.t_heads;
@@ -1316,90 +1191,46 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
     const CapConfig& c = m->c;
     const int R = B * K;
     const bool coca = c.arch == CAP_ARCH_COCA;
-    hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(s, &cs0);
-    if (enc_chain_on() && cs0 == hipStreamCaptureStatusNone) {
-        int dev = 0;
-        CAP_HIP_CHECK(hipGetDevice(&dev));
-        if (!m->enc_ev) CAP_HIP_CHECK(hipEventCreateWithFlags(&m->enc_ev, hipEventDisableTiming));
-        // the lock covers the enqueue: the event must be recorded before another thread may wait on it
-        std::lock_guard<std::mutex> lock(g_enc_chain.mu);
-        auto it = g_enc_chain.tail.find(dev);
-        if (it != g_enc_chain.tail.end() && it->second && it->second != m->enc_ev) CAP_HIP_CHECK(hipStreamWaitEvent(s, it->second, 0));
-        const int rc_img = run_image_side(m, pixels, fmt, B, s);
-        CAP_HIP_CHECK(hipEventRecord(m->enc_ev, s));
-        g_enc_chain.tail[dev] = m->enc_ev;
-        if (rc_img != 0) return rc_img;
+    TRY(run_image_side(m, pixels, fmt, B, s));
+    const Dec d = make_slice(m, 0, B, B, K, Lm);
+    if (K == 1) {
+        hipLaunchKernelGGL(init_seq_kernel, dim3(64), dim3(256), 0, s, d.seq, d.finished, d.lens, R, Lm, c.bos, c.pad);
     } else {
-        TRY(run_image_side(m, pixels, fmt, B, s));
+        TRY(launch_beam_init(d.beam, B, K, Lm, c.bos, c.pad, c.eos, s, coca ? BEAM_LEGACY_RAW : BEAM_HF_V5));
+        hipLaunchKernelGGL(iota_rows_kernel, dim3(64), dim3(256), 0, s, d.anc, R, Lm);
     }
-    // decode: independent row slices, one per stream (slice 0 stays on the caller's stream)
-    int ns = m->nslices;
-    if (ns > B) ns = B;
-    if (ns > 1) CAP_HIP_CHECK(hipEventRecord(m->ev_fork, s));
-    const int per = (B + ns - 1) / ns;
-    int rc = 0;
-    for (int si = 0; si < ns; ++si) {
-        const int b0 = si * per, Bs = (b0 + per <= B ? per : B - b0);
-        if (Bs <= 0) continue;
-        hipStream_t st = si == 0 ? s : m->aux[si - 1];
-        if (si > 0) CAP_HIP_CHECK(hipStreamWaitEvent(st, m->ev_fork, 0));
-        // the slice's launches; a failure stops the slice but NOT the joins below: the caller's stream must stay ordered
-        // after whatever the aux streams were given, or the shared arena is reused under them
-        auto slice = [&]() -> int {
-        const Dec d = make_slice(m, b0, Bs, B, K, Lm, si);
-        const int Rs = d.R;
-        if (K == 1) {
-            hipLaunchKernelGGL(init_seq_kernel, dim3(64), dim3(256), 0, st, d.seq, d.finished, d.lens, Rs, Lm, c.bos, c.pad);
-        } else {
-            TRY(launch_beam_init(d.beam, Bs, K, Lm, c.bos, c.pad, c.eos, st, coca ? BEAM_LEGACY_RAW : BEAM_HF_V5));
-            hipLaunchKernelGGL(iota_rows_kernel, dim3(64), dim3(256), 0, st, d.anc, Rs, Lm);
-        }
-        CAP_HIP_CHECK(hipGetLastError());
-        for (int t = 0; t + 1 < Lm; ++t) {
-            const int cur_len = t + 1;
-            if (si == 0) m->last_steps = t + 1;
-            const int* tokens = K == 1 ? d.seq : beam_running_tokens_p(d.beam, Bs, K, Lm, cur_len & 1);
-            const int* anc = K == 1 ? nullptr : d.anc + (size_t)(cur_len & 1) * Rs * Lm;
-            if (coca) TRY(run_coca_step(m, d, tokens, Lm, t, K, anc, Lm, st));
-            else TRY(run_decoder_step(m, d, tokens, Lm, t, K, anc, Lm, st));
-            if (out_step_logits) {
-                hipLaunchKernelGGL(copy_logits_kernel, dim3(1024), dim3(256), 0, st, d.logits, m->ldl,
-                                   out_step_logits + ((size_t)t * R + (size_t)b0 * K) * c.vocab, Rs, c.vocab);
-                CAP_HIP_CHECK(hipGetLastError());
-            }
-            ProfScope ps(m, st, K == 1 ? "greedy_select" : "beam_step", 0, (double)Rs * c.vocab * 4);
-            if (K == 1)
-                TRY(launch_greedy_select(d.logits, m->ldl, c.vocab, d.seq, Lm, t, Lm, c.eos, c.pad, d.finished, d.lens, Rs, st,
-                                         coca ? c.min_len : 0, coca ? 1 : 0));
-            else
-                TRY(launch_beam_step(d.beam, d.logits, m->ldl, c.vocab, Bs, K, Lm, cur_len, c.eos, lp, d.anc, Lm, st,
-                                     coca ? BEAM_LEGACY_RAW : BEAM_HF_V5, coca ? c.min_len : 0));
-            if (ns == 1) {
-                bool done;
-                TRY(poll_all_finished(m, t, Lm - 1, d.finished, Rs, K == 1 ? nullptr : beam_active_flag_p(d.beam, Bs, K, Lm), st, &done));
-                if (done) break;
-            }
-        }
-        if (K == 1) {
-            hipLaunchKernelGGL(copy_i32_kernel, dim3(64), dim3(256), 0, st, d.seq, out_ids + (size_t)b0 * Lm, (size_t)Rs * Lm);
-            if (out_len) hipLaunchKernelGGL(copy_i32_kernel, dim3(4), dim3(256), 0, st, d.lens, out_len + b0, (size_t)Rs);
+    CAP_HIP_CHECK(hipGetLastError());
+    for (int t = 0; t + 1 < Lm; ++t) {
+        const int cur_len = t + 1;
+        m->last_steps = t + 1;
+        const int* tokens = K == 1 ? d.seq : beam_running_tokens_p(d.beam, B, K, Lm, cur_len & 1);
+        const int* anc = K == 1 ? nullptr : d.anc + (size_t)(cur_len & 1) * R * Lm;
+        if (coca) TRY(run_coca_step(m, d, tokens, Lm, t, K, anc, Lm, s));
+        else TRY(run_decoder_step(m, d, tokens, Lm, t, K, anc, Lm, s));
+        if (out_step_logits) {
+            hipLaunchKernelGGL(copy_logits_kernel, dim3(1024), dim3(256), 0, s, d.logits, m->ldl,
+                               out_step_logits + (size_t)t * R * c.vocab, R, c.vocab);
             CAP_HIP_CHECK(hipGetLastError());
-        } else {
-            TRY(launch_beam_finalize(d.beam, Bs, K, Lm, out_ids + (size_t)b0 * Lm, out_len ? out_len + b0 : nullptr,
-                                     out_scores ? out_scores + b0 : nullptr, st));
         }
-        return 0;
-        };
-        if (rc == 0) rc = slice();
-        if (si > 0) {
-            if (hipEventRecord(m->ev_join[si - 1], st) != hipSuccess || hipStreamWaitEvent(s, m->ev_join[si - 1], 0) != hipSuccess) {
-                (void)hipStreamSynchronize(st);
-                if (rc == 0) { cap_set_error("cap_generate: cannot join a decode stream"); rc = -1; }
-            }
-        }
+        ProfScope ps(m, s, K == 1 ? "greedy_select" : "beam_step", 0, (double)R * c.vocab * 4);
+        if (K == 1)
+            TRY(launch_greedy_select(d.logits, m->ldl, c.vocab, d.seq, Lm, t, Lm, c.eos, c.pad, d.finished, d.lens, R, s,
+                                     coca ? c.min_len : 0, coca ? 1 : 0));
+        else
+            TRY(launch_beam_step(d.beam, d.logits, m->ldl, c.vocab, B, K, Lm, cur_len, c.eos, lp, d.anc, Lm, s,
+                                 coca ? BEAM_LEGACY_RAW : BEAM_HF_V5, coca ? c.min_len : 0));
+        bool done;
+        TRY(poll_all_finished(m, t, Lm - 1, d.finished, R, K == 1 ? nullptr : beam_active_flag_p(d.beam, B, K, Lm), s, &done));
+        if (done) break;
     }
-    return rc;
+    if (K == 1) {
+        hipLaunchKernelGGL(copy_i32_kernel, dim3(64), dim3(256), 0, s, d.seq, out_ids, (size_t)R * Lm);
+        if (out_len) hipLaunchKernelGGL(copy_i32_kernel, dim3(4), dim3(256), 0, s, d.lens, out_len, (size_t)R);
+        CAP_HIP_CHECK(hipGetLastError());
+    } else {
+        TRY(launch_beam_finalize(d.beam, B, K, Lm, out_ids, out_len, out_scores, s));
+    }
+    return 0;
 }
 
 }  // namespace
@@ -1413,20 +1244,8 @@ static void release_captioner(Captioner* m) {
         delete m->ws;
     }
     if (m->stage) (void)hipFree(m->stage);
+    if (m->absmax_dev) (void)hipFree(m->absmax_dev);
     if (m->host_flag) (void)hipHostFree(m->host_flag);
-    for (int i = 0; i < 3; ++i) {
-        if (m->aux[i]) (void)hipStreamDestroy(m->aux[i]);
-        if (m->ev_join[i]) (void)hipEventDestroy(m->ev_join[i]);
-    }
-    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-    xcd_chain_forget(m);
-    if (m->xcd_ev) (void)hipEventDestroy(m->xcd_ev);
-    enc_chain_forget(m);
-    if (m->enc_ev) (void)hipEventDestroy(m->enc_ev);
-    if (m->xcd_err_host) {
-        if (*m->xcd_err_host) fprintf(stderr, "libcaptioner_hip: persistent decode kernel reported error bits %d on a destroyed handle\n", *m->xcd_err_host);
-        (void)hipHostFree(m->xcd_err_host);
-    }
     delete m;
 }
 
@@ -1518,30 +1337,6 @@ static int create_impl(const CapConfig* cfg, Captioner* share, CapHandle* out) {
     m->P = g * g; m->NT = m->P + 1;
     m->Kpatch = text_only ? 0 : 3 * cfg->patch_size * cfg->patch_size;
     m->Kpad = (m->Kpatch + 63) / 64 * 64;
-    {
-        // decode slices: 1 by default.  Measured on MI355X (eager and captured into a hipGraph): row slices of ONE batch on
-        // their own streams tie at 2 (38.5 vs 39.1 ms) and lose at 3-4 - every slice is the same chain of ~2700 short
-        // dependent kernels and two such chains gain nothing from each other.  What does pay is overlapping WHOLE batches
-        // (engine.EnginePool: another batch's image tower fills the chain's idle CUs, +26-32 %); slices on top of the pool
-        // lose (7380 vs 8510 captions/s).  CAP_DECODE_SLICES=1..4 keeps the knob for A/B runs.
-        const char* env = getenv("CAP_DECODE_SLICES");
-        int ns = env ? atoi(env) : 1;
-        m->nslices = ns < 1 ? 1 : (ns > 4 ? 4 : ns);
-        bool ok = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; ok && i + 1 < m->nslices; ++i)
-            ok = hipStreamCreateWithFlags(&m->aux[i], hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { cap_set_error("cap_create: cannot create decode streams/events"); release_captioner(m); return -1; }
-        const char* fl = getenv("CAP_FUSE_LN");
-        m->fuse_ln = fl && atoi(fl) != 0;
-        for (int i = 0; i < m->nslices && !text_only; ++i) {
-            if (dev_alloc(m, (void**)&m->ln_cnt[i], 64 * sizeof(int)) != 0 || hipMemset(m->ln_cnt[i], 0, 64 * sizeof(int)) != hipSuccess) {
-                cap_set_error("cap_create: cannot allocate the split-K arrival counters");
-                release_captioner(m);
-                return -1;
-            }
-        }
-    }
     const int built = text_only ? (build_minilm(m) != 0)
                       : cfg->arch == CAP_ARCH_BLIP2 ? (build_blip2(m) != 0)
                       : cfg->arch == CAP_ARCH_COCA ? (build_coca(m) != 0 || build_arena_coca(m) != 0)
@@ -1549,32 +1344,6 @@ static int create_impl(const CapConfig* cfg, Captioner* share, CapHandle* out) {
     if (built) {
         release_captioner(m);       // the message of the failing step is kept
         return -1;
-    }
-    if (cfg->arch == CAP_ARCH_BLIP) {
-        // persistent decode-step kernel (decode_xcd.hip): OFF by default, CAP_DECODE_XCD=1 enables it for A/B runs.  Measured on
-        // MI355X at 256 rows (tools/xcd_phase_times.py): correct (every parity test passes on it), one launch per step instead
-        // of ~140, XCD-local barriers at 0.9 us - and still slower than the launch-per-kernel path: 200 us against 170 us per
-        // layer in split mode (135 against 120 in bf16), because partitioning the ROWS by XCD makes every XCD stream all the
-        // weights (8 x 33 MB per layer) and every workgroup re-read its XCD's whole activation block; DESIGN.md section 4.
-        const char* env = getenv("CAP_DECODE_XCD");
-        int n_cu = 0;
-        bool ok = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess;
-        m->n_cu = n_cu;
-        if (ok && env && atoi(env) != 0 && cfg->t_layers <= XCD_MAX_LAYERS &&
-            xcd_decode_supported(m->gdt, m->dt, cfg->t_hidden, cfg->t_ffn, cfg->t_heads, n_cu)) {
-            ok = dev_alloc(m, (void**)&m->xcd_bar, 2 * 8 * 64 * sizeof(int)) == 0 && hipMemset(m->xcd_bar, 0, 2 * 8 * 64 * sizeof(int)) == hipSuccess &&
-                 hipHostMalloc((void**)&m->xcd_err_host, sizeof(int), hipHostMallocMapped) == hipSuccess &&
-                 hipHostGetDevicePointer((void**)&m->xcd_err_dev, m->xcd_err_host, 0) == hipSuccess &&
-                 hipEventCreateWithFlags(&m->xcd_ev, hipEventDisableTiming) == hipSuccess;
-            if (!ok) { cap_set_error("cap_create: cannot set up the persistent decode kernel"); release_captioner(m); return -1; }
-            *m->xcd_err_host = 0;
-            m->use_xcd = true;
-            const char* dbg = getenv("CAP_XCD_DBG");
-            if (dbg && atoi(dbg) != 0 && (dev_alloc(m, (void**)&m->xcd_dbg, 4096 * 8) != 0 || hipMemset(m->xcd_dbg, 0, 4096 * 8) != hipSuccess)) {
-                release_captioner(m);
-                return -1;
-            }
-        }
     }
     if (m->replay && m->wcur != m->ws->ptrs.size()) {
         cap_set_error("cap_create_shared: the shared store holds %zu buffers, this configuration uses %zu", m->ws->ptrs.size(), m->wcur);
@@ -1633,6 +1402,26 @@ int cap_load_weight(CapHandle h, const char* name, const float* data, int on_dev
         }
         CAP_HIP_CHECK(hipMemcpyAsync(m->stage, data, (size_t)n * 4, hipMemcpyHostToDevice, s));
         src = m->stage;
+    }
+    bool any_g8 = false;
+    for (auto it = range.first; it != range.second; ++it) any_g8 |= it->second.dtype == CAP_DT_G8;
+    if (any_g8) {
+        // split mode stores 4096 * w as two fp16 halves: a tensor that does not fit fp16's range would be clipped silently -
+        // refuse it instead (real checkpoints sit far below the bound; this is the guard for the ones that do not)
+        if (!m->absmax_dev) CAP_HIP_CHECK(hipMalloc((void**)&m->absmax_dev, 256));
+        CAP_HIP_CHECK(hipMemsetAsync(m->absmax_dev, 0, 4, s));
+        TRY(launch_absmax_f32(src, (size_t)n, m->absmax_dev, s));
+        unsigned int bits = 0;
+        CAP_HIP_CHECK(hipMemcpyAsync(&bits, m->absmax_dev, 4, hipMemcpyDeviceToHost, s));
+        CAP_HIP_CHECK(hipStreamSynchronize(s));
+        float amax;
+        memcpy(&amax, &bits, 4);
+        if (!(amax * G8_WSCALE <= G8_AMAX)) {
+            cap_set_error("cap_load_weight: %s has max |w| = %g; the split-fp16 mode (CAP_F32_SPLIT / dtype \"f32s\") stores "
+                          "%g * w in fp16 and takes |w| <= %g (no NaN) - load this checkpoint with CAP_F32 or CAP_BF16",
+                          name, (double)amax, (double)G8_WSCALE, (double)(G8_AMAX / G8_WSCALE));
+            return -1;
+        }
     }
     for (auto it = range.first; it != range.second; ++it) {
         Slot& sl = it->second;
@@ -1704,15 +1493,6 @@ int cap_generate(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_
     Captioner* m = (Captioner*)h;
     TRY(check_call(m, B, num_beams, max_len, pixel_fmt));
     if (!pixels || !out_ids) { cap_set_error("cap_generate: null buffer"); return -1; }
-    if (m->xcd_err_host && *(volatile int*)m->xcd_err_host) {
-        // an earlier generate on this handle: a barrier of the persistent decode kernel timed out (1) or a workgroup was not on
-        // the XCD its index implies (2) - its captions were wrong.  The handle falls back to the launch-per-kernel path.
-        cap_set_error("cap_generate: the persistent decode kernel reported error bits %d in an earlier call on this handle; "
-                      "that call's captions are invalid (set CAP_DECODE_XCD=0 to avoid the kernel)", *m->xcd_err_host);
-        *m->xcd_err_host = 0;
-        m->use_xcd = false;
-        return -1;
-    }
     if (m->c.arch == CAP_ARCH_BLIP2) {
         if (num_beams != 1) { cap_set_error("cap_generate: BLIP-2 supports greedy decoding (num_beams = 1)"); return -1; }
         return run_generate_blip2(m, pixels, pixel_fmt, B, max_len, out_ids, out_len, out_step_logits, (hipStream_t)stream);
@@ -1723,14 +1503,13 @@ int cap_generate(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_
                         out_step_logits, (hipStream_t)stream);
 }
 
-/* diagnostics: the persistent decode kernel's per-barrier timestamps (100 MHz ticks) of the last launch, when the handle was
- * created under CAP_XCD_DBG=1; returns the number of values copied (0: not enabled). */
-int cap_debug_xcd_times(CapHandle h, long long* out, int n) {
-    Captioner* m = (Captioner*)h;
-    if (!m || !m->xcd_dbg || !out || n < 1) return 0;
-    n = n < 4096 ? n : 4096;
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, m->xcd_dbg, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-    return n;
+long long cap_g8_saturations(int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) { cap_set_error("cap_g8_saturations: device synchronisation failed"); return -1; }
+    unsigned long long total = 0;
+    if (cap_g8_clamped_gemm(&total, reset) != 0 || cap_g8_clamped_elementwise(&total, reset) != 0 ||
+        cap_g8_clamped_attention(&total, reset) != 0)
+        return -1;
+    return (long long)total;
 }
 
 int cap_profile_enable(CapHandle h, int on) {
@@ -1779,7 +1558,9 @@ int cap_op_gemm(int dtype, const void* A, const void* W, const float* bias, cons
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = C; p.ldc = N; p.bias = bias; p.resid = resid; p.ldr = N;
     p.M = M; p.N = N; p.K = K; p.gelu = gelu; p.out_f32 = out_f32; p.epi = EPI_STORE; p.splitk = 1;
+#ifdef CAP_EXPERIMENTS
     if (tile == 9 || tile == 13) { p.aux = resid; p.resid = nullptr; }   // instrumented kernel: `resid` is the cycle-count buffer
+#endif
     return launch_gemm(dt_of(dtype), p, tile, (hipStream_t)stream);
 }
 int cap_op_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps, void* out_t,

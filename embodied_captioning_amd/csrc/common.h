@@ -28,8 +28,11 @@ enum { CAP_DT_F32 = 0, CAP_DT_BF16 = 1, CAP_DT_G8 = 2 };
 // inside a row every group of 8 consecutive elements is 32 bytes = [8 hi halves | 8 lo halves]: a lane's MFMA operand
 // (8 consecutive k) is one 16-byte LDS read per half, with no unpacking.  Rows therefore need ld % 8 == 0.
 // Weights are stored scaled by G8_WSCALE (a power of two: exact) so that the lo halves of typical weights (|w| ~ 1e-2)
-// stay in fp16's normal range; the GEMM epilogue multiplies the accumulator by 1 / G8_WSCALE.  Activations are unscaled
-// and clamped to +-G8_AMAX (fp16's range) - values beyond that do not occur on this path.
+// stay in fp16's normal range; the GEMM epilogue multiplies the accumulator by 1 / G8_WSCALE.  Range: a weight tensor with
+// max |w| * G8_WSCALE > G8_AMAX (|w| > 15.87) is REJECTED at load (cap_load_weight names it; use CAP_F32 or CAP_BF16 for such
+// a checkpoint).  Activations are unscaled; a value beyond +-G8_AMAX (fp16's range) is clamped AND counted: every G8 store
+// bumps a device counter when it clamps, read through cap_g8_saturations() - the envelope inside which the
+// mode is fp32-grade is |activation| <= 65000 at every GEMM input, and leaving it is never silent.
 struct g8_t { unsigned int w; };                         // never dereferenced as a scalar: see store4 / g8_put
 constexpr float G8_WSCALE = 4096.0f;
 constexpr float G8_AMAX = 65000.0f;
@@ -44,6 +47,14 @@ __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// Values the G8 stores of THIS translation unit clamped (|x| > G8_AMAX) since the last reset (groups of 4 count once).  One instance per
+// .hip file (static linkage); CAP_DEFINE_G8_CLAMP_READER(name) below gives a file its host-side reader and captioner.hip sums
+// them in cap_g8_saturations().
+static __device__ unsigned int g_g8_clamped;
+__device__ __forceinline__ void g8_note_range(float absmax) {
+    if (!(absmax <= G8_AMAX)) atomicAdd(&g_g8_clamped, 1u);          // rare by construction: one compare per store otherwise
+}
 
 // ---- typed stores of GEMM operands: `row` points at element 0 of a row (a multiple of 8 elements from the buffer start
 // for g8_t), c is the column.  store4: c % 4 == 0, four consecutive columns.
@@ -61,6 +72,7 @@ __device__ __forceinline__ void store4(bf16_t* row, int c, float4 v) {
 __device__ __forceinline__ void store4(g8_t* row, int c, float4 v) {
     f16x4 hi, lo;
     const float x[4] = {v.x, v.y, v.z, v.w};
+    g8_note_range(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         f16_t h, l;
@@ -75,6 +87,7 @@ __device__ __forceinline__ void store1(float* row, int c, float v) { row[c] = v;
 __device__ __forceinline__ void store1(bf16_t* row, int c, float v) { row[c] = (bf16_t)v; }
 __device__ __forceinline__ void store1(g8_t* row, int c, float v) {
     f16_t hi, lo;
+    g8_note_range(fabsf(v));
     g8_split(v, hi, lo);
     char* g = (char*)row + (c >> 3) * 32 + (c & 7) * 2;
     *(f16_t*)g = hi;
@@ -122,6 +135,16 @@ template <> __device__ __forceinline__ float gelu_for<g8_t>(float x) { return ge
 // exceeds the 64 KiB default and returns the device's CU count in *n_cu (may be null).  Thread-safe; a handle per GPU in
 // one process works.  Returns 0, or -1 with cap_set_error.
 int cap_kernel_setup(const void* kernel, int lds_bytes, int* n_cu);
+
+// Host-side reader of a translation unit's g_g8_clamped: adds it to *total and optionally clears it (current device).
+#define CAP_DEFINE_G8_CLAMP_READER(name)                                                                              \
+    int name(unsigned long long* total, int reset) {                                                                  \
+        unsigned int v = 0, z = 0;                                                                                    \
+        CAP_HIP_CHECK(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_g8_clamped), sizeof(v)));                                  \
+        *total += v;                                                                                                  \
+        if (reset) CAP_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_g8_clamped), &z, sizeof(z)));                         \
+        return 0;                                                                                                     \
+    }
 
 // Host-side error plumbing (captioner.cpp owns the storage).
 void cap_set_error(const char* fmt, ...);

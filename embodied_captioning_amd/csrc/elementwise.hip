@@ -72,7 +72,7 @@ __global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __re
     X[(size_t)b * tokens * D + d] = cls[d] + pos[d];
 }
 
-#include "ln.h"   // LN_MAXV, ln_row, reduce_ln_row_wave (shared with the fused split-K GEMM consumer)
+#include "ln.h"   // LN_MAXV, ln_row
 
 template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, int ld_in,
@@ -602,6 +602,22 @@ int launch_greedy_select(const float* logits, int ld, int V, int* seq, int seq_l
     return 0;
 }
 
+__global__ void absmax_f32_kernel(const float* __restrict__ src, size_t n, unsigned int* out_bits) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float a = fabsf(src[i]);
+        m = (a > m || a != a) ? a : m;                   // a NaN sticks (and compares above every bound below)
+    }
+    const float w = (m != m) ? m : wave_max(m);
+    // non-negative floats order like their bit patterns; a NaN's pattern is above +inf's
+    if ((threadIdx.x & 63) == 0 || m != m) atomicMax(out_bits, __float_as_uint(w));
+}
+int launch_absmax_f32(const float* src, size_t n, unsigned int* out_bits, hipStream_t s) {
+    hipLaunchKernelGGL(absmax_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, n, out_bits);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_fill_i32(int* p, int v, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, v, n);
     CAP_HIP_CHECK(hipGetLastError());
@@ -617,3 +633,5 @@ int launch_copy_f32(const float* src, float* dst, size_t n, hipStream_t s) {
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+CAP_DEFINE_G8_CLAMP_READER(cap_g8_clamped_elementwise)

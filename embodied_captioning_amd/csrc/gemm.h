@@ -28,23 +28,12 @@ struct GemmParams {
     int p0, p1, p2, p3;
     const float* aux;
     void* C2;
-    // EPI_PARTIAL with ln_counter != nullptr (64x64 tile only): the split-K consumer runs INSIDE the GEMM kernel.  Every
-    // block bumps its M-tile's arrival counter after its partial slab is globally visible; the first 16 blocks of an
-    // M-tile wait for all ntn * splitk arrivals (the counters only grow: ln_target = value expected after this launch)
-    // and then each reduces + LayerNorms 4 of the tile's 64 rows (one per wave): y = sum_z partial[z] + bias + resid
-    // (slice order), LayerNorm(y) -> ln_out_t (T) / ln_out_f (fp32), y -> ln_y_out.  Removes one dependent launch, but the
-    // cross-XCD hand-over costs more than that launch on MI355X (captioner.hip, Captioner::fuse_ln): off by default.
-    int* ln_counter;
-    int ln_target;
-    const float *ln_gamma, *ln_beta;
-    float ln_eps;
-    void* ln_out_t;
-    float *ln_out_f, *ln_y_out;
 };
 
 // dtype: CAP_DT_F32 / CAP_DT_BF16.  tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 256x256 persistent LDS-DMA kernel
 // (bf16: second generation), 4 = 256x256 register-staged (takes a residual operand), 5 = first-generation LDS-DMA kernel,
 // 10/11/12 = second generation with the compiler / iglp_opt(0) / iglp_opt(1) schedule, 14/15 = half-slab four-stage
-// structure (gemm_big3_kernel; what tile 3 picks for K <= 1024) without / with iglp_opt(1), 9 and 13 = instrumented builds of
-// generations one and two (cycle stamps to GemmParams::aux; tools/gemm_cycles.py)
+// structure (gemm_big3_kernel; what tile 3 picks for K <= 1024) without / with iglp_opt(1); in a -DCAP_EXPERIMENTS build
+// (python -m embodied_captioning_amd.build --experiments) 9 and 13 = instrumented builds of generations one and two (cycle
+// stamps to GemmParams::aux; tools/gemm_cycles.py) - the default library does not contain them
 int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream);

@@ -23,7 +23,6 @@
 #include <type_traits>
 
 #include "gemm.h"
-#include "ln.h"
 
 namespace {
 
@@ -85,15 +84,7 @@ __device__ __forceinline__ void epi_store4(const GemmParams& p, int row, int col
     size_t o; void* base = p.C;
     if constexpr (EPI == EPI_PARTIAL) {          // split-K slice z: raw fp32 partial sums, reduced by the consumer
         float* dst = (float*)p.C + ((size_t)p.p3 * p.M + row) * p.ldc + col;
-        if (p.ln_counter) {
-            // consumer inside this kernel, possibly on another XCD (whose L2 is not coherent with this one): agent-scope
-            // stores go through to memory; no fence (a device-wide L2 write-back + invalidate per block costs far more
-            // than the launch it saves - measured +35 us per GEMM)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) __hip_atomic_store(dst + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            *(f32x4*)dst = v;
-        }
+        *(f32x4*)dst = v;
         return;
     } else if constexpr (EPI == EPI_STORE) {
         o = (size_t)row * p.ldc + col;
@@ -322,35 +313,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(G
             const int row = m0 + wm0 + i * 32 + rr;
             const f32x4 v = *(const f32x4*)(strip + rr * WN + cl);
             if (row < p.M && col < p.N) epi_store4<T, OUT_F32, EPI>(p, row, col, v, biasv);
-        }
-    }
-    if constexpr (EPI == EPI_PARTIAL && BM == 64 && BN == 64) {
-        if (p.ln_counter) {
-            // ---- fused split-K consumer (see GemmParams::ln_counter).  The partial slabs were written with agent-scope
-            // stores (epi_store4); once they are acknowledged (vmcnt(0)) and every wave of the block got here, the arrival
-            // is counted.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const int nb = ntn * S, myb = tn * S + kz;
-            (void)nb;
-            if (tid == 0) __hip_atomic_fetch_add(p.ln_counter + tm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (myb < 16) {                               // nb >= 16 is checked by the launcher
-                if (tid == 0) {
-                    // every block of the launch is resident (the launcher bounds the grid), so the missing arrivals are
-                    // running or about to; the iteration bound only turns a broken assumption into a wrong answer instead
-                    // of a hung GPU
-                    int it = 0;
-                    while ((int)((unsigned)__hip_atomic_load(p.ln_counter + tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                                 (unsigned)p.ln_target) < 0 && ++it < (1 << 22))
-                        __builtin_amdgcn_s_sleep(1);
-                }
-                __syncthreads();
-                asm volatile("" ::: "memory");            // the slab reads below stay below the wait
-                const int row = m0 + myb * 4 + wave;
-                if (row < p.M)
-                    reduce_ln_row_wave<T, true>((const float*)p.C, S, p.M, p.N, row, lane, p.bias, p.resid, p.ln_gamma, p.ln_beta,
-                                                p.ln_eps, (T*)p.ln_out_t, p.ln_out_f, p.ln_y_out);
-            }
         }
     }
 }
@@ -970,238 +932,6 @@ __global__ __launch_bounds__(512, 2) void gemm_big3_kernel(GemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the dummy groups before the LDS goes away
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Fourth structure: two wave groups in PING-PONG (the "8-phase" schedule of the CDNA4 guide, section 5, rebuilt for this
-// file's operand layouts).  The 8 waves of a 256x256 tile are 2 (M) x 4 (N), 128x64 outputs each; waves 0-3 (rows 0-127) and
-// waves 4-7 (rows 128-255) share every SIMD pairwise and run ONE BARRIER APART: between two barriers one group executes a
-// load segment (its LDS fragment reads + its share of the LDS-DMA staging) while the other executes an MFMA segment, then
-// they swap - the matrix pipe always has a wave whose operands are already in registers.
-//   K-tile     128 bytes per row: 64 bf16 / 32 G8 values; 64 KiB = four 16 KiB half-tiles [B0 | B1 | A0 | A1] (128 rows each),
-//              two K-tile buffers; a wave reads only A half (wave >> 2) and B half ((wave & 3) >> 1).
-//   phase      a wave's 128x64 tile is four 64x32 quadrants; a K-tile is 4 phases, each = {load segment, barrier, MFMA segment
-//              (16 bf16 / 24 G8 MFMAs), barrier}: Q00 (reads A-top 8 + B-left 4 fragments), Q01 (B-right 4), Q11 (A-bottom 8),
-//              Q10 (none).
-//   staging    every load segment issues ONE half-tile (2 LDS-DMA instructions per wave), 6 phases ahead of the phase that
-//              first reads its K-tile, in the order B0, B1, A0, A1: the B halves of K-tile T-2 are dead after its phase 1, the
-//              A halves after phase 2, so half-tile S of K-tile T may be overwritten from phase 4T-6+S on.  One counted wait
-//              per K-tile (phase 3: vmcnt(4) = the two youngest half-tiles stay in flight), one barrier later everybody's
-//              pieces are known to have landed, one more and the (later) group reads them.
-//   hazards    RAW: wait in the load segment of phase 4T-1, read in phase 4T (two barriers later for the early group, one
-//              for the late group - whose own wait is one barrier later too).  WAR: a B half is re-staged by the early group
-//              one barrier after the late group ISSUED its last reads of it, so those reads are retired (lgkmcnt(0)) before
-//              that barrier; A halves have two more barriers of slack.
-// The pipeline runs across output tiles (stage counter and buffer parity are global); the epilogue (big2_epilogue, no
-// barriers inside) sits between the last MFMA segment of a tile and the barrier that closes it.
-// LDS-DMA hidden from hipcc's wait bookkeeping (guide 5.7): with the builtin, hipcc put an s_waitcnt vmcnt(0) between the two
-// DMA instructions of every stage (it cannot prove that their run-time LDS destinations differ), which drains the whole
-// prefetch pipeline every phase - the kernel ran at HALF the speed of gemm_big2_kernel.  As an asm statement the DMA is
-// ordered only by the counted waits written in the kernel.  M0 (the LDS destination base) is written and restored inside.
-__device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
-template <typename T, bool OUT_F32, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
-    using vec = typename Mma<T>::vec;
-    constexpr bool G8 = is_g8<T>;
-    constexpr int EPC = Mma<T>::EPC, KT = 8 * EPC;       // K values per 128-byte row
-    constexpr int HALF = 128 * 128, KBUF = 4 * HALF;     // 16 KiB half-tile, 64 KiB K-tile buffer: B0 | B1 | A0 | A1
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int r16 = lane & 15, kg = lane >> 4;
-    const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256, ntiles = ntm * ntn;
-    const int nkt = p.K / KT;
-
-    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
-    const int nl = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
-    const int tq = ntiles >> 3, tr = ntiles & 7;
-    const int c0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
-    const int c1 = c0 + tq + (xcd < tr ? 1 : 0);
-    if (c0 + li >= c1) return;
-    const int ntl = (c1 - (c0 + li) + nl - 1) / nl;      // output tiles of this workgroup
-    const int NS = 4 * ntl * nkt;                        // half-tile stages = phases of this workgroup
-
-    // ---- staging side: stage S = K-tile S >> 2 (global over this workgroup's tiles), half S & 3
-    const int prow = lane >> 3, ppos = lane & 7;
-    const char* sp[4][2];                                // source of this lane's 2 pieces of each half, k = 0, of the tile being staged
-    int s_kt = 0, s_half = 0, s_par = 0, s_tile = c0 + li, S = 0;
-    auto set_stage_tile = [&](int t) {
-        const int tm = t / ntn, tn = t - tm * ntn;
-#pragma unroll
-        for (int h = 0; h < 4; ++h)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = (2 * wave + j) * 8 + prow;               // row inside the 128-row half
-                const int gch = ppos ^ ((row >> 1) & 7);
-                if (h < 2) {
-                    const int g = min(tn * 256 + h * 128 + row, p.N - 1);
-                    sp[h][j] = (const char*)((const T*)p.W + (size_t)g * p.ldw + gch * EPC);
-                } else {
-                    const int g = min(tm * 256 + (h - 2) * 128 + row, p.M - 1);
-                    sp[h][j] = (const char*)((const T*)p.A + (size_t)g * p.lda + gch * EPC);
-                }
-            }
-    };
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    auto stage_next = [&]() {                            // issue stage S (if any) and advance
-        if (S < NS) {
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + s_par * KBUF + s_half * HALF + (2 * wave) * 1024);
-            const size_t ko = (size_t)s_kt * 128;
-            // (the half index is wave-uniform: four copies of the two DMA instructions, one taken)
-            if (s_half == 0) { glds16_asm(sp[0][0] + ko, dst); glds16_asm(sp[0][1] + ko, dst + 1024); }
-            else if (s_half == 1) { glds16_asm(sp[1][0] + ko, dst); glds16_asm(sp[1][1] + ko, dst + 1024); }
-            else if (s_half == 2) { glds16_asm(sp[2][0] + ko, dst); glds16_asm(sp[2][1] + ko, dst + 1024); }
-            else { glds16_asm(sp[3][0] + ko, dst); glds16_asm(sp[3][1] + ko, dst + 1024); }
-            if (++s_half == 4) {
-                s_half = 0; s_par ^= 1;
-                if (++s_kt == nkt) {
-                    s_kt = 0; s_tile += nl;
-                    if (s_tile < c1) set_stage_tile(s_tile);
-                }
-            }
-        }
-        ++S;
-    };
-
-    // ---- compute side
-    vec af[4][2], bl[2][2], br[2][2];                   // [block][bf16: k-step 0 / 1 | G8: hi / lo]
-    auto frag_off = [&](int row, int f) { return G8 ? swz_off(row, 2 * kg + f) : swz_off(row, 4 * f + kg); };
-    auto read_a = [&](const char* kb, int rh) {
-        const char* a = kb + (2 + wr) * HALF;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int f = 0; f < 2; ++f) af[i][f] = *(const vec*)(a + frag_off(rh * 64 + i * 16 + r16, f));
-    };
-    auto read_b = [&](const char* kb, int ch, vec (&b)[2][2]) {
-        const char* bb = kb + (wc >> 1) * HALF;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int f = 0; f < 2; ++f) b[j][f] = *(const vec*)(bb + frag_off((wc & 1) * 64 + ch * 32 + j * 16 + r16, f));
-    };
-    f32x4 acc[8][4];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    };
-    auto mma_block = [&](f32x4& c, const vec (&b)[2], const vec (&a)[2]) {
-        if constexpr (G8) {                              // hi.lo, lo.hi, hi.hi (Mma<g8_t>): W fragment first = MFMA A operand
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[1], a[0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[0], a[1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[0], a[0], c, 0, 0, 0);
-        } else {
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], a[1], c, 0, 0, 0);
-        }
-    };
-
-    // ---- prologue: K-tile 0 and half of K-tile 1 in flight
-    set_stage_tile(s_tile);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) stage_next();
-    if (NS >= 6) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    CAP_RAW_BARRIER();                                   // K-tile 0 has landed (everybody's pieces)
-    if (wr == 1) CAP_RAW_BARRIER();                      // the late group: one barrier behind from here on
-    zero_acc();
-
-    int tile = c0 + li, kt = 0, par = 0;
-    for (int q = 0; q < NS; q += 4) {
-        const char* kb = smem + par * KBUF;
-        // ---------------- phase 0: Q00
-        stage_next();
-        read_b(kb, 0, bl);
-        __builtin_amdgcn_sched_barrier(0);
-        read_a(kb, 0);
-        CAP_RAW_BARRIER();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) mma_block(acc[i][j], bl[j], af[i]);
-        __builtin_amdgcn_s_setprio(0);
-        CAP_RAW_BARRIER();
-        // ---------------- phase 1: Q01 (last reads of this K-tile's B halves: retired before the barrier, see WAR above)
-        stage_next();
-        read_b(kb, 1, br);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        CAP_RAW_BARRIER();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) mma_block(acc[i][2 + j], br[j], af[i]);
-        __builtin_amdgcn_s_setprio(0);
-        CAP_RAW_BARRIER();
-        // ---------------- phase 2: Q11
-        stage_next();
-        read_a(kb, 1);
-        CAP_RAW_BARRIER();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) mma_block(acc[4 + i][2 + j], br[j], af[i]);
-        __builtin_amdgcn_s_setprio(0);
-        CAP_RAW_BARRIER();
-        // ---------------- phase 3: Q10; the K-tile read next must have landed: stages up to 4 (ktg + 1) + 3 = q + 7, the
-        // youngest issued is min(q + 9, NS - 1) -> that many half-tiles (x 2 DMA instructions) may stay in flight
-        stage_next();
-        if (q + 9 < NS) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (q + 8 < NS) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        CAP_RAW_BARRIER();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) mma_block(acc[4 + i][j], bl[j], af[i]);
-        __builtin_amdgcn_s_setprio(0);
-        par ^= 1;
-        if (++kt == nkt) {
-            // output tile finished: bias (plain loads; hipcc drains the DMA queue for them - the next K-tile is long landed or
-            // about to), activation, convert, whole-line stores through the wave-private strips.  No barrier inside.
-            const int tm = tile / ntn, tn = tile - tm * ntn;
-            char* strip = smem + 2 * KBUF + wave * (16 * 144);
-            float* bias_w = (float*)(smem + 2 * KBUF + 8 * 16 * 144 + wave * 256);     // this wave's 64 bias values
-            const bool has_bias = EPI != EPI_PARTIAL && p.bias != nullptr;
-            if (has_bias) {
-                const int col = min(tn * 256 + wc * 64 + lane, p.N - 1);
-                bias_w[lane] = p.bias[col];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            big2_epilogue<T, OUT_F32, EPI, 8, 4>(p, acc, strip, has_bias ? (const char*)bias_w : nullptr, tm * 256 + wr * 128,
-                                                 tn * 256 + wc * 64, lane);
-            zero_acc();
-            kt = 0; tile += nl;
-        }
-        CAP_RAW_BARRIER();
-    }
-    if (wr == 0) CAP_RAW_BARRIER();                      // pairs with the late group's extra barrier
-}
-
-template <typename T, bool OUT_F32, int EPI>
-int launch_pp(const GemmParams& p, hipStream_t stream) {
-    constexpr int LDS = 2 * 4 * 128 * 128 + 8 * 16 * 144 + 8 * 256;      // two K-tile buffers + epilogue strips + bias rows
-    auto kern = gemm_pp_kernel<T, OUT_F32, EPI>;
-    int n_cu = 0;
-    if (cap_kernel_setup((const void*)kern, LDS, &n_cu) != 0) return -1;
-    const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    const int grid = ntiles < n_cu ? ntiles : n_cu;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, p);
-    CAP_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
 template <bool OUT_F32, int EPI, int SCHED = 0>
 int launch_big3(const GemmParams& p, hipStream_t stream) {
     // four half-slab stages, bias ping-pong (2 KiB) + per-wave bias scratch (8 KiB), dummy DMA sink (2 KiB), strips
@@ -1216,19 +946,12 @@ int launch_big3(const GemmParams& p, hipStream_t stream) {
     return 0;
 }
 
-// CAP_GEMM_CUS=n (A/B knob): the persistent 256x256 kernels take at most n CUs, leaving the rest to kernels of other streams
-static int gemm_cu_cap() {
-    static const int cap = [] { const char* e = getenv("CAP_GEMM_CUS"); return e ? atoi(e) : 0; }();
-    return cap;
-}
-
 template <typename T, bool OUT_F32, int EPI, int VAR, bool PROF, int NWM = 2, int NWN = 4>
 int launch_big2(const GemmParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 512 * 128 + 2 * 1024 + 8 * 16 * 144;   // two stages + bias ping-pong + epilogue strips
     auto kern = gemm_big2_kernel<T, OUT_F32, EPI, VAR, PROF, NWM, NWN>;
     int n_cu = 0;
     if (cap_kernel_setup((const void*)kern, LDS, &n_cu) != 0) return -1;
-    if (gemm_cu_cap() > 0 && gemm_cu_cap() < n_cu) n_cu = gemm_cu_cap();
     const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int grid = ntiles < n_cu ? ntiles : n_cu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWM * NWN * 64), LDS, stream, p);
@@ -1265,21 +988,15 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
 
 template <typename T, bool OUT_F32, int EPI>
 int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
-    if (tile == 16) {                                   // ping-pong kernel (gemm_pp_kernel): A/B only - measured level with
-                                                        // gemm_big2_kernel on every shape (tools/bench_gemm_split.py, bench_gemm.py)
-        if constexpr (sizeof(T) == 2 || is_g8<T>) {
-            if (p.K >= 2 * 8 * Mma<T>::EPC && !p.resid) return launch_pp<T, OUT_F32, EPI>(p, stream);
-        }
-        tile = 3;
-    }
     if (tile >= 10 && tile <= 13) {
         if constexpr (is_g8<T>) {
             if (p.K >= 64 && !p.resid) {
                 if (tile == 10) return launch_big2<T, OUT_F32, EPI, 0, false>(p, stream);
                 if (tile == 11) return launch_big2<T, OUT_F32, EPI, 1, false>(p, stream);
                 if (tile == 12) return launch_big2<T, OUT_F32, EPI, 2, false>(p, stream);
-                // 13: the shipped schedule with cycle stamps to p.aux (tools/bench_gemm_split.py --cycles)
+#ifdef CAP_EXPERIMENTS        // 13: the shipped schedule with cycle stamps to p.aux (tools/bench_gemm_split.py --cycles)
                 if constexpr (!OUT_F32 && EPI == EPI_STORE) return launch_big2<T, OUT_F32, EPI, 1, true>(p, stream);
+#endif
                 return launch_big2<T, OUT_F32, EPI, 1, false>(p, stream);
             }
         }
@@ -1292,13 +1009,17 @@ int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
                 if (tile == 12) return launch_big2<T, OUT_F32, EPI, 2, false>(p, stream);
                 if (tile == 14) return launch_big3<OUT_F32, EPI>(p, stream);
                 if (tile == 15) return launch_big3<OUT_F32, EPI, 1>(p, stream);
+#ifdef CAP_EXPERIMENTS
                 if constexpr (!OUT_F32 && EPI == EPI_STORE) return launch_big2<T, OUT_F32, EPI, 2, true>(p, stream);
+#endif
             }
         }
         tile = 3;
     }
     if (tile == 9) {                                    // instrumented main loop: per-wave cycle counts to p.aux
+#ifdef CAP_EXPERIMENTS
         if constexpr (sizeof(T) == 2 && !is_g8<T> && !OUT_F32 && EPI == EPI_STORE) return launch_big<T, OUT_F32, EPI, 4>(p, stream);
+#endif
         tile = 3;
     }
     if ((tile == 3 || tile == 5) && p.resid) tile = 4;  // the LDS-DMA kernels have no residual operand
@@ -1385,17 +1106,6 @@ int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream) {
         cap_set_error("launch_gemm: bias / resid / C must be 16-byte aligned");
         return -1;
     }
-    if (p.epi == EPI_PARTIAL && p.ln_counter) {
-        const int nb = ((p.N + 63) / 64) * p.splitk, grid = ((p.M + 63) / 64) * nb;
-        if (tile != 2 || nb < 16 || p.ldc != p.N || p.N > 256 * LN_MAXV || grid > 512) {
-            cap_set_error("launch_gemm: fused split-K consumer needs the 64x64 tile, >= 16 blocks per 64-row tile, ldc == N "
-                          "and a grid that is resident at once (N=%d splitk=%d grid=%d)", p.N, p.splitk, grid);
-            return -1;
-        }
-    } else if (p.ln_counter) {
-        cap_set_error("launch_gemm: ln_counter is only meaningful with EPI_PARTIAL");
-        return -1;
-    }
     if (tile == 0) {
         // 256x256 (one 8-wave block per CU) once at least half the CUs get a tile: between 128 and 255 such tiles the
         // 128x128 kernel would need two rounds of its 512 resident blocks (measured on the OPT prefill, 1056 x 7680 x 2560:
@@ -1411,3 +1121,5 @@ int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream) {
     cap_set_error("launch_gemm: unknown dtype %d", dtype);
     return -1;
 }
+
+CAP_DEFINE_G8_CLAMP_READER(cap_g8_clamped_gemm)

@@ -26,7 +26,6 @@ struct SkinnyParams {
     const float* bias;        // finished output only
     bf16_t* out; int ldc;     // part == null (S == 1): act(sum + bias) as bf16
     float* part;              // non-null: part[z][M][N] fp32 slice sums instead of `out`
-    int xk;                   // 1; 0 = bandwidth ablation (every activation fragment from k = 0: L1 hits, wrong sums)
     int M, N, S, nks, act;
     int G, units;             // row groups of 32 (ceil(M / 32)); units = row tiles x S    // nks = k-steps of 32 per wave; act 0 none, 1 GELU(erf), 2 ReLU
 };
@@ -63,13 +62,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(SkinnyParams p) {
     // activations: every fragment of the wave's K range, straight to registers (L2 hits)
     const bf16_t* ap[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) ap[t] = p.A + (size_t)min(m0 + t * 16 + r16, p.M - 1) * p.lda + kw * p.xk + kg * 8;
+    for (int t = 0; t < 2; ++t) ap[t] = p.A + (size_t)min(m0 + t * 16 + r16, p.M - 1) * p.lda + kw + kg * 8;
     bf16x8 af[2][SK_MAXKS];
 #pragma unroll
     for (int j = 0; j < SK_MAXKS; ++j)
         if (j < p.nks) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) af[t][j] = *(const bf16x8*)(ap[t] + j * 32 * p.xk);
+            for (int t = 0; t < 2; ++t) af[t][j] = *(const bf16x8*)(ap[t] + j * 32);
         }
     // weights: lane -> (row q*8 + lane/8, 16-byte position lane%8); the swizzle is applied on the source side
     const bf16_t* wsrc[QN];
@@ -203,8 +202,6 @@ int launch_gemm_skinny(const void* A, int lda, const void* W, int ldw, const flo
     }
     SkinnyParams p;
     p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.bias = bias; p.out = (bf16_t*)out; p.ldc = ldc;
-    static const int abl = getenv("CAP_SKINNY_ABL") ? atoi(getenv("CAP_SKINNY_ABL")) : 0;
-    p.xk = abl == 1 ? 0 : 1;
     p.part = part; p.M = M; p.N = N; p.S = S; p.nks = K / (nw * 32 * S); p.act = act;
     p.G = (M + 31) / 32; p.units = (N / tr) * S;
     const dim3 grid(((p.units + 7) / 8) * 8 * p.G);

@@ -1,4 +1,4 @@
-// LayerNorm building blocks shared by elementwise.hip and the fused split-K consumer in gemm.hip.
+// LayerNorm building block of elementwise.hip (one wave per row).
 #pragma once
 #include "common.h"
 
@@ -36,61 +36,4 @@ __device__ __forceinline__ void ln_row(const float4 (&v)[MAXV], int nv, int lane
             if (out_t) store4(out_t, c, o);
         }
     }
-}
-
-
-// 16 bytes of a split-K slab.  COHERENT: agent-scope loads (the slab was written by blocks of the same kernel, maybe on
-// another XCD: must not be served from this XCD's L2).
-template <bool COHERENT>
-__device__ __forceinline__ float4 load_slab4(const float* p) {
-    if constexpr (COHERENT) {
-        float4 r;
-        r.x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r.z = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r.w = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return r;
-    } else {
-        return *(const float4*)p;
-    }
-}
-
-// One wave reduces row `row` of S fp32 split-K slices (+ bias + residual, summed in slice order), optionally writes the
-// sum (y_out) and LayerNorms it.  Exactly the arithmetic of reduce_layernorm_kernel<T, float>.
-template <typename T, bool COHERENT = false, int MAXV = LN_MAXV>
-__device__ __forceinline__ void reduce_ln_row_wave(const float* __restrict__ part, int S, int M, int D, int row, int lane,
-                                                   const float* __restrict__ bias, const float* resid,
-                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   float eps, T* out_t, float* out_f, float* y_out) {
-    const int nv = (D + 255) / 256;
-    float4 v[MAXV];
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = lane * 4 + i * 256;
-        if (i < nv && c < D) {
-            float4 a = load_slab4<COHERENT>(part + (size_t)row * D + c);
-            if (S == 4) {
-                const float4 b1 = load_slab4<COHERENT>(part + ((size_t)1 * M + row) * D + c);
-                const float4 b2 = load_slab4<COHERENT>(part + ((size_t)2 * M + row) * D + c);
-                const float4 b3 = load_slab4<COHERENT>(part + ((size_t)3 * M + row) * D + c);
-                a.x = ((a.x + b1.x) + b2.x) + b3.x; a.y = ((a.y + b1.y) + b2.y) + b3.y;
-                a.z = ((a.z + b1.z) + b2.z) + b3.z; a.w = ((a.w + b1.w) + b2.w) + b3.w;
-            } else {
-#pragma unroll 4
-                for (int z = 1; z < S; ++z) {
-                    const float4 b = load_slab4<COHERENT>(part + ((size_t)z * M + row) * D + c);
-                    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-                }
-            }
-            if (bias) { const float4 b = *(const float4*)(bias + c); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-            if (resid) {
-                const float4 b = *(const float4*)(resid + (size_t)row * D + c);
-                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-            }
-            v[i] = a;
-            if (y_out) *(float4*)(y_out + (size_t)row * D + c) = a;
-        }
-    }
-    ln_row<T, MAXV>(v, nv, lane, D, gamma, beta, eps, out_t ? out_t + (size_t)row * D : nullptr,
-              out_f ? out_f + (size_t)row * D : nullptr);
 }

@@ -41,6 +41,13 @@ int launch_fill_i32(int* p, int v, size_t n, hipStream_t s);
 int launch_fill_f32(float* p, float v, size_t n, hipStream_t s);
 int launch_copy_f32(const float* src, float* dst, size_t n, hipStream_t s);
 
+// max |src[i]| as the bit pattern of a non-negative float, atomically max-ed into *out_bits (caller zeroes it)
+int launch_absmax_f32(const float* src, size_t n, unsigned int* out_bits, hipStream_t s);
+// per-file readers of the G8 clamp counter (common.h)
+int cap_g8_clamped_gemm(unsigned long long* total, int reset);
+int cap_g8_clamped_elementwise(unsigned long long* total, int reset);
+int cap_g8_clamped_attention(unsigned long long* total, int reset);
+
 // ---- attention.hip ---------------------------------------------------------------------------
 // ViT self-attention over a fused qkv buffer [B*N, 3*H*64] (T) -> ctx [B*N, H*64] (T); scale = 1/8.
 // impl 0 = auto (MFMA for bf16 when N <= 256, scalar otherwise), 1 = scalar, 2 = MFMA.

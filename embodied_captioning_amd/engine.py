@@ -102,6 +102,16 @@ class CaptionerEngine:
     def device_bytes(self) -> int:
         return int(self.lib.cap_device_bytes(self._h))
 
+    def saturations(self, reset: bool = False) -> int:
+        """Split mode ("f32s") only has a finite range: values beyond +-65000 at a GEMM input are clamped - and counted.
+        Returns the count on this engine's GPU since the last reset (0 = every value was inside the fp32-grade envelope);
+        synchronises the device.  Weights outside the mode's range never get this far: load_state_dict raises."""
+        with torch.cuda.device(self.device):
+            n = int(self.lib.cap_g8_saturations(int(reset)))
+        if n < 0:
+            raise N.CaptionerHipError(f"cap_g8_saturations: {N.last_error()}")
+        return n
+
     def set_early_exit(self, poll_steps: int) -> None:
         """Leave the decode loop once every caption is finished, as HF generate does; the device state is looked at every
         `poll_steps` steps (one stream synchronisation each).  0 = never (default): no host sync inside generate."""
@@ -228,11 +238,11 @@ class EnginePool:
     K/V caches); the weights exist ONCE - engines 1.. are created on engine 0's weight store (cap_create_shared).
 
     One `cap_generate` is a chain of ~2 800 dependent kernels; between two dependent kernels of one HIP queue the GPU
-    idles for the dispatch hand-over.  Independent batches do not depend on each other, so another
-    queue's kernel can run in that gap: measured (tools/two_stream_experiment.py) 6 570 -> 8 260 captions/s with two
-    streams, 8 670 with three.  (The kernels themselves time-slice rather than co-run - tools/phase_overlap_probe.py -
-    so the floor is one batch's summed kernel time.)  Every batch is computed by exactly the kernels of a single engine:
-    results are the same bits.
+    idles for the dispatch hand-over, and the decode kernels' small grids leave CUs free.  Independent batches do not depend
+    on each other, so kernels of another queue run in those gaps AND next to them: in the pooled rocprofv3 trace kernels of
+    different streams do co-run ("Overlapping whole batches"), and a pooled step is SHORTER than the sum
+    of one batch's kernel durations.  What bounds the pool is the MFMA-bound image side, which two batches cannot run faster
+    than one after the other.  Every batch is computed by exactly the kernels of a single engine: results are the same bits.
 
         pool = EnginePool(arch, n=3, dtype="bf16", max_batch=256)
         pool.load_state_dict(sd)

@@ -157,6 +157,15 @@ int cap_generate(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_
  * (sentence-transformers Pooling(mean) + Normalize).  All pointers are device pointers. */
 int cap_embed_text(CapHandle h, const int32_t* ids, const int32_t* lens, int B, int L, float* out, void* stream);
 
+/* Range guard of CAP_F32_SPLIT.  Weights: cap_load_weight refuses (returns -1, message names the tensor) a tensor bound for
+ * a GEMM-operand slot whose max |w| exceeds 65000 / 4096 = 15.87 or that holds a NaN - nothing is clipped silently.
+ * Activations: every kernel that writes a GEMM operand clamps to +-65000 (fp16's range) and COUNTS what it clamped; this
+ * returns the count on the current device since the last reset (groups of four adjacent elements count once), -1 on error.
+ * It synchronises the device.  0 means every value of every generate / encode since the reset was inside the envelope in
+ * which the mode is fp32-grade; anything else means "run this checkpoint / input in CAP_F32".
+ * Reference behaviour replaced: none (fp32 torch on the CPU has no such range) - this is the honesty clause of the fast mode. */
+long long cap_g8_saturations(int reset);
+
 /* Bytes of device memory this handle allocated: its arena, plus the weights if it is the handle that created them
  * (cap_create); a cap_create_shared handle reports its arena only. */
 size_t cap_device_bytes(CapHandle h);
@@ -164,9 +173,6 @@ size_t cap_device_bytes(CapHandle h);
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  While enabled every launch of the
  * tagged kernels is bracketed by an event pair; cap_profile_report synchronises the stream and writes a JSON object
  * {"tag": {"launches": n, "ms": total, "flops": f, "bytes": b}, ...} into buf. */
-/* Diagnostics of the persistent decode-step kernel (handles created under CAP_XCD_DBG=1): 100 MHz timestamps taken after
- * every XCD-local barrier of the last launch by one workgroup; returns the number of values copied (0: not enabled). */
-int cap_debug_xcd_times(CapHandle h, long long* out, int n);
 int cap_profile_enable(CapHandle h, int on);
 int cap_profile_report(CapHandle h, char* buf, size_t buf_bytes);
 

@@ -442,35 +442,3 @@ def test_pool_engines_share_one_copy_of_the_weights():
         CaptionerEngine(dataclasses.replace(arch, t_layers=arch.t_layers + 1), dtype="f32s", max_batch=B, max_beams=1, max_len=L,
                         share_weights_with=pool.engines[1])
     pool.engines[1].close(); pool.engines[2].close(); own.close()
-
-
-@pytest.mark.parametrize("dtype", ["f32s", "bf16"])
-def test_persistent_decode_kernel_gives_the_same_captions(dtype, monkeypatch):
-    """CAP_DECODE_XCD=1: all layers of a decode step in ONE launch, rows partitioned by XCD, XCD-local software barriers
-    (csrc/decode_xcd.hip; off by default because it measures slower at batch 256 - DESIGN.md section 4).  Same goldens as the
-    launch-per-kernel path: greedy + beams (ancestry table) exact in split mode, concurrent launches from a stream pool
-    (workgroups are then NOT placed on XCD blockIdx % 8: the kernel reads its XCD from the hardware) and no error bits."""
-    from embodied_captioning_amd.engine import EnginePool
-    monkeypatch.setenv("CAP_DECODE_XCD", "1")
-    g, meta, arch, sd, px = golden_inputs("blip_tiny_eos")
-    B, L, K = meta["batch"], meta["max_length"], meta["beams"]
-    eng = _engine(arch, dtype, B, K, L)
-    eng.load_state_dict(sd)
-    seq = eng.generate(px.cuda(), max_length=L)["sequences"].cpu().numpy()
-    b = eng.generate(px.cuda(), num_beams=K, max_length=L)
-    ref = pad_to(g["greedy_sequences"], L, arch.pad)
-    if dtype in EXACT:
-        assert np.array_equal(seq, ref)
-        assert np.array_equal(b["sequences"].cpu().numpy(), pad_to(g["beam_sequences"], L, arch.pad or arch.eos))
-        np.testing.assert_allclose(b["sequences_scores"].cpu().numpy(), g["beam_scores"], rtol=0, atol=1e-3)
-    else:
-        exact, diverged, bad = token_parity(seq, ref, g["greedy_margin"], BF16_TAU)
-        assert bad is None, bad
-    pool = EnginePool(arch, n=3, dtype=dtype, max_batch=B, max_beams=K, max_len=L, weights_of=eng)
-    outs = pool.generate_many([px.cuda()] * 6, threads=True, max_length=L)
-    torch.cuda.synchronize()
-    for o in outs:
-        assert np.array_equal(o["sequences"].cpu().numpy(), seq)
-    pool.close()
-    eng.generate(px.cuda(), max_length=L)          # would raise if an earlier launch had reported error bits
-    eng.close()
