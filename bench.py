@@ -193,8 +193,18 @@ def encoder_only(eng, px, arch, steps=5):
             "tflops": round(fl / dt / 1e12, 1), "gflop_per_image": round(arch.encoder_flops_per_image() / 1e9, 3)}
 
 
+DEC_GEMM_TAGS = ("dec_gemm_qkv", "dec_gemm_so", "dec_gemm_cq", "dec_gemm_co", "dec_gemm_f1", "dec_gemm_f2")
+HBM_PEAK_GBPS = 8000.0                                                 # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
+FP32_MFMA_PEAK = 157.3                                                 # the pipe the reference's fp32 arithmetic would need
+
+
 def roofline_pass(eng, px, L, dtype, arch, batch):
-    """Per-kernel HIP-event timing (events recorded on the launch stream inside the library)."""
+    """Per-kernel HIP-event timing (events recorded on the launch stream inside the library).
+
+    roofline.achieved / frac follow SURVEY.md 8(d): ALGORITHMIC flops of the dominant kernel's launches = 2 M N K of the Linear
+    layers, divided by the launch duration and by the dense peak of the MFMA pipe the kernel runs on.  What the split kernel
+    executes (three fp16 products per MAC) and how busy the pipe was are separate keys (executed_tflops / frac_executed /
+    mfma_busy_pmc), as is the ratio to the fp32 MFMA pipe the same arithmetic would otherwise need (frac_vs_fp32_mfma)."""
     eng.profile(True)
     reps = 2
     for _ in range(reps):
@@ -210,25 +220,47 @@ def roofline_pass(eng, px, L, dtype, arch, batch):
     fl = sum(rep[t]["flops"] for t in ENC_GEMM_TAGS if t in rep)
     ms = sum(rep[t]["ms"] for t in ENC_GEMM_TAGS if t in rep)
     n = sum(rep[t]["launches"] for t in ENC_GEMM_TAGS if t in rep)
-    # 2 M N K per launch is what the Linear layer asks for; the split kernel's algorithm spends THREE fp16 MFMA products on
-    # each of them (hi.hi + hi.lo + lo.hi), so the flops it has to execute - and that its pipe, the fp16 MFMA, is priced
-    # for - are 3x that.  Both rates are in the line; frac = executed / peak of the pipe the kernel runs on.
     k = MFMA_PER_PRODUCT[dtype]
-    alg = fl / (ms * 1e-3) / 1e12
-    achieved = k * alg
+    alg = fl / (ms * 1e-3) / 1e12                    # 2 M N K / t
     peak = PEAK_TFLOPS[dtype]
-    roof = {"bound": "mfma", "kernel": KERNEL_NAME[dtype], "achieved": round(achieved, 2),
-            "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-            "flops_per_launch": k * fl / n, "avg_launch_us": round(1e3 * ms / n, 2), "launches_per_step": n // reps,
-            "mfma_products_per_mac": k, "linear_layer_tflops": round(alg, 2), "linear_layer_flops_per_launch": fl / n,
-            "frac_linear_layer": round(alg / peak, 4),
-            "note": "achieved = MFMA flops the kernel executes per second (mfma_products_per_mac x 2MNK / t) against the dense "
-                    "peak of the MFMA pipe it runs on (MI355X_MICROARCH.md); linear_layer_tflops = 2MNK / t.  "
-                    + ("The same Linear layers on the exact-product fp32 MFMA pipe (peak 157.3) are the f32_exact leg."
-                       if k == 3 else "")}
-    roof["traffic"], roof["traffic_source"] = pmc_traffic(dtype)
+    pm = pmc_summary(dtype)
+    roof = {"bound": "mfma", "kernel": KERNEL_NAME[dtype], "achieved": round(alg, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(alg / peak, 4), "traffic": pm["enc_gemm"].get("traffic"),
+            "algorithmic_flops_per_launch": fl / n, "avg_launch_us": round(1e3 * ms / n, 2), "launches_per_step": n // reps,
+            "algorithmic_bytes_per_launch": round(sum(rep[t]["bytes"] for t in ENC_GEMM_TAGS if t in rep) / n),
+            "mfma_products_per_mac": k, "executed_tflops": round(k * alg, 2), "frac_executed": round(k * alg / peak, 4),
+            "mfma_busy_pmc": pm["enc_gemm"].get("mfma_busy"), "frac_vs_fp32_mfma": round(alg / FP32_MFMA_PEAK, 3),
+            "traffic_source": pm["source"],
+            "note": "achieved = 2MNK of the ViT Linear layers per launch / HIP-event launch time; frac = achieved / dense peak of "
+                    "the MFMA pipe the kernel runs on (MI355X_MICROARCH.md).  executed_tflops counts the MFMA products the "
+                    "algorithm spends per MAC (split mode: hi.hi + hi.lo + lo.hi = 3); mfma_busy_pmc = SQ_VALU_MFMA_BUSY_CYCLES / "
+                    "(GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of the same launches in the committed counter pass; frac_vs_fp32_mfma = "
+                    "achieved / 157.3 TFLOP/s, the pipe exact fp32 products need (the f32_exact leg runs there)"}
+    # decode side: HBM-bound kernels as bytes/s against the HBM peak.  cross-attention = the image's fp32 K/V blocks of the rows
+    # still open; decode GEMMs = weights + activations + split-K slabs per launch (what the ProfScope of each launch counts)
+    dec = {}
+    if "dec_cross_attn" in rep:
+        r = rep["dec_cross_attn"]
+        g = r["bytes"] / (r["ms"] * 1e-3) / 1e9
+        dec["cross_attention"] = {"bound": "hbm", "achieved": round(g, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": round(g / HBM_PEAK_GBPS, 4), "traffic": pm["cross_attention"].get("traffic"),
+                                  "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"]),
+                                  "avg_launch_us": round(1e3 * r["ms"] / r["launches"], 2), "launches_per_step": r["launches"] // reps,
+                                  "ms_per_step": round(r["ms"] / reps, 3),
+                                  "note": "algorithmic bytes = K and V blocks of every row (ended captions are skipped by the kernel "
+                                          "but counted here, so achieved overstates the stream once captions end; traffic is the PMC figure)"}
+    tags = [t for t in DEC_GEMM_TAGS if t in rep]
+    if tags:
+        by = sum(rep[t]["bytes"] for t in tags); ms_d = sum(rep[t]["ms"] for t in tags); nl = sum(rep[t]["launches"] for t in tags)
+        g = by / (ms_d * 1e-3) / 1e9
+        dec["gemm"] = {"bound": "hbm", "achieved": round(g, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(g / HBM_PEAK_GBPS, 4),
+                       "traffic": pm["decode_gemm"].get("traffic"), "algorithmic_bytes_per_launch": round(by / nl),
+                       "avg_launch_us": round(1e3 * ms_d / nl, 2), "launches_per_step": nl // reps, "ms_per_step": round(ms_d / reps, 3),
+                       "kernel": pm["decode_gemm"].get("kernel")}
+    dec_ms = sum(r["ms"] for t, r in rep.items() if t.startswith("dec_") or t in ("greedy_select", "beam_step")) / reps
+    dec["ms_per_step_all_decode_kernels"] = round(dec_ms, 3)
     total_ms = sum(r["ms"] for r in rep.values()) / reps
-    return roof, kernels, total_ms
+    return roof, kernels, total_ms, dec
 
 
 def host_cores() -> int:
@@ -247,43 +279,82 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-PMC_FILES = {"f32s": "r02_bench_pmc.json", "bf16": "r02_bench_bf16_pmc.json"}
+PMC_FILES = {"f32s": "r03_bench_pmc.json", "bf16": "r03_bench_bf16_pmc.json"}
+PMC_FALLBACK = {"f32s": "r02_bench_pmc.json", "bf16": "r02_bench_bf16_pmc.json"}
 
 
-def pmc_traffic(dtype):
-    """(HBM bytes per launch of the encoder GEMM kernel, source) - NOT measured by this process: rocprofv3 cannot run inside
-    the bench, so the figure is read from the committed counter passes of this same command (tools/profile_round.sh ->
-    profiles/<file>: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE) and tagged with that file's name.
-    (None, None) when there is no such file for the mode."""
-    fn = PMC_FILES.get(dtype)
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", fn)))
-        n = b = 0.0
-        pat = (r"gemm_big2_kernel(I4g8_tLb[01]ELi0E|<g8_t, (true|false), 0,)" if dtype == "f32s"
-               else r"gemm_big[23]_kernel(I(DF16b|u6__bf16)?Lb[01]ELi0E|ILb[01]ELi0E|<(__bf16, )?(true|false), 0,)")
+def pmc_summary(dtype):
+    """Counter figures of the committed rocprofv3 --pmc passes of THIS command (tools/profile_round.sh -> profiles/<file>) -
+    NOT measured by this process: rocprofv3 cannot run inside the bench.  Per kernel class, weighted by launches:
+    traffic = FETCH_SIZE x 2 (the gfx950 correction) + WRITE_SIZE in bytes per launch; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES /
+    (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs).  Empty entries when there is no file for the mode."""
+    out = {"enc_gemm": {}, "cross_attention": {}, "decode_gemm": {}, "source": None}
+    d = None
+    for fn in (PMC_FILES.get(dtype), PMC_FALLBACK.get(dtype)):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            out["source"] = f"profiles/{fn} (committed rocprofv3 --pmc passes of this command, not this run)"
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    if d is None:
+        return out
+    enc = (r"gemm_(big2|enc)_kernel(I4g8_tLb[01]ELi0E|<g8_t, (true|false), 0,)" if dtype == "f32s"
+           else r"gemm_big[23]_kernel(I(DF16b|u6__bf16)?Lb[01]ELi0E|ILb[01]ELi0E|<(__bf16, )?(true|false), 0,)")
+    classes = {"enc_gemm": enc, "cross_attention": r"decode_attention_(online|shared)_kernel",
+               "decode_gemm": r"gemm_(kernel|rows_kernel)<[^>]*, (true|false), 4>|gemm_rows_kernel|gemm_kernel<(g8_t|__bf16|float), 64, 64, 32, 32, 6, 3, false, 0>"}
+    for cls, pat in classes.items():
+        n = b = busy = act = 0.0
+        names = []
         for k, v in d.items():
-            # EPI_STORE instantiations of the encoder GEMM kernel, mangled or demangled
             if re.search(pat, k) and "hbm_read_bytes_corrected" in v:
-                n += v["launches_per_pass"]
-                b += v["launches_per_pass"] * (v["hbm_read_bytes_corrected"] + v.get("hbm_write_bytes", 0.0))
-        return (round(b / n), f"profiles/{fn} (committed rocprofv3 --pmc passes of this command, not this run)") if n else (None, None)
+                w = v["launches_per_pass"]
+                n += w
+                b += w * (v["hbm_read_bytes_corrected"] + v.get("hbm_write_bytes", 0.0))
+                busy += w * v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+                act += w * v.get("GRBM_GUI_ACTIVE", 0.0)
+                names.append(k.split("(")[0][:80])
+        if n:
+            out[cls] = {"traffic": round(b / n), "mfma_busy": round(busy / (act / 8 * 1024), 4) if act else None,
+                        "kernel": "; ".join(sorted(set(names)))[:240]}
+    return out
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
     except Exception:  # noqa: BLE001
-        return None, None
+        pass
+    return "unknown"
 
 
 def cpu_baseline(sd, arch, L, sample):
-    """The CPU oracle (PyTorch-CPU restatement of the reference path) timed on this host's cores."""
+    """The CPU oracle (PyTorch-CPU restatement of the reference path, parity-locked to HF by tests/golden) timed on this host's
+    cores, per SURVEY.md 8(d): config 1's 8 frames and a `sample`-frame (64) batch, greedy max_length L, fp32; one warm-up, then
+    the MEDIAN of 5 runs each; torch threads = the cores this process may use.  `value` is the 64-frame figure (the larger
+    batch is the faster of the two per caption)."""
+    import statistics
     from oracle import blip_ref as R
     torch.set_num_threads(host_cores())
-    px = synthetic_pixels(sample, arch.image_size, seed=0)
-    R.greedy_generate(sd, arch, px[:2], 4)                       # warm-up (thread pool, allocator)
-    t0 = time.perf_counter()
-    out = R.greedy_generate(sd, arch, px, L)
-    dt = time.perf_counter() - t0
-    # HF stops when every row is finished; keep all L-1 steps comparable with the GPU run
-    return {"value": round(sample / dt, 3), "unit": "captions/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{sample} frames 224x224, encoder + greedy max_length={L}, fp32, {dt:.1f}s wall, "
-                      f"oracle/blip_ref.py on {torch.get_num_threads()} threads"}, out
+    runs, out = {}, None
+    for name, n in (("config1_8_frames", 8), (f"batch_{sample}_frames", sample)):
+        px = synthetic_pixels(n, arch.image_size, seed=0)
+        R.greedy_generate(sd, arch, px, L)                       # the warm-up run (thread pool, allocator, page-in)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            out = R.greedy_generate(sd, arch, px, L)
+            ts.append(time.perf_counter() - t0)
+        med = statistics.median(ts)
+        runs[name] = {"frames": n, "captions_per_s": round(n / med, 3), "median_s": round(med, 3), "runs_s": [round(t, 3) for t in ts]}
+    big = runs[f"batch_{sample}_frames"]
+    return {"value": big["captions_per_s"], "unit": "captions/s", "cores": host_cores(), "torch_threads": torch.get_num_threads(),
+            "os_cpu_count": os.cpu_count(), "cpu_model": cpu_model(), "kind": "port",
+            "sample": f"{sample} frames 224x224, encoder + greedy max_length={L}, fp32, oracle/blip_ref.py on {torch.get_num_threads()} threads: "
+                      f"1 warm-up + median of 5 runs ({big['median_s']} s); config 1 (8 frames) timed the same way",
+            "runs": runs}, out
 
 
 def main_coca(a):
@@ -449,7 +520,7 @@ def extra_mode(arch, sd, px, L, B, dev, dtype, streams, ref_ids, golden):
     dt, (ids, _) = timed_steps(runner, px, L, steps, 2 if dtype == "bf16" else 1, 1, lambda i, l: (i, l))
     if streams > 1:
         runner.close()
-    roof, _, _ = roofline_pass(eng, px, L, dtype, arch, B)
+    roof, _, _, _ = roofline_pass(eng, px, L, dtype, arch, B)
     out = {"value": round(B * steps / dt, 2), "unit": "captions/s", "ms_per_step": round(1e3 * dt / steps, 3), "streams": streams,
            "roofline": roof, "rows_identical_to_headline": round(float((ids == ref_ids).all(dim=1).float().mean().item()), 4)}
     if golden is not None:
@@ -616,12 +687,20 @@ def main():
         if a.streams > 1:                    # the timed steps ran on the pool's engines: this one has not touched its arena yet
             eng.generate(px, num_beams=1, max_length=L)
             torch.cuda.synchronize()
-        roof, kernels, kernel_ms = roofline_pass(eng, px, L, a.dtype, arch, B)
-        log(f"roofline pass done: {roof['achieved']} TFLOP/s executed on the encoder GEMMs ({roof['linear_layer_tflops']} as 2MNK/t)")
+        if a.streams > 1:
+            # one batch at a time on one stream: what a caller without the pool gets, and the basis of the per-kernel figures
+            # below (kernel_ms_per_step sums ONE stream's kernel durations; the pooled ms_per_step is shorter because kernels
+            # of different batches co-run)
+            sdt, _ = timed_steps(eng, px, L, a.steps, 1, 1, lambda i, l: (i, l), a.beams)
+            line["single_stream"] = {"value": round(B * a.steps / sdt, 2), "unit": "captions/s", "ms_per_step": round(1e3 * sdt / a.steps, 3),
+                                     "steps": a.steps, "streams": 1}
+        roof, kernels, kernel_ms, dec = roofline_pass(eng, px, L, a.dtype, arch, B)
+        log(f"roofline pass done: {roof['achieved']} TFLOP/s as 2MNK/t on the encoder GEMMs ({roof['executed_tflops']} executed)")
         line["roofline"] = roof
+        line["decode"] = dec
         line["kernels"] = {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                            for k, v in kernels.items()}
-        line["kernel_ms_per_step"] = round(kernel_ms, 3)
+        line["kernel_ms_per_step"] = round(kernel_ms, 3)           # sum of ONE stream's kernel durations (see single_stream)
         line["encoder_only"] = encoder_only(eng, px, arch)
         golden = None
         try:
@@ -643,7 +722,7 @@ def main():
             log(f"cpu baseline: {a.cpu_sample} captions on {host_cores()} host threads")
             cb, _ = cpu_baseline(sd, arch, L, a.cpu_sample)
             line["cpu_baseline"] = cb
-            line["vs_cpu_baseline"] = round(value / cb["value"], 1)
+            line["vs_cpu_baseline"] = round(value / cb["value"], 1)       # context only: the roofline fractions judge the kernels
         print(json.dumps(line))
     else:
         eng.close()

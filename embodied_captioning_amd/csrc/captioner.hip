@@ -1009,20 +1009,47 @@ Dec make_slice(Captioner* m, int b0, int B, int Btot, int K, int Lm) {
     return d;
 }
 
+// K slices of a decode GEMM: a function of (N, K, operand type) ONLY - never of the row count, so a caption's sums are ordered
+// the same way alone and in a batch of 256.  bf16 / split mode run the "rows" kernel (gemm_rows_kernel: the block's K range
+// over its four waves): as many slices as still give every wave a slab, keep the grid within one round of the CUs at the
+// nominal 256 rows, and at most 4 (more slices write and re-read more partial sums than they save).  fp32 mode: the
+// register-staged 64x64 tile with >= 3 slabs per slice.
+int decode_splitk(const Captioner* m, int N, int K, int max_S) {
+    if (m->gdt == CAP_DT_F32) {
+        const int nk = K / 32;
+        for (int cand : {4, 2})
+            if (cand <= max_S && nk % cand == 0 && nk / cand >= 3) return cand;
+        return 1;
+    }
+    const int nk = K / (m->gdt == CAP_DT_BF16 ? 64 : 32), tiles = 4 * ((N + 63) / 64);
+    for (int cand : {4, 3, 2})
+        if (cand <= max_S && nk % cand == 0 && nk / cand >= 4 && tiles * cand <= 256) return cand;
+    return 1;
+}
+inline int decode_tile(const Captioner* m) { return m->gdt == CAP_DT_F32 ? 2 : 6; }
+
 int gemm_partial(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, float* part, int R, int N,
                  int K, int max_S, int* S_out) {
-    const int slab = m->dt == CAP_DT_BF16 ? 64 : 32;
-    const int nk = K / slab;
-    int S = 1;
-    for (int cand : {8, 4, 2})
-        if (cand <= max_S && nk % cand == 0 && nk / cand >= 3) { S = cand; break; }
+    const int S = decode_splitk(m, N, K, max_S);
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = part; p.ldc = N; p.M = R; p.N = N; p.K = K;
     p.out_f32 = 1; p.epi = EPI_PARTIAL; p.splitk = S;
     *S_out = S;
     ProfScope ps(m, s, tag, 2.0 * R * N * K, ((double)R * K + (double)N * K) * m->esz + (double)S * R * N * 4);
-    return launch_gemm(m->gdt, p, 2, s);
+    return launch_gemm(m->gdt, p, decode_tile(m), s);
+}
+
+// A finished decode projection (bias + activation -> operand type): fc1 of the text layers.  Same kernel family as the
+// split-K ones at every row count.
+int gemm_rows(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, void* C, const float* bias, int R, int N,
+              int K, int act) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = C; p.ldc = N; p.bias = bias; p.ldr = N; p.M = R; p.N = N; p.K = K;
+    p.gelu = act; p.out_f32 = 0; p.epi = EPI_STORE; p.splitk = 1;
+    ProfScope ps(m, s, tag, 2.0 * R * N * K, ((double)R * K + (double)N * K + (double)R * N) * m->esz);
+    return launch_gemm(m->gdt, p, m->gdt == CAP_DT_F32 ? 0 : 6, s);
 }
 
 // Decode-sized GEMM whose consumer is a LayerNorm: split K over S blocks per tile (every block's slabs are all in flight
@@ -1032,20 +1059,14 @@ int gemm_partial(Captioner* m, hipStream_t s, const char* tag, const void* A, co
 int gemm_splitk_reduce_ln(Captioner* m, hipStream_t s, const Dec& d, const char* tag, const void* A, const void* W,
                           const float* bias, const float* g, const float* b, float eps, int N, int K, void* out_t,
                           float* out_f, float* y_out) {
-    const int slab = m->dt == CAP_DT_BF16 ? 64 : 32;
-    const int nk = K / slab;
-    int S = 1;
-    // at most 4 slices: 8 slices write and re-read twice the partial sums for nothing (pooled: split mode +2 % and -1.6 %
-    // joules per caption, bf16 +3 %, CoCa beam-5 +1 %)
-    for (int cand : {4, 2})
-        if (nk % cand == 0 && nk / cand >= 3) { S = cand; break; }
+    const int S = decode_splitk(m, N, K, 4);
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = d.dpart; p.ldc = N; p.M = d.R; p.N = N; p.K = K;
     p.out_f32 = 1; p.epi = EPI_PARTIAL; p.splitk = S;
     {
         ProfScope ps(m, s, tag, 2.0 * d.R * N * K, ((double)d.R * K + (double)N * K) * m->esz + (double)S * d.R * N * 4);
-        TRY(launch_gemm(m->gdt, p, 2, s));
+        TRY(launch_gemm(m->gdt, p, decode_tile(m), s));
     }
     ProfScope ps(m, s, "dec_reduce_ln", 0, (double)(S + 2) * d.R * N * 4 + (double)d.R * N * m->esz);
     return launch_reduce_layernorm(m->gdt, d.dpart, S, bias, d.dx, g, b, eps, out_t, out_f, y_out, d.R, N, s, true);
@@ -1095,7 +1116,7 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
                                         T, 0, 0, m->gdt, skip));
         }
         TRY(gemm_splitk_ln(m, s, d, "dec_gemm_co", d.dctx, L.w_co, L.b_co, L.co_g, L.co_b, T, T));
-        TRY(gemm(m, s, "dec_gemm_f1", d.dx_t, T, L.w_f1, T, d.dh, F, L.b_f1, nullptr, R, F, T, 1, 0));
+        TRY(gemm_rows(m, s, "dec_gemm_f1", d.dx_t, L.w_f1, d.dh, L.b_f1, R, F, T, 1));
         TRY(gemm_splitk_ln(m, s, d, "dec_gemm_f2", d.dh, L.w_f2, L.b_f2, L.f_g, L.f_b, T, F));
     }
     TRY(gemm(m, s, "dec_gemm_tr", d.dx_t, T, m->w_tr, T, d.dy, T, m->b_tr, nullptr, R, T, T, 1, 1));
@@ -1146,7 +1167,7 @@ int run_coca_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, int
         // x += out_proj(ctx) ; ln = LayerNorm_2(x)
         TRY(gemm_splitk_reduce_ln(m, s, d, "coca_gemm_o", d.dctx, b.w_o, b.b_o, b.ln2_g, b.ln2_b, c.t_eps, E, E, d.dx_t, nullptr, d.dx));
         // x += c_proj(gelu(c_fc(ln))) ; ln = LayerNorm of the next block (or ln_final)
-        TRY(gemm(m, s, "coca_gemm_fc", d.dx_t, E, b.w_fc, E, d.dh, F, b.b_fc, nullptr, R, F, E, 1, 0));
+        TRY(gemm_rows(m, s, "coca_gemm_fc", d.dx_t, b.w_fc, d.dh, b.b_fc, R, F, E, 1));
         TRY(gemm_splitk_reduce_ln(m, s, d, "coca_gemm_pr", d.dh, b.w_pr, b.b_pr, next_g, next_b, c.t_eps, E, F, d.dx_t, nullptr, d.dx));
     }
     TRY(gemm(m, s, "coca_gemm_vocab", d.dx_t, E, m->w_cvocab, E, d.logits, m->ldl, nullptr, nullptr, R, c.vocab, E, 0, 1));
@@ -1561,6 +1582,14 @@ int cap_op_gemm(int dtype, const void* A, const void* W, const float* bias, cons
 #ifdef CAP_EXPERIMENTS
     if (tile == 9 || tile == 13) { p.aux = resid; p.resid = nullptr; }   // instrumented kernel: `resid` is the cycle-count buffer
 #endif
+    return launch_gemm(dt_of(dtype), p, tile, (hipStream_t)stream);
+}
+int cap_op_gemm_partial(int dtype, const void* A, const void* W, float* part, int M, int N, int K, int splitk, int tile,
+                        void* stream) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = part; p.ldc = N; p.M = M; p.N = N; p.K = K;
+    p.out_f32 = 1; p.epi = EPI_PARTIAL; p.splitk = splitk;
     return launch_gemm(dt_of(dtype), p, tile, (hipStream_t)stream);
 }
 int cap_op_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps, void* out_t,

@@ -32,6 +32,9 @@ struct GemmParams {
 
 // dtype: CAP_DT_F32 / CAP_DT_BF16.  tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 256x256 persistent LDS-DMA kernel
 // (bf16: second generation), 4 = 256x256 register-staged (takes a residual operand), 5 = first-generation LDS-DMA kernel,
+// 6 = decode "rows" kernel (64x64 tile, the block's K range split over its four waves with private LDS-DMA pipelines; bf16 /
+// G8 with the plain-store or split-K epilogue - its sums are ordered differently from the other tiles': callers use it for
+// a given (N, K) at EVERY row count or not at all),
 // 10/11/12 = second generation with the compiler / iglp_opt(0) / iglp_opt(1) schedule, 14/15 = half-slab four-stage
 // structure (gemm_big3_kernel; what tile 3 picks for K <= 1024) without / with iglp_opt(1); in a -DCAP_EXPERIMENTS build
 // (python -m embodied_captioning_amd.build --experiments) 9 and 13 = instrumented builds of generations one and two (cycle

@@ -138,7 +138,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(G
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BUF = (BM + BN) * 128;                   // bytes per LDS buffer: A tile then W tile
 
-    // XCD-aware, bijective remap of the linear block id (guide T1): blocks b, b+8, ... share an XCD.
+    // XCD-aware, bijective remap of the linear block id (guide T1): blocks b, b+8, ... share an XCD, and each XCD walks a
+    // contiguous run of logical ids.  Logical order: row tile fastest, then column tile, K slice slowest - so the blocks that
+    // read the same W slice (all row tiles of one (column tile, K slice)) sit in ONE XCD's L2 and the slice leaves HBM once,
+    // and an XCD's run stays inside one or two K slices, so it pulls only that part of A.  (With the column tile fastest, as
+    // before, the four row tiles of a 256-row decode GEMM landed on four XCDs and W crossed the fabric four times: 3.6x the
+    // algorithmic bytes by the counters, profiles/r02_bench_pmc.json.)  Placement is a speed heuristic only.
     const int S = EPI == EPI_PARTIAL ? p.splitk : 1;
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nwg = ntm * ntn * S;
     int bid = blockIdx.x;
@@ -146,11 +151,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(G
         int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int kz = bid % S;
-    bid /= S;
+    const int tm = bid % ntm;
+    bid /= ntm;
+    const int tn = bid % ntn, kz = bid / ntn;
     if constexpr (EPI == EPI_PARTIAL) p.p3 = kz;
     const int Ks = p.K / S;                                  // K extent of this block
-    const int tm = bid / ntn, tn = bid - tm * ntn;
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -932,6 +937,164 @@ __global__ __launch_bounds__(512, 2) void gemm_big3_kernel(GemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the dummy groups before the LDS goes away
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Decode-sized GEMM ("rows": a few hundred activation rows against a weight matrix that is read once).  These launches are
+// not bound by flops or by HBM but by the serial chain load -> LDS -> barrier -> fragments -> MFMA of a small tile: the
+// register-staged 64x64 tile (gemm_kernel) spends one barrier per 128-byte K-slab for 12 MFMAs per wave.  Here a workgroup
+// still owns a 64x64 output tile (the decomposition with the least operand traffic per CU when ~200 workgroups are wanted:
+// (64 + 64) rows per slab), but its K range is split over its FOUR WAVES, each with a PRIVATE pipeline:
+//   * wave w takes the block's slabs w, w + 4, ... and accumulates the whole 64x64 tile over them (48 MFMAs per slab for
+//     16 ds_read_b128 of fragments: half the LDS bytes per MFMA of the 2x2 wave grid);
+//   * its slabs arrive by LDS-DMA into a wave-private ring of two 16 KiB buffers (A rows then W rows, XOR chunk swizzle on
+//     the source address); the only ordering is the wave's own counted vmcnt - NO workgroup barrier in the loop, a wave
+//     starts its MFMAs when ITS first slab lands and the second slab's DMA runs under them;
+//   * operands swapped (W fragment as the MFMA's A): a lane's 4 accumulators are 4 consecutive output columns;
+//   * one barrier per launch: the four partial tiles meet in LDS (each wave parks its tile in its own ring), are summed in
+//     wave order 0..3 - a fixed order: the result depends on (N, K, split) only, never on the row count - and leave through
+//     the common epilogue (scale / bias / GELU / G8 or fp32 or split-K slab) as whole 256-byte rows.
+// Block ids: XCD-aware remap, row tile fastest (see gemm_kernel).  T = g8_t (32 k per slab, 3 MFMAs per product) or bf16
+// (64 k per slab).
+template <typename T, bool OUT_F32, int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmParams p) {
+    using vec = typename Mma<T>::vec;
+    constexpr bool G8 = is_g8<T>;
+    constexpr int EPC = Mma<T>::EPC, SLAB = 8 * EPC;      // K elements per 128-byte slab row
+    constexpr int BUF = 128 * 128, RING = 2 * BUF;        // one slab of the tile: 64 A rows + 64 W rows; two per wave
+    constexpr int PITCH = 272;                            // reduce image: 64 rows x 256 payload bytes, pitch 272 (conflict-free b128)
+    static_assert(64 * PITCH <= RING, "the partial tile must fit in the wave's ring");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int S = EPI == EPI_PARTIAL ? p.splitk : 1;
+    const int ntm = (p.M + 63) / 64, ntn = (p.N + 63) / 64, nwg = ntm * ntn * S;
+    int bid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid % ntm;
+    bid /= ntm;
+    const int tn = bid % ntn, kz = bid / ntn;
+    if constexpr (EPI == EPI_PARTIAL) p.p3 = kz;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int nkb = p.K / S / SLAB;                        // slabs of this block
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kg = lane >> 4;
+    char* ring = smem + wave * RING;
+
+    // this lane's 8 A and 8 W source pointers (slab 0 of the block): piece q = rows 8q .. 8q+7, lane = (row, 16-byte position)
+    const int prow = lane >> 3, ppos = lane & 7;
+    const char* pa[8];
+    const char* pb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int row = q * 8 + prow;
+        const int gch = ppos ^ ((row >> 1) & 7);
+        const int ga = min(m0 + row, p.M - 1), gb = min(n0 + row, p.N - 1);
+        pa[q] = (const char*)((const T*)p.A + (size_t)ga * p.lda + (size_t)kz * (p.K / S) + gch * EPC);
+        pb[q] = (const char*)((const T*)p.W + (size_t)gb * p.ldw + (size_t)kz * (p.K / S) + gch * EPC);
+    }
+    auto issue = [&](int kt, char* buf) {                  // 16 DMA instructions: the slab's 16 KiB
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(pa[q] + (size_t)kt * 128), CAP_LPTR(buf + q * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(pb[q] + (size_t)kt * 128), CAP_LPTR(buf + 64 * 128 + q * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+    const int n = (nkb - wave + 3) >> 2;                   // slabs of this wave: wave, wave + 4, ...
+    if (n > 0) issue(wave, ring);
+    if (n > 1) issue(wave + 4, ring + BUF);
+    for (int t = 0; t < n; ++t) {
+        // the wave's own DMA is all that writes its ring: slab t has landed once at most the next slab's 16 pieces are open
+        if (t + 1 < n) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const char* a_s = ring + (t & 1) * BUF;
+        const char* b_s = a_s + 64 * 128;
+        if constexpr (G8) {
+            vec ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bh[j] = *(const vec*)(b_s + swz_off(j * 16 + r16, 2 * kg));
+                bl[j] = *(const vec*)(b_s + swz_off(j * 16 + r16, 2 * kg + 1));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ah[i] = *(const vec*)(a_s + swz_off(i * 16 + r16, 2 * kg));
+                al[i] = *(const vec*)(a_s + swz_off(i * 16 + r16, 2 * kg + 1));
+            }
+            // fragments are in registers: the buffer may take the slab after next
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (t + 2 < n) issue(wave + 4 * (t + 2), ring + (t & 1) * BUF);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                }
+        } else {
+            vec af[2][4], bf[2][4];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bf[ks][j] = *(const vec*)(b_s + swz_off(j * 16 + r16, ks * 4 + kg));
+                    af[ks][j] = *(const vec*)(a_s + swz_off(j * 16 + r16, ks * 4 + kg));
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (t + 2 < n) issue(wave + 4 * (t + 2), ring + (t & 1) * BUF);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+        }
+    }
+    // park the partial tile in the wave's own ring (its DMA and its reads are done): C[16 i + r16][16 j + 4 kg .. + 3]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(f32x4*)(ring + (i * 16 + r16) * PITCH + (j * 16 + 4 * kg) * 4) = acc[i][j];
+    __syncthreads();
+    // sum the four partial tiles (wave order) and store: thread -> 16 bytes of a row, 16 threads per 256-byte row
+    const int c4 = tid & 15, col = n0 + c4 * 4;
+    f32x4 biasv = 0.f;
+    if (EPI != EPI_PARTIAL && p.bias && col < p.N) biasv = *(const f32x4*)(p.bias + col);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rr = (tid >> 4) + q * 16, row = m0 + rr;
+        const char* src = smem + rr * PITCH + c4 * 16;
+        f32x4 v = *(const f32x4*)src;
+        v += *(const f32x4*)(src + RING);
+        v += *(const f32x4*)(src + 2 * RING);
+        v += *(const f32x4*)(src + 3 * RING);
+        if (row < p.M && col < p.N) epi_store4<T, OUT_F32, EPI>(p, row, col, v, biasv);
+    }
+}
+
+template <typename T, bool OUT_F32, int EPI>
+int launch_rows(const GemmParams& p, hipStream_t stream) {
+    constexpr int LDS = 4 * 2 * 128 * 128;               // four wave-private rings of two 16 KiB slabs
+    auto kern = gemm_rows_kernel<T, OUT_F32, EPI>;
+    if (cap_kernel_setup((const void*)kern, LDS, nullptr) != 0) return -1;
+    const int S = EPI == EPI_PARTIAL ? p.splitk : 1;
+    const int grid = ((p.M + 63) / 64) * ((p.N + 63) / 64) * S;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, p);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 template <bool OUT_F32, int EPI, int SCHED = 0>
 int launch_big3(const GemmParams& p, hipStream_t stream) {
     // four half-slab stages, bias ping-pong (2 KiB) + per-wave bias scratch (8 KiB), dummy DMA sink (2 KiB), strips
@@ -1021,6 +1184,10 @@ int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
         if constexpr (sizeof(T) == 2 && !is_g8<T> && !OUT_F32 && EPI == EPI_STORE) return launch_big<T, OUT_F32, EPI, 4>(p, stream);
 #endif
         tile = 3;
+    }
+    if (tile == 6) {                                    // decode "rows" kernel: wave-private K pipelines (gemm_rows_kernel)
+        if constexpr ((sizeof(T) == 2 || is_g8<T>) && (EPI == EPI_STORE || EPI == EPI_PARTIAL)) return launch_rows<T, OUT_F32, EPI>(p, stream);
+        tile = 2;                                       // fp32 mode / cache-scatter epilogues: the register-staged 64x64 tile
     }
     if ((tile == 3 || tile == 5) && p.resid) tile = 4;  // the LDS-DMA kernels have no residual operand
     if (tile == 3) {

@@ -182,6 +182,11 @@ int cap_profile_report(CapHandle h, char* buf, size_t buf_bytes);
  * stored as [8 fp16 hi | 8 fp16 lo]; q|k|v, caches and partial sums are fp32. */
 int cap_op_gemm(int dtype, const void* A, const void* W, const float* bias, const float* resid, void* C, int M, int N,
                 int K, int gelu, int out_f32, int tile, void* stream);
+/* split-K form of the decode GEMMs: part[z][M][N] fp32 = A[:, z-th K slice] . W[:, z-th K slice]^T, no bias (the consumer -
+ * cap_op_reduce_layernorm, or the decode attention kernels - sums the slices in order).  K % (slab * splitk) == 0 with slab =
+ * 32 (fp32, split) / 64 (bf16); tile as cap_op_gemm (2 = the 64x64 decode tile). */
+int cap_op_gemm_partial(int dtype, const void* A, const void* W, float* part, int M, int N, int K, int splitk, int tile,
+                        void* stream);
 int cap_op_layernorm(int dtype, const float* in, const float* gamma, const float* beta, float eps, void* out_t,
                      float* out_f, int M, int D, void* stream);
 int cap_op_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, void* stream);

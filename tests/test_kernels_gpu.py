@@ -32,7 +32,7 @@ DT = {"f32": (0, torch.float32), "bf16": (1, torch.bfloat16)}
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 6])
 @pytest.mark.parametrize("shape", [(256, 256, 128), (197, 768, 768), (300, 200, 192), (33, 7632, 64), (1, 64, 64), (520, 516, 3072),
                                    (70000, 768, 128)])
 def test_gemm_bias_against_fp64(lib, dtype, tile, shape):

@@ -49,7 +49,7 @@ def test_g8_container_round_trips_on_the_host():
     assert np.all(np.abs(wb - x * 1e-3) <= np.maximum(np.abs(x * 1e-3) * 2.0 ** -22, 2.0 ** -25 / G8_WSCALE))
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6])
 @pytest.mark.parametrize("shape", [(256, 256, 128), (197, 768, 768), (300, 200, 192), (33, 7632, 64), (1, 64, 64), (520, 516, 3072),
                                    (2000, 2304, 768), (70000, 768, 96)])
 @gpu
@@ -93,7 +93,7 @@ def test_split_gemm_tiles_are_bit_identical(lib):
 
 
 @gpu
-@pytest.mark.parametrize("tile", [0, 2, 3])
+@pytest.mark.parametrize("tile", [0, 2, 3, 6])
 def test_split_gemm_gelu_into_g8_output(lib, tile):
     M, N, K = 600, 3072, 256
     g = torch.Generator().manual_seed(11)
@@ -105,6 +105,46 @@ def test_split_gemm_gelu_into_g8_output(lib, tile):
     want = torch.nn.functional.gelu(A.double() @ W.double().T + bias.double())
     got = torch.from_numpy(g8_decode(out.cpu().numpy())).double()
     assert (got - want).abs().max().item() < 1e-5
+
+
+@gpu
+@pytest.mark.parametrize("dtype", ["f32s", "bf16"])
+@pytest.mark.parametrize("shape", [(256, 768, 768, 4), (256, 2304, 768, 1), (256, 768, 3072, 4), (37, 768, 768, 3), (640, 768, 768, 2),
+                                   (5, 200, 384, 1), (256, 768, 768, 6)])
+def test_decode_rows_kernel_split_k_slices_and_row_invariance(lib, dtype, shape):
+    """The decode GEMM kernel (tile 6: 64x64 tile, the block's K range split over its four waves, partial tiles summed in wave
+    order): split-K slices sum to the fp64 product of the original operands; and a row's sums do not depend on how many rows
+    the launch has or where the row sits - the property the captioner's batch invariance rests on."""
+    M, N, K, S = shape
+    slab = 32 if dtype == "f32s" else 64
+    if K % (slab * S):
+        pytest.skip("K does not divide into whole slabs per slice")
+    tag = SPLIT if dtype == "f32s" else 1
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + S)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    if dtype == "f32s":
+        Ad, Wd = _g8(A), _g8(W, G8_WSCALE)
+        scale, tol = 1.0, 1e-5 * math.sqrt(max(K, 256) / 256)          # the slabs come out already divided by the weight scale
+        ref = A.double() @ W.double().T
+    else:
+        Ad, Wd = A.to(torch.bfloat16).cuda(), W.to(torch.bfloat16).cuda()
+        scale, tol = 1.0, 2e-4 * math.sqrt(K / 64)
+        ref = Ad.double().cpu() @ Wd.double().cpu().T
+    part = torch.full((S, M, N), float("nan"), dtype=torch.float32, device="cuda")
+    _check(lib, lib.cap_op_gemm_partial(tag, _p(Ad), _p(Wd), _p(part), M, N, K, S, 6, _stream()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(part).all()
+    got = part.double().sum(0).cpu() * scale
+    assert (got - ref).abs().max().item() < tol
+    # the same rows alone (first 3, and 3 from the middle): bit-identical partial sums
+    for r0 in (0, M // 2):
+        n = min(3, M - r0)
+        sub = torch.full((S, n, N), float("nan"), dtype=torch.float32, device="cuda")
+        Asub = Ad[r0:r0 + n].contiguous()
+        _check(lib, lib.cap_op_gemm_partial(tag, _p(Asub), _p(Wd), _p(sub), n, N, K, S, 6, _stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(sub, part[:, r0:r0 + n])
 
 
 @gpu
