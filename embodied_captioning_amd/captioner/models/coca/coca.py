@@ -35,6 +35,11 @@ class CoCa(CaptioningPredictor):
         # num_beams 1 (default) = the wrapper's call in the reference, generate(generation_type="top_k", top_k=1) (coca.py:29);
         # > 1 = the model's `_generate_beamsearch` with one beam group (coca_model.py:335-482; SURVEY config 5 asks beam 5)
         self.num_beams = int(getattr(cfg, "num_beams", 1) or 1)
+        # optional: the model's beam GROUPS (its generate() defaults are 6 beams in 3 groups, coca_model.py:218-219)
+        g = getattr(cfg, "num_beam_groups", None)
+        self.num_beam_groups = int(g) if g else None
+        if self.num_beam_groups and self.num_beams % self.num_beam_groups:
+            raise ValueError(f"num_beams ({self.num_beams}) must be a multiple of num_beam_groups ({self.num_beam_groups})")
         dtype = getattr(cfg, "dtype", None) or "bf16"
         if int(getattr(cfg, "streams", 1) or 1) > 1:
             logger.warning("captioner.streams > 1 is implemented for arch_name 'blip' only: running one engine")
@@ -59,11 +64,19 @@ class CoCa(CaptioningPredictor):
                 raise RuntimeError(f"Pretrained weights ({ck}) not found for model {name}.")   # factory.py:309-314
             self.arch = CocaArch(image_size=image_size) if image_size else CocaArch()
             sd = load_state_dict_file(ck)
-            try:
-                import open_clip
-                self.tokenizer = open_clip
-            except Exception:  # noqa: BLE001
-                logger.warning("open_clip is not installed: captions are returned as space-separated token ids")
+        # detokeniser (coca.py:30 `open_clip.decode`): open_clip itself when it is installed, else the CLIP BPE vocabulary read
+        # from files next to the checkpoint (cfg.tokenizer_dir / the checkpoint's directory: vocab.json, merges.txt or
+        # bpe_simple_vocab_16e6.txt[.gz]) through captioner/clip_bpe.py; with neither, ids are returned as text
+        self.bpe = None
+        try:
+            import open_clip
+            self.tokenizer = open_clip
+        except Exception:  # noqa: BLE001
+            from ...clip_bpe import ClipBpeDecoder
+            self.bpe = ClipBpeDecoder.find(getattr(cfg, "tokenizer_dir", None), getattr(cfg, "checkpoint_name", None))
+            if self.bpe is None and not name.startswith("procedural-coca"):
+                logger.warning("no CLIP BPE vocabulary (vocab.json / merges.txt / bpe_simple_vocab_16e6.txt.gz) next to the "
+                               "checkpoint and open_clip is not installed: captions are returned as space-separated token ids")
         self.engine = CaptionerEngine(self.arch, dtype=dtype, max_batch=self.batch_size, max_beams=self.num_beams,
                                       max_len=self.arch.seq_len, device=self._device)
         # HF generate stops once every caption has its EOS; look every few steps (cfg early_exit_poll, 0 = never)
@@ -107,6 +120,8 @@ class CoCa(CaptioningPredictor):
         if self.tokenizer is not None:
             text = self.tokenizer.decode(torch.tensor(ids))
             return text.split("<end_of_text>")[0].replace("<start_of_text>", "")       # coca.py:30
+        if self.bpe is not None:
+            return self.bpe.caption(ids)
         a = self.arch
         return " ".join(str(i) for i in ids if i not in (a.sot, a.eos, a.pad))
 
@@ -115,7 +130,8 @@ class CoCa(CaptioningPredictor):
         px = self.preprocess(images)
         seqs, lens = [], []
         for i in range(0, px.shape[0], self.batch_size):
-            out = self.engine.generate(px[i:i + self.batch_size].to(self._device), num_beams=self.num_beams, max_length=self.arch.seq_len)
+            out = self.engine.generate(px[i:i + self.batch_size].to(self._device), num_beams=self.num_beams, max_length=self.arch.seq_len,
+                                       num_beam_groups=self.num_beam_groups)
             seqs.append(out["sequences"]); lens.append(out["lengths"])
         seq, ln = torch.cat(seqs).cpu(), torch.cat(lens).cpu()
         return {"texts": [self.decode(r[:n]) for r, n in zip(seq.tolist(), ln.tolist())], "sequences": seq, "lengths": ln}

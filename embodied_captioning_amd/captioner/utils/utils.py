@@ -5,7 +5,9 @@ over, engine.EnginePool; 1 = one engine; the BLIP-2 / CoCa wrappers run one engi
 early_exit_poll (look for "every caption finished" every n decode steps; None = 4), max_new_tokens (BLIP-2: tokens to
 generate, HF's name; None = 20 as HF's generate default - `max_length` is BLIP's / CoCa's total length and is not read by
 BLIP-2).  dtype: "f32s" (default for BLIP: fp32-grade split-fp16 GEMMs, token-identical to the fp32 reference), "bf16",
-"f32"; None = the architecture's default."""
+"f32"; None = the architecture's default.  CoCa: num_beam_groups (the model's beam groups, coca_model.py:218-219; None = one
+group), tokenizer_dir (directory holding the CLIP BPE vocabulary - vocab.json / merges.txt / bpe_simple_vocab_16e6.txt.gz -
+when it is not next to the checkpoint and open_clip is not installed)."""
 
 
 class Configuration:
@@ -17,7 +19,7 @@ class Configuration:
 class CaptionerField:
     def __init__(self, arch_name=None, model_name=None, checkpoint_name=None, height=None, width=None,
                  num_beams=1, max_length=20, dtype=None, batch_size=8, device="cuda:0", image_size=None, streams=1,
-                 early_exit_poll=None, max_new_tokens=None):
+                 early_exit_poll=None, max_new_tokens=None, num_beam_groups=None, tokenizer_dir=None):
         self.arch_name = arch_name
         self.model_name = model_name
         self.checkpoint_name = checkpoint_name
@@ -32,3 +34,5 @@ class CaptionerField:
         self.streams = streams
         self.early_exit_poll = early_exit_poll
         self.max_new_tokens = max_new_tokens
+        self.num_beam_groups = num_beam_groups
+        self.tokenizer_dir = tokenizer_dir

@@ -437,8 +437,7 @@ int build_arena_coca(Captioner* m) {
     TRY(dev_alloc(m, (void**)&m->logits, R * (size_t)m->ldl * 4));
     m->ccache.resize(c.t_layers + c.mm_layers);
     for (auto& p : m->ccache) TRY(dev_alloc(m, &p, 2 * R * H * Lm * 64 * e));
-    if (c.max_beams > 1)
-        TRY(dev_alloc(m, &m->beam, beam_state_bytes((int)Bm, c.max_beams, (int)Lm)));
+    TRY(dev_alloc(m, &m->beam, beam_state_bytes((int)Bm, c.max_beams, (int)Lm)));      // (a 1-beam search exists: beam groups)
     return 0;
 }
 
@@ -1208,13 +1207,16 @@ static int run_image_side(Captioner* m, const void* pixels, int fmt, int B, hipS
 }
 
 int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm, float lp, int32_t* out_ids,
-                 int32_t* out_len, float* out_scores, float* out_step_logits, hipStream_t s) {
+                 int32_t* out_len, float* out_scores, float* out_step_logits, hipStream_t s, bool force_beam = false) {
+    // force_beam: K == 1 runs as a 1-beam BEAM search (the scorer's bookkeeping, no forced EOS) instead of the greedy loop -
+    // what a beam group of size one is (cap_generate_groups)
     const CapConfig& c = m->c;
     const int R = B * K;
     const bool coca = c.arch == CAP_ARCH_COCA;
+    const bool greedy = K == 1 && !force_beam;
     TRY(run_image_side(m, pixels, fmt, B, s));
     const Dec d = make_slice(m, 0, B, B, K, Lm);
-    if (K == 1) {
+    if (greedy) {
         hipLaunchKernelGGL(init_seq_kernel, dim3(64), dim3(256), 0, s, d.seq, d.finished, d.lens, R, Lm, c.bos, c.pad);
     } else {
         TRY(launch_beam_init(d.beam, B, K, Lm, c.bos, c.pad, c.eos, s, coca ? BEAM_LEGACY_RAW : BEAM_HF_V5));
@@ -1224,8 +1226,8 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
     for (int t = 0; t + 1 < Lm; ++t) {
         const int cur_len = t + 1;
         m->last_steps = t + 1;
-        const int* tokens = K == 1 ? d.seq : beam_running_tokens_p(d.beam, B, K, Lm, cur_len & 1);
-        const int* anc = K == 1 ? nullptr : d.anc + (size_t)(cur_len & 1) * R * Lm;
+        const int* tokens = greedy ? d.seq : beam_running_tokens_p(d.beam, B, K, Lm, cur_len & 1);
+        const int* anc = greedy ? nullptr : d.anc + (size_t)(cur_len & 1) * R * Lm;
         if (coca) TRY(run_coca_step(m, d, tokens, Lm, t, K, anc, Lm, s));
         else TRY(run_decoder_step(m, d, tokens, Lm, t, K, anc, Lm, s));
         if (out_step_logits) {
@@ -1233,18 +1235,18 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
                                out_step_logits + (size_t)t * R * c.vocab, R, c.vocab);
             CAP_HIP_CHECK(hipGetLastError());
         }
-        ProfScope ps(m, s, K == 1 ? "greedy_select" : "beam_step", 0, (double)R * c.vocab * 4);
-        if (K == 1)
+        ProfScope ps(m, s, greedy ? "greedy_select" : "beam_step", 0, (double)R * c.vocab * 4);
+        if (greedy)
             TRY(launch_greedy_select(d.logits, m->ldl, c.vocab, d.seq, Lm, t, Lm, c.eos, c.pad, d.finished, d.lens, R, s,
                                      coca ? c.min_len : 0, coca ? 1 : 0));
         else
             TRY(launch_beam_step(d.beam, d.logits, m->ldl, c.vocab, B, K, Lm, cur_len, c.eos, lp, d.anc, Lm, s,
                                  coca ? BEAM_LEGACY_RAW : BEAM_HF_V5, coca ? c.min_len : 0));
         bool done;
-        TRY(poll_all_finished(m, t, Lm - 1, d.finished, R, K == 1 ? nullptr : beam_active_flag_p(d.beam, B, K, Lm), s, &done));
+        TRY(poll_all_finished(m, t, Lm - 1, d.finished, R, greedy ? nullptr : beam_active_flag_p(d.beam, B, K, Lm), s, &done));
         if (done) break;
     }
-    if (K == 1) {
+    if (greedy) {
         hipLaunchKernelGGL(copy_i32_kernel, dim3(64), dim3(256), 0, s, d.seq, out_ids, (size_t)R * Lm);
         if (out_len) hipLaunchKernelGGL(copy_i32_kernel, dim3(4), dim3(256), 0, s, d.lens, out_len, (size_t)R);
         CAP_HIP_CHECK(hipGetLastError());
@@ -1522,6 +1524,30 @@ int cap_generate(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_
     // beam group (coca_model.py:335-482; length_penalty is the scorer's: pass 1.0 for the reference's default)
     return run_generate(m, pixels, pixel_fmt, B, num_beams, max_len, length_penalty, out_ids, out_len, out_scores,
                         out_step_logits, (hipStream_t)stream);
+}
+
+int cap_generate_groups(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_beams, int num_beam_groups, int max_len,
+                        float length_penalty, int32_t* out_ids, int32_t* out_len, float* out_scores, void* stream) {
+    Captioner* m = (Captioner*)h;
+    TRY(check_call(m, B, num_beams, max_len, pixel_fmt));
+    if (!pixels || !out_ids) { cap_set_error("cap_generate_groups: null buffer"); return -1; }
+    if (m->c.arch != CAP_ARCH_COCA) {
+        cap_set_error("cap_generate_groups: beam groups are the CoCa loop's (coca_model.py:335-482); HF's group beam search for the "
+                      "other architectures needs a diversity penalty, which this library does not implement");
+        return -1;
+    }
+    if (num_beam_groups < 1 || num_beam_groups > num_beams || num_beams % num_beam_groups != 0) {
+        cap_set_error("cap_generate_groups: num_beams (%d) must be a multiple of num_beam_groups (%d) (BeamSearchScorer's own check)",
+                      num_beams, num_beam_groups);
+        return -1;
+    }
+    // The reference's loop runs its groups one after the other on the SAME logits with only MinLength / RepetitionPenalty(1.0)
+    // as processors (coca_model.py:236-241: no HammingDiversity processor), every group starts from the same scores (:380-384),
+    // and finalize picks the best hypothesis over all groups of an image: the groups are identical searches of
+    // num_beams / num_beam_groups beams, and the result is that of ONE of them.  That one is what runs here.
+    const int sub = num_beams / num_beam_groups;
+    return run_generate(m, pixels, pixel_fmt, B, sub, max_len, length_penalty, out_ids, out_len, out_scores, nullptr,
+                        (hipStream_t)stream, /*force_beam=*/true);
 }
 
 long long cap_g8_saturations(int reset) {

@@ -193,11 +193,13 @@ class CaptionerEngine:
         return out
 
     def generate(self, pixels: torch.Tensor, num_beams: int = 1, max_length: Optional[int] = None,
-                 length_penalty: float = 1.0, output_logits: bool = False) -> Dict[str, torch.Tensor]:
+                 length_penalty: float = 1.0, output_logits: bool = False, num_beam_groups: Optional[int] = None) -> Dict[str, torch.Tensor]:
         """Returns device tensors: sequences int32 [B, max_length] (incl. BOS), lengths int32 [B],
         sequences_scores fp32 [B] (beams only), logits fp32 [max_length-1, B*num_beams, vocab] (optional).
         BLIP-2: max_length counts NEW tokens (HF max_new_tokens); sequences are those new tokens only (no image
-        placeholders / BOS), logits [max_length, B, vocab]."""
+        placeholders / BOS), logits [max_length, B, vocab].
+        num_beam_groups (CoCa): the reference's `_generate_beamsearch` with that many beam groups (coca_model.py:335-482;
+        its `generate()` defaults are 6 beams in 3 groups) - cap_generate_groups; no per-step logits in that mode."""
         pixels, fmt = self._pixels(pixels)
         B = pixels.shape[0]
         L = max_length or self.max_len
@@ -210,6 +212,14 @@ class CaptionerEngine:
             # zeros, not empty: with early exit the steps after the last executed one are never written (callers see 0, not
             # stale memory); `last_decode_steps` tells how many steps ran
             logits = torch.zeros((steps, B * num_beams, self.arch.vocab), dtype=torch.float32, device=self.device)
+        if num_beam_groups is not None:
+            if output_logits:
+                raise ValueError("per-step logits are not recorded by the group beam search")
+            with torch.cuda.device(self.device):
+                N.check(self.lib.cap_generate_groups(self._h, C.c_void_p(pixels.data_ptr()), fmt, B, num_beams, int(num_beam_groups), L,
+                                                     C.c_float(length_penalty), C.c_void_p(ids.data_ptr()), C.c_void_p(lens.data_ptr()),
+                                                     C.c_void_p(scores.data_ptr()), C.c_void_p(_stream_ptr(self.device))), "cap_generate_groups")
+            return {"sequences": ids, "lengths": lens, "sequences_scores": scores}
         with torch.cuda.device(self.device):
             N.check(self.lib.cap_generate(self._h, C.c_void_p(pixels.data_ptr()), fmt, B, num_beams, L,
                                           C.c_float(length_penalty), C.c_void_p(ids.data_ptr()),

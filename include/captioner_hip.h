@@ -151,6 +151,15 @@ int cap_generate(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_
                  float length_penalty, int32_t* out_ids, int32_t* out_len, float* out_scores,
                  float* out_step_logits, void* stream);
 
+/* CoCa's `_generate_beamsearch` with beam GROUPS (reference coca_model.py:335-482; `generate()` defaults num_beams = 6,
+ * num_beam_groups = 3, :218-219): num_beams % num_beam_groups == 0, each group a beam search of num_beams / num_beam_groups
+ * beams, the best hypothesis over an image's groups returned.  The reference attaches no diversity processor (:236-241), so
+ * its groups are identical searches and the result equals ONE search of num_beams / num_beam_groups beams - which is what this
+ * entry point runs (a group of one beam runs as a 1-beam BEAM search, not as cap_generate's greedy loop).  Outputs as
+ * cap_generate; B <= max_batch, num_beams <= max_beams.  CAP_ARCH_COCA only. */
+int cap_generate_groups(CapHandle h, const void* pixels, int pixel_fmt, int B, int num_beams, int num_beam_groups, int max_len,
+                        float length_penalty, int32_t* out_ids, int32_t* out_len, float* out_scores, void* stream);
+
 /* Sentence encoder (CAP_ARCH_MINILM handle; weights by HF BertModel names as sentence-transformers stores them):
  * WordPiece ids int32 [B, L] incl. [CLS]/[SEP] (rows padded with any valid id), lens int32 [B] = valid tokens per row
  * -> out fp32 [B, t_hidden]: mean of the last hidden states over the valid tokens, L2-normalised

@@ -299,3 +299,91 @@ def generate_beamsearch(sd, a, pixels: Tensor, num_beams: int = 5, seq_len: Opti
         if lens[b] < width:
             out[b, lens[b]] = a.eos
     return {"sequences": out, "scores": torch.tensor(best_scores), "image_embs": image_embs}
+
+
+@torch.no_grad()
+def generate_beamsearch_groups(sd, a, pixels: Tensor, num_beams: int = 6, num_beam_groups: int = 3, seq_len: Optional[int] = None,
+                               min_seq_len: Optional[int] = None, image_embs: Optional[Tensor] = None):
+    """coca_model.py:335-482 LITERALLY, with its beam groups (the `generate()` defaults are num_beams = 6, num_beam_groups = 3,
+    :218-219): per step ONE forward over all B * num_beams rows (:394-401), then group by group (:403-466) the rows of that
+    group (:409-415), MinLength on their logits, + the group's running scores, top 2 * group_size over group_size * V (:429-432),
+    `BeamSearchScorer.process(..., group_index=g)` (a `BeamHypotheses` per (image, group), :440-449), and the group's rows of
+    `input_ids` reordered in place (:455-457).  `finalize` (:472-481) adds the open beams of every (image, group) that is not
+    done and returns the best hypothesis over ALL groups of an image (the legacy scorer's `num_beam_hyps_to_keep = 1`).
+    No diversity processor is attached (:236-241), so nothing couples the groups.  **PARITY UNPINNED** as everything CoCa here.
+    Returns {"sequences", "scores", "group_sequences": per (image, group) best hypothesis - for the test of the equivalence
+    with ONE search of num_beams / num_beam_groups beams that the product relies on}."""
+    seq_len = seq_len or a.seq_len
+    min_seq_len = a.min_seq_len if min_seq_len is None else min_seq_len
+    assert seq_len > min_seq_len and num_beams % num_beam_groups == 0
+    if image_embs is None:
+        _, image_embs = encode_image(sd, a, pixels)
+    B, K, G = image_embs.shape[0], num_beams, num_beam_groups
+    g = K // G                                                                 # num_sub_beams
+    embs = torch.repeat_interleave(image_embs, K, dim=0)
+    input_ids = torch.full((B * K, 1), a.sot, dtype=torch.int64)
+    hyps = [_BeamHyps(g) for _ in range(B * G)]                                # index = batch_idx * G + group (scorer's batch_group_idx)
+    done = [False] * (B * G)
+    beam_scores = torch.full((B, K), -1e9, dtype=torch.float32)
+    beam_scores[:, ::g] = 0                                                    # :383
+    beam_scores = beam_scores.view(B * K)
+    while True:
+        current_tokens = torch.zeros(B * K, dtype=torch.int64)
+        logits_all = last_logits_full(sd, a, embs, input_ids)
+        V = logits_all.shape[-1]
+        cur_len = input_ids.shape[-1] + 1
+        for gi in range(G):
+            rows = [b * K + i for b in range(B) for i in range(gi * g, (gi + 1) * g)]          # batch_group_indices
+            rows_t = torch.tensor(rows)
+            group_ids = input_ids[rows_t]
+            logits = logits_all[rows_t].clone()
+            if group_ids.shape[1] < min_seq_len:
+                logits[:, a.eos] = float("-inf")
+            scores = (logits + beam_scores[rows_t][:, None]).view(B, g * V)
+            top_v, top_i = torch.topk(scores, 2 * g, dim=1, largest=True, sorted=True)
+            next_idx, next_tok = top_i // V, top_i % V
+            nb_scores = torch.zeros(B, g); nb_tok = torch.full((B, g), a.pad, dtype=torch.int64); nb_idx = torch.zeros(B, g, dtype=torch.int64)
+            for b in range(B):
+                bg = b * G + gi
+                if done[bg]:
+                    continue
+                slot = 0
+                for rank in range(2 * g):
+                    tok, sc, bi = int(next_tok[b, rank]), float(top_v[b, rank]), b * g + int(next_idx[b, rank])   # index into the GROUP's rows
+                    if tok == a.eos:
+                        if rank >= g:
+                            continue
+                        hyps[bg].add(group_ids[bi].clone(), sc, generated_len=cur_len)
+                    else:
+                        nb_scores[b, slot], nb_tok[b, slot], nb_idx[b, slot] = sc, tok, bi
+                        slot += 1
+                    if slot == g:
+                        break
+                done[bg] = done[bg] or hyps[bg].is_done(float(top_v[b].max()), cur_len)
+            beam_scores[rows_t] = nb_scores.view(B * g)
+            beam_idx = nb_idx.view(B * g)
+            input_ids[rows_t] = group_ids[beam_idx]                            # :455
+            current_tokens[rows_t] = nb_tok.view(B * g)
+        input_ids = torch.cat([input_ids, current_tokens.unsqueeze(-1)], dim=-1)
+        if all(done) or input_ids.shape[1] >= seq_len:
+            break
+    for bg in range(B * G):                                                    # finalize: open beams of unfinished (image, group)s
+        if done[bg]:
+            continue
+        for i in range(g):
+            row = bg * g + i                                                   # = batch_idx * K + group * g + i
+            hyps[bg].add(input_ids[row], float(beam_scores[row]), generated_len=input_ids.shape[-1])
+    best, best_scores, per_group = [], [], []
+    for b in range(B):
+        cands = [bm for gi in range(G) for bm in hyps[b * G + gi].beams]
+        s, h = sorted(cands, key=lambda x: x[0])[-1]
+        best.append(h); best_scores.append(s)
+        per_group.append([sorted(hyps[b * G + gi].beams, key=lambda x: x[0])[-1] for gi in range(G)])
+    lens = [len(h) for h in best]
+    width = min(max(lens) + 1, seq_len)
+    out = torch.full((B, width), a.pad, dtype=torch.int64)
+    for b, h in enumerate(best):
+        out[b, : lens[b]] = h
+        if lens[b] < width:
+            out[b, lens[b]] = a.eos
+    return {"sequences": out, "scores": torch.tensor(best_scores), "group_best": per_group, "image_embs": image_embs}

@@ -159,3 +159,25 @@ def test_beam_search_restatement_unpinned_properties():
         body = [t for t in row if t != a.pad]
         assert len(body) >= a.min_seq_len and (body[-1] == a.eos or len(body) == a.seq_len)
         assert a.eos not in body[:-1]
+
+
+@pytest.mark.parametrize("seed,boost,K,G", [(3, 2.0, 6, 3), (3, 0.0, 4, 2), (5, 4.0, 3, 3), (5, 1.0, 6, 1)])
+def test_beam_groups_literal_loop_unpinned_equals_one_search_of_a_group(seed, boost, K, G):
+    """The reference's `_generate_beamsearch` with beam GROUPS (coca_model.py:403-466; generate() defaults 6 beams / 3 groups),
+    restated literally, against ONE search of K / G beams: without a diversity processor (:236-241) the groups never see each
+    other, start from the same scores and rank the same candidates, so every group ends with the same best hypothesis and
+    `finalize` returns it - the equivalence cap_generate_groups relies on.  (Both sides are restatements: unpinned.)"""
+    from embodied_captioning_amd.config import CocaArch
+    from embodied_captioning_amd.weights import procedural_coca_state_dict, synthetic_pixels
+    from oracle import coca_ref as R
+    a = CocaArch.tiny()
+    sd = procedural_coca_state_dict(a, seed, eos_boost=boost)
+    px = synthetic_pixels(3, a.image_size, seed=seed)
+    _, embs = R.encode_image(sd, a, px)
+    lit = R.generate_beamsearch_groups(sd, a, px, num_beams=K, num_beam_groups=G, image_embs=embs)
+    one = R.generate_beamsearch(sd, a, px, num_beams=K // G, image_embs=embs)
+    assert torch.equal(lit["sequences"], one["sequences"])
+    assert (lit["scores"] - one["scores"]).abs().max().item() < 1e-6
+    for per_image in lit["group_best"]:
+        for score, hyp in per_image[1:]:
+            assert torch.equal(hyp, per_image[0][1]) and abs(score - per_image[0][0]) < 1e-6

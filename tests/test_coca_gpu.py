@@ -207,3 +207,57 @@ def test_coca_beam_search_unpinned_vit_l14_336_first_steps():
     for r, n in zip(seq, ln):
         assert (r[n:] == a.pad).all() and (n == a.seq_len or r[n - 1] == a.eos)
     eng.close()
+
+
+@pytest.mark.parametrize("boost,K,G", [(2.0, 6, 3), (0.0, 4, 2), (4.0, 3, 3), (1.0, 6, 1), (3.0, 8, 4)])
+def test_coca_beam_groups_unpinned_tiny_fp32_matches_the_literal_group_loop(boost, K, G):
+    """cap_generate_groups (the reference's `generate()` defaults are 6 beams in 3 groups, coca_model.py:218-219) against the
+    LITERAL restatement of the reference's group loop (oracle/coca_ref.generate_beamsearch_groups): sequences, lengths, scores.
+    Group size one (K == G) is a 1-beam BEAM search - not the greedy loop, whose forced EOS it lacks."""
+    from embodied_captioning_amd._native import CaptionerHipError
+    from embodied_captioning_amd.config import CocaArch
+    from embodied_captioning_amd.engine import CaptionerEngine
+    from embodied_captioning_amd.weights import procedural_coca_state_dict, synthetic_pixels
+    from oracle import coca_ref as R
+    a = CocaArch.tiny()
+    B = 5
+    sd = procedural_coca_state_dict(a, 3, eos_boost=boost)
+    px = synthetic_pixels(B, a.image_size, seed=3)
+    eng = CaptionerEngine(a, dtype="f32", max_batch=B, max_beams=K, max_len=a.seq_len)
+    eng.load_state_dict(sd)
+    _, embs = R.encode_image(sd, a, px)
+    ref = R.generate_beamsearch_groups(sd, a, px, num_beams=K, num_beam_groups=G, image_embs=embs)
+    out = eng.generate(px.cuda(), num_beams=K, num_beam_groups=G, max_length=a.seq_len, length_penalty=1.0)
+    want, lens = _beam_expected(ref, a.seq_len, a.pad)
+    assert np.array_equal(out["sequences"].cpu().numpy(), want), (out["sequences"].cpu().numpy(), want)
+    assert np.array_equal(out["lengths"].cpu().numpy(), lens)
+    np.testing.assert_allclose(out["sequences_scores"].cpu().numpy(), ref["scores"].numpy(), rtol=0, atol=1e-3)
+    with pytest.raises(CaptionerHipError, match="multiple of num_beam_groups"):
+        eng.generate(px.cuda(), num_beams=K, num_beam_groups=K + 1 if K > 1 else 2, max_length=a.seq_len)
+    eng.close()
+
+
+def test_coca_wrapper_beam_groups_and_bpe_text(tmp_path):
+    """The plugin with the model's own generate() defaults (6 beams, 3 groups) and a CLIP BPE vocabulary next to nothing but a
+    `tokenizer_dir`: captions come back as TEXT without open_clip (reference coca.py:30 `open_clip.decode`)."""
+    from PIL import Image
+    from embodied_captioning_amd.captioner.clip_bpe import vocab_from_merges
+    from embodied_captioning_amd.captioner.utils.utils import Configuration
+    from embodied_captioning_amd.captioner.utils.utils_captioner import select_captioner
+    # a toy vocabulary for the tiny arch (512 ids, sot / eos = 510 / 511) in the HF layout: byte symbols, then the two specials
+    import json
+    sym = vocab_from_merges([])[:510] + ["<start_of_text>", "<end_of_text>"]
+    (tmp_path / "vocab.json").write_text(json.dumps({s_: i for i, s_ in enumerate(sym)}), encoding="utf-8")
+    rng = np.random.default_rng(0)
+    ims = [Image.fromarray(rng.integers(0, 256, size=(40, 52, 3), dtype=np.uint8), "RGB") for _ in range(3)]
+    cfg = Configuration(arch_name="coca", model_name="procedural-coca-tiny:1:4.0", height=224, width=224, dtype="f32", num_beams=6,
+                        num_beam_groups=3, tokenizer_dir=str(tmp_path)).captioner
+    model = select_captioner(cfg).eval()
+    if model.tokenizer is not None:
+        pytest.skip("open_clip is installed: the wrapper uses it")
+    out = model.generate_batch(ims)
+    a = model.arch
+    for text, row, n in zip(out["texts"], out["sequences"].tolist(), out["lengths"].tolist()):
+        body = [t for t in row[:n] if t not in (a.sot, a.eos)]
+        assert text == model.bpe.decode(body)            # cut at <end_of_text>, <start_of_text> dropped (coca.py:30)
+        assert "<start_of_text>" not in text and "<end_of_text>" not in text and len(text) >= len(body)

@@ -126,3 +126,72 @@ def test_save_record_round_trip(tmp_path):
     assert f.endswith("episode_3_step_17.npz")
     back = np.load(f, allow_pickle=True)["arr_0"].item()
     assert back["instances"]["captions"] == inst["captions"] and np.array_equal(back["image"], img)
+
+
+def _toy_bpe(tmp_path):
+    """A small CLIP-style BPE: merge rules in SimpleTokenizer's file format (header line, "left right" pairs)."""
+    merges = [("t", "h"), ("th", "e</w>"), ("c", "a"), ("ca", "t</w>"), ("s", "a"), ("sa", "t</w>"), ("o", "n</w>"),
+              ("m", "a"), ("ma", "t</w>"), ("Ã", "©</w>"), ("c", "a"), ("f", "Ã©</w>")]
+    merges = list(dict.fromkeys(merges))
+    text = "#version: toy\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n"
+    return merges, text
+
+
+def test_clip_bpe_decoder_rebuilds_the_simpletokenizer_vocabulary_and_decodes(tmp_path):
+    """captioner/clip_bpe.py stands in for `open_clip.decode` (reference coca.py:30).  The vocabulary order is SimpleTokenizer's
+    (256 byte symbols, the same + </w>, one symbol per merge, <start_of_text>, <end_of_text>); decoding maps symbols back to
+    bytes, UTF-8 with errors=replace, </w> -> space."""
+    import gzip
+    from embodied_captioning_amd.captioner.clip_bpe import ClipBpeDecoder, bytes_to_unicode, vocab_from_merges
+    b2u = bytes_to_unicode()
+    assert len(b2u) == 256 and len(set(b2u.values())) == 256 and b2u[ord("a")] == "a" and b2u[ord(" ")] == chr(256 + 32)
+    merges, text = _toy_bpe(tmp_path)
+    with gzip.open(tmp_path / "bpe_simple_vocab_16e6.txt.gz", "wt", encoding="utf-8") as f:
+        f.write(text)
+    dec = ClipBpeDecoder.find(str(tmp_path))
+    vocab = vocab_from_merges(merges)
+    assert len(vocab) == 512 + len(merges) + 2 and vocab[-2:] == ["<start_of_text>", "<end_of_text>"]
+    sid = {s: i for i, s in enumerate(vocab)}
+    ids = [sid["<start_of_text>"], sid["the</w>"], sid["cat</w>"], sid["sat</w>"], sid["on</w>"], sid["the</w>"], sid["mat</w>"],
+           sid["c"], sid["a"], sid["fÃ©</w>"], sid["<end_of_text>"], 0, 0]
+    assert dec.decode(ids[:-2]) == "<start_of_text>the cat sat on the mat café <end_of_text>"
+    assert dec.caption(ids) == "the cat sat on the mat café "                  # coca.py:30: cut at EOT, drop SOT (pad = '!' is cut off)
+    assert dec.decode([sid["Ã"]]) == "�"                                    # half a UTF-8 sequence: errors="replace"
+    # the same vocabulary as HF-style vocab.json
+    import json
+    d2 = tmp_path / "hf"
+    d2.mkdir()
+    (d2 / "vocab.json").write_text(json.dumps(sid), encoding="utf-8")
+    assert ClipBpeDecoder.find(None, str(d2 / "model.safetensors")).decode(ids[:-2]) == dec.decode(ids[:-2])
+    (tmp_path / "empty").mkdir()
+    assert ClipBpeDecoder.find(str(tmp_path / "empty"), str(tmp_path / "empty" / "weights.pt")) is None
+
+
+def test_clip_bpe_decoder_agrees_with_the_hf_clip_tokenizer_on_its_own_files(tmp_path):
+    """Third-party pin of the decode algorithm: transformers' CLIPTokenizer built from the same vocab.json + merges.txt decodes
+    the same ids to the same text (it strips the ends and spells the specials <|startoftext|> / <|endoftext|>)."""
+    import json
+    transformers = pytest.importorskip("transformers")
+    from embodied_captioning_amd.captioner.clip_bpe import ClipBpeDecoder, vocab_from_merges
+    merges, text = _toy_bpe(tmp_path)
+    (tmp_path / "merges.txt").write_text(text, encoding="utf-8")
+    vocab = vocab_from_merges(merges, ("<|startoftext|>", "<|endoftext|>"))
+    sid = {s: i for i, s in enumerate(vocab)}
+    (tmp_path / "vocab.json").write_text(json.dumps(sid), encoding="utf-8")
+    try:
+        tok = transformers.CLIPTokenizer(vocab=sid, merges=[tuple(m) for m in merges])         # transformers 5.x signature
+        assert len(tok.get_vocab()) == len(sid)
+    except Exception as e:  # noqa: BLE001
+        pytest.skip(f"CLIPTokenizer cannot be built from a vocabulary in this transformers version: {e!r}")
+    ours = ClipBpeDecoder.from_vocab_json(str(tmp_path / "vocab.json"))
+    ours_m = ClipBpeDecoder.from_merges_file(str(tmp_path / "merges.txt"))
+    words = ["the</w>", "cat</w>", "sat</w>", "on</w>", "mat</w>", "c", "a", "fÃ©</w>", "t", "h", "e</w>"]
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        ids = [sid[words[i]] for i in rng.integers(0, len(words), size=9)]
+        want = tok.decode(ids, skip_special_tokens=False, clean_up_tokenization_spaces=False)
+        assert ours.decode(ids).strip() == want.strip()
+        assert ours_m.decode(ids) == ours.decode(ids)
+    full = [sid["<|startoftext|>"], sid["the</w>"], sid["cat</w>"], sid["<|endoftext|>"]]
+    assert ours.caption(full) == "the cat "
