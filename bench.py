@@ -52,8 +52,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--max-length", type=int, default=20)
-    ap.add_argument("--dtype", default="f32s", choices=["bf16", "f32", "f32s"],
-                    help="f32s (default; token-identical to the fp32 reference) | bf16 (fastest, near-tie token flips) | f32")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32", "f32s"],
+                    help="f32s (token-identical to the fp32 reference; default for blip and blip2) | bf16 (fastest, near-tie token flips; "
+                         "default for coca - SURVEY config 5 names bf16 - and minilm) | f32")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --frames in total, sharded contiguously over the "
                     "ranks (distributed.caption_shard: micro-batches of --batch on the stream pool, ONE caption all-gather at "
                     "the end); value = frames / wall time, scaling = strong")
@@ -359,8 +360,6 @@ def cpu_baseline(sd, arch, L, sample):
 
 def main_coca(a):
     """Extra (non-headline) measurement: CoCa ViT-L/14 at --image-size, batch --batch (default 128 here), top-k(1)."""
-    if a.dtype == "f32s":      # the split mode is built for BLIP; these lines measure the bf16 path
-        a.dtype = "bf16"
     from embodied_captioning_amd.config import CocaArch
     from embodied_captioning_amd.weights import procedural_coca_state_dict
     torch.cuda.set_device(0)
@@ -403,7 +402,7 @@ def main_coca(a):
 def main_minilm(a):
     """Extra (non-headline) measurement: the caption-embedding step (all-MiniLM-L6-v2 shapes) on one batch of --batch
     caption-sized token rows (3..24 tokens), with the CPU restatement timed beside it."""
-    if a.dtype == "f32s":      # the split mode is built for BLIP; these lines measure the bf16 path
+    if a.dtype == "f32s":      # the sentence encoder has no split mode
         a.dtype = "bf16"
     from embodied_captioning_amd.config import MiniLMArch
     from embodied_captioning_amd.engine import TextEncoderEngine
@@ -459,8 +458,6 @@ def main_minilm(a):
 def main_blip2(a):
     """Extra (non-headline) measurement: BLIP-2 OPT-2.7b geometry (the reference's production captioner, blip2.py:19-22),
     batch --batch (default 32 here), greedy, 20 new tokens; seeded weights (3.7 B parameters are drawn on the host first)."""
-    if a.dtype == "f32s":      # the split mode is built for BLIP; these lines measure the bf16 path
-        a.dtype = "bf16"
     from embodied_captioning_amd.config import Blip2Arch
     from embodied_captioning_amd.weights import procedural_blip2_state_dict
     torch.cuda.set_device(0)
@@ -591,6 +588,8 @@ def main_strong(a, arch, sd, dev, rank, world):
 
 def main():
     a = parse()
+    if a.dtype is None:
+        a.dtype = {"blip": "f32s", "blip2": "f32s", "coca": "bf16", "minilm": "bf16"}[a.model]
     if a.model == "coca":
         return main_coca(a)
     if a.model == "blip2":

@@ -40,7 +40,7 @@ class CoCa(CaptioningPredictor):
         self.num_beam_groups = int(g) if g else None
         if self.num_beam_groups and self.num_beams % self.num_beam_groups:
             raise ValueError(f"num_beams ({self.num_beams}) must be a multiple of num_beam_groups ({self.num_beam_groups})")
-        dtype = getattr(cfg, "dtype", None) or "bf16"
+        dtype = getattr(cfg, "dtype", None) or "f32s"      # fp32-grade default (token-identical to the fp32 restatement); "bf16" is ~2x faster
         if int(getattr(cfg, "streams", 1) or 1) > 1:
             logger.warning("captioner.streams > 1 is implemented for arch_name 'blip' only: running one engine")
         self._device = torch.device(getattr(cfg, "device", "cuda:0") or "cuda:0")

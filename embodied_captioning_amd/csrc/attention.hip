@@ -1192,9 +1192,9 @@ __global__ __launch_bounds__(256, 2) void decode_attention_shared_kernel(const T
 // ---- attentional pooler: Q learned queries (already layer-normed and projected on the host, identical for every
 // image) attend over the N image tokens.  One thread per query, K/V tiles broadcast from LDS, online softmax; head_dim is
 // a template parameter (CoCa ViT-L/14: 768 / 8 heads = 96).  ~1 % of the CoCa encoder's flops.
-template <typename T, int HD>
+template <typename T, int HD, typename TO = T>
 __global__ __launch_bounds__(64) void pool_attention_kernel(const float* __restrict__ qp, const T* __restrict__ kv,
-                                                            T* __restrict__ out, int N, int Q, int E, int heads) {
+                                                            TO* __restrict__ out, int N, int Q, int E, int heads) {
     constexpr int KT = 32;
     __shared__ float Ks[KT][HD + 1];
     __shared__ float Vs[KT][HD + 1];
@@ -1229,9 +1229,9 @@ __global__ __launch_bounds__(64) void pool_attention_kernel(const float* __restr
     }
     if (q < Q) {
         const float inv = 1.0f / l;
-        T* op = out + ((size_t)b * Q + q) * E + h * HD;
+        TO* orow = out + ((size_t)b * Q + q) * E;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) op[d] = from_f32<T>(o[d] * inv);
+        for (int d = 0; d < HD; ++d) store1(orow, h * HD + d, o[d] * inv);
     }
 }
 
@@ -1285,11 +1285,11 @@ __global__ __launch_bounds__(64) void text_attention_kernel(const T* __restrict_
 // of 64 queries): lane = query, its q and output rows in registers (HDP = head_dim padded to 32/64/96/128), keys staged 32 at
 // a time into LDS as fp32, online softmax.  causal_off >= 0: query i sees keys j <= i + causal_off.  A correctness-first
 // kernel (VALU dot products); the hot ViT-B/L paths keep their MFMA kernels.
-template <typename T, int HDP>
+template <typename T, int HDP, typename TO = T>
 __global__ __launch_bounds__(64) void generic_attention_kernel(const T* __restrict__ q, long ldq, long qbs,
                                                                const T* __restrict__ k, long ldk, long kbs,
                                                                const T* __restrict__ v, long ldv, long vbs,
-                                                               T* __restrict__ out, long ldo, long obs, int Lq, int Lk,
+                                                               TO* __restrict__ out, long ldo, long obs, int Lq, int Lk,
                                                                int H, int hd, int causal_off, float scale) {
     __shared__ float Ks[32 * HDP], Vs[32 * HDP];
     const int nqb = (Lq + 63) / 64;
@@ -1329,19 +1329,19 @@ __global__ __launch_bounds__(64) void generic_attention_kernel(const T* __restri
     }
     if (live) {
         const float inv = 1.0f / l;
-        T* op = out + (size_t)b * obs + (size_t)qi * ldo + h * hd;
+        TO* orow = out + (size_t)b * obs + (size_t)qi * ldo;          // row base: a multiple of 8 elements for a G8 output
 #pragma unroll
         for (int d = 0; d < HDP; ++d)
-            if (d < hd) op[d] = from_f32<T>(o[d] * inv);
+            if (d < hd) store1(orow, h * hd + d, o[d] * inv);
     }
 }
 
 // One query per (batch, head) against a short history (OPT decode step): lanes = keys for the scores, lanes = head
 // dimensions for the weighted sum; q and the probabilities pass through LDS.
-template <typename T>
+template <typename T, typename TO = T>
 __global__ __launch_bounds__(64) void generic_decode_attention_kernel(const T* __restrict__ q, long qbs, const T* __restrict__ k,
                                                                       long ldk, long kbs, const T* __restrict__ v, long ldv,
-                                                                      long vbs, T* __restrict__ out, long obs, int Lk, int H,
+                                                                      long vbs, TO* __restrict__ out, long obs, int Lk, int H,
                                                                       int hd, float scale) {
     __shared__ float qs[128], ps[1024];
     const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
@@ -1373,7 +1373,7 @@ __global__ __launch_bounds__(64) void generic_decode_attention_kernel(const T* _
     for (int d = lane; d < hd; d += 64) {
         float o = 0.f;
         for (int j = 0; j < Lk; ++j) o = fmaf(ps[j], to_f32(v[(size_t)b * vbs + (size_t)j * ldv + h * hd + d]), o);
-        out[(size_t)b * obs + h * hd + d] = from_f32<T>(o * inv);
+        store1(out + (size_t)b * obs, h * hd + d, o * inv);
     }
 }
 
@@ -1383,9 +1383,9 @@ __global__ __launch_bounds__(64) void generic_decode_attention_kernel(const T* _
 // P.V with a 4-way sum through LDS.  head_dim a multiple of 8, <= 128; past + 1 <= 1024.
 // HD8 = head_dim / 8 when it is known at compile time (10: OPT-2.7b, 8, 16), 0 = any: with a constant trip count a lane's
 // 16-byte loads of a key row are all issued before the first FMA (a runtime loop serialises load -> fma, 10 round trips).
-template <typename T, int HD8>
+template <typename T, int HD8, typename TO = T>
 __global__ __launch_bounds__(64) void opt_decode_attention_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
-                                                                  T* __restrict__ out, int Tw, int H, int hd, int Lmax, int past,
+                                                                  TO* __restrict__ out, int Tw, int H, int hd, int Lmax, int past,
                                                                   float scale) {
     __shared__ float qs[128], ps[1024], os[4][128];
     const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
@@ -1461,7 +1461,7 @@ __global__ __launch_bounds__(64) void opt_decode_attention_kernel(const T* __res
     for (int e = 0; e < 8; ++e) os[jg][dc + e] = o[e];
     __syncthreads();
     const float inv = 1.0f / l;
-    for (int d = lane; d < hd; d += 64) out[(size_t)b * Tw + h * hd + d] = from_f32<T>((os[0][d] + os[1][d] + os[2][d] + os[3][d]) * inv);
+    for (int d = lane; d < hd; d += 64) store1(out + (size_t)b * Tw, h * hd + d, (os[0][d] + os[1][d] + os[2][d] + os[3][d]) * inv);
 }
 
 // OPT decoder inputs.  Prefill: row (b, j) of x[B, P, T] = (j < nq ? projected query (b, j) : token table[bos]) + position
@@ -1506,7 +1506,7 @@ __global__ void rows_broadcast_kernel(const float* __restrict__ src, float* __re
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
         const float x = src[i % ((size_t)n * D)];
         dst_f[i] = x;
-        dst_t[i] = from_f32<T>(x);
+        store1(dst_t + (i - i % D), (int)(i % D), x);
     }
 }
 
@@ -1578,7 +1578,7 @@ int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
         if (N <= 224) return launch_split_kc<7, true>(qkv, ctx, B, N, H, s);
         return launch_split_kc<4, false>(qkv, ctx, B, N, H, s);                  // chunks of 128 keys, online softmax
     }
-    if (out_dtype != dtype && !(dtype == CAP_DT_F32 && out_dtype == CAP_DT_G8 && head_dim == 64 && !causal)) {
+    if (out_dtype != dtype && !(dtype == CAP_DT_F32 && out_dtype == CAP_DT_G8)) {
         cap_set_error("vit_attention: output type %d for input type %d is not supported here", out_dtype, dtype);
         return -1;
     }
@@ -1591,7 +1591,7 @@ int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
         const char* base = (const char*)qkv;
         const size_t e = dtype == CAP_DT_BF16 ? 2 : 4;
         return launch_generic_attention(dtype, base, 3 * D, (long)N * 3 * D, base + D * e, 3 * D, (long)N * 3 * D, base + 2 * D * e,
-                                        3 * D, (long)N * 3 * D, ctx, D, (long)N * D, B, N, N, H, head_dim, causal ? 0 : -1, s);
+                                        3 * D, (long)N * 3 * D, ctx, D, (long)N * D, B, N, N, H, head_dim, causal ? 0 : -1, s, out_dtype);
     }
     const int kb = (N + 31) / 32;
     const bool mfma_ok = dtype == CAP_DT_BF16 && (kb == 1 || kb == 7 || kb == 9 || kb == 19);
@@ -1721,13 +1721,22 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
 
 int launch_generic_attention(int dtype, const void* q, long ldq, long qbs, const void* k, long ldk, long kbs, const void* v,
                              long ldv, long vbs, void* out, long ldo, long obs, int B, int Lq, int Lk, int H, int hd,
-                             int causal_off, hipStream_t s) {
+                             int causal_off, hipStream_t s, int out_dtype) {
     if (hd < 8 || hd > 128 || B < 1 || Lq < 1 || Lk < 1) { cap_set_error("generic_attention: head_dim %d / shape unsupported", hd); return -1; }
+    if (out_dtype < 0) out_dtype = dtype;
+    const bool g8o = out_dtype == CAP_DT_G8;               // split mode: fp32 q / k / v in, the context is the next GEMM's G8 operand
+    if (out_dtype != dtype && !(dtype == CAP_DT_F32 && g8o && ldo % 8 == 0 && obs % 8 == 0)) {
+        cap_set_error("generic_attention: output type %d for input type %d is not supported here", out_dtype, dtype);
+        return -1;
+    }
     const float scale = 1.0f / sqrtf((float)hd);
     if (Lq == 1 && Lk <= 1024 && hd % 8 == 0) {       // decode step: one query per (batch, head)
         if (dtype == CAP_DT_BF16)
             hipLaunchKernelGGL(generic_decode_attention_kernel<bf16_t>, dim3(B * H), dim3(64), 0, s, (const bf16_t*)q, qbs, (const bf16_t*)k,
                                ldk, kbs, (const bf16_t*)v, ldv, vbs, (bf16_t*)out, obs, Lk, H, hd, scale);
+        else if (g8o)
+            hipLaunchKernelGGL((generic_decode_attention_kernel<float, g8_t>), dim3(B * H), dim3(64), 0, s, (const float*)q, qbs, (const float*)k,
+                               ldk, kbs, (const float*)v, ldv, vbs, (g8_t*)out, obs, Lk, H, hd, scale);
         else
             hipLaunchKernelGGL(generic_decode_attention_kernel<float>, dim3(B * H), dim3(64), 0, s, (const float*)q, qbs, (const float*)k,
                                ldk, kbs, (const float*)v, ldv, vbs, (float*)out, obs, Lk, H, hd, scale);
@@ -1736,12 +1745,12 @@ int launch_generic_attention(int dtype, const void* q, long ldq, long qbs, const
     }
     const int hdp = hd <= 32 ? 32 : hd <= 64 ? 64 : hd <= 96 ? 96 : 128;
     const dim3 grid(B * H * ((Lq + 63) / 64));
-#define CAP_GA(TT, HDP)                                                                                                \
-    hipLaunchKernelGGL((generic_attention_kernel<TT, HDP>), grid, dim3(64), 0, s, (const TT*)q, ldq, qbs, (const TT*)k, ldk, \
-                       kbs, (const TT*)v, ldv, vbs, (TT*)out, ldo, obs, Lq, Lk, H, hd, causal_off, scale)
-#define CAP_GA_T(TT)                                                                                                   \
-    do { if (hdp == 32) CAP_GA(TT, 32); else if (hdp == 64) CAP_GA(TT, 64); else if (hdp == 96) CAP_GA(TT, 96); else CAP_GA(TT, 128); } while (0)
-    if (dtype == CAP_DT_BF16) CAP_GA_T(bf16_t); else CAP_GA_T(float);
+#define CAP_GA(TT, HDP, TO)                                                                                            \
+    hipLaunchKernelGGL((generic_attention_kernel<TT, HDP, TO>), grid, dim3(64), 0, s, (const TT*)q, ldq, qbs, (const TT*)k, ldk, \
+                       kbs, (const TT*)v, ldv, vbs, (TO*)out, ldo, obs, Lq, Lk, H, hd, causal_off, scale)
+#define CAP_GA_T(TT, TO)                                                                                               \
+    do { if (hdp == 32) CAP_GA(TT, 32, TO); else if (hdp == 64) CAP_GA(TT, 64, TO); else if (hdp == 96) CAP_GA(TT, 96, TO); else CAP_GA(TT, 128, TO); } while (0)
+    if (dtype == CAP_DT_BF16) CAP_GA_T(bf16_t, bf16_t); else if (g8o) CAP_GA_T(float, g8_t); else CAP_GA_T(float, float);
 #undef CAP_GA_T
 #undef CAP_GA
     CAP_HIP_CHECK(hipGetLastError());
@@ -1749,20 +1758,27 @@ int launch_generic_attention(int dtype, const void* q, long ldq, long qbs, const
 }
 
 int launch_opt_decode_attention(int dtype, const void* qkv, void* kc, void* vc, void* out, int B, int T, int H, int Lmax,
-                                int past, hipStream_t s) {
+                                int past, hipStream_t s, int out_dtype) {
+    if (out_dtype < 0) out_dtype = dtype;
+    if (out_dtype != dtype && !(dtype == CAP_DT_F32 && out_dtype == CAP_DT_G8 && T % 8 == 0)) {
+        cap_set_error("opt_decode_attention: output type %d for input type %d is not supported here", out_dtype, dtype);
+        return -1;
+    }
     const int hd = H > 0 ? T / H : 0;
     if (B < 1 || H < 1 || T % H != 0 || hd % 8 != 0 || hd > 128 || past < 0 || past + 1 > 1024 || past >= Lmax) {
         cap_set_error("opt_decode_attention: unsupported shape T=%d H=%d past=%d Lmax=%d", T, H, past, Lmax);
         return -1;
     }
     const float scale = 1.0f / sqrtf((float)hd);
-#define CAP_ODA(TT, H8)                                                                                                 \
-    hipLaunchKernelGGL((opt_decode_attention_kernel<TT, H8>), dim3(B * H), dim3(64), 0, s, (const TT*)qkv, (TT*)kc, (TT*)vc,  \
-                       (TT*)out, T, H, hd, Lmax, past, scale)
+#define CAP_ODA(TT, H8, TO)                                                                                             \
+    hipLaunchKernelGGL((opt_decode_attention_kernel<TT, H8, TO>), dim3(B * H), dim3(64), 0, s, (const TT*)qkv, (TT*)kc, (TT*)vc,  \
+                       (TO*)out, T, H, hd, Lmax, past, scale)
     if (dtype == CAP_DT_BF16) {
-        if (hd == 80) CAP_ODA(bf16_t, 10); else if (hd == 64) CAP_ODA(bf16_t, 8); else if (hd == 128) CAP_ODA(bf16_t, 16); else CAP_ODA(bf16_t, 0);
+        if (hd == 80) CAP_ODA(bf16_t, 10, bf16_t); else if (hd == 64) CAP_ODA(bf16_t, 8, bf16_t); else if (hd == 128) CAP_ODA(bf16_t, 16, bf16_t); else CAP_ODA(bf16_t, 0, bf16_t);
+    } else if (out_dtype == CAP_DT_G8) {
+        if (hd == 80) CAP_ODA(float, 10, g8_t); else if (hd == 64) CAP_ODA(float, 8, g8_t); else if (hd == 128) CAP_ODA(float, 16, g8_t); else CAP_ODA(float, 0, g8_t);
     } else {
-        if (hd == 80) CAP_ODA(float, 10); else if (hd == 64) CAP_ODA(float, 8); else if (hd == 128) CAP_ODA(float, 16); else CAP_ODA(float, 0);
+        if (hd == 80) CAP_ODA(float, 10, float); else if (hd == 64) CAP_ODA(float, 8, float); else if (hd == 128) CAP_ODA(float, 16, float); else CAP_ODA(float, 0, float);
     }
 #undef CAP_ODA
     CAP_HIP_CHECK(hipGetLastError());
@@ -1791,6 +1807,8 @@ int launch_kv_append(int dtype, const void* qkv, void* kc, void* vc, int B, int 
 int launch_rows_broadcast(int dtype, const float* src, float* dst_f, void* dst_t, int B, int n, int D, hipStream_t s) {
     if (dtype == CAP_DT_BF16)
         hipLaunchKernelGGL(rows_broadcast_kernel<bf16_t>, dim3(256), dim3(256), 0, s, src, dst_f, (bf16_t*)dst_t, B, n, D);
+    else if (dtype == CAP_DT_G8)
+        hipLaunchKernelGGL(rows_broadcast_kernel<g8_t>, dim3(256), dim3(256), 0, s, src, dst_f, (g8_t*)dst_t, B, n, D);
     else
         hipLaunchKernelGGL(rows_broadcast_kernel<float>, dim3(256), dim3(256), 0, s, src, dst_f, (float*)dst_t, B, n, D);
     CAP_HIP_CHECK(hipGetLastError());
@@ -1814,17 +1832,23 @@ int launch_text_attention(int dtype, const void* qkv, const int* lens, void* ctx
 }
 
 int launch_pool_attention(int dtype, const float* qp, const void* kv, void* out, int B, int N, int Q, int E, int heads,
-                          hipStream_t s) {
+                          hipStream_t s, int out_dtype) {
+    if (out_dtype < 0) out_dtype = dtype;
+    if (out_dtype != dtype && !(dtype == CAP_DT_F32 && out_dtype == CAP_DT_G8 && E % 8 == 0)) {
+        cap_set_error("pool_attention: output type %d for input type %d is not supported here", out_dtype, dtype);
+        return -1;
+    }
     const int hd = E / heads;
     if (hd * heads != E || (hd != 64 && hd != 96)) {
         cap_set_error("pool_attention: head_dim %d not supported (64 or 96)", hd);
         return -1;
     }
     dim3 grid(B * heads, (Q + 63) / 64);
-#define CAP_POOL(TT, HDV)                                                                                     \
-    hipLaunchKernelGGL((pool_attention_kernel<TT, HDV>), grid, dim3(64), 0, s, qp, (const TT*)kv, (TT*)out, N, Q, E, heads)
-    if (dtype == CAP_DT_BF16) { if (hd == 64) CAP_POOL(bf16_t, 64); else CAP_POOL(bf16_t, 96); }
-    else { if (hd == 64) CAP_POOL(float, 64); else CAP_POOL(float, 96); }
+#define CAP_POOL(TT, HDV, TO)                                                                                 \
+    hipLaunchKernelGGL((pool_attention_kernel<TT, HDV, TO>), grid, dim3(64), 0, s, qp, (const TT*)kv, (TO*)out, N, Q, E, heads)
+    if (dtype == CAP_DT_BF16) { if (hd == 64) CAP_POOL(bf16_t, 64, bf16_t); else CAP_POOL(bf16_t, 96, bf16_t); }
+    else if (out_dtype == CAP_DT_G8) { if (hd == 64) CAP_POOL(float, 64, g8_t); else CAP_POOL(float, 96, g8_t); }
+    else { if (hd == 64) CAP_POOL(float, 64, float); else CAP_POOL(float, 96, float); }
 #undef CAP_POOL
     CAP_HIP_CHECK(hipGetLastError());
     return 0;

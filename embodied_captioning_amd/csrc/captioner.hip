@@ -579,7 +579,7 @@ int build_blip2(Captioner* m) {
         TRY(walloc(m, &L.w_qkv, (size_t)3 * Q * Q * m->esz));
         TRY(walloc(m, (void**)&L.b_qkv, (size_t)3 * Q * 4));
         for (int j = 0; j < 3; ++j) {
-            add_slot(m, p + "attention.attention." + nm[j] + ".weight", (char*)L.w_qkv + (size_t)j * Q * Q * m->esz, m->dt, Q, Q);
+            add_slot(m, p + "attention.attention." + nm[j] + ".weight", (char*)L.w_qkv + (size_t)j * Q * Q * m->esz, m->gdt, Q, Q);
             add_slot(m, p + "attention.attention." + nm[j] + ".bias", L.b_qkv + (size_t)j * Q, CAP_DT_F32, 1, Q);
         }
         TRY(reg_mat(m, p + "attention.output.dense.weight", &L.w_so, Q, Q));
@@ -592,7 +592,7 @@ int build_blip2(Captioner* m) {
             TRY(walloc(m, &L.w_ckv, (size_t)2 * Q * D * m->esz));
             TRY(walloc(m, (void**)&L.b_ckv, (size_t)2 * Q * 4));
             for (int j = 0; j < 2; ++j) {
-                add_slot(m, p + "crossattention.attention." + nm[j + 1] + ".weight", (char*)L.w_ckv + (size_t)j * Q * D * m->esz, m->dt, Q, D);
+                add_slot(m, p + "crossattention.attention." + nm[j + 1] + ".weight", (char*)L.w_ckv + (size_t)j * Q * D * m->esz, m->gdt, Q, D);
                 add_slot(m, p + "crossattention.attention." + nm[j + 1] + ".bias", L.b_ckv + (size_t)j * Q, CAP_DT_F32, 1, Q);
             }
             TRY(reg_mat(m, p + "crossattention.output.dense.weight", &L.w_co, Q, Q));
@@ -614,8 +614,8 @@ int build_blip2(Captioner* m) {
     // token table twice: fp32 rows for the lookup, compute dtype as the tied LM head
     TRY(walloc(m, (void**)&m->o_tok, (size_t)V * T * 4));
     add_slot(m, lm + "embed_tokens.weight", m->o_tok, CAP_DT_F32, V, T);
-    if (m->dt == CAP_DT_F32) m->o_tok_t = m->o_tok;
-    else { TRY(walloc(m, &m->o_tok_t, (size_t)V * T * m->esz)); add_slot(m, lm + "embed_tokens.weight", m->o_tok_t, m->dt, V, T); }
+    if (m->gdt == CAP_DT_F32) m->o_tok_t = m->o_tok;
+    else { TRY(walloc(m, &m->o_tok_t, (size_t)V * T * m->esz)); add_slot(m, lm + "embed_tokens.weight", m->o_tok_t, m->gdt, V, T); }
     TRY(reg_f32(m, lm + "embed_positions.weight", &m->o_pos, (int64_t)(c.max_pos + 2) * T));
     const size_t Bm = c.max_batch, Lmax = nq + 1 + c.max_len;
     m->ol.resize(c.t_layers);
@@ -626,7 +626,7 @@ int build_blip2(Captioner* m) {
         TRY(walloc(m, &L.w_qkv, (size_t)3 * T * T * m->esz));
         TRY(walloc(m, (void**)&L.b_qkv, (size_t)3 * T * 4));
         for (int j = 0; j < 3; ++j) {
-            add_slot(m, p + "self_attn." + pn[j] + ".weight", (char*)L.w_qkv + (size_t)j * T * T * m->esz, m->dt, T, T);
+            add_slot(m, p + "self_attn." + pn[j] + ".weight", (char*)L.w_qkv + (size_t)j * T * T * m->esz, m->gdt, T, T);
             add_slot(m, p + "self_attn." + pn[j] + ".bias", L.b_qkv + (size_t)j * T, CAP_DT_F32, 1, T);
         }
         TRY(reg_mat(m, p + "self_attn.out_proj.weight", &L.w_o, T, T));
@@ -684,33 +684,34 @@ int run_qformer(Captioner* m, int B, hipStream_t s) {
     const CapConfig& c = m->c;
     const int D = c.v_hidden, Q = c.q_hidden, F = c.q_ffn, H = c.q_heads, nq = c.num_query_tokens, NT = m->NT, R = B * nq, hd = Q / H;
     const size_t e = m->esz;
-    TRY(launch_rows_broadcast(m->dt, m->q_x0, m->qx, m->qx_t, B, nq, Q, s));
+    const int af = m->gdt == CAP_DT_G8 ? 1 : 0;     // split mode: what the attention kernels read (q, k, v) is fp32, only GEMM operands are G8
+    TRY(launch_rows_broadcast(m->gdt, m->q_x0, m->qx, m->qx_t, B, nq, Q, s));
     for (int i = 0; i < c.q_layers; ++i) {
         const QLayer& L = m->ql[i];
-        TRY(gemm(m, s, "qf_gemm_qkv", m->qx_t, Q, L.w_qkv, Q, m->qqkv, 3 * Q, L.b_qkv, nullptr, R, 3 * Q, Q, 0, 0));
+        TRY(gemm(m, s, "qf_gemm_qkv", m->qx_t, Q, L.w_qkv, Q, m->qqkv, 3 * Q, L.b_qkv, nullptr, R, 3 * Q, Q, 0, af));
         {
             ProfScope ps(m, s, "qf_self_attn", 4.0 * B * H * (double)nq * nq * hd, (double)R * 4 * Q * e);
             const char* base = (const char*)m->qqkv;
             TRY(launch_generic_attention(m->dt, base, 3 * Q, (long)nq * 3 * Q, base + Q * e, 3 * Q, (long)nq * 3 * Q, base + 2 * Q * e, 3 * Q,
-                                         (long)nq * 3 * Q, m->qctx, Q, (long)nq * Q, B, nq, nq, H, hd, -1, s));
+                                         (long)nq * 3 * Q, m->qctx, Q, (long)nq * Q, B, nq, nq, H, hd, -1, s, m->gdt));
         }
         TRY(gemm(m, s, "qf_gemm_so", m->qctx, Q, L.w_so, Q, m->qy, Q, L.b_so, m->qx, R, Q, Q, 0, 1));
-        TRY(launch_layernorm(m->dt, m->qy, Q, L.so_g, L.so_b, c.q_eps, m->qx_t, m->qx, R, Q, s));
+        TRY(launch_layernorm(m->gdt, m->qy, Q, L.so_g, L.so_b, c.q_eps, m->qx_t, m->qx, R, Q, s));
         if (L.cross) {
-            TRY(gemm(m, s, "qf_gemm_cq", m->qx_t, Q, L.w_cq, Q, m->qqkv, Q, L.b_cq, nullptr, R, Q, Q, 0, 0));
-            TRY(gemm(m, s, "qf_gemm_ckv", m->emb_t, D, L.w_ckv, D, m->qkvimg, 2 * Q, L.b_ckv, nullptr, B * NT, 2 * Q, D, 0, 0));
+            TRY(gemm(m, s, "qf_gemm_cq", m->qx_t, Q, L.w_cq, Q, m->qqkv, Q, L.b_cq, nullptr, R, Q, Q, 0, af));
+            TRY(gemm(m, s, "qf_gemm_ckv", m->emb_t, D, L.w_ckv, D, m->qkvimg, 2 * Q, L.b_ckv, nullptr, B * NT, 2 * Q, D, 0, af));
             {
                 ProfScope ps(m, s, "qf_cross_attn", 4.0 * B * H * (double)nq * NT * hd, (double)B * NT * 2 * Q * e);
                 const char* kv = (const char*)m->qkvimg;
                 TRY(launch_generic_attention(m->dt, m->qqkv, Q, (long)nq * Q, kv, 2 * Q, (long)NT * 2 * Q, kv + Q * e, 2 * Q, (long)NT * 2 * Q,
-                                             m->qctx, Q, (long)nq * Q, B, nq, NT, H, hd, -1, s));
+                                             m->qctx, Q, (long)nq * Q, B, nq, NT, H, hd, -1, s, m->gdt));
             }
             TRY(gemm(m, s, "qf_gemm_co", m->qctx, Q, L.w_co, Q, m->qy, Q, L.b_co, m->qx, R, Q, Q, 0, 1));
-            TRY(launch_layernorm(m->dt, m->qy, Q, L.co_g, L.co_b, c.q_eps, m->qx_t, m->qx, R, Q, s));
+            TRY(launch_layernorm(m->gdt, m->qy, Q, L.co_g, L.co_b, c.q_eps, m->qx_t, m->qx, R, Q, s));
         }
         TRY(gemm(m, s, "qf_gemm_f1", m->qx_t, Q, L.w_f1, Q, m->qh, F, L.b_f1, nullptr, R, F, Q, 1, 0));
         TRY(gemm(m, s, "qf_gemm_f2", m->qh, F, L.w_f2, F, m->qy, Q, L.b_f2, m->qx, R, Q, F, 0, 1));
-        TRY(launch_layernorm(m->dt, m->qy, Q, L.f_g, L.f_b, c.q_eps, m->qx_t, m->qx, R, Q, s));
+        TRY(launch_layernorm(m->gdt, m->qy, Q, L.f_g, L.f_b, c.q_eps, m->qx_t, m->qx, R, Q, s));
     }
     return 0;
 }
@@ -722,26 +723,27 @@ int run_opt(Captioner* m, int B, int L, int past, hipStream_t s) {
     const int T = c.t_hidden, G = c.t_ffn, H = c.t_heads, hd = T / H, R = B * L;
     const int Lmax = c.num_query_tokens + 1 + c.max_len;
     const size_t e = m->esz;
+    const int af = m->gdt == CAP_DT_G8 ? 1 : 0;     // split mode: q | k | v for the attention kernels and the caches are fp32
     for (int i = 0; i < c.t_layers; ++i) {
         const OLayer& Ly = m->ol[i];
-        TRY(launch_layernorm(m->dt, m->ox, T, Ly.ln1_g, Ly.ln1_b, c.t_eps, m->oh_t, nullptr, R, T, s));
-        TRY(gemm(m, s, "opt_gemm_qkv", m->oh_t, T, Ly.w_qkv, T, m->oqkv, 3 * T, Ly.b_qkv, nullptr, R, 3 * T, T, 0, 0));
+        TRY(launch_layernorm(m->gdt, m->ox, T, Ly.ln1_g, Ly.ln1_b, c.t_eps, m->oh_t, nullptr, R, T, s));
+        TRY(gemm(m, s, "opt_gemm_qkv", m->oh_t, T, Ly.w_qkv, T, m->oqkv, 3 * T, Ly.b_qkv, nullptr, R, 3 * T, T, 0, af));
         TRY(launch_kv_append(m->dt, m->oqkv, Ly.kc, Ly.vc, B, L, T, Lmax, past, s));
         {
             ProfScope ps(m, s, "opt_attn", 4.0 * B * H * (double)L * (past + L) * hd, 2.0 * B * (past + L) * T * e);
             if (past == 0)      // the prompt: causal self-attention over the fused q|k|v rows (MFMA kernel for bf16 heads wider than 64)
-                TRY(launch_vit_attention(m->dt, m->oqkv, m->octx, B, L, H, 0, s, hd, 1));
+                TRY(launch_vit_attention(m->dt, m->oqkv, m->octx, B, L, H, 0, s, hd, 1, m->gdt));
             else
                 TRY(launch_generic_attention(m->dt, m->oqkv, 3 * T, (long)L * 3 * T, Ly.kc, T, (long)Lmax * T, Ly.vc, T, (long)Lmax * T, m->octx, T,
-                                             (long)L * T, B, L, past + L, H, hd, past, s));
+                                             (long)L * T, B, L, past + L, H, hd, past, s, m->gdt));
         }
         TRY(gemm(m, s, "opt_gemm_o", m->octx, T, Ly.w_o, T, m->ox, T, Ly.b_o, m->ox, R, T, T, 0, 1));
-        TRY(launch_layernorm(m->dt, m->ox, T, Ly.ln2_g, Ly.ln2_b, c.t_eps, m->oh_t, nullptr, R, T, s));
+        TRY(launch_layernorm(m->gdt, m->ox, T, Ly.ln2_g, Ly.ln2_b, c.t_eps, m->oh_t, nullptr, R, T, s));
         TRY(gemm(m, s, "opt_gemm_f1", m->oh_t, T, Ly.w_f1, T, m->off, G, Ly.b_f1, nullptr, R, G, T, 2, 0));
         TRY(gemm(m, s, "opt_gemm_f2", m->off, G, Ly.w_f2, G, m->ox, T, Ly.b_f2, m->ox, R, T, G, 0, 1));
     }
     // final LayerNorm of each row's last new position, then the tied LM head (no bias)
-    TRY(launch_layernorm(m->dt, m->ox + (size_t)(L - 1) * T, L * T, m->o_lnf_g, m->o_lnf_b, c.t_eps, m->oh_t, nullptr, B, T, s));
+    TRY(launch_layernorm(m->gdt, m->ox + (size_t)(L - 1) * T, L * T, m->o_lnf_g, m->o_lnf_b, c.t_eps, m->oh_t, nullptr, B, T, s));
     return gemm(m, s, "opt_gemm_vocab", m->oh_t, T, m->o_tok_t, T, m->logits, m->ldl, nullptr, nullptr, B, c.vocab, T, 0, 1);
 }
 
@@ -753,7 +755,8 @@ int run_opt(Captioner* m, int B, int L, int past, hipStream_t s) {
 // (ln == false: bias + act -> out_t) or as slice sums for the reduce+LayerNorm consumer.  Otherwise the tiled split-K GEMM
 // with a reduce kernel.  The choice depends on dtype and (N, K) only - never on the row count.
 int opt_step_gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, const float* bias, int act,
-                  void* out_t, int B, int N, int K, bool ln, int* S_out) {
+                  void* out_t, int B, int N, int K, bool ln, int* S_out, int out_dt) {       // out_dt: type of out_t (split mode:
+                                                                                           // fp32 for q|k|v, G8 for a GEMM operand)
     const int S = m->dt == CAP_DT_BF16 ? skinny_plan(N, K, !ln) : 0;
     if (S >= 1) {
         ProfScope ps(m, s, tag, 2.0 * B * N * K, ((double)B * K + (double)N * K) * 2 + (ln ? (double)S * B * N * 4 : (double)B * N * 2));
@@ -761,7 +764,7 @@ int opt_step_gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, c
         return launch_gemm_skinny(A, K, W, K, bias, act, out_t, N, ln ? m->dpart : nullptr, B, N, K, s) == S ? 0 : -1;
     }
     TRY(gemm_partial(m, s, tag, A, W, m->dpart, B, N, K, 8, S_out));
-    if (!ln) TRY(launch_reduce_bias_act(m->dt, m->dpart, *S_out, bias, out_t, B, N, act, s));
+    if (!ln) TRY(launch_reduce_bias_act(out_dt, m->dpart, *S_out, bias, out_t, B, N, act, s));
     return 0;
 }
 
@@ -773,23 +776,23 @@ int run_opt_step(Captioner* m, int B, int past, hipStream_t s) {
     int S = 1;
     for (int i = 0; i < c.t_layers; ++i) {
         const OLayer& Ly = m->ol[i];
-        TRY(opt_step_gemm(m, s, "opt_gemm_qkv", m->oh_t, Ly.w_qkv, Ly.b_qkv, 0, m->oqkv, B, 3 * T, T, false, &S));
+        TRY(opt_step_gemm(m, s, "opt_gemm_qkv", m->oh_t, Ly.w_qkv, Ly.b_qkv, 0, m->oqkv, B, 3 * T, T, false, &S, m->dt));
         {
             ProfScope ps(m, s, "opt_attn", 4.0 * B * H * (double)(past + 1) * hd, 2.0 * B * (past + 1) * T * e);
             if (hd % 8 == 0 && hd <= 128)
-                TRY(launch_opt_decode_attention(m->dt, m->oqkv, Ly.kc, Ly.vc, m->octx, B, T, H, Lmax, past, s));
+                TRY(launch_opt_decode_attention(m->dt, m->oqkv, Ly.kc, Ly.vc, m->octx, B, T, H, Lmax, past, s, m->gdt));
             else {
                 TRY(launch_kv_append(m->dt, m->oqkv, Ly.kc, Ly.vc, B, 1, T, Lmax, past, s));
                 TRY(launch_generic_attention(m->dt, m->oqkv, 3 * T, 3 * T, Ly.kc, T, (long)Lmax * T, Ly.vc, T, (long)Lmax * T, m->octx, T, T, B, 1,
-                                             past + 1, H, hd, past, s));
+                                             past + 1, H, hd, past, s, m->gdt));
             }
         }
-        TRY(opt_step_gemm(m, s, "opt_gemm_o", m->octx, Ly.w_o, nullptr, 0, nullptr, B, T, T, true, &S));
-        TRY(launch_reduce_layernorm(m->dt, m->dpart, S, Ly.b_o, m->ox, Ly.ln2_g, Ly.ln2_b, c.t_eps, m->oh_t, nullptr, m->ox, B, T, s, true));
-        TRY(opt_step_gemm(m, s, "opt_gemm_f1", m->oh_t, Ly.w_f1, Ly.b_f1, 2, m->off, B, G, T, false, &S));
+        TRY(opt_step_gemm(m, s, "opt_gemm_o", m->octx, Ly.w_o, nullptr, 0, nullptr, B, T, T, true, &S, m->gdt));
+        TRY(launch_reduce_layernorm(m->gdt, m->dpart, S, Ly.b_o, m->ox, Ly.ln2_g, Ly.ln2_b, c.t_eps, m->oh_t, nullptr, m->ox, B, T, s, true));
+        TRY(opt_step_gemm(m, s, "opt_gemm_f1", m->oh_t, Ly.w_f1, Ly.b_f1, 2, m->off, B, G, T, false, &S, m->gdt));
         const bool last = i + 1 == c.t_layers;
-        TRY(opt_step_gemm(m, s, "opt_gemm_f2", m->off, Ly.w_f2, nullptr, 0, nullptr, B, T, G, true, &S));
-        TRY(launch_reduce_layernorm(m->dt, m->dpart, S, Ly.b_f2, m->ox, last ? m->o_lnf_g : m->ol[i + 1].ln1_g,
+        TRY(opt_step_gemm(m, s, "opt_gemm_f2", m->off, Ly.w_f2, nullptr, 0, nullptr, B, T, G, true, &S, m->gdt));
+        TRY(launch_reduce_layernorm(m->gdt, m->dpart, S, Ly.b_f2, m->ox, last ? m->o_lnf_g : m->ol[i + 1].ln1_g,
                                     last ? m->o_lnf_b : m->ol[i + 1].ln1_b, c.t_eps, m->oh_t, nullptr, m->ox, B, T, s, true));
     }
     return gemm(m, s, "opt_gemm_vocab", m->oh_t, T, m->o_tok_t, T, m->logits, m->ldl, nullptr, nullptr, B, c.vocab, T, 0, 1);
@@ -824,7 +827,7 @@ int run_generate_blip2(Captioner* m, const void* pixels, int fmt, int B, int max
             if (done) break;
         }
         TRY(launch_opt_token_inputs(m->seq, Lmax, P + t, m->o_tok, m->o_pos, m->ox, B, T, s));
-        TRY(launch_layernorm(m->dt, m->ox, T, m->ol[0].ln1_g, m->ol[0].ln1_b, c.t_eps, m->oh_t, nullptr, B, T, s));
+        TRY(launch_layernorm(m->gdt, m->ox, T, m->ol[0].ln1_g, m->ol[0].ln1_b, c.t_eps, m->oh_t, nullptr, B, T, s));
         TRY(run_opt_step(m, B, P + t, s));
     }
     hipLaunchKernelGGL(copy_new_tokens_kernel, dim3(64), dim3(256), 0, s, m->seq, Lmax, P, m->lens, out_ids, out_len, B, max_len);
@@ -967,15 +970,17 @@ int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_emb
 int run_coca_pool(Captioner* m, int B, float* tokens_out, hipStream_t s) {
     const CapConfig& c = m->c;
     const int D = c.v_hidden, E = m->E, Q = m->Q, NT = m->NT;
-    TRY(gemm(m, s, "gemm_pool_kv", m->emb_t, D, m->w_pool_kv, D, m->pool_kvbuf, 2 * E, m->b_pool_kv, nullptr, B * NT, 2 * E, D, 0, 0));
+    // split mode: k | v of the pooler are read by the attention kernel as fp32; its context is the out_proj GEMM's G8 operand
+    TRY(gemm(m, s, "gemm_pool_kv", m->emb_t, D, m->w_pool_kv, D, m->pool_kvbuf, 2 * E, m->b_pool_kv, nullptr, B * NT, 2 * E, D, 0,
+             m->gdt == CAP_DT_G8 ? 1 : 0));
     {
         ProfScope ps(m, s, "pool_attention", 4.0 * B * Q * (double)NT * E, (double)B * NT * 2 * E * m->esz);
-        TRY(launch_pool_attention(m->dt, m->pool_q, m->pool_kvbuf, m->pool_ctx, B, NT, Q, E, c.pool_heads, s));
+        TRY(launch_pool_attention(m->dt, m->pool_q, m->pool_kvbuf, m->pool_ctx, B, NT, Q, E, c.pool_heads, s, m->gdt));
     }
     TRY(gemm(m, s, "gemm_pool_o", m->pool_ctx, E, m->w_pool_o, E, m->pool_o, E, m->b_pool_o, nullptr, B * Q, E, E, 0, 1));
     float* tok = tokens_out ? tokens_out : m->img_tokens;
     TRY(launch_layernorm(m->dt, m->pool_o, E, m->lnpost_g, m->lnpost_b, c.v_eps, nullptr, tok, B * Q, E, s));
-    TRY(launch_layernorm(m->dt, tok, E, m->ones, m->zeros, c.v_eps, m->xhat, nullptr, B * Q, E, s));
+    TRY(launch_layernorm(m->gdt, tok, E, m->ones, m->zeros, c.v_eps, m->xhat, nullptr, B * Q, E, s));
     return 0;
 }
 
@@ -1020,7 +1025,10 @@ int decode_splitk(const Captioner* m, int N, int K, int max_S) {
             if (cand <= max_S && nk % cand == 0 && nk / cand >= 3) return cand;
         return 1;
     }
-    const int nk = K / (m->gdt == CAP_DT_BF16 ? 64 : 32), tiles = 4 * ((N + 63) / 64);
+    // nominal row count the grid is sized for: a property of the ARCHITECTURE's deployment (BLIP / CoCa decode a few hundred
+    // rows = images x beams at once; the OPT decoder of BLIP-2 a few dozen), never of the call
+    const int plan_rows = m->c.arch == CAP_ARCH_BLIP2 ? 64 : 256;
+    const int nk = K / (m->gdt == CAP_DT_BF16 ? 64 : 32), tiles = ((plan_rows + 63) / 64) * ((N + 63) / 64);
     for (int cand : {4, 3, 2})
         if (cand <= max_S && nk % cand == 0 && nk / cand >= 4 && tiles * cand <= 256) return cand;
     return 1;
@@ -1140,7 +1148,7 @@ int run_coca_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, int
     const size_t e = m->esz;
     const int nb = (int)m->cb.size();
     // x = tok_emb[token] + pos[t]  (raw sum to d.dx), ln = LayerNorm_{block0.ln_1}(x)
-    TRY(launch_embed(m->dt, tokens, tok_ld, t, m->tok_emb, m->tpos, m->cb[0].ln1_g, m->cb[0].ln1_b, c.t_eps, d.dx_t, nullptr, R, E, s,
+    TRY(launch_embed(m->gdt, tokens, tok_ld, t, m->tok_emb, m->tpos, m->cb[0].ln1_g, m->cb[0].ln1_b, c.t_eps, d.dx_t, nullptr, R, E, s,
                      d.dx));
     for (int bi = 0; bi < nb; ++bi) {
         const CBlock& b = m->cb[bi];
@@ -1153,7 +1161,7 @@ int run_coca_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, int
             TRY(gemm_partial(m, s, "coca_gemm_qkv", d.dx_t, b.w_in, d.dpart, R, 3 * E, E, 4, &S));
             ProfScope ps(m, s, "coca_self_attn", 4.0 * R * H * (t + 1) * 64, 2.0 * R * H * (t + 1) * 64 * e);
             TRY(launch_decode_attention(m->dt, nullptr, kc, vc, anc, Lm, 1, Lm, t + 1, d.dctx, R, H, 0, s, d.dpart, S, b.b_in,
-                                        3 * E, 0, 1));
+                                        3 * E, 0, 1, m->gdt));
         } else {
             TRY(gemm_partial(m, s, "coca_gemm_cq", d.dx_t, b.w_in, d.dpart, R, E, E, 4, &S));
             // cross K/V of multimodal layer i: [k|v][image][head][Q tokens][64]; token 0 (the pooled token) is skipped
@@ -1161,7 +1169,7 @@ int run_coca_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, int
             const char* cv = (char*)m->cross + ((((size_t)b.cross_idx * 2 + 1) * d.Btot + d.b0) * H * Q + 1) * 64 * e;
             ProfScope ps(m, s, "coca_cross_attn", 4.0 * R * H * (Q - 1) * 64, 2.0 * d.B * H * (Q - 1) * 64 * e);
             TRY(launch_decode_attention(m->dt, nullptr, ck, cv, nullptr, 0, K, Q, Q - 1, d.dctx, R, H, 0, s, d.dpart, S, b.b_in, E,
-                                        0, 0));
+                                        0, 0, m->gdt));
         }
         // x += out_proj(ctx) ; ln = LayerNorm_2(x)
         TRY(gemm_splitk_reduce_ln(m, s, d, "coca_gemm_o", d.dctx, b.w_o, b.b_o, b.ln2_g, b.ln2_b, c.t_eps, E, E, d.dx_t, nullptr, d.dx));
@@ -1292,8 +1300,8 @@ static int create_impl(const CapConfig* cfg, Captioner* share, CapHandle* out) {
         cap_set_error("cap_create: unknown dtype");
         return -1;
     }
-    if (cfg->compute_dtype == CAP_F32_SPLIT && cfg->arch != CAP_ARCH_BLIP) {
-        cap_set_error("cap_create: CAP_F32_SPLIT is built for CAP_ARCH_BLIP (the other architectures take CAP_F32 or CAP_BF16)");
+    if (cfg->compute_dtype == CAP_F32_SPLIT && cfg->arch == CAP_ARCH_MINILM) {
+        cap_set_error("cap_create: CAP_F32_SPLIT is built for the captioner architectures (the sentence encoder takes CAP_F32 or CAP_BF16)");
         return -1;
     }
     const bool text_only = cfg->arch == CAP_ARCH_MINILM;

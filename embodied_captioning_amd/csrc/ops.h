@@ -59,14 +59,14 @@ int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
 bool vit_attention_takes_g8(int N);
 int launch_generic_attention(int dtype, const void* q, long ldq, long qbs, const void* k, long ldk, long kbs, const void* v,
                              long ldv, long vbs, void* out, long ldo, long obs, int B, int Lq, int Lk, int H, int hd,
-                             int causal_off, hipStream_t s);
+                             int causal_off, hipStream_t s, int out_dtype = -1);   // out_dtype: see launch_vit_attention
 int launch_opt_prefill_inputs(const float* proj, const float* tok, const float* pos, float* x, int B, int nq, int T, int bos,
                               hipStream_t s);
 int launch_opt_token_inputs(const int* seq, int seq_ld, int cur, const float* tok, const float* pos, float* x, int B, int T,
                             hipStream_t s);
 // decode step of a pre-LN decoder: q|k|v row [B, 3T] -> appends k, v to caches [B][Lmax][T] at `past`, out [B, T]
 int launch_opt_decode_attention(int dtype, const void* qkv, void* kc, void* vc, void* out, int B, int T, int H, int Lmax,
-                                int past, hipStream_t s);
+                                int past, hipStream_t s, int out_dtype = -1);
 int launch_kv_append(int dtype, const void* qkv, void* kc, void* vc, int B, int L, int T, int Lmax, int pos0, hipStream_t s);
 int launch_rows_broadcast(int dtype, const float* src, float* dst_f, void* dst_t, int B, int n, int D, hipStream_t s);
 // single-query decode attention. q [R, H*64] (T).  K/V of row r, head h, position j at
@@ -85,7 +85,7 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
 // attentional pooler (CoCa): fixed projected queries qp fp32 [Q, E] shared by every image; kv (T) [B*N, 2E] with K in
 // columns [0,E) and V in [E,2E); heads of E/heads dims (64 or 96); out (T) [B*Q, E].  scale = 1/sqrt(head_dim).
 int launch_pool_attention(int dtype, const float* qp, const void* kv, void* out, int B, int N, int Q, int E, int heads,
-                          hipStream_t s);
+                          hipStream_t s, int out_dtype = -1);
 
 // ---- gemm_skinny.hip ---------------------------------------------------------------------------
 // Weight-streaming bf16 GEMM for a handful of rows (decode step of a large LM).  skinny_plan: K slices for (N, K) in the

@@ -18,7 +18,7 @@ OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 # "f32s" = CAP_F32_SPLIT: fp32 values carried into every GEMM as two fp16 halves, three fp16 MFMAs per product (fp32-grade
-# products, token-identical to the fp32 reference on the goldens, several times faster than "f32"); BLIP only.
+# products, token-identical to the fp32 reference on the goldens, several times faster than "f32"); BLIP, BLIP-2 and CoCa.
 _DTYPES = {"f32": N.CAP_F32, "fp32": N.CAP_F32, "float32": N.CAP_F32, "bf16": N.CAP_BF16, "bfloat16": N.CAP_BF16,
            "f32s": N.CAP_F32_SPLIT, "split": N.CAP_F32_SPLIT, "f32_split": N.CAP_F32_SPLIT}
 

@@ -46,7 +46,8 @@ enum { CAP_ARCH_BLIP = 0, CAP_ARCH_COCA = 1, CAP_ARCH_MINILM = 2, CAP_ARCH_BLIP2
  *                  hi.hi + hi.lo + lo.hi on the fp16 MFMA pipe: products good to ~2^-21 (fp32: 2^-24, bf16: 2^-9) at 3/16
  *                  of the fp32 pipe's cost; LayerNorm, softmax, attention, residual stream and K/V caches are fp32 as in
  *                  CAP_F32.  Token-identical to the fp32 reference on every golden fixture; the default of the plugin and
- *                  of bench.py.  CAP_ARCH_BLIP only. */
+ *                  of bench.py.  Every captioner architecture (BLIP, BLIP-2, CoCa); not the sentence encoder.  The mode has a
+ *                  finite range - see cap_g8_saturations. */
 enum { CAP_F32 = 0, CAP_BF16 = 1, CAP_F32_SPLIT = 2 };
 enum { CAP_PIX_F32_NCHW = 0, CAP_PIX_U8_NHWC = 1 }; /* normalised fp32 [B,3,H,W] | raw RGB uint8 [B,H,W,3] */
 

@@ -24,12 +24,14 @@ def _padded(text, L, pad):
     return out
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f32s"])
 @pytest.mark.parametrize("boost", [0.0, 4.0])
-def test_coca_tiny_fp32_matches_restatement(boost):
+def test_coca_tiny_fp32_matches_restatement(boost, dtype):
+    """fp32 and the split mode (fp32-grade products on the fp16 MFMA pipe) hold the same bar against the restatement."""
     from embodied_captioning_amd.config import CocaArch
     from oracle import coca_ref as R
     a = CocaArch.tiny()
-    sd, px, eng = _setup(a, 1, boost, 4, "f32")
+    sd, px, eng = _setup(a, 1, boost, 4, dtype)
     pooled, embs = R.encode_image(sd, a, px)
     tok = eng.encode(px.cuda()).cpu()                       # [B, Q, E]: row 0 pooled token (before visual.proj), rows 1.. image_embs
     assert (tok[:, 1:] - embs).abs().max().item() < 2e-4
@@ -92,6 +94,29 @@ def test_coca_vit_l14_full_size_bf16_encoder_and_first_tokens():
     eng.close()
 
 
+def test_coca_vit_l14_full_size_split_mode_unpinned_encoder_and_tokens():
+    """Real coca_ViT-L-14 shapes in the split mode, batch 2: pooled tokens within fp32 tolerance of the restatement (bf16: 0.25),
+    step-0 top-8 logits within 1e-3, greedy tokens over the first steps identical, nothing clamped."""
+    import dataclasses
+    from embodied_captioning_amd.config import CocaArch
+    from oracle import coca_ref as R
+    a = dataclasses.replace(CocaArch(), seq_len=8, min_seq_len=3)
+    sd, px, eng = _setup(a, 0, 2.0, 2, "f32s")
+    _, embs = R.encode_image(sd, a, px)
+    tok = eng.encode(px.cuda()).cpu()
+    err = (tok[:, 1:] - embs).abs().max().item()
+    assert err < 2e-3, err
+    out = eng.generate(px.cuda(), max_length=a.seq_len, output_logits=True)
+    ref = R.generate_top1(sd, a, px, image_embs=tok[:, 1:].contiguous())
+    assert np.array_equal(out["sequences"].cpu().numpy(), _padded(ref["text"], a.seq_len, a.pad))
+    r0 = ref["logits"][0]
+    top = torch.topk(torch.where(torch.isfinite(r0), r0, torch.full_like(r0, -1e30)), 8, dim=-1)
+    ours = torch.gather(out["logits"][0].cpu(), 1, top.indices)
+    assert (ours - top.values).abs().max().item() < 1e-3
+    assert eng.saturations(reset=True) == 0
+    eng.close()
+
+
 def test_coca_vit_l14_336_encoder_bf16():
     """SURVEY.md 8(d) config 5's input size: 336x336 -> 577 tokens (the online-softmax ViT attention kernel), with the
     position table of a 224-pixel checkpoint resized at load the way open_clip's force_image_size does."""
@@ -149,8 +174,9 @@ def _beam_expected(ref, L, pad):
     return want, np.array(lens)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f32s"])
 @pytest.mark.parametrize("boost,K", [(0.0, 5), (4.0, 5), (2.0, 3), (2.0, 1 + 5)])
-def test_coca_beam_search_unpinned_tiny_fp32_matches_restatement(boost, K):
+def test_coca_beam_search_unpinned_tiny_fp32_matches_restatement(boost, K, dtype):
     """Config 5's decode: the reference's `_generate_beamsearch` (coca_model.py:335-482, raw-logit scores, HF's legacy
     BeamSearchScorer, one beam group) on the device against its restatement oracle/coca_ref.generate_beamsearch - UNPINNED:
     neither open_clip nor the scorer (gone from transformers 5) can be run here."""
@@ -162,7 +188,7 @@ def test_coca_beam_search_unpinned_tiny_fp32_matches_restatement(boost, K):
     B = 5
     sd = procedural_coca_state_dict(a, 3, eos_boost=boost)
     px = synthetic_pixels(B, a.image_size, seed=3)
-    eng = CaptionerEngine(a, dtype="f32", max_batch=B, max_beams=K, max_len=a.seq_len)
+    eng = CaptionerEngine(a, dtype=dtype, max_batch=B, max_beams=K, max_len=a.seq_len)
     eng.load_state_dict(sd)
     _, embs = R.encode_image(sd, a, px)
     ref = R.generate_beamsearch(sd, a, px, num_beams=K, image_embs=embs)
