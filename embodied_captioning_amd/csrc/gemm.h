@@ -28,6 +28,7 @@ struct GemmParams {
     int p0, p1, p2, p3;
     const float* aux;
     void* C2;
+    int tile0, tile1;              // set by launch_big2 only: the range of 256 x 256 tiles one launch covers (0, 0 = all)
 };
 
 // dtype: CAP_DT_F32 / CAP_DT_BF16.  tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 256x256 persistent LDS-DMA kernel

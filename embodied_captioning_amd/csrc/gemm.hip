@@ -619,15 +619,18 @@ __device__ __forceinline__ void big2_epilogue(const GemmParams& p, const f32x4 (
 // (Cache-policy A/B on MI355X: non-temporal A loads -5..-20 %, non-temporal C stores within noise - neither kept.)
 // T = g8_t (split fp16): the same pipeline with 32 k values per 64 KiB stage ([hi | lo] chunk pairs) and three MFMAs per
 // product (see Mma<g8_t>); per stage and wave 96 MFMAs against 24 ds_read_b128.
-template <typename T, bool OUT_F32, int EPI, int VAR, bool PROF, int NWM = 2, int NWN = 4>
+// BM = 128: the same kernel on HALF tiles (the upper / lower 128 rows of a 256 x 256 tile; waves 64 x 64 each) - what the
+// launcher runs over the last, partial round of tiles (launch_big2).
+template <typename T, bool OUT_F32, int EPI, int VAR, bool PROF, int NWM = 2, int NWN = 4, int BM = 256>
 __global__ __launch_bounds__(NWM * NWN * 64, NWM * NWN == 8 ? 2 : 1) void gemm_big2_kernel(GemmParams p) {
     using vec = typename Mma<T>::vec;
     // wave grid NWM x NWN over the 256x256 tile: 2x4 = two waves per SIMD, 128x64 each (shipped).  2x2 = one wave per
     // SIMD with 128x128 each (256 accumulator registers, a third less LDS read traffic per flop) measured 7-25 % SLOWER
     // with the compiler's schedule (212 B/lane of scratch at 512 registers), so it is not instantiated.
-    constexpr int BM = 256, BN = 256, NW = NWM * NWN, WM = BM / NWM, WN = BN / NWN, MI = WM / 16, NI = WN / 16;
-    constexpr int PPW = 32 / NW;                         // 8-row DMA pieces of A (and of W) per wave per slab
-    constexpr int EPC = Mma<T>::EPC, STAGE = (BM + BN) * 128;      // 64 KiB
+    constexpr int BN = 256, NW = NWM * NWN, WM = BM / NWM, WN = BN / NWN, MI = WM / 16, NI = WN / 16;
+    constexpr int SUB = 256 / BM;                        // work items per 256-row tile (1, or 2 halves)
+    constexpr int PPA = BM / 8 / NW, PPW = BN / 8 / NW;  // 8-row DMA pieces of A / of W per wave per slab
+    constexpr int EPC = Mma<T>::EPC, STAGE = (BM + BN) * 128;      // 64 KiB (48 KiB for half tiles)
     constexpr int SCHED = VAR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -635,7 +638,11 @@ __global__ __launch_bounds__(NWM * NWN * 64, NWM * NWN == 8 ? 2 : 1) void gemm_b
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave / NWN) * WM, wn0 = (wave % NWN) * WN;
     const int r16 = lane & 15, kg = lane >> 4;
-    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, ntiles = ntm * ntn;
+    // the tile grid is always that of 256 x 256 tiles; this launch covers tiles [tile0, tile1) of it (0, 0 = all), as
+    // (tile1 - tile0) * SUB work items: item x = sub-tile x % SUB of tile tile0 + x / SUB
+    const int ntm = (p.M + 255) / 256, ntn = (p.N + BN - 1) / BN;
+    const int tile0 = p.tile1 > 0 ? p.tile0 : 0;
+    const int ntiles = ((p.tile1 > 0 ? p.tile1 : ntm * ntn) - tile0) * SUB;
     const int nk = p.K / (8 * EPC);
 
     const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
@@ -646,32 +653,39 @@ __global__ __launch_bounds__(NWM * NWN * 64, NWM * NWN == 8 ? 2 : 1) void gemm_b
 
     // issue side of the pipeline: byte pointers (k = 0) of this lane's 4 A and 4 W pieces of the tile being fetched
     const int prow = lane >> 3, ppos = lane & 7;
-    const char* pa[PPW];
+    const char* pa[PPA];
     const char* pb[PPW];
-    auto set_ptrs = [&](int t) {
+    auto set_ptrs = [&](int x) {
+        const int t = tile0 + x / SUB, sub = x % SUB;
         const int tm = t / ntn, tn = t - tm * ntn;
+#pragma unroll
+        for (int j = 0; j < PPA; ++j) {
+            const int row = (wave * PPA + j) * 8 + prow;
+            const int gch = ppos ^ ((row >> 1) & 7);
+            const int ga = min(tm * 256 + sub * BM + row, p.M - 1);
+            pa[j] = (const char*)((const T*)p.A + (size_t)ga * p.lda + gch * EPC);
+        }
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             const int row = (wave * PPW + j) * 8 + prow;
             const int gch = ppos ^ ((row >> 1) & 7);
-            const int ga = min(tm * BM + row, p.M - 1), gb = min(tn * BN + row, p.N - 1);
-            pa[j] = (const char*)((const T*)p.A + (size_t)ga * p.lda + gch * EPC);
+            const int gb = min(tn * BN + row, p.N - 1);
             pb[j] = (const char*)((const T*)p.W + (size_t)gb * p.ldw + gch * EPC);
         }
     };
     auto issue = [&](int kt, char* stage) {
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-            const int rowbase = (wave * PPW + j) * 8;
-            __builtin_amdgcn_global_load_lds(CAP_GPTR(pa[j] + (size_t)kt * 128), CAP_LPTR(stage + rowbase * 128), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(CAP_GPTR(pb[j] + (size_t)kt * 128), CAP_LPTR(stage + BM * 128 + rowbase * 128), 16, 0, 0);
+            if (j < PPA)
+                __builtin_amdgcn_global_load_lds(CAP_GPTR(pa[j] + (size_t)kt * 128), CAP_LPTR(stage + (wave * PPA + j) * 8 * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(pb[j] + (size_t)kt * 128), CAP_LPTR(stage + BM * 128 + (wave * PPW + j) * 8 * 128), 16, 0, 0);
         }
     };
     char* bias_lds = smem + 2 * STAGE;
     const bool has_bias = EPI != EPI_PARTIAL && p.bias != nullptr;
-    auto issue_bias = [&](int t, int slot) {
+    auto issue_bias = [&](int x, int slot) {
         if (has_bias && wave == 0) {
-            const int tn = t % ntn;
+            const int tn = (tile0 + x / SUB) % ntn;
             const float* sb = p.bias + min(tn * BN + lane * 4, p.N - 4);
             __builtin_amdgcn_global_load_lds(CAP_GPTR(sb), CAP_LPTR(bias_lds + slot * 1024), 16, 0, 0);
         }
@@ -693,8 +707,9 @@ __global__ __launch_bounds__(NWM * NWN * 64, NWM * NWN == 8 ? 2 : 1) void gemm_b
     if (itile < c1) { set_ptrs(itile); issue_bias(itile, 0); issue(0, smem); advance(); }
 
     for (; tile < c1; tile += nl, ++tcount) {
-        const int tm = tile / ntn, tn = tile - tm * ntn;
-        const int m0 = tm * BM, n0 = tn * BN;
+        const int ft = tile0 + tile / SUB;
+        const int tm = ft / ntn, tn = ft - tm * ntn;
+        const int m0 = tm * 256 + (tile % SUB) * BM, n0 = tn * BN;
         f32x4 acc[MI][NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -1109,13 +1124,33 @@ int launch_big3(const GemmParams& p, hipStream_t stream) {
     return 0;
 }
 
+// Tiles go round-robin over one workgroup per CU.  When the last round is at most half full, its tiles are cut into their
+// upper and lower 128 rows and run as a second launch of the half-tile instantiation on twice as many workgroups: the cut is
+// along M, so every output element is the same sum as before (bit-identical: tests/test_split_gpu.py), and the tail round costs
+// ~0.7 of a tile time instead of a whole one (a half tile moves 48 KiB per stage for half the MFMAs: it runs at the LDS-DMA fill
+// rate).  ViT-B/16 at batch 256: 197 x 3 tiles of N = 768 over 256 CUs are 2.31 rounds - 3 before, ~2.7 now (fc2 -10 %, proj -6 %).
 template <typename T, bool OUT_F32, int EPI, int VAR, bool PROF, int NWM = 2, int NWN = 4>
 int launch_big2(const GemmParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * 512 * 128 + 2 * 1024 + 8 * 16 * 144;   // two stages + bias ping-pong + epilogue strips
+    constexpr int LDS_H = 2 * 384 * 128 + 2 * 1024 + 8 * 16 * 144;
     auto kern = gemm_big2_kernel<T, OUT_F32, EPI, VAR, PROF, NWM, NWN>;
     int n_cu = 0;
     if (cap_kernel_setup((const void*)kern, LDS, &n_cu) != 0) return -1;
     const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const int rounds = ntiles / n_cu, tail = ntiles - rounds * n_cu;
+    if constexpr (NWM * NWN == 8 && !PROF) {
+        if (rounds >= 1 && tail > 0 && 2 * tail <= n_cu) {
+            auto kern_h = gemm_big2_kernel<T, OUT_F32, EPI, VAR, PROF, NWM, NWN, 128>;
+            if (cap_kernel_setup((const void*)kern_h, LDS_H, nullptr) != 0) return -1;
+            GemmParams q = p;
+            q.tile0 = 0; q.tile1 = rounds * n_cu;
+            hipLaunchKernelGGL(kern, dim3(n_cu), dim3(NWM * NWN * 64), LDS, stream, q);
+            q.tile0 = rounds * n_cu; q.tile1 = ntiles;
+            hipLaunchKernelGGL(kern_h, dim3(2 * tail), dim3(NWM * NWN * 64), LDS_H, stream, q);
+            CAP_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
     const int grid = ntiles < n_cu ? ntiles : n_cu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWM * NWN * 64), LDS, stream, p);
     CAP_HIP_CHECK(hipGetLastError());

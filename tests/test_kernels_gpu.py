@@ -383,3 +383,29 @@ def test_lds_dma_gemm_kernels_match_generic_kernel_bitwise(lib):
                 out = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
                 run(tile, out)
                 assert torch.equal(out, ref), (M, N, K, tile)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("tile", [2, 3, 4, 5, 6])
+def test_gemm_partial_row_tile_writes_nothing_outside_c(lib, dtype, tile):
+    """Round 1's unexplained GEMM fault showed a wrong result on the LDS-DMA tile at M = 197 (one partial row tile) right
+    before the abort - the signature of an out-of-bounds WRITE.  C sits between two canary bands here (and the bias vector at
+    the very end of its allocation); after the launch the bands must be untouched and C must be right."""
+    M, N, K = 197, 768, 768
+    tag, tdt = DT[dtype]
+    if tile == 6 and dtype == "f32":
+        pytest.skip("the rows kernel is a bf16 / split kernel")
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g).to(tdt).cuda()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(tdt).cuda()
+    pad = 64 * N
+    buf = torch.full((pad + M * N + pad,), 12345.0, dtype=torch.float32, device="cuda")
+    Cv = buf[pad: pad + M * N].view(M, N)
+    bias_store = torch.zeros(4096 + N, device="cuda")
+    bias = bias_store[4096:]
+    bias.copy_(torch.randn(N, generator=g))
+    _check(lib, lib.cap_op_gemm(tag, _p(A), _p(W), _p(bias), _p(None), _p(Cv), M, N, K, 0, 1, tile, _stream()))
+    torch.cuda.synchronize()
+    assert (buf[:pad] == 12345.0).all() and (buf[pad + M * N:] == 12345.0).all()
+    ref = A.double().cpu() @ W.double().cpu().T + bias.double().cpu()
+    assert (Cv.cpu().double() - ref).abs().max().item() < 2e-4 * math.sqrt(K / 64)
