@@ -11,6 +11,8 @@
 //  decode_attention    one new query per (row, head) against cached keys (self-attention cache with per-position
 //                      ancestor indirection for beams, or the beam-shared cross-attention cache). HBM-bound:
 //                      8 lanes x 16 B cover one 128-byte key row, 8 keys per wave-instruction.
+#include <algorithm>
+
 #include "ops.h"
 
 namespace {
@@ -870,14 +872,40 @@ template <> struct Raw8<bf16_t> {
     bf16x8 r;
     __device__ __forceinline__ void load(const bf16_t* p) { r = *(const bf16x8*)p; }
     __device__ __forceinline__ void load_nt(const bf16_t* p) { r = __builtin_nontemporal_load((const bf16x8*)p); }
+    __device__ __forceinline__ void load_row(const void* base, size_t ri, int dch) { load((const bf16_t*)base + ri * 64 + dch * 8); }
+    __device__ __forceinline__ void load_row_nt(const void* base, size_t ri, int dch) { load_nt((const bf16_t*)base + ri * 64 + dch * 8); }
     __device__ __forceinline__ void zero() { for (int i = 0; i < 8; ++i) r[i] = (bf16_t)0.f; }
     __device__ __forceinline__ float get(int i) const { return (float)r[i]; }
     __device__ __forceinline__ void set(int i, float x) { r[i] = (bf16_t)x; }
+};
+// KV24 (common.h): eight head dimensions dch * 8 .. + 7 of a 192-byte row = 16 bytes of upper halves + 8 bytes of third bytes
+// -> eight fp32 values, one v_perm_b32 each.  Raw8<T>::load_row(base, ri, dch) reads those eight dimensions of the 64-wide KV
+// row `ri` of a cache of element type T (the other specialisations: plain typed rows).
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <> struct Raw8<kv24_t> {
+    u32x4_t hi; unsigned int lo0, lo1;
+    __device__ __forceinline__ void load_row(const void* base, size_t ri, int dch) {
+        const char* row = (const char*)base + ri * KV24_ROW;
+        hi = *(const u32x4_t*)(row + dch * 16);
+        const uint2 l = *(const uint2*)(row + 128 + dch * 8);
+        lo0 = l.x; lo1 = l.y;
+    }
+    __device__ __forceinline__ void load_row_nt(const void* base, size_t ri, int dch) { load_row(base, ri, dch); }
+    __device__ __forceinline__ void zero() { hi = 0u; lo0 = lo1 = 0u; }
+    __device__ __forceinline__ float get(int i) const {
+        const unsigned int w = hi[i >> 1], l = (i < 4) ? lo0 : lo1;
+        // result bytes: [0, third byte, upper half low byte, upper half high byte]; v_perm_b32: selector 0-3 = bytes of the
+        // second operand, 4-7 = bytes of the first, 0x0c = zero
+        const unsigned int sel = ((i & 1) ? 0x07060000u : 0x05040000u) | ((unsigned)(i & 3) << 8) | 0x0cu;
+        return __uint_as_float(__builtin_amdgcn_perm(w, l, sel));
+    }
 };
 template <> struct Raw8<float> {
     f32x4 a, b;
     __device__ __forceinline__ void load(const float* p) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
     __device__ __forceinline__ void load_nt(const float* p) { load(p); }
+    __device__ __forceinline__ void load_row(const void* base, size_t ri, int dch) { load((const float*)base + ri * 64 + dch * 8); }
+    __device__ __forceinline__ void load_row_nt(const void* base, size_t ri, int dch) { load_row(base, ri, dch); }
     __device__ __forceinline__ void zero() { a = 0.f; b = 0.f; }
     __device__ __forceinline__ float get(int i) const { return i < 4 ? a[i] : b[i - 4]; }
     __device__ __forceinline__ void set(int i, float x) { if (i < 4) a[i] = x; else b[i - 4] = x; }
@@ -982,7 +1010,7 @@ __global__ __launch_bounds__(256, 3) void decode_attention_wave_kernel(const T* 
 // walked in chunks of 64 keys.  A chunk's 8 K loads and 8 V loads (16 B per lane, one 128-byte key row per 8 lanes)
 // are all issued into raw registers before any arithmetic; with ~4 waves per SIMD that keeps >100 KB in flight per
 // CU, which is what streaming the beam-shared K/V cache at HBM rate needs.  Online softmax across chunks (fp32).
-template <typename T, int G, bool DB, bool NT = false, typename TO = T>
+template <typename T, int G, bool DB, bool NT = false, typename TO = T, typename TKV = T>      // TKV: element type of the K/V cache
 __global__ __launch_bounds__(256, 3) void decode_attention_online_kernel(const T* __restrict__ q, const T* __restrict__ kbase,
                                                                       const T* __restrict__ vbase,
                                                                       const int* __restrict__ anc, int anc_ld,
@@ -1004,21 +1032,21 @@ __global__ __launch_bounds__(256, 3) void decode_attention_online_kernel(const T
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
 
-    auto issue = [&](Raw8<T>(&kr)[G], Raw8<T>(&vr)[G], int k0) {
+    auto issue = [&](Raw8<TKV>(&kr)[G], Raw8<TKV>(&vr)[G], int k0) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int key = k0 + g * 8 + ksub;
             if (key < n_keys) {
                 const int src = anc ? anc[(size_t)row * anc_ld + key] : src0;
-                const size_t off = (((size_t)src * H + h) * kv_ld + key) * 64 + dch * 8;
-                if constexpr (NT) { kr[g].load_nt(kbase + off); vr[g].load_nt(vbase + off); }
-                else { kr[g].load(kbase + off); vr[g].load(vbase + off); }
+                const size_t ri = ((size_t)src * H + h) * kv_ld + key;
+                if constexpr (NT) { kr[g].load_row_nt(kbase, ri, dch); vr[g].load_row_nt(vbase, ri, dch); }
+                else { kr[g].load_row(kbase, ri, dch); vr[g].load_row(vbase, ri, dch); }
             } else {
                 kr[g].zero(); vr[g].zero();
             }
         }
     };
-    auto consume = [&](const Raw8<T>(&kr)[G], const Raw8<T>(&vr)[G], int k0) {
+    auto consume = [&](const Raw8<TKV>(&kr)[G], const Raw8<TKV>(&vr)[G], int k0) {
         float sc[G], cm = -INFINITY;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -1047,10 +1075,10 @@ __global__ __launch_bounds__(256, 3) void decode_attention_online_kernel(const T
 
     Part8 pq;
     if (qs.part) pq.issue(qs, R, row, qs.col0 + h * 64 + dch * 8);
-    Raw8<T> ka[G], va[G];
+    Raw8<TKV> ka[G], va[G];
     issue(ka, va, 0);
     if constexpr (DB) {
-        Raw8<T> kb[G], vb[G];
+        Raw8<TKV> kb[G], vb[G];
         if (CH < n_keys) issue(kb, vb, CH);
         if (qs.part) pq.finish<T>(qs, qv); else load8<T>(q + (size_t)row * Dh + h * 64 + dch * 8, qv);
 #pragma unroll
@@ -1092,7 +1120,7 @@ __global__ __launch_bounds__(256, 3) void decode_attention_online_kernel(const T
 // one wave per (image, head) streams the block once and serves all NB query rows from the same registers - with one wave per
 // (row, head) the NB rows each pull the block through L2 (CoCa 336, 5 beams: 500 MB of L2 traffic per launch, 81 us).  Chunking
 // (G) and the per-row operation order are those of decode_attention_online_kernel: a row's result has the same bits.
-template <typename T, int G, int NB, typename TO = T>
+template <typename T, int G, int NB, typename TO = T, typename TKV = T>
 __global__ __launch_bounds__(256, 2) void decode_attention_shared_kernel(const T* __restrict__ q, const T* __restrict__ kbase,
                                                                       const T* __restrict__ vbase, int kv_ld, int n_keys,
                                                                       TO* __restrict__ out, int n_img, int H, QSource qs,
@@ -1113,14 +1141,14 @@ __global__ __launch_bounds__(256, 2) void decode_attention_shared_kernel(const T
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[b][e] = 0.f;
     }
-    Raw8<T> kr[G], vr[G];
+    Raw8<TKV> kr[G], vr[G];
     auto issue = [&](int k0) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int key = k0 + g * 8 + ksub;
             if (key < n_keys) {
-                const size_t off = (((size_t)img * H + h) * kv_ld + key) * 64 + dch * 8;
-                kr[g].load(kbase + off); vr[g].load(vbase + off);
+                const size_t ri = ((size_t)img * H + h) * kv_ld + key;
+                kr[g].load_row(kbase, ri, dch); vr[g].load_row(vbase, ri, dch);
             } else {
                 kr[g].zero(); vr[g].zero();
             }
@@ -1626,8 +1654,12 @@ int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
 int launch_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             hipStream_t s, const float* q_part, int q_S, const float* q_bias, int q_ld, int q_col0,
-                            int append_kv, int out_dtype, const int* skip_rows) {
+                            int append_kv, int out_dtype, const int* skip_rows, int kv24) {
     if (out_dtype < 0) out_dtype = dtype;
+    if (kv24 && !(dtype == CAP_DT_F32 && impl == 0 && !anc && !append_kv && n_keys > 32)) {
+        cap_set_error("decode_attention: a KV24 cache is the split / fp32 modes' cross-attention cache (no ancestry, > 32 keys)");
+        return -1;
+    }
     if (out_dtype != dtype && !(dtype == CAP_DT_F32 && out_dtype == CAP_DT_G8 && impl == 0)) {
         cap_set_error("decode_attention: output type %d for input type %d is not supported here", out_dtype, dtype);
         return -1;
@@ -1664,19 +1696,21 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
     // beams of an image over its shared block (cross-attention, no ancestry): one wave per (image, head) for all beams
     if (impl == 0 && !anc && ng8 > 4 && rows_per_kv >= 2 && rows_per_kv <= 5 && R % rows_per_kv == 0 && !append_kv) {
         const int n_img = R / rows_per_kv;
-#define CAP_DA_SHARED(TT, GG, NBB, TOO)                                                                                 \
-    hipLaunchKernelGGL((decode_attention_shared_kernel<TT, GG, NBB, TOO>), dim3((n_img * H + 3) / 4), dim3(256), 0, s,     \
+#define CAP_DA_SHARED(TT, GG, NBB, TOO, TKK)                                                                            \
+    hipLaunchKernelGGL((decode_attention_shared_kernel<TT, GG, NBB, TOO, TKK>), dim3((n_img * H + 3) / 4), dim3(256), 0, s, \
                        (const TT*)q, (const TT*)kbase, (const TT*)vbase, kv_ld, n_keys, (TOO*)out, n_img, H, qs, skip_rows)
-#define CAP_DA_SHARED_NB(TT, GG, TOO)                                                                                   \
+#define CAP_DA_SHARED_NB(TT, GG, TOO, TKK)                                                                              \
     switch (rows_per_kv) {                                                                                             \
-        case 2: CAP_DA_SHARED(TT, GG, 2, TOO); break;                                                                  \
-        case 3: CAP_DA_SHARED(TT, GG, 3, TOO); break;                                                                  \
-        case 4: CAP_DA_SHARED(TT, GG, 4, TOO); break;                                                                  \
-        default: CAP_DA_SHARED(TT, GG, 5, TOO); break;                                                                 \
+        case 2: CAP_DA_SHARED(TT, GG, 2, TOO, TKK); break;                                                             \
+        case 3: CAP_DA_SHARED(TT, GG, 3, TOO, TKK); break;                                                             \
+        case 4: CAP_DA_SHARED(TT, GG, 4, TOO, TKK); break;                                                             \
+        default: CAP_DA_SHARED(TT, GG, 5, TOO, TKK); break;                                                            \
     }
-        if (dtype == CAP_DT_BF16) CAP_DA_SHARED_NB(bf16_t, 5, bf16_t)
-        else if (out_dtype == CAP_DT_G8) CAP_DA_SHARED_NB(float, 7, g8_t)
-        else CAP_DA_SHARED_NB(float, 7, float)
+        if (dtype == CAP_DT_BF16) CAP_DA_SHARED_NB(bf16_t, 5, bf16_t, bf16_t)
+        else if (out_dtype == CAP_DT_G8 && kv24) CAP_DA_SHARED_NB(float, 7, g8_t, kv24_t)
+        else if (out_dtype == CAP_DT_G8) CAP_DA_SHARED_NB(float, 7, g8_t, float)
+        else if (kv24) CAP_DA_SHARED_NB(float, 7, float, kv24_t)
+        else CAP_DA_SHARED_NB(float, 7, float, float)
 #undef CAP_DA_SHARED_NB
 #undef CAP_DA_SHARED
         CAP_HIP_CHECK(hipGetLastError());
@@ -1689,13 +1723,22 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
         } else if (out_dtype == CAP_DT_G8) {      // split mode: fp32 caches, the context row is the next GEMM's G8 operand
             if (ng8 <= 1) CAP_DA_WAVE_O(float, 1, g8_t); else if (ng8 <= 2) CAP_DA_WAVE_O(float, 2, g8_t);
             else if (ng8 <= 4) CAP_DA_WAVE_O(float, 4, g8_t);
+            else if (kv24)
+                hipLaunchKernelGGL((decode_attention_online_kernel<float, 7, false, false, g8_t, kv24_t>), dim3((R * H + 3) / 4), dim3(256), 0,
+                                   s, (const float*)q, (const float*)kbase, (const float*)vbase, anc, anc_ld, rows_per_kv, kv_ld,
+                                   n_keys, (g8_t*)out, R, H, qs, skip_rows);
             else
                 hipLaunchKernelGGL((decode_attention_online_kernel<float, 7, false, false, g8_t>), dim3((R * H + 3) / 4), dim3(256), 0,
                                    s, (const float*)q, (const float*)kbase, (const float*)vbase, anc, anc_ld, rows_per_kv, kv_ld,
                                    n_keys, (g8_t*)out, R, H, qs, skip_rows);
         } else {
             if (ng8 <= 1) CAP_DA_WAVE(float, 1); else if (ng8 <= 2) CAP_DA_WAVE(float, 2);
-            else if (ng8 <= 4) CAP_DA_WAVE(float, 4); else CAP_DA_ONLINE(float, false);
+            else if (ng8 <= 4) CAP_DA_WAVE(float, 4);
+            else if (kv24)
+                hipLaunchKernelGGL((decode_attention_online_kernel<float, 7, false, false, float, kv24_t>), dim3((R * H + 3) / 4), dim3(256), 0,
+                                   s, (const float*)q, (const float*)kbase, (const float*)vbase, anc, anc_ld, rows_per_kv, kv_ld,
+                                   n_keys, (float*)out, R, H, qs, skip_rows);
+            else CAP_DA_ONLINE(float, false);
         }
         CAP_HIP_CHECK(hipGetLastError());
         return 0;
@@ -1715,6 +1758,21 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
         hipLaunchKernelGGL(decode_attention_kernel<float>, grid, dim3(256), lds, s, (const float*)q,
                            (const float*)kbase, (const float*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys,
                            (float*)out, H);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+__global__ void pack_kv24_kernel(const float* __restrict__ src, char* __restrict__ dst, size_t n_rows) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows * 16; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i >> 4;
+        const int d = (int)(i & 15) * 4;
+        const float4 v = *(const float4*)(src + r * 64 + d);
+        kv24_store4(dst + r * KV24_ROW, d, v.x, v.y, v.z, v.w);
+    }
+}
+int launch_pack_kv24(const float* src, void* dst, size_t n_rows, hipStream_t s) {
+    const int grid = (int)std::min<size_t>((n_rows * 16 + 255) / 256, 4096);
+    hipLaunchKernelGGL(pack_kv24_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, src, (char*)dst, n_rows);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }

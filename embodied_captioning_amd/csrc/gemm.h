@@ -28,6 +28,7 @@ struct GemmParams {
     int p0, p1, p2, p3;
     const float* aux;
     void* C2;
+    int kv24;                      // EPI_CROSSKV with an fp32 output: 1 = pack the K/V rows as KV24 (common.h) instead of fp32
     int tile0, tile1;              // set by launch_big2 only: the range of 256 x 256 tiles one launch covers (0, 0 = all)
 };
 

@@ -109,6 +109,9 @@ __device__ __forceinline__ void epi_store4(const GemmParams& p, int row, int col
         }
     }
     if constexpr (OUT_F32) {
+        if constexpr (EPI == EPI_CROSSKV) {
+            if (p.kv24) { kv24_store4((char*)base + (o >> 6) * KV24_ROW, (int)(o & 63), v[0], v[1], v[2], v[3]); return; }
+        }
         *(f32x4*)((float*)base + o) = v;
     } else if constexpr (is_g8<T>) {
         static_assert(!is_g8<T> || EPI == EPI_STORE || EPI == EPI_PARTIAL, "G8 output exists for plain row-major stores only");
@@ -529,6 +532,9 @@ __device__ __forceinline__ void epi_store_f32(const GemmParams& p, int row, int 
     }
     void* base;
     const size_t o = epi_offset<EPI>(p, row, col, base);
+    if constexpr (EPI == EPI_CROSSKV) {
+        if (p.kv24) { kv24_store4((char*)base + (o >> 6) * KV24_ROW, (int)(o & 63), v[0], v[1], v[2], v[3]); return; }
+    }
     *(f32x4*)((float*)base + o) = v;
 }
 

@@ -217,7 +217,10 @@ int cap_op_gemm_skinny(const void* A, const void* W, const float* bias, int act,
 int cap_op_gemm_skinny_slices(int N, int K, int finished);
 int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int32_t* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
-                            void* stream);
+                            void* stream);        /* impl | 16: kbase / vbase are KV24 caches (no ancestry, > 32 keys) */
+/* The split mode's cross-attention K/V cache layout: fp32 rows [n_rows, 64] -> KV24 rows of 192 bytes (64 x the upper 16 bits of
+ * the value rounded to 24 bits | 64 x its third byte) - what the cross-K/V GEMM's epilogue writes in CAP_F32_SPLIT. */
+int cap_op_pack_kv24(const float* src, void* dst, size_t n_rows, void* stream);
 /* The candidate selection of a beam step alone (first step: running score 0 for beam 0 of an item, -1e9 for the others):
  * logits fp32 [B*K][ld] -> the 2K best (score, token) per row, best first, ties to the lower token id; legacy_raw: scores are
  * raw logits + running score (CoCa), else log-softmax + running score (HF v5); masked_id >= 0: that token scores -inf (legacy

@@ -318,3 +318,58 @@ def test_split_mode_counts_the_activations_it_clamps(lib):
     eng.generate(px.cuda(), max_length=meta["max_length"])
     assert eng.saturations(reset=True) == 0
     eng.close()
+
+
+@gpu
+@pytest.mark.parametrize("dtype", [0, SPLIT])
+@pytest.mark.parametrize("n_keys,beams", [(197, 1), (197, 3), (255, 5), (577, 1), (40, 2)])
+def test_kv24_cross_attention_cache_is_the_rounded_fp32_cache_bit_for_bit(lib, dtype, n_keys, beams):
+    """The split mode's cross-attention K/V cache is KV24: the value rounded to its upper 24 bits, 3 bytes per element (192-byte
+    head rows = 64 upper halves | 64 third bytes).  (1) the pack kernel writes exactly round-to-nearest of the fp32 bits; (2) the
+    decode attention kernels on a KV24 cache give the SAME BITS as on an fp32 cache holding the rounded values - one row per
+    block (greedy) and the shared-block kernel (2-5 beams); (3) against the unrounded values the context moves by ~2^-17."""
+    Bimg, H, kv_ld = 3, 2, n_keys + 3
+    R = Bimg * beams
+    g = torch.Generator().manual_seed(n_keys + beams)
+    q = torch.randn(R, H * 64, generator=g)
+    K = torch.randn(Bimg, H, kv_ld, 64, generator=g)
+    V = torch.randn(Bimg, H, kv_ld, 64, generator=g) * torch.logspace(-3, 2, 64)          # five decades: the format keeps fp32's range
+    rows = Bimg * H * kv_ld
+
+    def pack(x):
+        d = torch.zeros(rows * 192, dtype=torch.uint8, device="cuda")
+        _check(lib, lib.cap_op_pack_kv24(_p(x.cuda().contiguous()), _p(d), rows, _stream()))
+        return d
+
+    def rounded(x):
+        b = x.contiguous().view(torch.int32)
+        return (((b + 0x80) >> 8) << 8).view(torch.float32)
+
+    Kp, Vp = pack(K), pack(V)
+    torch.cuda.synchronize()
+    # (1) layout: upper halves then third bytes, per row
+    raw = Vp.cpu().numpy().reshape(rows, 192)
+    bits = (rounded(V).view(torch.int32).numpy().astype(np.uint32).reshape(rows, 64)) >> 8
+    assert np.array_equal(raw[:, :128].view(np.uint16), (bits >> 8).astype(np.uint16))
+    assert np.array_equal(raw[:, 128:], (bits & 0xFF).astype(np.uint8))
+    # (2) same bits as the fp32 cache of rounded values
+    Kr, Vr = rounded(K).cuda(), rounded(V).cuda()
+    qd = q.cuda()
+    out24 = torch.full((R, H * 64), float("nan"), dtype=torch.float32, device="cuda")
+    out32 = torch.full((R, H * 64), float("nan"), dtype=torch.float32, device="cuda")
+    _check(lib, lib.cap_op_decode_attention(dtype, _p(qd), _p(Kp), _p(Vp), None, 0, beams, kv_ld, n_keys, _p(out24), R, H, 16, _stream()))
+    _check(lib, lib.cap_op_decode_attention(dtype, _p(qd), _p(Kr), _p(Vr), None, 0, beams, kv_ld, n_keys, _p(out32), R, H, 0, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out24.view(torch.int32), out32.view(torch.int32))
+    # (3) distance to the unrounded cache
+    outx = torch.empty_like(out32)
+    Kd, Vd = K.cuda(), V.cuda()
+    _check(lib, lib.cap_op_decode_attention(dtype, _p(qd), _p(Kd), _p(Vd), None, 0, beams, kv_ld, n_keys, _p(outx), R, H, 0, _stream()))
+    torch.cuda.synchronize()
+    a = torch.from_numpy(g8_decode(out24.cpu().numpy())) if dtype == SPLIT else out24.cpu()
+    b = torch.from_numpy(g8_decode(outx.cpu().numpy())) if dtype == SPLIT else outx.cpu()
+    assert (a - b).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item())
+    # a KV24 cache with an ancestry table or a short history is refused
+    anc = torch.zeros(R, kv_ld, dtype=torch.int32, device="cuda")
+    assert lib.cap_op_decode_attention(dtype, _p(qd), _p(Kp), _p(Vp), _p(anc), kv_ld, 1, kv_ld, n_keys, _p(out24), R, H, 16, _stream()) != 0
+    assert b"KV24" in lib.cap_last_error()
