@@ -310,7 +310,9 @@ def pmc_summary(dtype):
         for k, v in d.items():
             if re.search(pat, k) and "hbm_read_bytes_corrected" in v:
                 w = v["launches_per_pass"]
-                n += w
+                # a Linear layer whose last tile round is cut runs as TWO launches (256-row tiles, then the 128-row halves of the
+                # tail round): bytes and cycles of both count, the layer counts once
+                n += 0 if (cls == "enc_gemm" and re.search(r", 128>|Li128E", k)) else w
                 b += w * (v["hbm_read_bytes_corrected"] + v.get("hbm_write_bytes", 0.0))
                 busy += w * v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
                 act += w * v.get("GRBM_GUI_ACTIVE", 0.0)
@@ -350,11 +352,13 @@ def cpu_baseline(sd, arch, L, sample):
             ts.append(time.perf_counter() - t0)
         med = statistics.median(ts)
         runs[name] = {"frames": n, "captions_per_s": round(n / med, 3), "median_s": round(med, 3), "runs_s": [round(t, 3) for t in ts]}
-    big = runs[f"batch_{sample}_frames"]
-    return {"value": big["captions_per_s"], "unit": "captions/s", "cores": host_cores(), "torch_threads": torch.get_num_threads(),
+    big, small = runs[f"batch_{sample}_frames"], runs["config1_8_frames"]
+    best = max(big, small, key=lambda r: r["captions_per_s"])       # the CPU's better figure is the baseline (small batches fit its caches)
+    return {"value": best["captions_per_s"], "unit": "captions/s", "cores": host_cores(), "torch_threads": torch.get_num_threads(),
             "os_cpu_count": os.cpu_count(), "cpu_model": cpu_model(), "kind": "port",
-            "sample": f"{sample} frames 224x224, encoder + greedy max_length={L}, fp32, oracle/blip_ref.py on {torch.get_num_threads()} threads: "
-                      f"1 warm-up + median of 5 runs ({big['median_s']} s); config 1 (8 frames) timed the same way",
+            "sample": f"config 1 (8 frames) and {sample} frames 224x224, encoder + greedy max_length={L}, fp32, oracle/blip_ref.py on "
+                      f"{torch.get_num_threads()} threads: 1 warm-up + median of 5 runs each; value = the better of the two "
+                      f"({best['frames']} frames, median {best['median_s']} s)",
             "runs": runs}, out
 
 

@@ -1145,7 +1145,9 @@ int launch_big2(const GemmParams& p, hipStream_t stream) {
     const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int rounds = ntiles / n_cu, tail = ntiles - rounds * n_cu;
     if constexpr (NWM * NWN == 8 && !PROF) {
-        if (rounds >= 1 && tail > 0 && 2 * tail <= n_cu) {
+        // only where a round is a large share of the launch: with many rounds (fc1: 9 + a 0.23 tail, cross-K/V: 55) the second
+        // launch's boundary and ramp cost what the shorter tail saves (measured: fc1 688 -> 699 us with the cut, fc2 683 -> 613)
+        if (rounds >= 1 && rounds <= 4 && tail > 0 && 2 * tail <= n_cu) {
             auto kern_h = gemm_big2_kernel<T, OUT_F32, EPI, VAR, PROF, NWM, NWN, 128>;
             if (cap_kernel_setup((const void*)kern_h, LDS_H, nullptr) != 0) return -1;
             GemmParams q = p;

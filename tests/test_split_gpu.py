@@ -76,11 +76,11 @@ def test_split_gemm_is_fp32_grade(lib, tile, shape):
 
 
 @gpu
-@pytest.mark.parametrize("shape", [(520, 768, 768), (66000, 768, 192), (40000, 3072, 64)])
+@pytest.mark.parametrize("shape", [(520, 768, 768), (66000, 768, 192), (17000, 3072, 64)])
 def test_split_gemm_tiles_are_bit_identical(lib, shape):
     """Batch invariance: the tile shape follows the row count, so every tile shape must produce the same bits.  The two large
-    shapes have a last round of 256 x 256 tiles that is less than half full on 256 CUs (774 = 3 x 256 + 6 and 1884 = 7 x 256 +
-    92 tiles): the LDS-DMA kernel runs those tiles as 128-row halves in a second launch (launch_big2) - same bits."""
+    shapes have a last round of 256 x 256 tiles that is less than half full on 256 CUs (774 = 3 x 256 + 6 and 804 = 3 x 256 +
+    36 tiles): the LDS-DMA kernel runs those tiles as 128-row halves in a second launch (launch_big2) - same bits."""
     M, N, K = shape
     g = torch.Generator().manual_seed(3)
     Ad, Wd = _g8(torch.randn(M, K, generator=g)), _g8(torch.randn(N, K, generator=g) / math.sqrt(K), G8_WSCALE)
