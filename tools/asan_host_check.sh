@@ -9,7 +9,7 @@ mkdir -p "$B"
 CLANG=/opt/rocm/lib/llvm/bin/clang
 FLAGS="-O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -fsanitize=address -fno-gpu-sanitize -fno-omit-frame-pointer"
 pids=()
-for f in captioner gemm gemm_skinny elementwise attention beam preprocess decode_xcd; do
+for f in captioner gemm gemm_skinny elementwise attention beam preprocess; do
   hipcc $FLAGS -c "$ROOT/embodied_captioning_amd/csrc/$f.hip" -o "$B/$f.o" & pids+=($!)
   if [ ${#pids[@]} -ge 4 ]; then wait "${pids[0]}"; pids=("${pids[@]:1}"); fi
 done
