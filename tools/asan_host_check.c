@@ -33,8 +33,10 @@ int main(void) {
     EXPECT(cap_create(&c, &h) != 0 && strstr(cap_last_error(), "unknown arch"));
     c = blip_cfg(); c.compute_dtype = 9;
     EXPECT(cap_create(&c, &h) != 0 && strstr(cap_last_error(), "dtype"));
-    c = blip_cfg(); c.arch = CAP_ARCH_COCA;                     /* split mode is BLIP only */
+    c = blip_cfg(); c.arch = CAP_ARCH_COCA;                     /* CoCa without its pooler / multimodal geometry */
     EXPECT(cap_create(&c, &h) != 0);
+    c = blip_cfg(); c.arch = CAP_ARCH_MINILM; c.t_heads = 2;    /* the sentence encoder has no split mode */
+    EXPECT(cap_create(&c, &h) != 0 && strstr(cap_last_error(), "CAP_F32_SPLIT"));
     c = blip_cfg(); c.v_heads = 3;                              /* head_dim != 64 */
     EXPECT(cap_create(&c, &h) != 0 && strstr(cap_last_error(), "head_dim"));
     c = blip_cfg(); c.max_beams = 99;
@@ -58,6 +60,7 @@ int main(void) {
     EXPECT(cap_load_weight(NULL, "x", w, 0, 2, shape, NULL) != 0);
     EXPECT(cap_finalize_weights(NULL) != 0);
     EXPECT(cap_destroy(NULL) == 0);
+    EXPECT(cap_generate_groups(NULL, w, 0, 1, 6, 3, 8, 1.0f, NULL, NULL, NULL, NULL) != 0);
     EXPECT(cap_set_early_exit(NULL, 2) != 0);
     EXPECT(cap_last_decode_steps(NULL) == -1);
     EXPECT(cap_device_bytes(NULL) == 0);
