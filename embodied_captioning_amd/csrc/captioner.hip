@@ -1032,7 +1032,7 @@ int decode_splitk(const Captioner* m, int N, int K, int max_S) {
     // rows = images x beams at once; the OPT decoder of BLIP-2 a few dozen), never of the call
     const int plan_rows = m->c.arch == CAP_ARCH_BLIP2 ? 64 : 256;
     const int nk = K / (m->gdt == CAP_DT_BF16 ? 64 : 32), tiles = ((plan_rows + 63) / 64) * ((N + 63) / 64);
-    for (int cand : {4, 3, 2})
+    for (int cand : {8, 6, 5, 4, 3, 2})      // (> 4 only where the caller allows it: the OPT decoder's weight streams at a few dozen rows)
         if (cand <= max_S && nk % cand == 0 && nk / cand >= 4 && tiles * cand <= 256) return cand;
     return 1;
 }

@@ -975,7 +975,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big3_kernel(GemmParams p) {
 //     the common epilogue (scale / bias / GELU / G8 or fp32 or split-K slab) as whole 256-byte rows.
 // Block ids: XCD-aware remap, row tile fastest (see gemm_kernel).  T = g8_t (32 k per slab, 3 MFMAs per product) or bf16
 // (64 k per slab).
-template <typename T, bool OUT_F32, int EPI>
+// AP = 8-row pieces of A a slab brings in: 8 (64 rows), 4 or 2 when the launch has at most 32 / 16 rows in all (one image, a
+// few dozen rows of the OPT decoder): the rows beyond M are clamped duplicates whose traffic - as much as the W tile's - and
+// MFMAs would be wasted.  A row's sums are the same for every AP (same slabs, same order): batch invariance is not touched.
+template <typename T, bool OUT_F32, int EPI, int AP = 8>
 __global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmParams p) {
     using vec = typename Mma<T>::vec;
     constexpr bool G8 = is_g8<T>;
@@ -1016,13 +1019,14 @@ __global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmParams p) {
         pa[q] = (const char*)((const T*)p.A + (size_t)ga * p.lda + (size_t)kz * (p.K / S) + gch * EPC);
         pb[q] = (const char*)((const T*)p.W + (size_t)gb * p.ldw + (size_t)kz * (p.K / S) + gch * EPC);
     }
-    auto issue = [&](int kt, char* buf) {                  // 16 DMA instructions: the slab's 16 KiB
+    auto issue = [&](int kt, char* buf) {                  // 8 + AP DMA instructions: the slab's W rows and its live A rows
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            __builtin_amdgcn_global_load_lds(CAP_GPTR(pa[q] + (size_t)kt * 128), CAP_LPTR(buf + q * 1024), 16, 0, 0);
+            if (q < AP) __builtin_amdgcn_global_load_lds(CAP_GPTR(pa[q] + (size_t)kt * 128), CAP_LPTR(buf + q * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(CAP_GPTR(pb[q] + (size_t)kt * 128), CAP_LPTR(buf + 64 * 128 + q * 1024), 16, 0, 0);
         }
     };
+    constexpr int MIA = (AP + 1) / 2;                      // 16-row blocks of A that hold rows of the problem
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -1035,8 +1039,13 @@ __global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmParams p) {
     if (n > 1) issue(wave + 4, ring + BUF);
     for (int t = 0; t < n; ++t) {
         // the wave's own DMA is all that writes its ring: slab t has landed once at most the next slab's 16 pieces are open
-        if (t + 1 < n) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t + 1 < n) {
+            if constexpr (AP == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if constexpr (AP == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         const char* a_s = ring + (t & 1) * BUF;
         const char* b_s = a_s + 64 * 128;
         if constexpr (G8) {
@@ -1047,7 +1056,7 @@ __global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmParams p) {
                 bl[j] = *(const vec*)(b_s + swz_off(j * 16 + r16, 2 * kg + 1));
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < MIA; ++i) {
                 ah[i] = *(const vec*)(a_s + swz_off(i * 16 + r16, 2 * kg));
                 al[i] = *(const vec*)(a_s + swz_off(i * 16 + r16, 2 * kg + 1));
             }
@@ -1055,7 +1064,7 @@ __global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmParams p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (t + 2 < n) issue(wave + 4 * (t + 2), ring + (t & 1) * BUF);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MIA; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
@@ -1069,14 +1078,14 @@ __global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     bf[ks][j] = *(const vec*)(b_s + swz_off(j * 16 + r16, ks * 4 + kg));
-                    af[ks][j] = *(const vec*)(a_s + swz_off(j * 16 + r16, ks * 4 + kg));
+                    if (j < MIA) af[ks][j] = *(const vec*)(a_s + swz_off(j * 16 + r16, ks * 4 + kg));
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (t + 2 < n) issue(wave + 4 * (t + 2), ring + (t & 1) * BUF);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MIA; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
@@ -1104,16 +1113,22 @@ __global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmParams p) {
     }
 }
 
-template <typename T, bool OUT_F32, int EPI>
-int launch_rows(const GemmParams& p, hipStream_t stream) {
+template <typename T, bool OUT_F32, int EPI, int AP>
+int launch_rows_ap(const GemmParams& p, hipStream_t stream) {
     constexpr int LDS = 4 * 2 * 128 * 128;               // four wave-private rings of two 16 KiB slabs
-    auto kern = gemm_rows_kernel<T, OUT_F32, EPI>;
+    auto kern = gemm_rows_kernel<T, OUT_F32, EPI, AP>;
     if (cap_kernel_setup((const void*)kern, LDS, nullptr) != 0) return -1;
     const int S = EPI == EPI_PARTIAL ? p.splitk : 1;
     const int grid = ((p.M + 63) / 64) * ((p.N + 63) / 64) * S;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, p);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
+}
+template <typename T, bool OUT_F32, int EPI>
+int launch_rows(const GemmParams& p, hipStream_t stream) {
+    if (p.M <= 16) return launch_rows_ap<T, OUT_F32, EPI, 2>(p, stream);
+    if (p.M <= 32) return launch_rows_ap<T, OUT_F32, EPI, 4>(p, stream);
+    return launch_rows_ap<T, OUT_F32, EPI, 8>(p, stream);
 }
 
 template <bool OUT_F32, int EPI, int SCHED = 0>

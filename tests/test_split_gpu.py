@@ -113,7 +113,7 @@ def test_split_gemm_gelu_into_g8_output(lib, tile):
 @gpu
 @pytest.mark.parametrize("dtype", ["f32s", "bf16"])
 @pytest.mark.parametrize("shape", [(256, 768, 768, 4), (256, 2304, 768, 1), (256, 768, 3072, 4), (37, 768, 768, 3), (640, 768, 768, 2),
-                                   (5, 200, 384, 1), (256, 768, 768, 6)])
+                                   (5, 200, 384, 1), (256, 768, 768, 6), (32, 2560, 2560, 4), (20, 768, 3072, 2), (16, 768, 768, 4)])
 def test_decode_rows_kernel_split_k_slices_and_row_invariance(lib, dtype, shape):
     """The decode GEMM kernel (tile 6: 64x64 tile, the block's K range split over its four waves, partial tiles summed in wave
     order): split-K slices sum to the fp64 product of the original operands; and a row's sums do not depend on how many rows
