@@ -580,6 +580,132 @@ __global__ __launch_bounds__(256, 1) void vit_attention_f32_mfma(const float* __
 
 
 // ------------------------------------------------------------------------------------------------
+// The same exact-product fp32 MFMA attention for heads of ANY width up to 96 (a multiple of 8: BLIP-2's ViT-g/14 has 88) and
+// any token count: K and V of such a head do not fit in LDS whole (257 keys x 88 dims x 4 B x 2 = 181 KB), so the keys are
+// walked in chunks of KC blocks of 32 with an online softmax across chunks (running maximum, denominator and rescaled context -
+// the arithmetic of vit_attention_split's chunked mode).  A workgroup = one (image, head, group of 4 query tiles), one 32-query
+// tile per wave whose state (m, l, O) lives in registers; the K / V chunk is shared by the 4 waves (KC = 3: 2 x 96 rows x 100
+// floats = 77 KB, two workgroups per CU).  V columns beyond the head width are zero in LDS (the third 32-wide block of O is
+// partly padding and is not stored).  fp32 q | k | v in (what the qkv GEMM writes in fp32 mode, and in split mode when the head is
+// not 64 wide), context out as fp32 or G8.  Replaces the VALU kernel generic_attention_kernel for the ViT tower: BLIP-2 OPT-2.7b
+// geometry, 32 frames: 45 ms of ViT-g attention per generate before.
+template <int KC, int NDB, typename TO>
+__global__ __launch_bounds__(256, 2) void vit_attention_f32_mfma_wide(const float* __restrict__ qkv, TO* __restrict__ ctx, int N, int H,
+                                                                      int HD, int QG) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NPC = KC * 32, PITCH = NDB * 32 + 4;    // floats per K / V row in LDS (conflict-free ds_read_b128 as with 68)
+    float* Ks = (float*)smem;
+    float* Vs = Ks + NPC * PITCH;
+    const int qg = blockIdx.x % QG, bh = blockIdx.x / QG, b = bh / H, h = bh % H;
+    const int D = H * HD, ld = 3 * D, nks = HD >> 3, nch = HD >> 2;
+    const int tid = threadIdx.x, lane = tid & 63, r32 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* base = qkv + (size_t)b * N * ld + h * HD;
+    const int nqt = (N + 31) / 32, nkb = nqt;
+    const float c1 = LOG2E / sqrtf((float)HD);
+
+    const int qt = qg * 4 + wave;                         // this wave's query tile (past the end: it still helps to fill the chunk)
+    const bool live = qt < nqt;
+    const int q = qt * 32 + r32, qc = min(q, N - 1);
+    f32x4 qf[12];                                         // up to 96 dims: k-step ks covers dims 8 ks .. 8 ks + 7 (4 per lane half)
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks)
+        qf[ks] = ks < nks ? *(const f32x4*)(base + (size_t)qc * ld + (2 * ks + hh) * 4) : f32x4(0.f);
+    float m = -INFINITY, l = 0.f;
+    f32x16 o[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
+
+    for (int c0 = 0; c0 < nkb; c0 += KC) {
+        if (c0 > 0) __syncthreads();                      // every wave is done with the previous chunk
+        for (int i = tid; i < NPC * (PITCH / 4); i += 256) {
+            const int row = i / (PITCH / 4), ch = i - row * (PITCH / 4);
+            f32x4 kv = 0.f, vv = 0.f;
+            if (ch < nch) {
+                const float* src = base + (size_t)min(c0 * 32 + row, N - 1) * ld + ch * 4;
+                kv = *(const f32x4*)(src + D);
+                vv = *(const f32x4*)(src + 2 * D);
+            }
+            *(f32x4*)(Ks + row * PITCH + ch * 4) = kv;
+            *(f32x4*)(Vs + row * PITCH + ch * 4) = vv;    // zero beyond the head width: the padding columns of O stay 0
+        }
+        __syncthreads();
+        if (!live) continue;
+        f32x16 s[KC];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[kc][e] = 0.f;
+            if (c0 + kc < nkb) {
+#pragma unroll
+                for (int ks = 0; ks < 12; ++ks) {
+                    if (ks < nks) {
+                        const f32x4 a = *(const f32x4*)(Ks + (kc * 32 + r32) * PITCH + (2 * ks + hh) * 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s[kc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], qf[ks][j], s[kc], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // scores of this chunk for query column r32: key(kc, e) = (c0 + kc) * 32 + (e & 3) + 8 (e >> 2) + 4 hh
+        float cm = -INFINITY;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = (c0 + kc) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (key >= N) s[kc][e] = -INFINITY;       // padding keys and key blocks past the end
+                cm = fmaxf(cm, s[kc][e]);
+            }
+        cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+        const float mn = fmaxf(m, cm);
+        const float alpha = __builtin_amdgcn_exp2f((m - mn) * c1);      // first chunk: exp2(-inf) = 0 and l, o are 0
+        l *= alpha;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+        m = mn;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pe = __builtin_amdgcn_exp2f((s[kc][e] - mn) * c1);
+                s[kc][e] = pe;
+                l += pe;
+            }
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            if (c0 + kc >= nkb) continue;                 // (its probabilities are all zero)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kc * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * PITCH + db * 32 + r32], s[kc][e], o[db], 0, 0, 0);
+                if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (live && q < N) {
+        const float inv = 1.0f / l;
+        TO* op = ctx + ((size_t)b * N + q) * D;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = db * 32 + 8 * g + 4 * hh;       // 4 consecutive dims; HD % 4 == 0: inside or outside together
+                if (d0 < HD)
+                    store4(op, h * HD + d0, make_float4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Split-fp16 ViT attention (CAP_F32_SPLIT): q|k|v arrive as G8 (the qkv GEMM writes its output that way), both matrix
 // products run on the fp16 MFMA pipe as hi.lo + lo.hi + hi.hi (common.h), softmax in fp32, context out as G8.  Dataflow of
 // vit_attention_mfma: S^T = K.Q^T (a lane owns a query column), O^T = V^T.P^T with P taken from the S^T accumulators.
@@ -1591,6 +1717,23 @@ int launch_f32_mfma_kb(const void* qkv, void* ctx, int B, int N, int H, hipStrea
 
 }  // namespace
 
+template <typename TO>
+int launch_f32_mfma_wide(const void* qkv, void* ctx, int B, int N, int H, int hd, hipStream_t s) {
+    const int nqt = (N + 31) / 32, QG = (nqt + 3) / 4;
+    const int ndb = (hd + 31) / 32;
+    const int lds = 2 * 3 * 32 * (ndb * 32 + 4) * 4;
+#define CAP_WIDE(NDBB)                                                                                                \
+    do {                                                                                                               \
+        auto kern = vit_attention_f32_mfma_wide<3, NDBB, TO>;                                                          \
+        if (cap_kernel_setup((const void*)kern, lds, nullptr) != 0) return -1;                                          \
+        hipLaunchKernelGGL(kern, dim3(B * H * QG), dim3(256), lds, s, (const float*)qkv, (TO*)ctx, N, H, hd, QG);          \
+    } while (0)
+    if (ndb == 1) CAP_WIDE(1); else if (ndb == 2) CAP_WIDE(2); else CAP_WIDE(3);
+#undef CAP_WIDE
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 bool vit_attention_takes_g8(int N) { return N >= 1; }     // any token count: the keys are walked in chunks
 
 int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, hipStream_t s, int head_dim, int causal,
@@ -1613,6 +1756,11 @@ int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
     if (head_dim > 64 && head_dim <= 128 && head_dim % 8 == 0 && dtype == CAP_DT_BF16 && impl != 1) {
         if ((N + 31) / 32 == 9) return launch_flash_wide<9, 5>(qkv, ctx, B, N, H, head_dim, causal, s);   // ViT-g/14 of BLIP-2: 88-wide heads, 257 tokens
         if (N <= 64) return launch_flash_wide<2, 2>(qkv, ctx, B, N, H, head_dim, causal, s);               // OPT prefill: 80-wide heads, 33 positions, causal
+    }
+    if (dtype == CAP_DT_F32 && !causal && impl != 1 && head_dim != 64 && head_dim % 8 == 0 && head_dim <= 96) {
+        // exact-product fp32 MFMA attention for wide heads (BLIP-2's ViT-g: 88), keys in chunks; fp32 or G8 context
+        return out_dtype == CAP_DT_G8 ? launch_f32_mfma_wide<g8_t>(qkv, ctx, B, N, H, head_dim, s)
+                                      : launch_f32_mfma_wide<float>(qkv, ctx, B, N, H, head_dim, s);
     }
     if (head_dim != 64 || causal) {   // any other width / length, or a causal mask at width 64: generic kernel over the fused qkv rows
         const long D = (long)H * head_dim;

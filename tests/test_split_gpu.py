@@ -373,3 +373,28 @@ def test_kv24_cross_attention_cache_is_the_rounded_fp32_cache_bit_for_bit(lib, d
     anc = torch.zeros(R, kv_ld, dtype=torch.int32, device="cuda")
     assert lib.cap_op_decode_attention(dtype, _p(qd), _p(Kp), _p(Vp), _p(anc), kv_ld, 1, kv_ld, n_keys, _p(out24), R, H, 16, _stream()) != 0
     assert b"KV24" in lib.cap_last_error()
+
+
+@gpu
+@pytest.mark.parametrize("dtype", [0, SPLIT])
+@pytest.mark.parametrize("N,hd", [(257, 88), (33, 80), (100, 96), (197, 40), (300, 72), (31, 8)])
+def test_wide_head_fp32_mfma_attention_fp32_and_g8_context(lib, dtype, N, hd):
+    """Heads that are not 64 wide in the fp32 / split modes (BLIP-2's ViT-g/14: 88 at 257 tokens): the exact-product fp32 MFMA
+    kernel with the keys walked in chunks of 96 and an online softmax, fp32 q | k | v in, context out as fp32 (CAP_F32) or G8
+    (CAP_F32_SPLIT) - against a float64 reference and against the VALU kernel (impl 1) on the same inputs."""
+    B, H = 2, 3
+    g = torch.Generator().manual_seed(N * 7 + hd)
+    qkv = torch.randn(B * N, 3 * H * hd, generator=g) * 1.5
+    qd = qkv.cuda()
+    a = torch.full((B * N, H * hd), float("nan"), dtype=torch.float32, device="cuda")
+    b = torch.full_like(a, float("nan"))
+    _check(lib, lib.cap_op_vit_attention_hd(dtype, _p(qd), _p(a), B, N, H, hd, 0, _stream()))
+    _check(lib, lib.cap_op_vit_attention_hd(dtype, _p(qd), _p(b), B, N, H, hd, 1, _stream()))
+    torch.cuda.synchronize()
+    x = qkv.double().view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    sc = (x[0] @ x[1].transpose(-1, -2)) / hd ** 0.5
+    ref = (torch.softmax(sc, -1) @ x[2]).permute(0, 2, 1, 3).reshape(B * N, H * hd)
+    dec = (lambda t: torch.from_numpy(g8_decode(t.cpu().numpy()))) if dtype == SPLIT else (lambda t: t.cpu())
+    assert torch.isfinite(dec(a)).all()
+    assert (dec(a).double() - ref).abs().max().item() < 2e-5
+    assert (dec(a) - dec(b)).abs().max().item() < 2e-5
