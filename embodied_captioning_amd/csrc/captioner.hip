@@ -1568,7 +1568,7 @@ int cap_generate_groups(CapHandle h, const void* pixels, int pixel_fmt, int B, i
 long long cap_g8_saturations(int reset) {
     if (hipDeviceSynchronize() != hipSuccess) { cap_set_error("cap_g8_saturations: device synchronisation failed"); return -1; }
     unsigned long long total = 0;
-    if (cap_g8_clamped_gemm(&total, reset) != 0 || cap_g8_clamped_elementwise(&total, reset) != 0 ||
+    if (cap_g8_clamped_gemm(&total, reset) != 0 || cap_g8_clamped_gemm_pp(&total, reset) != 0 || cap_g8_clamped_elementwise(&total, reset) != 0 ||
         cap_g8_clamped_attention(&total, reset) != 0)
         return -1;
     return (long long)total;
@@ -1621,7 +1621,7 @@ int cap_op_gemm(int dtype, const void* A, const void* W, const float* bias, cons
     p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = C; p.ldc = N; p.bias = bias; p.resid = resid; p.ldr = N;
     p.M = M; p.N = N; p.K = K; p.gelu = gelu; p.out_f32 = out_f32; p.epi = EPI_STORE; p.splitk = 1;
 #ifdef CAP_EXPERIMENTS
-    if (tile == 9 || tile == 13) { p.aux = resid; p.resid = nullptr; }   // instrumented kernel: `resid` is the cycle-count buffer
+    if (tile == 9 || tile == 13 || tile == 14 || tile == 21) { p.aux = resid; p.resid = nullptr; }   // instrumented kernels: `resid` is the cycle-count buffer
 #endif
     return launch_gemm(dt_of(dtype), p, tile, (hipStream_t)stream);
 }

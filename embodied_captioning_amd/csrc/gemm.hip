@@ -20,53 +20,10 @@
 // Edge tiles clamp their load rows and guard their stores.  Workgroup ids are remapped so each XCD (blockIdx % 8) walks
 // a contiguous run of tiles that share A panels in its L2.
 #include <stdlib.h>
-#include <type_traits>
 
-#include "gemm.h"
+#include "gemm_tile.h"
 
 namespace {
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-    using vec = bf16x8;
-    static constexpr int EPC = 8;          // elements per 16-byte chunk
-    __device__ static __forceinline__ void run(f32x16& acc, const vec& a, const vec& b) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-    }
-    // 16x16x32: lane (r16 = lane & 15, kg = lane >> 4) supplies row r16, k = 8 kg .. 8 kg + 7 of a 32-wide k-step;
-    // D[4 kg + e][r16].  Every bf16 GEMM kernel of this file accumulates with THIS instruction, k-steps in ascending
-    // order, so a row of C has the same bits whichever tile shape its batch size selects (batch invariance).
-    __device__ static __forceinline__ void run16(f32x4& acc, const vec& a, const vec& b) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
-    }
-};
-template <> struct Mma<float> {
-    using vec = f32x4;
-    static constexpr int EPC = 4;
-    __device__ static __forceinline__ void run(f32x16& acc, const vec& a, const vec& b) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
-    }
-};
-
-// G8 (split fp16, common.h): a 128-byte slab row holds 32 k values as chunks [H0 L0 H1 L1 H2 L2 H3 L3]; lane (r16, kg)
-// of a 16x16x32 MFMA takes the hi chunk 2 kg and the lo chunk 2 kg + 1 of its row, and every product is three MFMAs in
-// THIS order (all kernels, so a row of C has the same bits whichever tile shape its batch size selects):
-//   acc += a_hi.w_lo;  acc += a_lo.w_hi;  acc += a_hi.w_hi
-template <> struct Mma<g8_t> {
-    using vec = f16x8;
-    static constexpr int EPC = 4;
-    __device__ static __forceinline__ void run(f32x16&, const vec&, const vec&) {}     // (32x32 path unused)
-    __device__ static __forceinline__ void run16(f32x4& acc, const vec& a, const vec& b) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
-    }
-};
-template <typename T> constexpr bool is_g8 = std::is_same<T, g8_t>::value;
-
-__device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // NOT HIP's uint4: its union members defeat SROA and
-                                                                  // the staging registers end up in scratch
 
 // Store 4 consecutive output columns (col % 4 == 0, never straddles a 64-wide head).
 template <typename T, bool OUT_F32, int EPI, bool RESID = true>
@@ -334,10 +291,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(G
 //     under slab k's 32 MFMAs per wave;
 //   * the next tile's first slab is issued BEFORE this tile's epilogue, so the C write-back (through wave-private LDS
 //     strips that alias the stage buffer just drained) overlaps the DMA instead of leaving the CU idle.
-// s_barrier is IntrNoMem for the compiler: pin LDS accesses on their side of it with empty memory-clobber asm
-#define CAP_RAW_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-#define CAP_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
-#define CAP_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 // VAR selects the scheduling of the inner k-step loop: 0 compiler scheduled (fp32), 2 iglp_opt(0), 3 iglp_opt(1) (bf16),
 // 4 = 3 + cycle stamps (diagnostic build, tools/gemm_cycles.py).  (A manual register double-buffer + sched_group_barrier
@@ -494,119 +447,6 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
 
 // Epilogue stores of the second-generation kernel: values are final (bias / GELU applied, converted); these only map
 // (row, col) to the destination of the epilogue in use and store 16 bytes (8 bf16 or 4 fp32 consecutive columns).
-template <int EPI>
-__device__ __forceinline__ size_t epi_offset(const GemmParams& p, int row, int col, void*& base) {
-    base = p.C;
-    if constexpr (EPI == EPI_PARTIAL) {
-        return ((size_t)p.p3 * p.M + row) * p.ldc + col;
-    } else if constexpr (EPI == EPI_STORE) {
-        return (size_t)row * p.ldc + col;
-    } else if constexpr (EPI == EPI_PATCH) {
-        const int b = row / p.p0, pp = row - b * p.p0;
-        return ((size_t)b * (p.p0 + 1) + 1 + pp) * p.ldc + col;
-    } else if constexpr (EPI == EPI_CROSSKV) {
-        const int NT = p.p0, H = p.p1, B = p.p2, Dh = H * 64;
-        const int b = row / NT, t = row - b * NT;
-        const int l = col / (2 * Dh), r = col - l * 2 * Dh, kv = r / Dh, hd = r - kv * Dh, h = hd >> 6, d = hd & 63;
-        return (((((size_t)l * 2 + kv) * B + b) * H + h) * NT + t) * 64 + d;
-    } else {  // EPI_QKVCACHE
-        const int H = p.p1, Dh = H * 64;
-        if (col < Dh) return (size_t)row * Dh + col;
-        const int kv = col / Dh - 1, hd = col % Dh, h = hd >> 6, d = hd & 63;
-        base = p.C2;
-        return ((((size_t)kv * p.p0 + row) * H + h) * p.p2 + p.p3) * 64 + d;
-    }
-}
-template <typename T, int EPI>
-__device__ __forceinline__ void epi_store_raw(const GemmParams& p, int row, int col, u32x4 raw, bool full) {
-    void* base;
-    const size_t o = epi_offset<EPI>(p, row, col, base);
-    if (full) *(u32x4*)((T*)base + o) = raw;
-    else *(unsigned long long*)((T*)base + o) = (unsigned long long)raw[0] | ((unsigned long long)raw[1] << 32);   // N % 8 == 4 tail
-}
-template <int EPI>
-__device__ __forceinline__ void epi_store_f32(const GemmParams& p, int row, int col, f32x4 v) {
-    if constexpr (EPI == EPI_PATCH) {
-        const int pp = row % p.p0;
-        v += *(const f32x4*)(p.aux + (size_t)(1 + pp) * p.N + col);
-    }
-    void* base;
-    const size_t o = epi_offset<EPI>(p, row, col, base);
-    if constexpr (EPI == EPI_CROSSKV) {
-        if (p.kv24) { kv24_store4((char*)base + (o >> 6) * KV24_ROW, (int)(o & 63), v[0], v[1], v[2], v[3]); return; }
-    }
-    *(f32x4*)((float*)base + o) = v;
-}
-
-// Epilogue shared by the second-generation kernels.  acc[i][j][e] = C[row0 + 16 i + r16][col0 + 16 j + 4 kg + e]: bias /
-// GELU / convert in that layout, then a wave-private LDS strip (16 rows x 128 payload bytes, row pitch 144) turns "4
-// consecutive columns per lane" into "16 consecutive bytes per lane, 8 lanes per 128-byte row": every global store
-// instruction writes 8 whole cache lines.  The strip is outside the stage buffers, so no barrier is involved.
-// bias_w: LDS address of the fp32 bias of this wave's first column (nullptr: none).
-template <typename T, bool OUT_F32, int EPI, int MI, int NI>
-__device__ __forceinline__ void big2_epilogue(const GemmParams& p, const f32x4 (&acc)[MI][NI], char* strip,
-                                              const char* bias_w, int row0, int col0, int lane) {
-    const int r16 = lane & 15, kg = lane >> 4;
-    const int act = EPI != EPI_PARTIAL ? p.gelu : 0;     // uniform: 1 = exact-erf GELU, 2 = ReLU
-    f32x4 biasv[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) biasv[j] = bias_w ? *(const f32x4*)(bias_w + (j * 16 + 4 * kg) * 4) : f32x4(0.f);
-    const int srow = lane >> 3, spiece = lane & 7;
-    constexpr bool F32OUT = OUT_F32 || EPI == EPI_PARTIAL || EPI == EPI_PATCH;
-    constexpr bool G8OUT = !F32OUT && is_g8<T>;         // 4 bytes per element like fp32: 32 columns = four [hi | lo] groups
-    static_assert(!G8OUT || EPI == EPI_STORE, "G8 output exists for plain row-major stores only");
-    constexpr int NPB = (F32OUT || G8OUT) ? 2 : 4;      // 16-column blocks per 128-byte strip row
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-        for (int jp = 0; jp < NI / NPB; ++jp) {
-#pragma unroll
-            for (int jj = 0; jj < NPB; ++jj) {
-                const int j = jp * NPB + jj;
-                f32x4 v = acc[i][j];
-                if constexpr (is_g8<T>) v *= (1.0f / G8_WSCALE);
-                if (EPI != EPI_PARTIAL) v += biasv[j];
-                if (act == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_for<T>(v[e]);
-                } else if (act == 2) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                if constexpr (F32OUT) {
-                    *(f32x4*)(strip + r16 * 144 + (jj * 16 + 4 * kg) * 4) = v;
-                } else if constexpr (G8OUT) {
-                    store4((g8_t*)(strip + r16 * 144), jj * 16 + 4 * kg, make_float4(v[0], v[1], v[2], v[3]));
-                } else {
-                    bf16x4 w;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) w[e] = (bf16_t)v[e];
-                    *(bf16x4*)(strip + r16 * 144 + (jj * 16 + 4 * kg) * 2) = w;
-                }
-            }
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int row = row0 + i * 16 + rr * 8 + srow;
-                if constexpr (F32OUT) {
-                    const f32x4 v = *(const f32x4*)(strip + (rr * 8 + srow) * 144 + spiece * 16);
-                    const int col = col0 + jp * 32 + spiece * 4;
-                    if (row < p.M && col < p.N) epi_store_f32<EPI>(p, row, col, v);
-                } else if constexpr (G8OUT) {
-                    // the strip row is the 128-byte image of 32 G8 elements: copy it out as it is (N % 8 == 0: a group's
-                    // two 16-byte pieces are inside or outside together)
-                    const u32x4 raw = *(const u32x4*)(strip + (rr * 8 + srow) * 144 + spiece * 16);
-                    const int col = col0 + jp * 32 + spiece * 4;
-                    if (row < p.M && col < p.N) epi_store_raw<T, EPI>(p, row, col, raw, true);
-                } else {
-                    const u32x4 raw = *(const u32x4*)(strip + (rr * 8 + srow) * 144 + spiece * 16);
-                    const int col = col0 + jp * 64 + spiece * 8;
-                    if (row < p.M && col < p.N) epi_store_raw<T, EPI>(p, row, col, raw, col + 8 <= p.N);
-                }
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // bf16 256x256 persistent kernel, second generation.  Same LDS-DMA staging, swizzle and XCD-aware tile walk as
 // gemm_big_kernel; what changed follows from in-kernel cycle accounting (tools/gemm_cycles.py: the old epilogue cost
@@ -746,7 +586,32 @@ __global__ __launch_bounds__(NWM * NWN * 64, NWM * NWN == 8 ? 2 : 1) void gemm_b
             const char* b_s = a_s + BM * 128;
             if constexpr (SCHED == 1) __builtin_amdgcn_iglp_opt(0);
             if constexpr (SCHED == 2) __builtin_amdgcn_iglp_opt(1);
-            if constexpr (is_g8<T>) {
+            if constexpr (is_g8<T> && VAR == 3) {
+                // A fragments double buffered: block i + 1's two reads are issued before block i's 12 MFMAs
+                vec bh[NI], bl[NI], ah[2], al[2];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    bh[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, 2 * kg));
+                    bl[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, 2 * kg + 1));
+                }
+                ah[0] = *(const vec*)(a_s + swz_off(wm0 + r16, 2 * kg));
+                al[0] = *(const vec*)(a_s + swz_off(wm0 + r16, 2 * kg + 1));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    if (i + 1 < MI) {
+                        ah[(i + 1) & 1] = *(const vec*)(a_s + swz_off(wm0 + (i + 1) * 16 + r16, 2 * kg));
+                        al[(i + 1) & 1] = *(const vec*)(a_s + swz_off(wm0 + (i + 1) * 16 + r16, 2 * kg + 1));
+                    }
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i & 1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i & 1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i & 1], acc[i][j], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (is_g8<T>) {
                 vec bh[NI], bl[NI];
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
@@ -1157,6 +1022,9 @@ int launch_big2(const GemmParams& p, hipStream_t stream) {
     auto kern = gemm_big2_kernel<T, OUT_F32, EPI, VAR, PROF, NWM, NWN>;
     int n_cu = 0;
     if (cap_kernel_setup((const void*)kern, LDS, &n_cu) != 0) return -1;
+#ifdef CAP_EXPERIMENTS      // power probe: the same kernel on a part of the chip (tools/bench_gemm_split.py --cus)
+    if (const char* e = getenv("CAP_EXP_CUS")) n_cu = std::min(n_cu, std::max(8, atoi(e)));
+#endif
     const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int rounds = ntiles / n_cu, tail = ntiles - rounds * n_cu;
     if constexpr (NWM * NWN == 8 && !PROF) {
@@ -1209,6 +1077,14 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
 
 template <typename T, bool OUT_F32, int EPI>
 int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
+#ifdef CAP_EXPERIMENTS
+    if (tile == 14 || tile == 15) {
+        if constexpr (is_g8<T> && !OUT_F32 && EPI == EPI_STORE) {
+            if (tile == 14) return launch_big2<T, OUT_F32, EPI, 3, true>(p, stream);
+            return launch_big2<T, OUT_F32, EPI, 3, false>(p, stream);
+        }
+    }
+#endif
     if (tile >= 10 && tile <= 13) {
         if constexpr (is_g8<T>) {
             if (p.K >= 64 && !p.resid) {
@@ -1339,6 +1215,13 @@ int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream) {
         const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
         tile = (t256 >= 256 || (t256 >= 128 && p.M >= 256)) ? 3 : (t128 >= 256 ? 1 : 2);   // few rows: a 256-row tile is mostly padding
+    }
+    // split fp16, 256x256: the kernel with the wave groups half a stage apart (gemm_pp.hip) wherever it takes the shape;
+    // gemm_big2_kernel<g8_t> stays reachable as tiles 10-12 (A/B, bit-identical) and takes what is left (resid, K < 64, ...)
+    if (dtype == CAP_DT_G8 && (tile == 3 || tile == 20 || tile == 21)) {
+        const int rc = launch_gemm_pp(p, tile == 21, stream);
+        if (rc != -2) return rc;
+        tile = 3;
     }
     if (dtype == CAP_DT_BF16) return launch_t<bf16_t>(p, tile, stream);
     if (dtype == CAP_DT_F32) return launch_t<float>(p, tile, stream);

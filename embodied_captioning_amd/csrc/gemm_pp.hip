@@ -1,0 +1,421 @@
+// Split-fp16 (G8) 256x256 persistent GEMM with the two wave groups HALF A STAGE APART (gfx950 / CDNA4).
+//
+// gemm_big2_kernel<g8_t> (gemm.hip) runs its eight waves in phase: after the one barrier of a 32-k stage every wave issues
+// its eight LDS-DMA instructions, pulls its W and first A fragments out of LDS and only then starts on its 96 MFMAs.  In-kernel
+// cycle stamps on an otherwise idle chip (tools/bench_gemm_pp.py --cycles, 64 workgroups, 2.39 GHz): 4 600 cycles per stage
+// against 3 072 of MFMA issue - of which 700-1 100 per wave go into ISSUING the DMA (the CU's one texture-address unit takes a
+// 1 KiB DMA instruction every ~16 cycles, 64 of them per stage, and all eight waves queue up behind it right after the
+// barrier while neither wave of a SIMD issues an MFMA).  Here the waves of a SIMD never start a stage together:
+//   * wave grid 2 x 4 as before; group 0 = waves 0-3 = the upper BM/2 rows of the tile, group 1 = waves 4-7 = the lower half;
+//     waves w and w + 4 share a SIMD and the same 64 W columns;
+//   * time runs in HALF-stage steps with one barrier each; group 0 multiplies stage S in steps 2S and 2S+1, group 1 in steps
+//     2S+1 and 2S+2.  At every barrier one wave of each SIMD is at a stage start (twelve fragment reads, then its DMA issue, then
+//     its first MFMA) while its partner is in the middle of a stage with its operands in registers and 48 MFMAs to issue;
+//   * the group that starts a stage issues the step's DMA in that start-up gap: group 0 in step 2S the upper A half, W and the
+//     tile's bias row of stage S+1, group 1 in step 2S+1 the lower A half of stage S+1.  Each group confirms ITS OWN pieces
+//     (vmcnt(0)) right before the barrier at which it starts the stage they belong to - one whole stage time after issuing them;
+//   * A fragments are double buffered in registers (block i+1 is read under block i's 12 MFMAs); fragment reads and their
+//     counted lgkmcnt waits are asm statements (hipcc waits lgkmcnt(0), i.e. also for the block it has just requested);
+//   * epilogue without LDS: fp32 output is the accumulator layout as it is (16 bytes per lane); G8 output pairs lanes with
+//     v_permlane16_swap_b32 (pp_epilogue_body).
+// Hazards (buffers S & 1):
+//   RAW  upper A / W of stage S+1: issued by group 0 in step 2S, confirmed by group 0 before the barrier of step 2S+2 (their first
+//        reader; group 1 reads W in step 2S+3).  Lower A of stage S+1: issued by group 1 in step 2S+1, confirmed before the barrier
+//        of step 2S+3, its first reader.
+//   WAR  the DMA of step 2S (stage S+1) overwrites upper A / W of stage S-1: group 0 read them in steps 2S-2, 2S-1, group 1 read its
+//        W fragments at the start of step 2S-1 - all retired (consumed by MFMAs) before the barrier of step 2S.  The DMA of step
+//        2S+1 overwrites lower A of stage S-1, read by group 1 in steps 2S-1, 2S.
+// Sums are formed exactly as in every other G8 kernel (three MFMAs per product, k ascending): results are bit-identical to
+// gemm_big2_kernel's and to the register-staged tiles' (tests/test_split_gpu.py).
+// Measured (MI355X, 256 frames of ViT-B/16, us per launch against gemm_big2_kernel): qkv 441 / 470, proj 164 / 168, fc1 632 /
+// 670, fc2 556 / 585; cycles per stage 3 760-4 080 against 4 600 at 64 workgroups - on the whole chip the shader clock then
+// settles ~10 % lower (1.93 against 2.13 GHz: the board's power limit), which is why the gain in time is a third of the gain
+// in cycles.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "gemm_tile.h"
+
+namespace {
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Fragment reads and their waits are asm statements: hipcc waits with lgkmcnt(0) for the fragments it reads itself, i.e. also
+// for the block it has just requested.  Here block i + 1's two reads stay in flight while block i is multiplied (LDS returns
+// in order: lgkmcnt(2)).  The wait "modifies" the fragments it releases, so no MFMA that uses them can be placed before it.
+template <int OFF> __device__ __forceinline__ void ds_read16(f16x8& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void wait_lgkm(f16x8& a, f16x8& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void wait_lgkm(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Epilogue without an LDS round trip.  acc[i][j][e] = C[row0 + 16 i + r16][col0 + 16 j + 4 kg + e]: a lane's four values are
+// four consecutive columns, i.e. 16 bytes of an fp32 row as they are.  A G8 row image is [8 hi | 8 lo] per 8 columns; lanes kg
+// and kg + 1 (kg even) hold the two halves of one such group and trade 8 bytes with v_permlane16_swap_b32 (gfx950: odd 16-lane
+// rows of the first register <-> even rows of the second): the even lane ends up with the group's 8 hi halves, the odd lane with
+// its 8 lo halves - 16 contiguous bytes each, at the byte offset an fp32 row would have.  One store instruction writes 16 rows x
+// 64 bytes; the next j completes the 128-byte lines.
+// The instruction count per four values is what a tile's epilogue costs (one wave per SIMD runs it while its partner waits at a
+// barrier): the activation is a template parameter (ACT: 0 none, 1 GELU, 2 ReLU, -1 = read p.gelu per value - edge tiles only),
+// interior tiles (FULL) store unguarded through one running pointer, clamped groups are counted in a register and added to the
+// translation unit's counter once per tile.
+template <bool OUT_F32, int EPI, int MI, int NI, int ACT, bool FULL>
+__device__ __forceinline__ void pp_epilogue_body(const GemmParams& p, const f32x4 (&acc)[MI][NI], const f32x4 (&biasv)[NI], int row0,
+                                                 int col0, int lane) {
+    using T [[maybe_unused]] = g8_t;
+    constexpr bool F32OUT = OUT_F32 || EPI == EPI_PARTIAL || EPI == EPI_PATCH;
+    static_assert(F32OUT || EPI == EPI_STORE, "G8 output exists for plain row-major stores only");
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int act = ACT >= 0 ? ACT : p.gelu;
+    char* ptr = nullptr;                                 // EPI_STORE: this lane's 16 bytes of block (i = 0, j = 0); 4 bytes per element
+    size_t step = 0;
+    if constexpr (EPI == EPI_STORE) {
+        ptr = (char*)p.C + ((size_t)(row0 + r16) * p.ldc + col0 + 4 * kg) * 4;
+        step = (size_t)p.ldc * 64;
+    }
+    unsigned sat = 0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int row = row0 + i * 16 + r16;
+        const bool rok = FULL || row < p.M;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            f32x4 v = acc[i][j] * (1.0f / G8_WSCALE);
+            if (EPI != EPI_PARTIAL) v += biasv[j];
+            if (act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_for<T>(v[e]);
+            } else if (act == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            const int col = col0 + j * 16 + 4 * kg;
+            const bool ok = FULL || (rok && col < p.N);
+            if constexpr (F32OUT) {
+                if constexpr (EPI == EPI_STORE) {
+                    if (ok) *(f32x4*)(ptr + j * 64) = v;
+                } else {
+                    if (ok) epi_store_f32<EPI>(p, row, col, v);
+                }
+            } else {
+                sat += (ok && !(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) <= G8_AMAX)) ? 1u : 0u;
+                f16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f16_t h, l;
+                    g8_split(v[e], h, l);
+                    hi[e] = h; lo[e] = l;
+                }
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 hw = __builtin_bit_cast(u32x2, hi), lw = __builtin_bit_cast(u32x2, lo);
+                const auto s0 = __builtin_amdgcn_permlane16_swap(hw[0], lw[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(hw[1], lw[1], false, false);
+                u32x4 raw;
+                raw[0] = s0[0]; raw[1] = s1[0]; raw[2] = s0[1]; raw[3] = s1[1];
+                if (ok) *(u32x4*)(ptr + j * 64) = raw;
+            }
+        }
+        ptr += step;
+    }
+    if constexpr (!F32OUT) {
+        if (sat) atomicAdd(&g_g8_clamped, sat);          // same count as g8_note_range per group of four
+    }
+}
+
+template <bool OUT_F32, int EPI, int MI, int NI>
+__device__ __forceinline__ void pp_epilogue(const GemmParams& p, const f32x4 (&acc)[MI][NI], const char* bias_w, int row0, int col0,
+                                            int lane) {
+    const int kg = lane >> 4;
+    f32x4 biasv[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) biasv[j] = bias_w ? *(const f32x4*)(bias_w + (j * 16 + 4 * kg) * 4) : f32x4(0.f);
+    const int act = EPI != EPI_PARTIAL ? p.gelu : 0;
+    if (row0 + MI * 16 <= p.M && col0 + NI * 16 <= p.N) {
+        if (act == 0) pp_epilogue_body<OUT_F32, EPI, MI, NI, 0, true>(p, acc, biasv, row0, col0, lane);
+        else if (act == 1) pp_epilogue_body<OUT_F32, EPI, MI, NI, 1, true>(p, acc, biasv, row0, col0, lane);
+        else pp_epilogue_body<OUT_F32, EPI, MI, NI, 2, true>(p, acc, biasv, row0, col0, lane);
+    } else {
+        pp_epilogue_body<OUT_F32, EPI, MI, NI, -1, false>(p, acc, biasv, row0, col0, lane);
+    }
+}
+
+template <bool OUT_F32, int EPI, bool PROF, int BM = 256>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
+    using vec = f16x8;
+    constexpr int BN = 256, WM = BM / 2, MI = WM / 16, MH = MI / 2, NI = 4;
+    constexpr int SUB = 256 / BM;                        // work items per 256-row tile
+    constexpr int STAGE = (BM + BN) * 128;               // 64 KiB (48 KiB for half tiles)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const bias_rows = smem + 2 * STAGE;            // [2 slots][4 column groups][64 floats]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, wn0 = (wave & 3) * 64, wm0 = g * WM;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int ntn = (p.N + BN - 1) / BN;
+    const int tile0 = p.tile1 > 0 ? p.tile0 : 0;
+    const int nitems = ((p.tile1 > 0 ? p.tile1 : ((p.M + 255) / 256) * ntn) - tile0) * SUB;
+    const int nk = p.K / 32;
+
+    // XCD-aware walk, as in gemm_big2_kernel: XCD x owns the contiguous run [c0, c1) of work items
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int nl = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
+    const int tq = nitems >> 3, tr = nitems & 7;
+    const int c0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int c1 = c0 + tq + (xcd < tr ? 1 : 0);
+    const int first = c0 + li;
+    if (first >= c1) return;
+    const int ntl = (c1 - first + nl - 1) / nl;          // items of this workgroup
+    const int NS = ntl * nk;                             // stages of this workgroup
+
+    // ---- issue side.  The group that STARTS a stage in a step issues that step's DMA, between its twelve fragment reads and its
+    // first MFMA - where its issue slot is idle anyway, while the partner wave on its SIMD (mid-stage, operands in registers) has
+    // the matrix pipe to itself.  (All eight waves issuing right after the barrier, as gemm_big2_kernel does, costs every wave
+    // 700-1 100 cycles per stage in which neither wave of a SIMD issues an MFMA: the CU's one texture-address unit takes a 1 KiB
+    // DMA instruction every ~16 cycles, 64 of them per stage - tools/bench_gemm_pp.py --cycles.)
+    //   group 0, step 2S   : slot a of stage S + 1 = the upper A half (PQ pieces per wave), W (8 per wave), the tile's bias row
+    //   group 1, step 2S+1 : slot b of stage S + 1 = the lower A half (PQ pieces per wave)
+    constexpr int PQ = WM / 32;                          // 8-row pieces of one A half per wave of a group
+    const int wq = wave & 3;
+    const int prow = lane >> 3, ppos = lane & 7;
+    unsigned oa[PQ], ow[8], obias = 0;                   // byte offsets (k = 0) of this lane's pieces in A / W / bias
+    const bool has_bias = EPI != EPI_PARTIAL && p.bias != nullptr;
+    auto set_ptrs = [&](int x) __attribute__((always_inline)) {
+        const int item = first + x * nl;
+        const int t = tile0 + item / SUB, sub = item % SUB;
+        const int tm = t / ntn, tn = t - tm * ntn;
+#pragma unroll
+        for (int j = 0; j < PQ; ++j) {
+            const int row = (wq * PQ + j) * 8 + prow;    // row inside this group's half; WM % 16 == 0: both halves swizzle alike
+            const int gch = ppos ^ ((row >> 1) & 7);
+            const int ga = min(tm * 256 + sub * BM + wm0 + row, p.M - 1);
+            oa[j] = ((unsigned)ga * (unsigned)p.lda + gch * 4) * 4u;
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = (wq * 8 + j) * 8 + prow;
+                const int gch = ppos ^ ((row >> 1) & 7);
+                const int gw = min(tn * BN + row, p.N - 1);
+                ow[j] = ((unsigned)gw * (unsigned)p.ldw + gch * 4) * 4u;
+            }
+            obias = has_bias ? (unsigned)min(tn * BN + wn0 + lane, p.N - 1) * 4u : 0u;
+        }
+    };
+    int i_kt = 0, i_x = 0;
+    auto issue = [&](int s) __attribute__((always_inline)) {                            // this group's slot of stage s; then on to the next stage
+        char* st = smem + (s & 1) * STAGE;
+        const char* ab = (const char*)p.A + (size_t)i_kt * 128;
+#pragma unroll
+        for (int j = 0; j < PQ; ++j)
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(ab + oa[j]), CAP_LPTR(st + (wm0 + (wq * PQ + j) * 8) * 128), 16, 0, 0);
+        if (g == 0) {
+            const char* wb = (const char*)p.W + (size_t)i_kt * 128;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                __builtin_amdgcn_global_load_lds(CAP_GPTR(wb + ow[j]), CAP_LPTR(st + BM * 128 + (wq * 8 + j) * 1024), 16, 0, 0);
+            if (has_bias && i_kt == 0)                   // waves w and w + 4 share the 64 columns and the row
+                __builtin_amdgcn_global_load_lds(CAP_GPTR((const char*)p.bias + obias), CAP_LPTR(bias_rows + (i_x & 1) * 1024 + wq * 256), 4, 0, 0);
+        }
+        if (++i_kt == nk) {
+            i_kt = 0;
+            if (++i_x < ntl) set_ptrs(i_x);
+        }
+    };
+
+    // ---- compute side
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = 0.f;
+    vec bh[NI], bl[NI], ah[2], al[2];
+    const unsigned lds0 = (unsigned)(size_t)CAP_LPTR(smem);
+    const unsigned f_hi = swz_off(r16, 2 * kg), f_lo = swz_off(r16, 2 * kg + 1);   // + 128 * (16-aligned row): same swizzle
+    // a_hi.w_lo, a_lo.w_hi, a_hi.w_hi per accumulator - the order of every G8 kernel; the chains of two accumulators are
+    // interleaved, so that a wave that has the matrix pipe to itself never issues an MFMA that waits for the one before it
+    auto mma_pair = [&](f32x4& c0, f32x4& c1, int j, int sl) __attribute__((always_inline)) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[sl], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j + 1], ah[sl], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[sl], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j + 1], al[sl], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[sl], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j + 1], ah[sl], c1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma_block = [&](int i) __attribute__((always_inline)) {
+        mma_pair(acc[i][0], acc[i][1], 0, i & 1);
+        mma_pair(acc[i][2], acc[i][3], 2, i & 1);
+    };
+
+    long long prof_bar = 0, prof_epi = 0, prof_vm = 0, prof_iss = 0, prof_ew = 0;
+    const long long prof_c0 = PROF ? clock64() : 0, prof_w0 = PROF ? wall_clock64() : 0;
+
+    // A step = barrier + half a stage of MFMAs per group.  Before the barrier at which a group starts stage S it confirms that
+    // the slot IT issued for stage S (one stage time ago) has landed: the barrier then makes it visible to the other group too.
+    bool confirmed = false;                              // the wait already happened (before this wave's epilogue stores)
+    auto sync = [&](bool starts) __attribute__((always_inline)) {
+        const long long t0 = PROF ? clock64() : 0;
+        if (starts && !confirmed) wait_vm<0>();
+        confirmed = false;
+        const long long t1 = PROF ? clock64() : 0;
+        CAP_RAW_BARRIER();
+        if constexpr (PROF) { prof_vm += t1 - t0; prof_bar += clock64() - t1; }
+    };
+    auto half0 = [&](int S) __attribute__((always_inline)) {
+        const unsigned sa = lds0 + (S & 1) * STAGE;
+        const unsigned aH = sa + wm0 * 128 + f_hi, aL = sa + wm0 * 128 + f_lo;
+        const unsigned bH = sa + (BM + wn0) * 128 + f_hi, bL = sa + (BM + wn0) * 128 + f_lo;
+        // 12 reads; the first product needs the first four of them
+        ds_read16<0>(bl[0], bL); ds_read16<0>(ah[0], aH); ds_read16<0>(bh[0], bH); ds_read16<0>(al[0], aL);
+        ds_read16<2048>(bl[1], bL); ds_read16<2048>(bh[1], bH);
+        ds_read16<4096>(bl[2], bL); ds_read16<4096>(bh[2], bH);
+        ds_read16<6144>(bl[3], bL); ds_read16<6144>(bh[3], bH);
+        ds_read16<2048>(ah[1], aH); ds_read16<2048>(al[1], aL);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const long long t2 = PROF ? clock64() : 0;
+            if (S + 1 < NS) issue(S + 1);
+            if constexpr (PROF) prof_iss += clock64() - t2;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        wait_lgkm<6>(bl[0], ah[0], bh[0], al[0]); wait_lgkm<6>(bl[1], bh[1]);
+        mma_pair(acc[0][0], acc[0][1], 0, 0);
+        wait_lgkm<2>(bl[2], bh[2]); wait_lgkm<2>(bl[3], bh[3]);
+        mma_pair(acc[0][2], acc[0][3], 2, 0);
+        static_for<1, MH>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;       // i + 1 <= MH < MI: the first block of the second half included
+            ds_read16<(i + 1) * 2048>(ah[(i + 1) & 1], aH); ds_read16<(i + 1) * 2048>(al[(i + 1) & 1], aL);
+            wait_lgkm<2>(ah[i & 1], al[i & 1]);
+            mma_block(i);
+        });
+    };
+    int c_kt = 0, c_x = 0;
+    auto half1 = [&](int S) __attribute__((always_inline)) {
+        const unsigned sa = lds0 + (S & 1) * STAGE;
+        const unsigned aH = sa + wm0 * 128 + f_hi, aL = sa + wm0 * 128 + f_lo;
+        static_for<MH, MI>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i + 1 < MI) {
+                ds_read16<(i + 1) * 2048>(ah[(i + 1) & 1], aH); ds_read16<(i + 1) * 2048>(al[(i + 1) & 1], aL);
+                wait_lgkm<2>(ah[i & 1], al[i & 1]);
+            } else {
+                wait_lgkm<0>(ah[i & 1], al[i & 1]);
+            }
+            mma_block(i);
+        });
+        if (++c_kt == nk) {
+            // tile finished (for this group): bias / activation / convert / whole-line stores through this wave's strip; no
+            // barrier inside.  The other group is one half-stage away from the same point.
+            const long long e0 = PROF ? clock64() : 0;
+            wait_vm<0>();                                // this wave's pieces of the next stage: before the stores enter the counter
+            confirmed = true;
+            if constexpr (PROF) prof_ew += clock64() - e0;
+            const int item = first + c_x * nl;
+            const int t = tile0 + item / SUB, sub = item % SUB;
+            const int tm = t / ntn, tn = t - tm * ntn;
+            pp_epilogue<OUT_F32, EPI, MI, NI>(p, acc, has_bias ? bias_rows + (c_x & 1) * 1024 + wq * 256 : nullptr,
+                                              tm * 256 + sub * BM + wm0, tn * BN + wn0, lane);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = 0.f;
+            c_kt = 0;
+            ++c_x;
+            if constexpr (PROF) prof_epi += clock64() - e0;
+        }
+    };
+
+    set_ptrs(0);
+    issue(0);
+    // Both groups pass the same 2 NS + 1 barriers; each group's loop holds one whole stage of ITS work, so the fragment
+    // registers are not live around the back edge (one loop over half-steps for both groups spilled them).
+    if (g == 0) {
+        for (int S = 0; S < NS; ++S) {
+            sync(true);
+            half0(S);
+            sync(false);
+            half1(S);
+        }
+        sync(false);
+    } else {
+        sync(false);
+        for (int S = 0; S < NS; ++S) {
+            sync(true);
+            half0(S);
+            sync(false);
+            half1(S);
+        }
+    }
+    if constexpr (PROF) {
+        if (lane == 0 && p.aux) {
+            long long* d = (long long*)p.aux + ((size_t)blockIdx.x * 8 + wave) * 8;      // eight counters per wave
+            d[0] = clock64() - prof_c0; d[1] = wall_clock64() - prof_w0; d[2] = prof_vm; d[3] = prof_bar; d[4] = prof_epi;
+            d[5] = ntl; d[6] = prof_iss; d[7] = prof_ew;
+        }
+    }
+}
+
+template <bool OUT_F32, int EPI, bool PROF>
+int launch_pp_t(const GemmParams& p, hipStream_t stream) {
+    constexpr int EXTRA = 2 * 1024;                      // bias rows
+    constexpr int LDS = 2 * 512 * 128 + EXTRA, LDS_H = 2 * 384 * 128 + EXTRA;
+    auto kern = gemm_pp_kernel<OUT_F32, EPI, PROF, 256>;
+    int n_cu = 0;
+    if (cap_kernel_setup((const void*)kern, LDS, &n_cu) != 0) return -1;
+#ifdef CAP_EXPERIMENTS
+    if (const char* e = getenv("CAP_EXP_CUS")) n_cu = std::min(n_cu, std::max(8, atoi(e)));
+#endif
+    const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const int rounds = ntiles / n_cu, tail = ntiles - rounds * n_cu;
+    if (!PROF && rounds >= 1 && rounds <= 4 && tail > 0 && 2 * tail <= n_cu) {       // the tail round as half tiles: launch_big2
+        auto kern_h = gemm_pp_kernel<OUT_F32, EPI, PROF, 128>;
+        if (cap_kernel_setup((const void*)kern_h, LDS_H, nullptr) != 0) return -1;
+        GemmParams q = p;
+        q.tile0 = 0; q.tile1 = rounds * n_cu;
+        hipLaunchKernelGGL(kern, dim3(n_cu), dim3(512), LDS, stream, q);
+        q.tile0 = rounds * n_cu; q.tile1 = ntiles;
+        hipLaunchKernelGGL(kern_h, dim3(2 * tail), dim3(512), LDS_H, stream, q);
+        CAP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    const int grid = ntiles < n_cu ? ntiles : n_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, p);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+CAP_DEFINE_G8_CLAMP_READER(cap_g8_clamped_gemm_pp)
+
+// G8 operands only.  Returns -2 (nothing launched, no error set) when the shape or epilogue is not one this kernel takes:
+// the caller falls back to gemm_big2_kernel.  prof: cycle stamps to p.aux (-DCAP_EXPERIMENTS builds only).
+int launch_gemm_pp(const GemmParams& p, bool prof, hipStream_t stream) {
+    if (p.K < 64 || p.K % 32 != 0 || p.resid) return -2;
+    // 32-bit byte offsets inside A and W
+    if ((size_t)p.M * p.lda * 4 >= (1ull << 32) || (size_t)p.N * p.ldw * 4 >= (1ull << 32)) return -2;
+#ifdef CAP_EXPERIMENTS
+    if (prof) {
+        if (p.epi == EPI_STORE && !p.out_f32) return launch_pp_t<false, EPI_STORE, true>(p, stream);
+        return -2;
+    }
+#endif
+    switch (p.epi) {
+        case EPI_STORE: return p.out_f32 ? launch_pp_t<true, EPI_STORE, false>(p, stream) : launch_pp_t<false, EPI_STORE, false>(p, stream);
+        case EPI_PATCH: return launch_pp_t<true, EPI_PATCH, false>(p, stream);
+        case EPI_CROSSKV: return launch_pp_t<true, EPI_CROSSKV, false>(p, stream);
+        default: return -2;
+    }
+}

@@ -45,6 +45,7 @@ int launch_copy_f32(const float* src, float* dst, size_t n, hipStream_t s);
 int launch_absmax_f32(const float* src, size_t n, unsigned int* out_bits, hipStream_t s);
 // per-file readers of the G8 clamp counter (common.h)
 int cap_g8_clamped_gemm(unsigned long long* total, int reset);
+int cap_g8_clamped_gemm_pp(unsigned long long* total, int reset);
 int cap_g8_clamped_elementwise(unsigned long long* total, int reset);
 int cap_g8_clamped_attention(unsigned long long* total, int reset);
 

@@ -34,7 +34,7 @@ SHAPES = [("qkv", 50432, 2304, 768, 0, 0, (3, 16)), ("proj", 50432, 768, 768, 0,
           ("crosskv", 50432, 18432, 768, 0, 1, (3, 16)), ("sq8k", 8192, 8192, 8192, 0, 1, (3, 16)),
           ("vocab", 256, 30524, 768, 0, 1, (1, 2, 3)), ("dec768", 256, 768, 768, 0, 1, (1, 2)),
           ("dec_f1", 256, 3072, 768, 1, 0, (1, 2)), ("dec_qkv", 256, 2304, 768, 0, 1, (1, 2))]
-for name, M, N, K, gelu, f32out, tiles in ([] if "--cycles" in sys.argv else SHAPES):
+for name, M, N, K, gelu, f32out, tiles in ([] if "--cycles" in sys.argv or "--cus" in sys.argv else SHAPES):
     A = g8(torch.randn(M, K, device="cuda"))
     W = g8(torch.randn(N, K, device="cuda") / K ** 0.5, 4096.0)
     bias = torch.randn(N, device="cuda")
@@ -59,6 +59,42 @@ for name, M, N, K, gelu, f32out, tiles in ([] if "--cycles" in sys.argv else SHA
             tf = 2.0 * M * N * K / us / 1e6
             line += f"  tile{tile}: {us:8.1f} us {tf:6.1f} TF ({3 * tf:6.0f} exec)"
     print(line, flush=True)
+
+if "--cus" in sys.argv:
+    # the instrumented kernel on 256 / 128 / 64 / 32 workgroups (experiments build, CAP_EXP_CUS): does the clock rise when fewer
+    # CUs draw power?  M is scaled with the CU count so that every workgroup walks the same number of tiles
+    PT = int(os.environ.get("PROF_TILE", "13"))
+    for cus in (256, 64):
+        os.environ["CAP_EXP_CUS"] = str(cus)
+        for name, M0, N, K in [("qkv", 50432, 2304, 768), ("k3072", 50432, 768, 3072)]:
+            M = (M0 * cus // 256 + 255) // 256 * 256
+            A = g8(torch.randn(M, K, device="cuda"))
+            W = g8(torch.randn(N, K, device="cuda") / K ** 0.5, 4096.0)
+            out = torch.zeros(M, N, device="cuda", dtype=torch.float32)
+            dbg = torch.zeros(256 * 8 * 6, device="cuda", dtype=torch.int64)
+            def run():
+                rc = lib.cap_op_gemm(SPLIT, C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(0), C.c_void_p(dbg.data_ptr()),
+                                     C.c_void_p(out.data_ptr()), M, N, K, 0, 0, PT, s)
+                assert rc == 0, lib.cap_last_error()
+            for _ in range(30):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(60):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 60
+            d = dbg.view(256, 8, 6).double().cpu()
+            d = d[d[:, 0, 0] > 0]
+            cyc, wall, dma, bar, epi, tc = [d[:, :, i] for i in range(6)]
+            mhz = (cyc / (wall / 100.0)).mean().item()
+            nst = (tc * (K // 32)).mean().item()
+            tf = 2.0 * M * N * K / us / 1e6
+            print(f"cus {cus:3d} {name:6s} M={M}: {us:7.1f} us {tf:6.1f} TF = {tf / cus:.3f} TF/CU  clock {mhz:7.1f} MHz  per stage "
+                  f"{(cyc.mean().item() - epi.mean().item()) / nst:.0f} cycles (dma-wait {dma.mean().item() / nst:.0f}, barrier-wait "
+                  f"{bar.mean().item() / nst:.0f})  blocks {d.shape[0]}", flush=True)
+    sys.exit(0)
 
 if "--cycles" in sys.argv:
     # in-kernel cycle accounting of the shipped schedule (tile 13 = instrumented build, G8 output): per wave, shader cycles in
