@@ -60,37 +60,37 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
     }
 }
 
-// Epilogue without an LDS round trip.  acc[i][j][e] = C[row0 + 16 i + r16][col0 + 16 j + 4 kg + e]: a lane's four values are
-// four consecutive columns, i.e. 16 bytes of an fp32 row as they are.  A G8 row image is [8 hi | 8 lo] per 8 columns; lanes kg
-// and kg + 1 (kg even) hold the two halves of one such group and trade 8 bytes with v_permlane16_swap_b32 (gfx950: odd 16-lane
-// rows of the first register <-> even rows of the second): the even lane ends up with the group's 8 hi halves, the odd lane with
-// its 8 lo halves - 16 contiguous bytes each, at the byte offset an fp32 row would have.  One store instruction writes 16 rows x
-// 64 bytes; the next j completes the 128-byte lines.
-// The instruction count per four values is what a tile's epilogue costs (one wave per SIMD runs it while its partner waits at a
-// barrier): the activation is a template parameter (ACT: 0 none, 1 GELU, 2 ReLU, -1 = read p.gelu per value - edge tiles only),
-// interior tiles (FULL) store unguarded through one running pointer, clamped groups are counted in a register and added to the
-// translation unit's counter once per tile.
+// Epilogue.  acc[i][j][e] = C[row0 + 16 i + r16][col0 + 16 j + 4 kg + e]: consecutive LANES hold consecutive ROWS, and a store
+// instruction costs one L1 line access per lane group that is contiguous in memory - storing straight from this layout (16
+// bytes per lane, 64 scattered pieces per instruction) measured ~270 cycles per instruction, 8 500-9 500 cycles per tile and
+// group whatever the arithmetic in front of it (tools/bench_gemm_pp.py --cycles).  So the 16 x 32-column piece of a row block goes
+// through an LDS strip (16 rows x 128 payload bytes, pitch 144: conflict-free both ways) and leaves as 2 x 8 whole 128-byte
+// lines, as in big2_epilogue - but here one wave per SIMD runs the epilogue while its partner waits at a barrier, so every
+// cycle of it is matrix-pipe idle time and the instruction count per value matters:
+//   * two strips per wave slot, software pipelined: piece n + 1 is computed and written while piece n is read back and stored
+//     (waves w and w + 4 run their epilogues in different steps and share a slot);
+//   * ACT is a template parameter (0 none, 1 GELU, 2 ReLU; -1 = read p.gelu per piece, edge tiles only), interior tiles
+//     (FULL) store unguarded through two running pointers, clamped groups are counted in a register and added to the
+//     translation unit's counter once per tile;
+//   * a G8 output piece is the strip row image [8 hi | 8 lo] per 8 columns: two 8-byte writes per four values.
 template <bool OUT_F32, int EPI, int MI, int NI, int ACT, bool FULL>
-__device__ __forceinline__ void pp_epilogue_body(const GemmParams& p, const f32x4 (&acc)[MI][NI], const f32x4 (&biasv)[NI], int row0,
-                                                 int col0, int lane) {
+__device__ __forceinline__ void pp_epilogue_body(const GemmParams& p, const f32x4 (&acc)[MI][NI], const f32x4 (&biasv)[NI], char* strip2,
+                                                 int row0, int col0, int lane) {
     using T [[maybe_unused]] = g8_t;
     constexpr bool F32OUT = OUT_F32 || EPI == EPI_PARTIAL || EPI == EPI_PATCH;
     static_assert(F32OUT || EPI == EPI_STORE, "G8 output exists for plain row-major stores only");
-    const int r16 = lane & 15, kg = lane >> 4;
+    static_assert(NI == 4, "two 32-column pieces per row block");
+    constexpr int NP = MI * 2;                           // pieces: (i, jp)
+    constexpr int SPITCH = 144, SBYTES = 16 * SPITCH;
+    const int r16 = lane & 15, kg = lane >> 4, srow = lane >> 3, spiece = lane & 7;
     const int act = ACT >= 0 ? ACT : p.gelu;
-    char* ptr = nullptr;                                 // EPI_STORE: this lane's 16 bytes of block (i = 0, j = 0); 4 bytes per element
-    size_t step = 0;
-    if constexpr (EPI == EPI_STORE) {
-        ptr = (char*)p.C + ((size_t)(row0 + r16) * p.ldc + col0 + 4 * kg) * 4;
-        step = (size_t)p.ldc * 64;
-    }
     unsigned sat = 0;
+    auto compute = [&](int n) __attribute__((always_inline)) {           // piece n -> strip n & 1
+        const int i = n >> 1, jp = n & 1;
+        char* st = strip2 + (n & 1) * SBYTES + r16 * SPITCH;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int row = row0 + i * 16 + r16;
-        const bool rok = FULL || row < p.M;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = jp * 2 + jj;
             f32x4 v = acc[i][j] * (1.0f / G8_WSCALE);
             if (EPI != EPI_PARTIAL) v += biasv[j];
             if (act == 1) {
@@ -100,15 +100,10 @@ __device__ __forceinline__ void pp_epilogue_body(const GemmParams& p, const f32x
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            const int col = col0 + j * 16 + 4 * kg;
-            const bool ok = FULL || (rok && col < p.N);
             if constexpr (F32OUT) {
-                if constexpr (EPI == EPI_STORE) {
-                    if (ok) *(f32x4*)(ptr + j * 64) = v;
-                } else {
-                    if (ok) epi_store_f32<EPI>(p, row, col, v);
-                }
+                *(f32x4*)(st + (jj * 16 + 4 * kg) * 4) = v;
             } else {
+                const bool ok = FULL || (row0 + i * 16 + r16 < p.M && col0 + j * 16 + 4 * kg < p.N);
                 sat += (ok && !(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) <= G8_AMAX)) ? 1u : 0u;
                 f16x4 hi, lo;
 #pragma unroll
@@ -117,36 +112,63 @@ __device__ __forceinline__ void pp_epilogue_body(const GemmParams& p, const f32x
                     g8_split(v[e], h, l);
                     hi[e] = h; lo[e] = l;
                 }
-                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                const u32x2 hw = __builtin_bit_cast(u32x2, hi), lw = __builtin_bit_cast(u32x2, lo);
-                const auto s0 = __builtin_amdgcn_permlane16_swap(hw[0], lw[0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(hw[1], lw[1], false, false);
-                u32x4 raw;
-                raw[0] = s0[0]; raw[1] = s1[0]; raw[2] = s0[1]; raw[3] = s1[1];
-                if (ok) *(u32x4*)(ptr + j * 64) = raw;
+                // columns c = jj * 16 + 4 kg .. + 3 of the 32-column piece: group c >> 3 (32 bytes), hi halves at 2 (c & 7)
+                char* gp = st + ((jj * 16 + 4 * kg) >> 3) * 32 + ((4 * kg) & 7) * 2;
+                *(f16x4*)gp = hi;
+                *(f16x4*)(gp + 16) = lo;
             }
         }
-        ptr += step;
+    };
+    // read side: lane (srow, spiece) moves 16 bytes of strip row rr * 8 + srow: 4 columns at col0 + jp * 32 + spiece * 4
+    char* ptr0 = nullptr;
+    char* ptr1 = nullptr;
+    size_t step = 0;
+    if constexpr (EPI == EPI_STORE) {
+        ptr0 = (char*)p.C + ((size_t)(row0 + srow) * p.ldc + col0 + spiece * 4) * 4;
+        ptr1 = ptr0 + (size_t)p.ldc * 32;
+        step = (size_t)p.ldc * 64;
+    }
+    auto drain = [&](int n) __attribute__((always_inline)) {
+        const int i = n >> 1, jp = n & 1;
+        const char* st = strip2 + (n & 1) * SBYTES + srow * SPITCH + spiece * 16;
+        const u32x4 r0 = *(const u32x4*)st, r1 = *(const u32x4*)(st + 8 * SPITCH);
+        const int col = col0 + jp * 32 + spiece * 4;
+        const int rowa = row0 + i * 16 + srow, rowb = rowa + 8;
+        const bool cok = FULL || col < p.N;
+        if constexpr (EPI == EPI_STORE) {
+            if (FULL || (cok && rowa < p.M)) *(u32x4*)(ptr0 + jp * 128) = r0;
+            if (FULL || (cok && rowb < p.M)) *(u32x4*)(ptr1 + jp * 128) = r1;
+            if (jp == 1) { ptr0 += step; ptr1 += step; }
+        } else {
+            if (FULL || (cok && rowa < p.M)) epi_store_f32<EPI>(p, rowa, col, __builtin_bit_cast(f32x4, r0));
+            if (FULL || (cok && rowb < p.M)) epi_store_f32<EPI>(p, rowb, col, __builtin_bit_cast(f32x4, r1));
+        }
+    };
+    compute(0);
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        if (n + 1 < NP) compute(n + 1);
+        drain(n);
     }
     if constexpr (!F32OUT) {
-        if (sat) atomicAdd(&g_g8_clamped, sat);          // same count as g8_note_range per group of four
+        if (sat) atomicAdd(&g_g8_clamped, sat);          // same count as g8_note_range per stored group of four
     }
 }
 
 template <bool OUT_F32, int EPI, int MI, int NI>
-__device__ __forceinline__ void pp_epilogue(const GemmParams& p, const f32x4 (&acc)[MI][NI], const char* bias_w, int row0, int col0,
-                                            int lane) {
+__device__ __forceinline__ void pp_epilogue(const GemmParams& p, const f32x4 (&acc)[MI][NI], const char* bias_w, char* strip2, int row0,
+                                            int col0, int lane) {
     const int kg = lane >> 4;
     f32x4 biasv[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) biasv[j] = bias_w ? *(const f32x4*)(bias_w + (j * 16 + 4 * kg) * 4) : f32x4(0.f);
     const int act = EPI != EPI_PARTIAL ? p.gelu : 0;
     if (row0 + MI * 16 <= p.M && col0 + NI * 16 <= p.N) {
-        if (act == 0) pp_epilogue_body<OUT_F32, EPI, MI, NI, 0, true>(p, acc, biasv, row0, col0, lane);
-        else if (act == 1) pp_epilogue_body<OUT_F32, EPI, MI, NI, 1, true>(p, acc, biasv, row0, col0, lane);
-        else pp_epilogue_body<OUT_F32, EPI, MI, NI, 2, true>(p, acc, biasv, row0, col0, lane);
+        if (act == 0) pp_epilogue_body<OUT_F32, EPI, MI, NI, 0, true>(p, acc, biasv, strip2, row0, col0, lane);
+        else if (act == 1) pp_epilogue_body<OUT_F32, EPI, MI, NI, 1, true>(p, acc, biasv, strip2, row0, col0, lane);
+        else pp_epilogue_body<OUT_F32, EPI, MI, NI, 2, true>(p, acc, biasv, strip2, row0, col0, lane);
     } else {
-        pp_epilogue_body<OUT_F32, EPI, MI, NI, -1, false>(p, acc, biasv, row0, col0, lane);
+        pp_epilogue_body<OUT_F32, EPI, MI, NI, -1, false>(p, acc, biasv, strip2, row0, col0, lane);
     }
 }
 
@@ -158,6 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     constexpr int STAGE = (BM + BN) * 128;               // 64 KiB (48 KiB for half tiles)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const bias_rows = smem + 2 * STAGE;            // [2 slots][4 column groups][64 floats]
+    char* const strips = bias_rows + 2048;               // [4 wave slots][2 strips][16 rows x 144 B]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -325,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
             const int item = first + c_x * nl;
             const int t = tile0 + item / SUB, sub = item % SUB;
             const int tm = t / ntn, tn = t - tm * ntn;
-            pp_epilogue<OUT_F32, EPI, MI, NI>(p, acc, has_bias ? bias_rows + (c_x & 1) * 1024 + wq * 256 : nullptr,
+            pp_epilogue<OUT_F32, EPI, MI, NI>(p, acc, has_bias ? bias_rows + (c_x & 1) * 1024 + wq * 256 : nullptr, strips + wq * (2 * 16 * 144),
                                               tm * 256 + sub * BM + wm0, tn * BN + wn0, lane);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -369,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 
 template <bool OUT_F32, int EPI, bool PROF>
 int launch_pp_t(const GemmParams& p, hipStream_t stream) {
-    constexpr int EXTRA = 2 * 1024;                      // bias rows
+    constexpr int EXTRA = 2 * 1024 + 4 * 2 * 16 * 144;   // bias rows + epilogue strips
     constexpr int LDS = 2 * 512 * 128 + EXTRA, LDS_H = 2 * 384 * 128 + EXTRA;
     auto kern = gemm_pp_kernel<OUT_F32, EPI, PROF, 256>;
     int n_cu = 0;
@@ -409,6 +432,7 @@ int launch_gemm_pp(const GemmParams& p, bool prof, hipStream_t stream) {
 #ifdef CAP_EXPERIMENTS
     if (prof) {
         if (p.epi == EPI_STORE && !p.out_f32) return launch_pp_t<false, EPI_STORE, true>(p, stream);
+        if (p.epi == EPI_STORE && p.out_f32) return launch_pp_t<true, EPI_STORE, true>(p, stream);
         return -2;
     }
 #endif

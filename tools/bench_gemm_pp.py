@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""A/B of the skewed-group split GEMM (gemm_pp.hip, tile 20) against gemm_big2_kernel (tile 3) on the encoder shapes (GPU box).
+"""A/B of the skewed-group split GEMM (gemm_pp.hip, tile 20 = what tile 3 selects) against gemm_big2_kernel (tile 10) on the encoder shapes (GPU box).
     python tools/bench_gemm_pp.py            # bit-identity + interleaved timing
     python tools/bench_gemm_pp.py --cycles   # in-kernel cycle stamps of both (experiments build), on 256 and 64 workgroups"""
 import ctypes as C
@@ -42,15 +42,15 @@ if "--cycles" in sys.argv:
             A = g8(torch.randn(M, K, device="cuda"))
             W = g8(torch.randn(N, K, device="cuda") / K ** 0.5, True)
             out = torch.zeros(M, N, device="cuda", dtype=torch.float32)
-            for tile in (13, 21):
+            for tile, f32o in ((13, 0), (21, 0), (21, 1)):
                 st = 8 if tile == 21 else 6
                 dbg = torch.zeros(256 * 8 * st, device="cuda", dtype=torch.int64)
                 for _ in range(30):
-                    gemm(A, W, None, out, M, N, K, 0, 0, tile, dbg)
+                    gemm(A, W, None, out, M, N, K, 0, f32o, tile, dbg)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(60):
-                    gemm(A, W, None, out, M, N, K, 0, 0, tile, dbg)
+                    gemm(A, W, None, out, M, N, K, 0, f32o, tile, dbg)
                 e1.record()
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) * 1e3 / 60
@@ -61,7 +61,7 @@ if "--cycles" in sys.argv:
                 nst = (tc * (K // 32)).mean().item()
                 tf = 2.0 * M * N * K / us / 1e6
                 extra = f" issue {d[:, :, 6].mean().item() / nst:.0f}" if st == 8 else ""
-                print(f"cus {cus:3d} {name:6s} tile {tile}: {us:7.1f} us {tf:6.1f} TF  clock {mhz:7.1f} MHz  per stage "
+                print(f"cus {cus:3d} {name:6s} tile {tile} f32out {f32o}: {us:7.1f} us {tf:6.1f} TF  clock {mhz:7.1f} MHz  per stage "
                       f"{(cyc.mean().item() - epi.mean().item()) / nst:.0f} cycles (vm-wait {dma.mean().item() / nst:.0f} barrier "
                       f"{bar.mean().item() / nst:.0f}{extra})  epilogue/tile {(epi / tc).mean().item():.0f}", flush=True)
                 if st == 8:
@@ -75,19 +75,19 @@ for name, M, N, K, gelu, f32out in SHAPES:
     W = g8(torch.randn(N, K, device="cuda") / K ** 0.5, True)
     bias = torch.randn(N, device="cuda")
     outs = {}
-    for tile in (3, 20):
+    for tile in (10, 20):
         out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32)
         gemm(A, W, bias, out, M, N, K, gelu, f32out, tile)
         torch.cuda.synchronize()
         outs[tile] = out
-    same = torch.equal(outs[3].view(torch.int32), outs[20].view(torch.int32))
+    same = torch.equal(outs[10].view(torch.int32), outs[20].view(torch.int32))
     line = f"{name:6s} M={M} N={N} K={K}: identical={same}"
     if not same:
-        d = (outs[3] - outs[20]).abs()
-        line += f" maxdiff={d.max().item():.3e} nan20={torch.isnan(outs[20]).sum().item()} nan3={torch.isnan(outs[3]).sum().item()}"
-    out = outs[3]
+        d = (outs[10] - outs[20]).abs()
+        line += f" maxdiff={d.max().item():.3e} nan20={torch.isnan(outs[20]).sum().item()} nan10={torch.isnan(outs[10]).sum().item()}"
+    out = outs[10]
     for rep in range(3):
-        for tile in (3, 20):
+        for tile in (10, 20):
             for _ in range(3):
                 gemm(A, W, bias, out, M, N, K, gelu, f32out, tile)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
