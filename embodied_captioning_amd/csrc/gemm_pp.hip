@@ -27,10 +27,17 @@
 //        2S+1 overwrites lower A of stage S-1, read by group 1 in steps 2S-1, 2S.
 // Sums are formed exactly as in every other G8 kernel (three MFMAs per product, k ascending): results are bit-identical to
 // gemm_big2_kernel's and to the register-staged tiles' (tests/test_split_gpu.py).
-// Measured (MI355X, 256 frames of ViT-B/16, us per launch against gemm_big2_kernel): qkv 441 / 470, proj 164 / 168, fc1 632 /
-// 670, fc2 556 / 585; cycles per stage 3 760-4 080 against 4 600 at 64 workgroups - on the whole chip the shader clock then
-// settles ~10 % lower (1.93 against 2.13 GHz: the board's power limit), which is why the gain in time is a third of the gain
-// in cycles.
+// Measured (MI355X, 256 frames of ViT-B/16, same process, us per launch against gemm_big2_kernel): qkv 435 / 476, proj 157 /
+// 178, fc1 640 / 690, fc2 551 / 605 (-7 .. -11 %).  In cycles (64 workgroups, clock at its 2.39 GHz ceiling): 3 710-3 750 per
+// stage against 4 600, epilogue 3 900 (fp32 out: the L1's store rate) / 7 200 (G8 out: VALU) per tile and group against 14 800
+// for all eight waves together.  On the whole chip the shader clock settles ~10 % lower than under gemm_big2_kernel (1.93
+// against 2.13 GHz: the board's power limit), so about half of the gain in cycles arrives as time.
+// Tried on this structure and not kept (tools/bench_gemm_pp.py --cycles, gpurun_out/r3_pp1[1-6]c.log): the epilogue spread over
+// the tile boundary, one row block (or one strip piece, pipelined) after each MFMA block - a wave issues a block's 12 MFMAs
+// before anything else, so its epilogue arithmetic still runs while ITS matrix instructions wait for the pipe, the steps at a
+// tile boundary got longer than the serial epilogue they replaced (boundary 10.6k against 8.5k cycles per tile, and the stage
+// loop itself 12 % slower); A fragments two blocks ahead instead of one (level); three accumulator chains per block in a row
+// instead of two interleaved (level).
 #include <stdlib.h>
 
 #include <algorithm>
