@@ -176,7 +176,8 @@ def pooled(a, arch, sd, **kw):
 
 KERNEL_NAME = {"bf16": "gemm_big3_kernel (K=768: qkv/proj/fc1) + gemm_big2_kernel (K=3072: fc2), 256x256 LDS-DMA, 16x16x32 bf16 MFMA",
                "f32": "gemm_big_kernel 256x256 LDS-DMA, 32x32x2 fp32 MFMA (ViT qkv/proj/fc1/fc2 launches)",
-               "f32s": "gemm_big2_kernel<g8_t> 256x256 LDS-DMA, split fp16: 3 x 16x16x32 f16 MFMA per product (ViT qkv/proj/fc1/fc2)"}
+               "f32s": "gemm_pp_kernel 256x256 LDS-DMA, wave groups half a stage apart, split fp16: 3 x 16x16x32 f16 MFMA per product "
+                       "(ViT qkv/proj/fc1/fc2)"}
 
 
 def encoder_only(eng, px, arch, steps=5):
@@ -300,7 +301,7 @@ def pmc_summary(dtype):
             continue
     if d is None:
         return out
-    enc = (r"gemm_(big2|enc)_kernel(I4g8_tLb[01]ELi0E|<g8_t, (true|false), 0,)" if dtype == "f32s"
+    enc = (r"gemm_pp_kernel(ILb[01]ELi0E|<(true|false), 0,)|gemm_(big2|enc)_kernel(I4g8_tLb[01]ELi0E|<g8_t, (true|false), 0,)" if dtype == "f32s"
            else r"gemm_big[23]_kernel(I(DF16b|u6__bf16)?Lb[01]ELi0E|ILb[01]ELi0E|<(__bf16, )?(true|false), 0,)")
     classes = {"enc_gemm": enc, "cross_attention": r"decode_attention_(online|shared)_kernel",
                "decode_gemm": r"gemm_(kernel|rows_kernel)<[^>]*, (true|false), 4>|gemm_rows_kernel|gemm_kernel<(g8_t|__bf16|float), 64, 64, 32, 32, 6, 3, false, 0>"}
