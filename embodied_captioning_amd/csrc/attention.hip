@@ -1003,28 +1003,31 @@ template <> struct Raw8<bf16_t> {
     __device__ __forceinline__ void zero() { for (int i = 0; i < 8; ++i) r[i] = (bf16_t)0.f; }
     __device__ __forceinline__ float get(int i) const { return (float)r[i]; }
     __device__ __forceinline__ void set(int i, float x) { r[i] = (bf16_t)x; }
+    static constexpr bool scaled = false;
+    __device__ __forceinline__ float scale() const { return 1.f; }
 };
-// KV24 (common.h): eight head dimensions dch * 8 .. + 7 of a 192-byte row = 16 bytes of upper halves + 8 bytes of third bytes
-// -> eight fp32 values, one v_perm_b32 each.  Raw8<T>::load_row(base, ri, dch) reads those eight dimensions of the 64-wide KV
-// row `ri` of a cache of element type T (the other specialisations: plain typed rows).
+// KV16 (common.h): eight head dimensions dch * 8 .. + 7 of a row = 16 bytes of int16 + the row's fp32 scale (the same word for
+// the 8 lanes of a key).  get(i) is the INTEGER as a float (one SDWA convert); the kernels apply scale() once per key to the
+// score and to the probability instead of once per element.  Raw8<T>::load_row(base, ri, dch) reads those eight dimensions of
+// the 64-wide KV row `ri` of a cache of element type T (the other specialisations: plain typed rows, scale() == 1).
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-template <> struct Raw8<kv24_t> {
-    u32x4_t hi; unsigned int lo0, lo1;
+template <> struct Raw8<kv16_t> {
+    u32x4_t q; float sc;
+    static constexpr bool scaled = true;
     __device__ __forceinline__ void load_row(const void* base, size_t ri, int dch) {
-        const char* row = (const char*)base + ri * KV24_ROW;
-        hi = *(const u32x4_t*)(row + dch * 16);
-        const uint2 l = *(const uint2*)(row + 128 + dch * 8);
-        lo0 = l.x; lo1 = l.y;
+        q = *(const u32x4_t*)((const char*)base + kv16_row_off(ri) + dch * 16);
+        sc = *(const float*)((const char*)base + kv16_scale_off(ri));
     }
-    __device__ __forceinline__ void load_row_nt(const void* base, size_t ri, int dch) { load_row(base, ri, dch); }
-    __device__ __forceinline__ void zero() { hi = 0u; lo0 = lo1 = 0u; }
+    __device__ __forceinline__ void load_row_nt(const void* base, size_t ri, int dch) {
+        q = __builtin_nontemporal_load((const u32x4_t*)((const char*)base + kv16_row_off(ri) + dch * 16));
+        sc = __builtin_nontemporal_load((const float*)((const char*)base + kv16_scale_off(ri)));
+    }
+    __device__ __forceinline__ void zero() { q = 0u; sc = 0.f; }
     __device__ __forceinline__ float get(int i) const {
-        const unsigned int w = hi[i >> 1], l = (i < 4) ? lo0 : lo1;
-        // result bytes: [0, third byte, upper half low byte, upper half high byte]; v_perm_b32: selector 0-3 = bytes of the
-        // second operand, 4-7 = bytes of the first, 0x0c = zero
-        const unsigned int sel = ((i & 1) ? 0x07060000u : 0x05040000u) | ((unsigned)(i & 3) << 8) | 0x0cu;
-        return __uint_as_float(__builtin_amdgcn_perm(w, l, sel));
+        const unsigned int w = q[i >> 1];
+        return (float)((i & 1) ? (short)(w >> 16) : (short)(w & 0xFFFFu));
     }
+    __device__ __forceinline__ float scale() const { return sc; }
 };
 template <> struct Raw8<float> {
     f32x4 a, b;
@@ -1035,6 +1038,8 @@ template <> struct Raw8<float> {
     __device__ __forceinline__ void zero() { a = 0.f; b = 0.f; }
     __device__ __forceinline__ float get(int i) const { return i < 4 ? a[i] : b[i - 4]; }
     __device__ __forceinline__ void set(int i, float x) { if (i < 4) a[i] = x; else b[i - 4] = x; }
+    static constexpr bool scaled = false;
+    __device__ __forceinline__ float scale() const { return 1.f; }
 };
 
 template <typename T, int NI, typename TO = T>
@@ -1142,7 +1147,9 @@ __global__ __launch_bounds__(256, 3) void decode_attention_online_kernel(const T
                                                                       const int* __restrict__ anc, int anc_ld,
                                                                       int rows_per_kv, int kv_ld, int n_keys,
                                                                       TO* __restrict__ out, int R, int H, QSource qs,
-                                                                      const int* __restrict__ skip) {
+                                                                      const int* __restrict__ skip, size_t ri0 = 0) {
+    // ri0: row index of the first K/V row the launch may touch, for caches addressed by row index (KV16: kbase / vbase are the
+    // bases of the layer's whole k / v block).
     // G = key groups (of 8 keys) per chunk, chosen by the launcher so the chunks are balanced (197 keys -> 4 x 56).
     // DB: two register buffers, the next chunk's loads are in flight while the current one is consumed.
     constexpr int CH = 8 * G;
@@ -1164,7 +1171,7 @@ __global__ __launch_bounds__(256, 3) void decode_attention_online_kernel(const T
             const int key = k0 + g * 8 + ksub;
             if (key < n_keys) {
                 const int src = anc ? anc[(size_t)row * anc_ld + key] : src0;
-                const size_t ri = ((size_t)src * H + h) * kv_ld + key;
+                const size_t ri = ri0 + ((size_t)src * H + h) * kv_ld + key;
                 if constexpr (NT) { kr[g].load_row_nt(kbase, ri, dch); vr[g].load_row_nt(vbase, ri, dch); }
                 else { kr[g].load_row(kbase, ri, dch); vr[g].load_row(vbase, ri, dch); }
             } else {
@@ -1179,6 +1186,7 @@ __global__ __launch_bounds__(256, 3) void decode_attention_online_kernel(const T
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) s = fmaf(qv[e], kr[g].get(e), s);
+            if constexpr (Raw8<TKV>::scaled) s *= kr[g].scale();
             s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
             sc[g] = (k0 + g * 8 + ksub < n_keys) ? s : -INFINITY;
             cm = fmaxf(cm, sc[g]);
@@ -1193,8 +1201,9 @@ __global__ __launch_bounds__(256, 3) void decode_attention_online_kernel(const T
         for (int g = 0; g < G; ++g) {
             const float p = expf(sc[g] - mn);
             l += p;
+            const float pv = Raw8<TKV>::scaled ? p * vr[g].scale() : p;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = fmaf(p, vr[g].get(e), o[e]);
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(pv, vr[g].get(e), o[e]);
         }
         m = mn;
     };
@@ -1250,7 +1259,7 @@ template <typename T, int G, int NB, typename TO = T, typename TKV = T>
 __global__ __launch_bounds__(256, 2) void decode_attention_shared_kernel(const T* __restrict__ q, const T* __restrict__ kbase,
                                                                       const T* __restrict__ vbase, int kv_ld, int n_keys,
                                                                       TO* __restrict__ out, int n_img, int H, QSource qs,
-                                                                      const int* __restrict__ skip) {
+                                                                      const int* __restrict__ skip, size_t ri0 = 0) {
     constexpr int CH = 8 * G;
     const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (unit >= n_img * H) return;
@@ -1273,7 +1282,7 @@ __global__ __launch_bounds__(256, 2) void decode_attention_shared_kernel(const T
         for (int g = 0; g < G; ++g) {
             const int key = k0 + g * 8 + ksub;
             if (key < n_keys) {
-                const size_t ri = ((size_t)img * H + h) * kv_ld + key;
+                const size_t ri = ri0 + ((size_t)img * H + h) * kv_ld + key;
                 kr[g].load_row(kbase, ri, dch); vr[g].load_row(vbase, ri, dch);
             } else {
                 kr[g].zero(); vr[g].zero();
@@ -1303,6 +1312,7 @@ __global__ __launch_bounds__(256, 2) void decode_attention_shared_kernel(const T
                 float sv = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sv = fmaf(qv[b][e], kr[g].get(e), sv);
+                if constexpr (Raw8<TKV>::scaled) sv *= kr[g].scale();
                 sv += __shfl_xor(sv, 1, 64); sv += __shfl_xor(sv, 2, 64); sv += __shfl_xor(sv, 4, 64);
                 sc[g] = (k0 + g * 8 + ksub < n_keys) ? sv : -INFINITY;
                 cm = fmaxf(cm, sc[g]);
@@ -1317,8 +1327,9 @@ __global__ __launch_bounds__(256, 2) void decode_attention_shared_kernel(const T
             for (int g = 0; g < G; ++g) {
                 const float pj = expf(sc[g] - mn);
                 l[b] += pj;
+                const float pw = Raw8<TKV>::scaled ? pj * vr[g].scale() : pj;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[b][e] = fmaf(pj, vr[g].get(e), o[b][e]);
+                for (int e = 0; e < 8; ++e) o[b][e] = fmaf(pw, vr[g].get(e), o[b][e]);
             }
             m[b] = mn;
         }
@@ -1802,10 +1813,11 @@ int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
 int launch_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             hipStream_t s, const float* q_part, int q_S, const float* q_bias, int q_ld, int q_col0,
-                            int append_kv, int out_dtype, const int* skip_rows, int kv24) {
+                            int append_kv, int out_dtype, const int* skip_rows, int kv16, size_t kv_row0) {
+    // kv16: kbase / vbase are the bases of KV16 blocks (common.h), the launch's first row has index kv_row0 in them
     if (out_dtype < 0) out_dtype = dtype;
-    if (kv24 && !(dtype == CAP_DT_F32 && impl == 0 && !anc && !append_kv && n_keys > 32)) {
-        cap_set_error("decode_attention: a KV24 cache is the split / fp32 modes' cross-attention cache (no ancestry, > 32 keys)");
+    if (kv16 && !(dtype == CAP_DT_F32 && impl == 0 && !anc && !append_kv && n_keys > 32)) {
+        cap_set_error("decode_attention: a KV16 cache is the split / fp32 modes' cross-attention cache (no ancestry, > 32 keys)");
         return -1;
     }
     if (out_dtype != dtype && !(dtype == CAP_DT_F32 && out_dtype == CAP_DT_G8 && impl == 0)) {
@@ -1846,7 +1858,7 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
         const int n_img = R / rows_per_kv;
 #define CAP_DA_SHARED(TT, GG, NBB, TOO, TKK)                                                                            \
     hipLaunchKernelGGL((decode_attention_shared_kernel<TT, GG, NBB, TOO, TKK>), dim3((n_img * H + 3) / 4), dim3(256), 0, s, \
-                       (const TT*)q, (const TT*)kbase, (const TT*)vbase, kv_ld, n_keys, (TOO*)out, n_img, H, qs, skip_rows)
+                       (const TT*)q, (const TT*)kbase, (const TT*)vbase, kv_ld, n_keys, (TOO*)out, n_img, H, qs, skip_rows, kv_row0)
 #define CAP_DA_SHARED_NB(TT, GG, TOO, TKK)                                                                              \
     switch (rows_per_kv) {                                                                                             \
         case 2: CAP_DA_SHARED(TT, GG, 2, TOO, TKK); break;                                                             \
@@ -1855,9 +1867,9 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
         default: CAP_DA_SHARED(TT, GG, 5, TOO, TKK); break;                                                            \
     }
         if (dtype == CAP_DT_BF16) CAP_DA_SHARED_NB(bf16_t, 5, bf16_t, bf16_t)
-        else if (out_dtype == CAP_DT_G8 && kv24) CAP_DA_SHARED_NB(float, 7, g8_t, kv24_t)
+        else if (out_dtype == CAP_DT_G8 && kv16) CAP_DA_SHARED_NB(float, 5, g8_t, kv16_t)       // (the online kernel's chunking: same bits per row)
         else if (out_dtype == CAP_DT_G8) CAP_DA_SHARED_NB(float, 7, g8_t, float)
-        else if (kv24) CAP_DA_SHARED_NB(float, 7, float, kv24_t)
+        else if (kv16) CAP_DA_SHARED_NB(float, 5, float, kv16_t)
         else CAP_DA_SHARED_NB(float, 7, float, float)
 #undef CAP_DA_SHARED_NB
 #undef CAP_DA_SHARED
@@ -1871,10 +1883,13 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
         } else if (out_dtype == CAP_DT_G8) {      // split mode: fp32 caches, the context row is the next GEMM's G8 operand
             if (ng8 <= 1) CAP_DA_WAVE_O(float, 1, g8_t); else if (ng8 <= 2) CAP_DA_WAVE_O(float, 2, g8_t);
             else if (ng8 <= 4) CAP_DA_WAVE_O(float, 4, g8_t);
-            else if (kv24)
-                hipLaunchKernelGGL((decode_attention_online_kernel<float, 7, false, false, g8_t, kv24_t>), dim3((R * H + 3) / 4), dim3(256), 0,
+            else if (kv16)
+                // chunks of 40 keys, one register buffer: 31.5 us per launch at 256 rows x 197 keys against 32.9 with chunks of 56
+                // and 32.7 / 31.7 / 68.7 double-buffered with 32 / 24 / 40 keys per chunk (tools/bench_cross_attention.py): with
+                // ~4 us of launch, 160 MB in the rest is the HBM rate
+                hipLaunchKernelGGL((decode_attention_online_kernel<float, 5, false, false, g8_t, kv16_t>), dim3((R * H + 3) / 4), dim3(256), 0,
                                    s, (const float*)q, (const float*)kbase, (const float*)vbase, anc, anc_ld, rows_per_kv, kv_ld,
-                                   n_keys, (g8_t*)out, R, H, qs, skip_rows);
+                                   n_keys, (g8_t*)out, R, H, qs, skip_rows, kv_row0);
             else
                 hipLaunchKernelGGL((decode_attention_online_kernel<float, 7, false, false, g8_t>), dim3((R * H + 3) / 4), dim3(256), 0,
                                    s, (const float*)q, (const float*)kbase, (const float*)vbase, anc, anc_ld, rows_per_kv, kv_ld,
@@ -1882,10 +1897,10 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
         } else {
             if (ng8 <= 1) CAP_DA_WAVE(float, 1); else if (ng8 <= 2) CAP_DA_WAVE(float, 2);
             else if (ng8 <= 4) CAP_DA_WAVE(float, 4);
-            else if (kv24)
-                hipLaunchKernelGGL((decode_attention_online_kernel<float, 7, false, false, float, kv24_t>), dim3((R * H + 3) / 4), dim3(256), 0,
+            else if (kv16)
+                hipLaunchKernelGGL((decode_attention_online_kernel<float, 5, false, false, float, kv16_t>), dim3((R * H + 3) / 4), dim3(256), 0,
                                    s, (const float*)q, (const float*)kbase, (const float*)vbase, anc, anc_ld, rows_per_kv, kv_ld,
-                                   n_keys, (float*)out, R, H, qs, skip_rows);
+                                   n_keys, (float*)out, R, H, qs, skip_rows, kv_row0);
             else CAP_DA_ONLINE(float, false);
         }
         CAP_HIP_CHECK(hipGetLastError());
@@ -1910,17 +1925,27 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
     return 0;
 }
 
-__global__ void pack_kv24_kernel(const float* __restrict__ src, char* __restrict__ dst, size_t n_rows) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows * 16; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t r = i >> 4;
-        const int d = (int)(i & 15) * 4;
-        const float4 v = *(const float4*)(src + r * 64 + d);
-        kv24_store4(dst + r * KV24_ROW, d, v.x, v.y, v.z, v.w);
-    }
+// fp32 rows [n_rows, 64] -> one KV16 block (common.h): what the cross-K/V GEMM's epilogue writes, as a kernel of its own (tests).
+// One wave per 4 rows: 16 lanes per row, 4 values per lane; the row maximum goes through two DPP-free shuffles.
+__global__ void pack_kv16_kernel(const float* __restrict__ src, char* __restrict__ dst, size_t n_rows) {
+    const size_t r = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int d = (int)(threadIdx.x & 15) * 4;
+    if (r >= n_rows) return;                             // (whole 16-lane groups leave together)
+    const float4 v = *(const float4*)(src + r * 64 + d);
+    float am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    am = fmaxf(am, __shfl_xor(am, 1, 64)); am = fmaxf(am, __shfl_xor(am, 2, 64));
+    am = fmaxf(am, __shfl_xor(am, 4, 64)); am = fmaxf(am, __shfl_xor(am, 8, 64));
+    float sc, inv;
+    kv16_scales(am, sc, inv);
+    uint2 w;
+    w.x = kv16_pack2(v.x, v.y, inv);
+    w.y = kv16_pack2(v.z, v.w, inv);
+    *(uint2*)(dst + kv16_row_off(r) + d * 2) = w;
+    if (d == 0) *(float*)(dst + kv16_scale_off(r)) = sc;
 }
-int launch_pack_kv24(const float* src, void* dst, size_t n_rows, hipStream_t s) {
-    const int grid = (int)std::min<size_t>((n_rows * 16 + 255) / 256, 4096);
-    hipLaunchKernelGGL(pack_kv24_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, src, (char*)dst, n_rows);
+int launch_pack_kv16(const float* src, void* dst, size_t n_rows, hipStream_t s) {
+    const size_t threads = n_rows * 16;
+    hipLaunchKernelGGL(pack_kv16_kernel, dim3((unsigned)((threads + 255) / 256 ? (threads + 255) / 256 : 1)), dim3(256), 0, s, src, (char*)dst, n_rows);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -112,8 +112,10 @@ struct Captioner {
     int gdt;                     // type of every GEMM operand (A and W): == dt, except CAP_F32_SPLIT: dt = fp32, gdt = G8
                                  // (split fp16, common.h) - there every kernel whose output feeds a GEMM writes G8
     int NT, P, Kpatch, Kpad;
-    bool kv24 = false;           // split mode: the cross-attention K/V cache is KV24 (3 bytes per element, common.h) instead of fp32
-    size_t kvrow = 0;            // bytes of one 64-wide head row of that cache
+    bool kv16 = false;           // split mode: the cross-attention K/V cache is KV16 (int16 + one scale per head row, common.h) instead of fp32
+    size_t kvrow = 0;            // bytes of one 64-wide head row of that cache (KV16: 132, amortised)
+    // bytes of one (layer, k | v) block of the cross cache holding `rows` head rows
+    size_t cross_block(size_t rows) const { return kv16 ? kv16_block_bytes(rows) : rows * kvrow; }
     size_t dev_bytes = 0;        // arena (+ the weights when this handle created the store)
     std::vector<void*> allocs;   // arena: owned by this handle
     WeightStore* ws = nullptr;   // weights: shared
@@ -423,7 +425,7 @@ int build_arena_coca(Captioner* m) {
     TRY(dev_alloc(m, (void**)&m->pool_o, Bm * Q * E * 4));
     TRY(dev_alloc(m, (void**)&m->img_tokens, Bm * Q * E * 4));
     TRY(dev_alloc(m, &m->xhat, Bm * Q * E * e));
-    TRY(dev_alloc(m, &m->cross, (size_t)c.mm_layers * 2 * Bm * H * Q * m->kvrow));
+    TRY(dev_alloc(m, &m->cross, (size_t)c.mm_layers * 2 * m->cross_block((size_t)Bm * H * Q)));
     TRY(dev_alloc(m, (void**)&m->seq, R * Lm * 4));
     TRY(dev_alloc(m, (void**)&m->finished, R * 4));
     TRY(dev_alloc(m, (void**)&m->lens, R * 4));
@@ -457,7 +459,7 @@ int build_arena(Captioner* m) {
     TRY(dev_alloc(m, &m->mlp, M * c.v_mlp * e));
     TRY(dev_alloc(m, (void**)&m->emb_f, M * D * 4));
     TRY(dev_alloc(m, &m->emb_t, M * D * e));
-    TRY(dev_alloc(m, &m->cross, (size_t)c.t_layers * 2 * Bm * H * NT * m->kvrow));
+    TRY(dev_alloc(m, &m->cross, (size_t)c.t_layers * 2 * m->cross_block((size_t)Bm * H * NT)));
     TRY(dev_alloc(m, (void**)&m->seq, R * Lm * 4));
     TRY(dev_alloc(m, (void**)&m->finished, R * 4));
     TRY(dev_alloc(m, (void**)&m->lens, R * 4));
@@ -498,7 +500,7 @@ int gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, int lda, c
     p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.bias = bias; p.resid = resid; p.ldr = ldc;
     p.M = M; p.N = N; p.K = K; p.gelu = gelu; p.out_f32 = out_f32; p.epi = epi;
     p.p0 = p0; p.p1 = p1; p.p2 = p2; p.p3 = p3; p.aux = aux; p.C2 = C2; p.splitk = 1;
-    p.kv24 = epi == EPI_CROSSKV && m->kv24 ? 1 : 0;
+    p.kv16 = epi == EPI_CROSSKV && m->kv16 ? 1 : 0;
     const double osz = out_f32 ? 4.0 : (double)m->esz;
     ProfScope ps(m, s, tag, 2.0 * M * N * K, ((double)M * K + (double)N * K) * m->esz + (double)M * N * osz);
     return launch_gemm(m->gdt, p, 0, s);   // tile 0 = auto (stream kernel for encoder-sized problems without residual)
@@ -1118,12 +1120,14 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
         {
             int S = 1;
             TRY(gemm_partial(m, s, "dec_gemm_cq", d.dx_t, L.w_cq, d.dpart, R, T, T, 4, &S));
-            // beam-shared cross K/V of layer i: [k|v][image (whole batch)][head][token][64]; this slice starts at image b0
-            const char* ck = (char*)m->cross + (((size_t)i * 2 + 0) * d.Btot + d.b0) * H * NT * m->kvrow;
-            const char* cv = (char*)m->cross + (((size_t)i * 2 + 1) * d.Btot + d.b0) * H * NT * m->kvrow;
+            // beam-shared cross K/V of layer i: [k|v][image (whole batch)][head][token][64]; this slice starts at image b0.  A KV16
+            // cache is addressed by row index inside the layer's k / v block: the kernel gets the block bases and the first row
+            const size_t blk = m->cross_block((size_t)d.Btot * H * NT), row0 = (size_t)d.b0 * H * NT;
+            const char* ck = (char*)m->cross + ((size_t)i * 2 + 0) * blk + (m->kv16 ? 0 : row0 * m->kvrow);
+            const char* cv = (char*)m->cross + ((size_t)i * 2 + 1) * blk + (m->kv16 ? 0 : row0 * m->kvrow);
             ProfScope ps(m, s, "dec_cross_attn", 4.0 * R * H * NT * 64, 2.0 * d.B * H * NT * m->kvrow);
             TRY(launch_decode_attention(m->dt, nullptr, ck, cv, nullptr, 0, K, NT, NT, d.dctx, R, H, 0, s, d.dpart, S, L.b_cq,
-                                        T, 0, 0, m->gdt, skip, m->kv24 ? 1 : 0));
+                                        T, 0, 0, m->gdt, skip, m->kv16 ? 1 : 0, m->kv16 ? row0 : 0));
         }
         TRY(gemm_splitk_ln(m, s, d, "dec_gemm_co", d.dctx, L.w_co, L.b_co, L.co_g, L.co_b, T, T));
         TRY(gemm_rows(m, s, "dec_gemm_f1", d.dx_t, L.w_f1, d.dh, L.b_f1, R, F, T, 1));
@@ -1168,11 +1172,12 @@ int run_coca_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, int
         } else {
             TRY(gemm_partial(m, s, "coca_gemm_cq", d.dx_t, b.w_in, d.dpart, R, E, E, 4, &S));
             // cross K/V of multimodal layer i: [k|v][image][head][Q tokens][64]; token 0 (the pooled token) is skipped
-            const char* ck = (char*)m->cross + ((((size_t)b.cross_idx * 2 + 0) * d.Btot + d.b0) * H * Q + 1) * m->kvrow;
-            const char* cv = (char*)m->cross + ((((size_t)b.cross_idx * 2 + 1) * d.Btot + d.b0) * H * Q + 1) * m->kvrow;
+            const size_t blk = m->cross_block((size_t)d.Btot * H * Q), row0 = (size_t)d.b0 * H * Q + 1;
+            const char* ck = (char*)m->cross + ((size_t)b.cross_idx * 2 + 0) * blk + (m->kv16 ? 0 : row0 * m->kvrow);
+            const char* cv = (char*)m->cross + ((size_t)b.cross_idx * 2 + 1) * blk + (m->kv16 ? 0 : row0 * m->kvrow);
             ProfScope ps(m, s, "coca_cross_attn", 4.0 * R * H * (Q - 1) * 64, 2.0 * d.B * H * (Q - 1) * m->kvrow);
             TRY(launch_decode_attention(m->dt, nullptr, ck, cv, nullptr, 0, K, Q, Q - 1, d.dctx, R, H, 0, s, d.dpart, S, b.b_in, E,
-                                        0, 0, m->gdt, nullptr, m->kv24 ? 1 : 0));
+                                        0, 0, m->gdt, nullptr, m->kv16 ? 1 : 0, m->kv16 ? row0 : 0));
         }
         // x += out_proj(ctx) ; ln = LayerNorm_2(x)
         TRY(gemm_splitk_reduce_ln(m, s, d, "coca_gemm_o", d.dctx, b.w_o, b.b_o, b.ln2_g, b.ln2_b, c.t_eps, E, E, d.dx_t, nullptr, d.dx));
@@ -1368,10 +1373,10 @@ static int create_impl(const CapConfig* cfg, Captioner* share, CapHandle* out) {
     m->gdt = cfg->compute_dtype == CAP_F32_SPLIT ? CAP_DT_G8 : m->dt;
     m->esz = m->dt == CAP_DT_BF16 ? 2 : 4;            // a G8 element is 4 bytes like fp32
     const int g = text_only ? 0 : cfg->image_size / cfg->patch_size;
-    // (the KV24 layout is read by the chunked cross-attention kernels: more than 32 keys per image - every real geometry; the
+    // (the KV16 layout is read by the chunked cross-attention kernels: more than 32 keys per image - every real geometry; the
     // fixture-sized ones keep fp32 rows)
-    m->kv24 = m->gdt == CAP_DT_G8 && ((cfg->arch == CAP_ARCH_BLIP && g * g + 1 > 32) || (cfg->arch == CAP_ARCH_COCA && cfg->pool_queries - 1 > 32));
-    m->kvrow = m->kv24 ? KV24_ROW : 64 * m->esz;
+    m->kv16 = m->gdt == CAP_DT_G8 && ((cfg->arch == CAP_ARCH_BLIP && g * g + 1 > 32) || (cfg->arch == CAP_ARCH_COCA && cfg->pool_queries - 1 > 32));
+    m->kvrow = m->kv16 ? 132 : 64 * m->esz;
     m->P = g * g; m->NT = m->P + 1;
     m->Kpatch = text_only ? 0 : 3 * cfg->patch_size * cfg->patch_size;
     m->Kpad = (m->Kpatch + 63) / 64 * 64;
@@ -1671,12 +1676,21 @@ int cap_op_gemm_skinny_slices(int N, int K, int finished) { return skinny_plan(N
 int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int32_t* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             void* stream) {
-    // impl bit 16: kbase / vbase are KV24 caches (cap_op_pack_kv24)
+    // impl bit 16: kbase / vbase are KV16 blocks (cap_op_pack_kv16) whose row 0 is the launch's first K/V row
     return launch_decode_attention(in_dt_of(dtype), q, kbase, vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, out, R, H, impl & 15,
-                                   (hipStream_t)stream, nullptr, 0, nullptr, 0, 0, 0, dt_of(dtype), nullptr, (impl >> 4) & 1);
+                                   (hipStream_t)stream, nullptr, 0, nullptr, 0, 0, 0, dt_of(dtype), nullptr, (impl >> 4) & 1, 0);
 }
-int cap_op_pack_kv24(const float* src, void* dst, size_t n_rows, void* stream) {
-    return launch_pack_kv24(src, dst, n_rows, (hipStream_t)stream);
+int cap_op_gemm_crosskv(int dtype, const void* A, const void* W, const float* bias, void* cache, int n_img, int tokens, int heads,
+                        int layers, int K, int kv16, void* stream) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = cache; p.ldc = 0; p.bias = bias;
+    p.M = n_img * tokens; p.N = layers * 2 * heads * 64; p.K = K; p.out_f32 = 1; p.epi = EPI_CROSSKV; p.splitk = 1;
+    p.p0 = tokens; p.p1 = heads; p.p2 = n_img; p.kv16 = kv16;
+    return launch_gemm(dt_of(dtype), p, 0, (hipStream_t)stream);
+}
+int cap_op_pack_kv16(const float* src, void* dst, size_t n_rows, void* stream) {
+    return launch_pack_kv16(src, dst, n_rows, (hipStream_t)stream);
 }
 int cap_op_beam_candidates(const float* logits, int ld, int V, int B, int K, int legacy_raw, int masked_id, float* out_val,
                            int32_t* out_idx, void* stream) {

@@ -28,7 +28,8 @@ struct GemmParams {
     int p0, p1, p2, p3;
     const float* aux;
     void* C2;
-    int kv24;                      // EPI_CROSSKV with an fp32 output: 1 = pack the K/V rows as KV24 (common.h) instead of fp32
+    int kv16;                      // EPI_CROSSKV with an fp32 output: 1 = write the K/V rows as KV16 blocks (common.h: int16 + one
+                                   // scale per head row; gemm_pp.hip is the only producer) instead of fp32; C = base of block (layer 0, k)
     int tile0, tile1;              // set by launch_big2 only: the range of 256 x 256 tiles one launch covers (0, 0 = all)
 };
 

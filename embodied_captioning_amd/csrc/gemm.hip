@@ -66,9 +66,6 @@ __device__ __forceinline__ void epi_store4(const GemmParams& p, int row, int col
         }
     }
     if constexpr (OUT_F32) {
-        if constexpr (EPI == EPI_CROSSKV) {
-            if (p.kv24) { kv24_store4((char*)base + (o >> 6) * KV24_ROW, (int)(o & 63), v[0], v[1], v[2], v[3]); return; }
-        }
         *(f32x4*)((float*)base + o) = v;
     } else if constexpr (is_g8<T>) {
         static_assert(!is_g8<T> || EPI == EPI_STORE || EPI == EPI_PARTIAL, "G8 output exists for plain row-major stores only");
@@ -1215,6 +1212,11 @@ int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream) {
         const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
         tile = (t256 >= 256 || (t256 >= 128 && p.M >= 256)) ? 3 : (t128 >= 256 ? 1 : 2);   // few rows: a 256-row tile is mostly padding
+    }
+    if (p.epi == EPI_CROSSKV && p.kv16) {               // int16 rows with one scale each: only gemm_pp.hip's epilogue builds them
+        const int rc = dtype == CAP_DT_G8 ? launch_gemm_pp(p, false, stream) : -2;
+        if (rc == -2) cap_set_error("launch_gemm: a KV16 cross-K/V cache needs G8 operands, K >= 64 and operands below 4 GB (K=%d)", p.K);
+        return rc == -2 ? -1 : rc;
     }
     // split fp16, 256x256: the kernel with the wave groups half a stage apart (gemm_pp.hip) wherever it takes the shape;
     // gemm_big2_kernel<g8_t> stays reachable as tiles 10-12 (A/B, bit-identical) and takes what is left (resid, K < 64, ...)

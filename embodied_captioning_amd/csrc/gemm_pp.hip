@@ -162,6 +162,63 @@ __device__ __forceinline__ void pp_epilogue_body(const GemmParams& p, const f32x
     }
 }
 
+// EPI_CROSSKV into a KV16 cache (common.h): a wave's 64 columns are one head of one (layer, k | v) block, so a row block's 16 x 64
+// values are 16 head rows: row maximum (16 values in the lane, then across the four lanes of the row), one scale per row,
+// int16 quantisation, and the 128-byte rows leave through the strips like every other output (two whole lines per lane pair of
+// reads).  Row r of a block = (image * heads + head) * tokens + token; rows live in groups of 32 (kv16_row_off / kv16_scale_off).
+template <int MI>
+__device__ __forceinline__ void pp_epilogue_kv16(const GemmParams& p, const f32x4 (&acc)[MI][4], const f32x4 (&biasv)[4], char* strip2,
+                                                 int row0, int col0, int lane) {
+    constexpr int SPITCH = 144, SBYTES = 16 * SPITCH;
+    if (col0 >= p.N) return;                             // (N % 64 == 0: a wave's columns are inside or outside together)
+    const int r16 = lane & 15, kg = lane >> 4, srow = lane >> 3, spiece = lane & 7;
+    const int NT = p.p0, H = p.p1, Dh = H * 64;
+    const int blk = col0 / Dh, h = (col0 - blk * Dh) >> 6;
+    char* base = (char*)p.C + (size_t)blk * kv16_block_bytes((size_t)p.p2 * H * NT);
+    // row -> (image, token) without a division per lane: rows of this block are row0 + x, x < 16 MI; n / NT for n < 2^16
+    const unsigned magic = 0xFFFFFFFFu / (unsigned)NT + 1u;
+    const int b0 = row0 / NT, t0 = row0 - b0 * NT;
+    auto block_row = [&](int x) -> size_t {
+        const unsigned n = (unsigned)(t0 + x), qd = __umulhi(n, magic);
+        return ((size_t)(b0 + (int)qd) * H + h) * NT + (n - qd * (unsigned)NT);
+    };
+    auto compute = [&](int i) __attribute__((always_inline)) {
+        f32x4 v[4];
+        float am = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = acc[i][j] * (1.0f / G8_WSCALE) + biasv[j];
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(v[j][0]), fabsf(v[j][1])), fmaxf(fabsf(v[j][2]), fabsf(v[j][3]))));
+        }
+        am = fmaxf(am, __shfl_xor(am, 16, 64));
+        am = fmaxf(am, __shfl_xor(am, 32, 64));
+        float sc, inv;
+        kv16_scales(am, sc, inv);
+        char* st = strip2 + (i & 1) * SBYTES + r16 * SPITCH + kg * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint2 w;
+            w.x = kv16_pack2(v[j][0], v[j][1], inv);
+            w.y = kv16_pack2(v[j][2], v[j][3], inv);
+            *(uint2*)(st + j * 32) = w;                  // dims 16 j + 4 kg .. + 3
+        }
+        if (kg == 0 && row0 + i * 16 + r16 < p.M) *(float*)(base + kv16_scale_off(block_row(i * 16 + r16))) = sc;
+    };
+    auto drain = [&](int i) __attribute__((always_inline)) {
+        const char* st = strip2 + (i & 1) * SBYTES + srow * SPITCH + spiece * 16;
+        const u32x4 q0 = *(const u32x4*)st, q1 = *(const u32x4*)(st + 8 * SPITCH);
+        const int xa = i * 16 + srow, xb = xa + 8;
+        if (row0 + xa < p.M) *(u32x4*)(base + kv16_row_off(block_row(xa)) + spiece * 16) = q0;
+        if (row0 + xb < p.M) *(u32x4*)(base + kv16_row_off(block_row(xb)) + spiece * 16) = q1;
+    };
+    compute(0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        if (i + 1 < MI) compute(i + 1);
+        drain(i);
+    }
+}
+
 template <bool OUT_F32, int EPI, int MI, int NI>
 __device__ __forceinline__ void pp_epilogue(const GemmParams& p, const f32x4 (&acc)[MI][NI], const char* bias_w, char* strip2, int row0,
                                             int col0, int lane) {
@@ -169,6 +226,12 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, const f32x4 (&a
     f32x4 biasv[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) biasv[j] = bias_w ? *(const f32x4*)(bias_w + (j * 16 + 4 * kg) * 4) : f32x4(0.f);
+    if constexpr (EPI == EPI_CROSSKV) {
+        if (p.kv16) {
+            pp_epilogue_kv16<MI>(p, acc, biasv, strip2, row0, col0, lane);
+            return;
+        }
+    }
     const int act = EPI != EPI_PARTIAL ? p.gelu : 0;
     if (row0 + MI * 16 <= p.M && col0 + NI * 16 <= p.N) {
         if (act == 0) pp_epilogue_body<OUT_F32, EPI, MI, NI, 0, true>(p, acc, biasv, strip2, row0, col0, lane);

@@ -93,9 +93,6 @@ __device__ __forceinline__ void epi_store_f32(const GemmParams& p, int row, int 
     }
     void* base;
     const size_t o = epi_offset<EPI>(p, row, col, base);
-    if constexpr (EPI == EPI_CROSSKV) {
-        if (p.kv24) { kv24_store4((char*)base + (o >> 6) * KV24_ROW, (int)(o & 63), v[0], v[1], v[2], v[3]); return; }
-    }
     *(f32x4*)((float*)base + o) = v;
 }
 

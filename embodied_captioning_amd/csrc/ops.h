@@ -82,9 +82,11 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
                             hipStream_t s, const float* q_part = nullptr, int q_S = 0, const float* q_bias = nullptr,
                             int q_ld = 0, int q_col0 = 0, int append_kv = 0, int out_dtype = -1,   // out_dtype: see launch_vit_attention
                             const int* skip_rows = nullptr,    // int32 [R] or null: rows with a non-zero flag are left untouched
-                            int kv24 = 0);                     // 1: kbase / vbase are KV24 caches (common.h; fp32 q, no ancestry, > 32 keys)
-// fp32 rows [n_rows, 64] -> KV24 rows (192 bytes each): what the cross-K/V GEMM's epilogue writes, as a kernel of its own (tests)
-int launch_pack_kv24(const float* src, void* dst, size_t n_rows, hipStream_t s);
+                            int kv16 = 0,                      // 1: kbase / vbase are the bases of KV16 blocks (common.h; fp32 q, no
+                            size_t kv_row0 = 0);               // ancestry, > 32 keys); kv_row0 = index of the launch's first row in them
+// fp32 rows [n_rows, 64] -> one KV16 block of kv16_block_bytes(n_rows) bytes: what the cross-K/V GEMM's epilogue writes, as a
+// kernel of its own (tests)
+int launch_pack_kv16(const float* src, void* dst, size_t n_rows, hipStream_t s);
 
 // attentional pooler (CoCa): fixed projected queries qp fp32 [Q, E] shared by every image; kv (T) [B*N, 2E] with K in
 // columns [0,E) and V in [E,2E); heads of E/heads dims (64 or 96); out (T) [B*Q, E].  scale = 1/sqrt(head_dim).

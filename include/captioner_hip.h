@@ -217,10 +217,16 @@ int cap_op_gemm_skinny(const void* A, const void* W, const float* bias, int act,
 int cap_op_gemm_skinny_slices(int N, int K, int finished);
 int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int32_t* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
-                            void* stream);        /* impl | 16: kbase / vbase are KV24 caches (no ancestry, > 32 keys) */
-/* The split mode's cross-attention K/V cache layout: fp32 rows [n_rows, 64] -> KV24 rows of 192 bytes (64 x the upper 16 bits of
- * the value rounded to 24 bits | 64 x its third byte) - what the cross-K/V GEMM's epilogue writes in CAP_F32_SPLIT. */
-int cap_op_pack_kv24(const float* src, void* dst, size_t n_rows, void* stream);
+                            void* stream);        /* impl | 16: kbase / vbase are KV16 blocks (no ancestry, > 32 keys) */
+/* The split mode's cross-attention K/V cache layout: fp32 rows [n_rows, 64] -> one KV16 block: per row 64 int16 and one fp32 scale
+   (x ~ q * scale, scale = max|x| / 32767 over the row), rows in groups of 32 = [32 x 128 bytes][32 scales] = 4224 bytes; dst holds
+   (n_rows + 31) / 32 groups.  The cross-K/V GEMM's epilogue writes this layout; the op exists for the kernel tests. */
+int cap_op_pack_kv16(const float* src, void* dst, size_t n_rows, void* stream);
+/* The cross-K/V GEMM as the image side runs it (replaces the per-layer key / value Linear calls of HF:modeling_blip_text.py:161-175):
+   A [n_img * tokens, K] x W [layers * 2 * heads * 64, K]^T + bias -> cache [layer][k | v][image][head][token][64]; kv16 = 1 (CAP_F32_SPLIT
+   only): every (layer, k | v) block is a KV16 block of (n_img * heads * tokens + 31) / 32 groups, else fp32 / bf16 rows. */
+int cap_op_gemm_crosskv(int dtype, const void* A, const void* W, const float* bias, void* cache, int n_img, int tokens, int heads,
+                        int layers, int K, int kv16, void* stream);
 /* The candidate selection of a beam step alone (first step: running score 0 for beam 0 of an item, -1e9 for the others):
  * logits fp32 [B*K][ld] -> the 2K best (score, token) per row, best first, ties to the lower token id; legacy_raw: scores are
  * raw logits + running score (CoCa), else log-softmax + running score (HF v5); masked_id >= 0: that token scores -inf (legacy

@@ -348,59 +348,107 @@ def test_split_mode_counts_the_activations_it_clamps(lib):
     eng.close()
 
 
+def _kv16_ref(x):
+    """numpy restatement of the KV16 quantisation (common.h): per 64-wide row, scale = max|x| / 32767, q = rint(x * (32767 / max|x|))."""
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 64)
+    am = np.abs(x).max(axis=1)
+    inv = np.where(am > 0, np.float32(32767.0) / np.where(am > 0, am, 1).astype(np.float32), np.float32(0)).astype(np.float32)
+    q = np.rint(x * inv[:, None]).astype(np.int16)
+    return q, (am * np.float32(1.0 / 32767.0)).astype(np.float32)
+
+
+def _kv16_unpack(raw, rows):
+    """bytes of a KV16 block -> (int16 [rows, 64], fp32 scales [rows]); groups of 32 rows = 32 x 128 B then 32 scales."""
+    g = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 4224)
+    q = g[:, :4096].reshape(-1, 128).view(np.int16)[:rows]
+    sc = g[:, 4096:].reshape(-1, 128).view(np.float32).reshape(-1)[:rows]
+    return q.copy(), sc.copy()
+
+
 @gpu
 @pytest.mark.parametrize("dtype", [0, SPLIT])
 @pytest.mark.parametrize("n_keys,beams", [(197, 1), (197, 3), (255, 5), (577, 1), (40, 2)])
-def test_kv24_cross_attention_cache_is_the_rounded_fp32_cache_bit_for_bit(lib, dtype, n_keys, beams):
-    """The split mode's cross-attention K/V cache is KV24: the value rounded to its upper 24 bits, 3 bytes per element (192-byte
-    head rows = 64 upper halves | 64 third bytes).  (1) the pack kernel writes exactly round-to-nearest of the fp32 bits; (2) the
-    decode attention kernels on a KV24 cache give the SAME BITS as on an fp32 cache holding the rounded values - one row per
-    block (greedy) and the shared-block kernel (2-5 beams); (3) against the unrounded values the context moves by ~2^-17."""
+def test_kv16_cross_attention_cache(lib, dtype, n_keys, beams):
+    """The split mode's cross-attention K/V cache is KV16: 64 int16 and one fp32 scale per head row, rows in groups of 32.  (1) the
+    pack kernel writes exactly the numpy restatement's integers and scales; (2) the decode attention kernels on a KV16 cache -
+    one row per block (greedy) and the shared-block kernel (2-5 beams) - give the fp64 attention over the DEQUANTISED values to
+    fp32 rounding; (3) against the unquantised cache the context moves by ~2^-15 of the row's largest element."""
     Bimg, H, kv_ld = 3, 2, n_keys + 3
     R = Bimg * beams
     g = torch.Generator().manual_seed(n_keys + beams)
     q = torch.randn(R, H * 64, generator=g)
     K = torch.randn(Bimg, H, kv_ld, 64, generator=g)
-    V = torch.randn(Bimg, H, kv_ld, 64, generator=g) * torch.logspace(-3, 2, 64)          # five decades: the format keeps fp32's range
+    V = torch.randn(Bimg, H, kv_ld, 64, generator=g) * torch.logspace(-1, 1, 64)          # two decades inside a row
+    V[0, 0, 5] = 0.0                                                                       # an all-zero row quantises to zeros
     rows = Bimg * H * kv_ld
+    nbytes = (rows + 31) // 32 * 4224
 
     def pack(x):
-        d = torch.zeros(rows * 192, dtype=torch.uint8, device="cuda")
-        _check(lib, lib.cap_op_pack_kv24(_p(x.cuda().contiguous()), _p(d), rows, _stream()))
+        d = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        _check(lib, lib.cap_op_pack_kv16(_p(x.cuda().contiguous()), _p(d), rows, _stream()))
         return d
-
-    def rounded(x):
-        b = x.contiguous().view(torch.int32)
-        return (((b + 0x80) >> 8) << 8).view(torch.float32)
 
     Kp, Vp = pack(K), pack(V)
     torch.cuda.synchronize()
-    # (1) layout: upper halves then third bytes, per row
-    raw = Vp.cpu().numpy().reshape(rows, 192)
-    bits = (rounded(V).view(torch.int32).numpy().astype(np.uint32).reshape(rows, 64)) >> 8
-    assert np.array_equal(raw[:, :128].view(np.uint16), (bits >> 8).astype(np.uint16))
-    assert np.array_equal(raw[:, 128:], (bits & 0xFF).astype(np.uint8))
-    # (2) same bits as the fp32 cache of rounded values
-    Kr, Vr = rounded(K).cuda(), rounded(V).cuda()
+    # (1) integers and scales
+    deq = {}
+    for name, x, pk in (("k", K, Kp), ("v", V, Vp)):
+        qi, sc = _kv16_unpack(pk.cpu().numpy().tobytes(), rows)
+        qr, sr = _kv16_ref(x.numpy())
+        assert np.array_equal(qi, qr) and np.array_equal(sc, sr)
+        assert np.abs(qi).max() <= 32767
+        deq[name] = torch.from_numpy(qi.astype(np.float64) * sc.astype(np.float64)[:, None]).view(Bimg, H, kv_ld, 64)
+    # (2) fp64 attention over the dequantised values
     qd = q.cuda()
-    out24 = torch.full((R, H * 64), float("nan"), dtype=torch.float32, device="cuda")
-    out32 = torch.full((R, H * 64), float("nan"), dtype=torch.float32, device="cuda")
-    _check(lib, lib.cap_op_decode_attention(dtype, _p(qd), _p(Kp), _p(Vp), None, 0, beams, kv_ld, n_keys, _p(out24), R, H, 16, _stream()))
-    _check(lib, lib.cap_op_decode_attention(dtype, _p(qd), _p(Kr), _p(Vr), None, 0, beams, kv_ld, n_keys, _p(out32), R, H, 0, _stream()))
+    out16 = torch.full((R, H * 64), float("nan"), dtype=torch.float32, device="cuda")
+    _check(lib, lib.cap_op_decode_attention(dtype, _p(qd), _p(Kp), _p(Vp), None, 0, beams, kv_ld, n_keys, _p(out16), R, H, 16, _stream()))
     torch.cuda.synchronize()
-    assert torch.equal(out24.view(torch.int32), out32.view(torch.int32))
-    # (3) distance to the unrounded cache
-    outx = torch.empty_like(out32)
-    Kd, Vd = K.cuda(), V.cuda()
-    _check(lib, lib.cap_op_decode_attention(dtype, _p(qd), _p(Kd), _p(Vd), None, 0, beams, kv_ld, n_keys, _p(outx), R, H, 0, _stream()))
-    torch.cuda.synchronize()
-    a = torch.from_numpy(g8_decode(out24.cpu().numpy())) if dtype == SPLIT else out24.cpu()
-    b = torch.from_numpy(g8_decode(outx.cpu().numpy())) if dtype == SPLIT else outx.cpu()
-    assert (a - b).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item())
-    # a KV24 cache with an ancestry table or a short history is refused
+    got = torch.from_numpy(g8_decode(out16.cpu().numpy())).double() if dtype == SPLIT else out16.cpu().double()
+
+    def ref(Kx, Vx):
+        qh = q.double().view(R, H, 64)
+        img = torch.arange(R) // beams
+        s = torch.einsum("rhd,rhkd->rhk", qh, Kx.double()[img][:, :, :n_keys]) / 8.0
+        return torch.einsum("rhk,rhkd->rhd", torch.softmax(s, -1), Vx.double()[img][:, :, :n_keys]).reshape(R, H * 64)
+
+    want = ref(deq["k"], deq["v"])
+    assert (got - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
+    # (3) distance to the unquantised cache: each V element is off by at most half a step of its row, 2^-16 of the row maximum
+    exact = ref(K, V)
+    assert (got - exact).abs().max().item() < 3e-4 * max(1.0, exact.abs().max().item())
+    # a KV16 cache with an ancestry table or a short history is refused
     anc = torch.zeros(R, kv_ld, dtype=torch.int32, device="cuda")
-    assert lib.cap_op_decode_attention(dtype, _p(qd), _p(Kp), _p(Vp), _p(anc), kv_ld, 1, kv_ld, n_keys, _p(out24), R, H, 16, _stream()) != 0
-    assert b"KV24" in lib.cap_last_error()
+    assert lib.cap_op_decode_attention(dtype, _p(qd), _p(Kp), _p(Vp), _p(anc), kv_ld, 1, kv_ld, n_keys, _p(out16), R, H, 16, _stream()) != 0
+    assert b"KV16" in lib.cap_last_error()
+
+
+@gpu
+@pytest.mark.parametrize("geom", [(3, 197, 12, 2, 768), (2, 50, 2, 3, 128), (5, 255, 12, 1, 768), (1, 197, 12, 1, 768), (9, 33, 1, 2, 64)])
+def test_cross_kv_gemm_writes_the_kv16_cache_of_its_fp32_output(lib, geom):
+    """The cross-K/V GEMM's KV16 epilogue (gemm_pp.hip: row maximum, scale, int16, 128-byte rows through the strips, groups of 32
+    rows) against the same GEMM with fp32 rows packed by the stand-alone kernel: identical integers and scales in every (layer,
+    k | v) block - ragged last group, rows of two images in one 16-row block, one image (72 tiles), one head."""
+    n_img, tokens, heads, layers, K = geom
+    M, N = n_img * tokens, layers * 2 * heads * 64
+    g = torch.Generator().manual_seed(M + N)
+    A = _g8(torch.randn(M, K, generator=g))
+    W = _g8(torch.randn(N, K, generator=g) / math.sqrt(K), G8_WSCALE)
+    bias = torch.randn(N, generator=g).cuda()
+    rows = n_img * heads * tokens
+    blk = (rows + 31) // 32 * 4224
+    c16 = torch.zeros(layers * 2 * blk, dtype=torch.uint8, device="cuda")
+    c32 = torch.full((layers * 2 * rows, 64), float("nan"), dtype=torch.float32, device="cuda")
+    _check(lib, lib.cap_op_gemm_crosskv(SPLIT, _p(A), _p(W), _p(bias), _p(c16), n_img, tokens, heads, layers, K, 1, _stream()))
+    _check(lib, lib.cap_op_gemm_crosskv(SPLIT, _p(A), _p(W), _p(bias), _p(c32), n_img, tokens, heads, layers, K, 0, _stream()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(c32).all()
+    ref = c32.cpu().numpy().reshape(layers * 2, rows, 64)
+    raw = c16.cpu().numpy().reshape(layers * 2, blk)
+    for b in range(layers * 2):
+        qi, sc = _kv16_unpack(raw[b].tobytes(), rows)
+        qr, sr = _kv16_ref(ref[b])
+        assert np.array_equal(sc, sr), b
+        assert np.array_equal(qi, qr), b
 
 
 @gpu
