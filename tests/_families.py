@@ -1,4 +1,4 @@
-"""Weight families for the parity envelope of the split mode (tests/test_envelope_gpu.py, tools/parity_envelope.py): transforms of
+"""Weight families for the parity envelope of the split mode (tests/test_envelope_gpu.py, tests/explore_parity_envelope.py): transforms of
 the procedural BLIP state dict that make it look like a TRAINED checkpoint in the ways that matter to a two-halves fp16
 representation - heavy-tailed weights, LayerNorm gains spread over orders of magnitude, a few massive residual channels, rows
 that LayerNorm squeezes far below 1, and activations beyond fp16's range.  Every transform is deterministic."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Exploration companion of tests/test_envelope_gpu.py: runs every weight family of tests/_families.py through the split mode
 and the CPU oracle and prints what held (greedy rows identical, smallest oracle top-2 margin, worst top-8 logit error,
-beam-3 scores, clamp count).    python tools/parity_envelope.py [n_frames] [family ...]"""
+beam-3 scores, clamp count).    python tests/explore_parity_envelope.py [n_frames] [family ...]"""
 import os
 import sys
 import time
