@@ -583,32 +583,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, NWM * NWN == 8 ? 2 : 1) void gemm_b
             const char* b_s = a_s + BM * 128;
             if constexpr (SCHED == 1) __builtin_amdgcn_iglp_opt(0);
             if constexpr (SCHED == 2) __builtin_amdgcn_iglp_opt(1);
-            if constexpr (is_g8<T> && VAR == 3) {
-                // A fragments double buffered: block i + 1's two reads are issued before block i's 12 MFMAs
-                vec bh[NI], bl[NI], ah[2], al[2];
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    bh[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, 2 * kg));
-                    bl[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, 2 * kg + 1));
-                }
-                ah[0] = *(const vec*)(a_s + swz_off(wm0 + r16, 2 * kg));
-                al[0] = *(const vec*)(a_s + swz_off(wm0 + r16, 2 * kg + 1));
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    if (i + 1 < MI) {
-                        ah[(i + 1) & 1] = *(const vec*)(a_s + swz_off(wm0 + (i + 1) * 16 + r16, 2 * kg));
-                        al[(i + 1) & 1] = *(const vec*)(a_s + swz_off(wm0 + (i + 1) * 16 + r16, 2 * kg + 1));
-                    }
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i & 1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i & 1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i & 1], acc[i][j], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else if constexpr (is_g8<T>) {
+            if constexpr (is_g8<T>) {
                 vec bh[NI], bl[NI];
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
@@ -1075,25 +1050,21 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
 template <typename T, bool OUT_F32, int EPI>
 int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
 #ifdef CAP_EXPERIMENTS
-    if (tile == 14 || tile == 15) {
-        if constexpr (is_g8<T> && !OUT_F32 && EPI == EPI_STORE) {
-            if (tile == 14) return launch_big2<T, OUT_F32, EPI, 3, true>(p, stream);
-            return launch_big2<T, OUT_F32, EPI, 3, false>(p, stream);
-        }
-    }
-#endif
-    if (tile >= 10 && tile <= 13) {
+    // split fp16: gemm_big2_kernel<g8_t>, the kernel gemm_pp.hip replaced, exists in experiments builds only - 10 = its schedule
+    // (iglp_opt(0)) as the A/B partner of tools/bench_gemm_pp.py, 13 = the same with cycle stamps to p.aux
+    if (tile == 10 || tile == 13) {
         if constexpr (is_g8<T>) {
             if (p.K >= 64 && !p.resid) {
-                if (tile == 10) return launch_big2<T, OUT_F32, EPI, 0, false>(p, stream);
-                if (tile == 11) return launch_big2<T, OUT_F32, EPI, 1, false>(p, stream);
-                if (tile == 12) return launch_big2<T, OUT_F32, EPI, 2, false>(p, stream);
-#ifdef CAP_EXPERIMENTS        // 13: the shipped schedule with cycle stamps to p.aux (tools/bench_gemm_split.py --cycles)
-                if constexpr (!OUT_F32 && EPI == EPI_STORE) return launch_big2<T, OUT_F32, EPI, 1, true>(p, stream);
-#endif
+                if constexpr (!OUT_F32 && EPI == EPI_STORE) {
+                    if (tile == 13) return launch_big2<T, OUT_F32, EPI, 1, true>(p, stream);
+                }
                 return launch_big2<T, OUT_F32, EPI, 1, false>(p, stream);
             }
         }
+    }
+#endif
+    if constexpr (is_g8<T>) {
+        if (tile >= 10 && tile <= 15) tile = 3;
     }
     if (tile >= 10 && tile <= 15) {                     // second-generation kernel (bf16): A/B ids, 13 = instrumented
         if constexpr (sizeof(T) == 2) {
@@ -1129,9 +1100,8 @@ int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
             if (p.K >= 128) return launch_big2<T, OUT_F32, EPI, 2, false>(p, stream);
             return launch_big<T, OUT_F32, EPI, 3>(p, stream);
         } else if constexpr (is_g8<T>) {
-            // split fp16: the second-generation pipeline with 32 k per stage.  10 / 11 / 12 pick the schedule for A/B runs.
-            // iglp_opt(0) measured +2..3 % over the compiler's schedule on every encoder shape (tools/bench_gemm_split.py)
-            if (p.K >= 64) return launch_big2<T, OUT_F32, EPI, 1, false>(p, stream);
+            // split fp16: launch_gemm sends tile 3 to gemm_pp.hip; what that kernel does not take (K < 64, operands beyond 4 GB)
+            // runs on the register-staged 256x256 tile
             return launch_cfg<T, 256, 256, 128, 64, 1, 2, OUT_F32, EPI>(p, stream);
         } else {
             return launch_big<T, OUT_F32, EPI, 0>(p, stream);
@@ -1139,7 +1109,7 @@ int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
     }
     if (tile == 5) {                                    // first-generation kernel, kept for A/B
         if constexpr (sizeof(T) == 2) return launch_big<T, OUT_F32, EPI, 3>(p, stream);
-        else if constexpr (is_g8<T>) return launch_big2<T, OUT_F32, EPI, 0, false>(p, stream);
+        else if constexpr (is_g8<T>) return launch_cfg<T, 256, 256, 128, 64, 1, 2, OUT_F32, EPI>(p, stream);
         else return launch_big<T, OUT_F32, EPI, 0>(p, stream);
     }
     if (tile == 4) return launch_cfg<T, 256, 256, 128, 64, 1, 2, OUT_F32, EPI>(p, stream);
@@ -1218,8 +1188,8 @@ int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream) {
         if (rc == -2) cap_set_error("launch_gemm: a KV16 cross-K/V cache needs G8 operands, K >= 64 and operands below 4 GB (K=%d)", p.K);
         return rc == -2 ? -1 : rc;
     }
-    // split fp16, 256x256: the kernel with the wave groups half a stage apart (gemm_pp.hip) wherever it takes the shape;
-    // gemm_big2_kernel<g8_t> stays reachable as tiles 10-12 (A/B, bit-identical) and takes what is left (resid, K < 64, ...)
+    // split fp16, 256x256: the kernel with the wave groups half a stage apart (gemm_pp.hip) wherever it takes the shape; what it
+    // declines (K < 64, operands beyond 4 GB, a residual operand) runs on the register-staged tiles
     if (dtype == CAP_DT_G8 && (tile == 3 || tile == 20 || tile == 21)) {
         const int rc = launch_gemm_pp(p, tile == 21, stream);
         if (rc != -2) return rc;

@@ -86,7 +86,7 @@ def test_split_gemm_tiles_are_bit_identical(lib, shape):
     Ad, Wd = _g8(torch.randn(M, K, generator=g)), _g8(torch.randn(N, K, generator=g) / math.sqrt(K), G8_WSCALE)
     bd = torch.randn(N, generator=g).cuda()
     outs = []
-    for tile in (1, 2, 3, 4, 10, 11, 12):
+    for tile in (1, 2, 3, 4):
         o = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
         _check(lib, lib.cap_op_gemm(SPLIT, _p(Ad), _p(Wd), _p(bd), _p(None), _p(o), M, N, K, 0, 1, tile, _stream()))
         outs.append(o)
@@ -100,15 +100,16 @@ def test_split_gemm_tiles_are_bit_identical(lib, shape):
 @pytest.mark.parametrize("shape", [(52000, 776, 64), (1000, 520, 96), (66000, 768, 192), (300, 2304, 768)])
 def test_split_gemm_g8_output_is_bit_identical_across_kernels(lib, shape, act):
     """The 256x256 kernel with the skewed wave groups (gemm_pp.hip: what tile 3 selects for G8 operands; its epilogue builds the
-    [8 hi | 8 lo] row image with v_permlane16_swap instead of an LDS strip) against gemm_big2_kernel (tile 10) and the
-    register-staged tiles: G8 output with bias and no activation / GELU / ReLU, ragged M and N edges, a half-tile tail launch
-    ((66000, 768): 774 tiles), clamped groups counted alike."""
+    [8 hi | 8 lo] row image in LDS strips and stores whole 128-byte lines) against the register-staged tiles: G8 output with
+    bias and no activation / GELU / ReLU, ragged M and N edges, a half-tile tail launch ((66000, 768): 774 tiles), clamped groups
+    counted alike.  (gemm_big2_kernel<g8_t>, the kernel it replaced, exists in experiments builds only: tools/bench_gemm_pp.py
+    checks bit-identity against it there.)"""
     M, N, K = shape
     g = torch.Generator().manual_seed(M + N + K + act)
     Ad, Wd = _g8(torch.randn(M, K, generator=g)), _g8(torch.randn(N, K, generator=g) / math.sqrt(K), G8_WSCALE)
     bd = (torch.randn(N, generator=g) * (3e4 if act == 0 else 1.0)).cuda()        # act 0: some outputs beyond +-65000
     outs, sats = [], []
-    for tile in (3, 10, 4, 1):
+    for tile in (3, 4, 1, 2):
         o = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")          # G8 container, 4 bytes per element
         lib.cap_g8_saturations(1)
         _check(lib, lib.cap_op_gemm(SPLIT, _p(Ad), _p(Wd), _p(bd), _p(None), _p(o), M, N, K, act, 0, tile, _stream()))
@@ -117,8 +118,7 @@ def test_split_gemm_g8_output_is_bit_identical_across_kernels(lib, shape, act):
         sats.append(lib.cap_g8_saturations(1))
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
-    # stored groups only; gemm_big2_kernel (tile 10) also counts the padding rows of its edge tiles (copies of row M - 1)
-    assert sats[0] == sats[2] == sats[3] and sats[1] >= sats[0], sats
+    assert sats[0] == sats[1] == sats[2] == sats[3], sats              # stored groups only
     if act == 0:
         assert sats[0] > 0
 

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Micro-benchmark of the split-fp16 (G8) GEMM over the captioner's shapes (GPU box only).
-    python tools/bench_gemm_split.py            # encoder shapes x schedule variants, decode shapes x tiles
-    python tools/bench_gemm_split.py --cycles   # in-kernel cycle accounting of the shipped schedule instead
+    python tools/bench_gemm_split.py            # encoder shapes (tile 3 = gemm_pp.hip), decode shapes x tiles
+    python tools/bench_gemm_split.py --cycles   # in-kernel cycle accounting of gemm_big2_kernel<g8_t> (experiments build; the
+                                                # kernel gemm_pp.hip replaced - tools/bench_gemm_pp.py --cycles shows both)
+    python tools/bench_gemm_split.py --cus      # the same kernel on 256 / 64 workgroups: clock and cycles per stage
 Prints 2MNK/t (the Linear layer's rate) and 3x that (MFMA flops executed) per variant."""
 import ctypes as C
 import os
@@ -29,9 +31,9 @@ def g8(x, scale=1.0):
     return d
 
 
-SHAPES = [("qkv", 50432, 2304, 768, 0, 0, (3, 16)), ("proj", 50432, 768, 768, 0, 1, (3, 16)),
-          ("fc1", 50432, 3072, 768, 1, 0, (3, 16)), ("fc2", 50432, 768, 3072, 0, 1, (3, 16)),
-          ("crosskv", 50432, 18432, 768, 0, 1, (3, 16)), ("sq8k", 8192, 8192, 8192, 0, 1, (3, 16)),
+SHAPES = [("qkv", 50432, 2304, 768, 0, 0, (3,)), ("proj", 50432, 768, 768, 0, 1, (3,)),
+          ("fc1", 50432, 3072, 768, 1, 0, (3,)), ("fc2", 50432, 768, 3072, 0, 1, (3,)),
+          ("crosskv", 50432, 18432, 768, 0, 1, (3,)), ("sq8k", 8192, 8192, 8192, 0, 1, (3,)),
           ("vocab", 256, 30524, 768, 0, 1, (1, 2, 3)), ("dec768", 256, 768, 768, 0, 1, (1, 2)),
           ("dec_f1", 256, 3072, 768, 1, 0, (1, 2)), ("dec_qkv", 256, 2304, 768, 0, 1, (1, 2))]
 for name, M, N, K, gelu, f32out, tiles in ([] if "--cycles" in sys.argv or "--cus" in sys.argv else SHAPES):
