@@ -46,7 +46,7 @@ struct GemmParams {
 // tools/bench_gemm_pp.py) - the default library does not contain them
 int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream);
 
-// Split-fp16 (G8) 256x256 persistent kernel with the two wave groups half a stage apart (gemm_pp.hip).  Returns -2 when the
+// 256x256 persistent kernel with the two wave groups half a stage apart (gemm_pp.hip; G8 and bf16 operands).  Returns -2 when the
 // shape / epilogue is not one it takes (nothing launched, no error set).  launch_gemm reaches it as tile 20 (21: cycle stamps
 // to p.aux in a -DCAP_EXPERIMENTS build).
-int launch_gemm_pp(const GemmParams& p, bool prof, hipStream_t stream);
+int launch_gemm_pp(int dtype, const GemmParams& p, bool prof, hipStream_t stream);

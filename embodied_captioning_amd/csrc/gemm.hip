@@ -1184,14 +1184,14 @@ int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream) {
         tile = (t256 >= 256 || (t256 >= 128 && p.M >= 256)) ? 3 : (t128 >= 256 ? 1 : 2);   // few rows: a 256-row tile is mostly padding
     }
     if (p.epi == EPI_CROSSKV && p.kv16) {               // int16 rows with one scale each: only gemm_pp.hip's epilogue builds them
-        const int rc = dtype == CAP_DT_G8 ? launch_gemm_pp(p, false, stream) : -2;
+        const int rc = dtype == CAP_DT_G8 ? launch_gemm_pp(dtype, p, false, stream) : -2;
         if (rc == -2) cap_set_error("launch_gemm: a KV16 cross-K/V cache needs G8 operands, K >= 64 and operands below 4 GB (K=%d)", p.K);
         return rc == -2 ? -1 : rc;
     }
-    // split fp16, 256x256: the kernel with the wave groups half a stage apart (gemm_pp.hip) wherever it takes the shape; what it
-    // declines (K < 64, operands beyond 4 GB, a residual operand) runs on the register-staged tiles
-    if (dtype == CAP_DT_G8 && (tile == 3 || tile == 20 || tile == 21)) {
-        const int rc = launch_gemm_pp(p, tile == 21, stream);
+    // split fp16 and bf16, 256x256: the kernel with the wave groups half a stage apart (gemm_pp.hip) wherever it takes the shape;
+    // what it declines (K below two stages, operands beyond 4 GB, a residual operand) runs on the older 256x256 kernels
+    if ((dtype == CAP_DT_G8 || dtype == CAP_DT_BF16) && (tile == 3 || tile == 20 || tile == 21)) {
+        const int rc = launch_gemm_pp(dtype, p, tile == 21, stream);
         if (rc != -2) return rc;
         tile = 3;
     }

@@ -51,13 +51,13 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // Fragment reads and their waits are asm statements: hipcc waits with lgkmcnt(0) for the fragments it reads itself, i.e. also
 // for the block it has just requested.  Here block i + 1's two reads stay in flight while block i is multiplied (LDS returns
 // in order: lgkmcnt(2)).  The wait "modifies" the fragments it releases, so no MFMA that uses them can be placed before it.
-template <int OFF> __device__ __forceinline__ void ds_read16(f16x8& d, unsigned addr) {
+template <int OFF, typename V> __device__ __forceinline__ void ds_read16(V& d, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
 }
-template <int N> __device__ __forceinline__ void wait_lgkm(f16x8& a, f16x8& b) {
+template <int N, typename V> __device__ __forceinline__ void wait_lgkm(V& a, V& b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
-template <int N> __device__ __forceinline__ void wait_lgkm(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
+template <int N, typename V> __device__ __forceinline__ void wait_lgkm(V& a, V& b, V& c, V& d) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
@@ -80,13 +80,52 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 //     (FULL) store unguarded through two running pointers, clamped groups are counted in a register and added to the
 //     translation unit's counter once per tile;
 //   * a G8 output piece is the strip row image [8 hi | 8 lo] per 8 columns: two 8-byte writes per four values.
-template <bool OUT_F32, int EPI, int MI, int NI, int ACT, bool FULL>
+template <typename T, bool OUT_F32, int EPI, int MI, int NI, int ACT, bool FULL>
 __device__ __forceinline__ void pp_epilogue_body(const GemmParams& p, const f32x4 (&acc)[MI][NI], const f32x4 (&biasv)[NI], char* strip2,
                                                  int row0, int col0, int lane) {
-    using T [[maybe_unused]] = g8_t;
+    constexpr bool G8 = is_g8<T>;
     constexpr bool F32OUT = OUT_F32 || EPI == EPI_PARTIAL || EPI == EPI_PATCH;
-    static_assert(F32OUT || EPI == EPI_STORE, "G8 output exists for plain row-major stores only");
+    static_assert(F32OUT || !G8 || EPI == EPI_STORE, "G8 output exists for plain row-major stores only");
     static_assert(NI == 4, "two 32-column pieces per row block");
+    if constexpr (!G8 && !F32OUT) {
+        // bf16 output: a strip row is the row block's whole 64 columns (128 bytes): one piece per row block
+        constexpr int SPITCH = 144, SBYTES = 16 * SPITCH;
+        const int r16 = lane & 15, kg = lane >> 4, srow = lane >> 3, spiece = lane & 7;
+        const int act = ACT >= 0 ? ACT : p.gelu;
+        auto compute = [&](int i) __attribute__((always_inline)) {
+            char* st = strip2 + (i & 1) * SBYTES + r16 * SPITCH + kg * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = acc[i][j];
+                if (EPI != EPI_PARTIAL) v += biasv[j];
+                if (act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_for<T>(v[e]);
+                } else if (act == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                bf16x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (bf16_t)v[e];
+                *(bf16x4*)(st + j * 32) = w;             // columns 16 j + 4 kg .. + 3
+            }
+        };
+        auto drain = [&](int i) __attribute__((always_inline)) {
+            const char* st = strip2 + (i & 1) * SBYTES + srow * SPITCH + spiece * 16;
+            const u32x4 r0 = *(const u32x4*)st, r1 = *(const u32x4*)(st + 8 * SPITCH);
+            const int col = col0 + spiece * 8, rowa = row0 + i * 16 + srow, rowb = rowa + 8;
+            if (FULL || (col < p.N && rowa < p.M)) epi_store_raw<T, EPI>(p, rowa, col, r0, FULL || col + 8 <= p.N);
+            if (FULL || (col < p.N && rowb < p.M)) epi_store_raw<T, EPI>(p, rowb, col, r1, FULL || col + 8 <= p.N);
+        };
+        compute(0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if (i + 1 < MI) compute(i + 1);
+            drain(i);
+        }
+        return;
+    }
     constexpr int NP = MI * 2;                           // pieces: (i, jp)
     constexpr int SPITCH = 144, SBYTES = 16 * SPITCH;
     const int r16 = lane & 15, kg = lane >> 4, srow = lane >> 3, spiece = lane & 7;
@@ -98,7 +137,8 @@ __device__ __forceinline__ void pp_epilogue_body(const GemmParams& p, const f32x
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int j = jp * 2 + jj;
-            f32x4 v = acc[i][j] * (1.0f / G8_WSCALE);
+            f32x4 v = acc[i][j];
+            if constexpr (G8) v *= (1.0f / G8_WSCALE);
             if (EPI != EPI_PARTIAL) v += biasv[j];
             if (act == 1) {
 #pragma unroll
@@ -219,14 +259,14 @@ __device__ __forceinline__ void pp_epilogue_kv16(const GemmParams& p, const f32x
     }
 }
 
-template <bool OUT_F32, int EPI, int MI, int NI>
+template <typename T, bool OUT_F32, int EPI, int MI, int NI>
 __device__ __forceinline__ void pp_epilogue(const GemmParams& p, const f32x4 (&acc)[MI][NI], const char* bias_w, char* strip2, int row0,
                                             int col0, int lane) {
     const int kg = lane >> 4;
     f32x4 biasv[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) biasv[j] = bias_w ? *(const f32x4*)(bias_w + (j * 16 + 4 * kg) * 4) : f32x4(0.f);
-    if constexpr (EPI == EPI_CROSSKV) {
+    if constexpr (EPI == EPI_CROSSKV && is_g8<T>) {
         if (p.kv16) {
             pp_epilogue_kv16<MI>(p, acc, biasv, strip2, row0, col0, lane);
             return;
@@ -234,17 +274,21 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, const f32x4 (&a
     }
     const int act = EPI != EPI_PARTIAL ? p.gelu : 0;
     if (row0 + MI * 16 <= p.M && col0 + NI * 16 <= p.N) {
-        if (act == 0) pp_epilogue_body<OUT_F32, EPI, MI, NI, 0, true>(p, acc, biasv, strip2, row0, col0, lane);
-        else if (act == 1) pp_epilogue_body<OUT_F32, EPI, MI, NI, 1, true>(p, acc, biasv, strip2, row0, col0, lane);
-        else pp_epilogue_body<OUT_F32, EPI, MI, NI, 2, true>(p, acc, biasv, strip2, row0, col0, lane);
+        if (act == 0) pp_epilogue_body<T, OUT_F32, EPI, MI, NI, 0, true>(p, acc, biasv, strip2, row0, col0, lane);
+        else if (act == 1) pp_epilogue_body<T, OUT_F32, EPI, MI, NI, 1, true>(p, acc, biasv, strip2, row0, col0, lane);
+        else pp_epilogue_body<T, OUT_F32, EPI, MI, NI, 2, true>(p, acc, biasv, strip2, row0, col0, lane);
     } else {
-        pp_epilogue_body<OUT_F32, EPI, MI, NI, -1, false>(p, acc, biasv, strip2, row0, col0, lane);
+        pp_epilogue_body<T, OUT_F32, EPI, MI, NI, -1, false>(p, acc, biasv, strip2, row0, col0, lane);
     }
 }
 
-template <bool OUT_F32, int EPI, bool PROF, int BM = 256>
+template <typename T, bool OUT_F32, int EPI, bool PROF, int BM = 256>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
-    using vec = f16x8;
+    // T = g8_t: 32 k values per 128-byte stage row, chunks [H0 L0 H1 L1 ..]: fragment 0 / 1 = the hi / lo chunk of k-group kg,
+    // three MFMAs per product.  T = bf16_t: 64 k values per row, fragment 0 / 1 = k-step 0 / 1 (chunks kg / 4 + kg), one MFMA each.
+    using vec = typename Mma<T>::vec;
+    constexpr bool G8 = is_g8<T>;
+    constexpr int ESZ = G8 ? 4 : 2, EPC = Mma<T>::EPC;   // bytes per element; elements per 16-byte chunk
     constexpr int BN = 256, WM = BM / 2, MI = WM / 16, MH = MI / 2, NI = 4;
     constexpr int SUB = 256 / BM;                        // work items per 256-row tile
     constexpr int STAGE = (BM + BN) * 128;               // 64 KiB (48 KiB for half tiles)
@@ -259,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     const int ntn = (p.N + BN - 1) / BN;
     const int tile0 = p.tile1 > 0 ? p.tile0 : 0;
     const int nitems = ((p.tile1 > 0 ? p.tile1 : ((p.M + 255) / 256) * ntn) - tile0) * SUB;
-    const int nk = p.K / 32;
+    const int nk = p.K / (8 * EPC);
 
     // XCD-aware walk, as in gemm_big2_kernel: XCD x owns the contiguous run [c0, c1) of work items
     const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
@@ -293,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
             const int row = (wq * PQ + j) * 8 + prow;    // row inside this group's half; WM % 16 == 0: both halves swizzle alike
             const int gch = ppos ^ ((row >> 1) & 7);
             const int ga = min(tm * 256 + sub * BM + wm0 + row, p.M - 1);
-            oa[j] = ((unsigned)ga * (unsigned)p.lda + gch * 4) * 4u;
+            oa[j] = ((unsigned)ga * (unsigned)p.lda + gch * EPC) * (unsigned)ESZ;
         }
         if (g == 0) {
 #pragma unroll
@@ -301,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
                 const int row = (wq * 8 + j) * 8 + prow;
                 const int gch = ppos ^ ((row >> 1) & 7);
                 const int gw = min(tn * BN + row, p.N - 1);
-                ow[j] = ((unsigned)gw * (unsigned)p.ldw + gch * 4) * 4u;
+                ow[j] = ((unsigned)gw * (unsigned)p.ldw + gch * EPC) * (unsigned)ESZ;
             }
             obias = has_bias ? (unsigned)min(tn * BN + wn0 + lane, p.N - 1) * 4u : 0u;
         }
@@ -335,16 +379,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         for (int j = 0; j < NI; ++j) acc[i][j] = 0.f;
     vec bh[NI], bl[NI], ah[2], al[2];
     const unsigned lds0 = (unsigned)(size_t)CAP_LPTR(smem);
-    const unsigned f_hi = swz_off(r16, 2 * kg), f_lo = swz_off(r16, 2 * kg + 1);   // + 128 * (16-aligned row): same swizzle
-    // a_hi.w_lo, a_lo.w_hi, a_hi.w_hi per accumulator - the order of every G8 kernel; the chains of two accumulators are
-    // interleaved, so that a wave that has the matrix pipe to itself never issues an MFMA that waits for the one before it
+    // fragment 0 / 1 of a row (names: "h" / "l" after the G8 case); + 128 * (16-aligned row): same swizzle
+    const unsigned f_hi = swz_off(r16, G8 ? 2 * kg : kg), f_lo = swz_off(r16, G8 ? 2 * kg + 1 : 4 + kg);
+    // G8: a_hi.w_lo, a_lo.w_hi, a_hi.w_hi per accumulator; bf16: k-step 0, k-step 1 - the order of every kernel of the type.  The
+    // chains of two accumulators are interleaved, so that a wave that has the matrix pipe to itself never issues an MFMA that
+    // waits for the one before it
     auto mma_pair = [&](f32x4& c0, f32x4& c1, int j, int sl) __attribute__((always_inline)) {
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[sl], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j + 1], ah[sl], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[sl], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j + 1], al[sl], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[sl], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j + 1], ah[sl], c1, 0, 0, 0);
+        if constexpr (G8) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[sl], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j + 1], ah[sl], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[sl], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j + 1], al[sl], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[sl], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j + 1], ah[sl], c1, 0, 0, 0);
+        } else {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[sl], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j + 1], ah[sl], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], al[sl], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j + 1], al[sl], c1, 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     auto mma_block = [&](int i) __attribute__((always_inline)) {
@@ -418,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
             const int item = first + c_x * nl;
             const int t = tile0 + item / SUB, sub = item % SUB;
             const int tm = t / ntn, tn = t - tm * ntn;
-            pp_epilogue<OUT_F32, EPI, MI, NI>(p, acc, has_bias ? bias_rows + (c_x & 1) * 1024 + wq * 256 : nullptr, strips + wq * (2 * 16 * 144),
+            pp_epilogue<T, OUT_F32, EPI, MI, NI>(p, acc, has_bias ? bias_rows + (c_x & 1) * 1024 + wq * 256 : nullptr, strips + wq * (2 * 16 * 144),
                                               tm * 256 + sub * BM + wm0, tn * BN + wn0, lane);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -460,11 +513,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     }
 }
 
-template <bool OUT_F32, int EPI, bool PROF>
+template <typename T, bool OUT_F32, int EPI, bool PROF>
 int launch_pp_t(const GemmParams& p, hipStream_t stream) {
     constexpr int EXTRA = 2 * 1024 + 4 * 2 * 16 * 144;   // bias rows + epilogue strips
     constexpr int LDS = 2 * 512 * 128 + EXTRA, LDS_H = 2 * 384 * 128 + EXTRA;
-    auto kern = gemm_pp_kernel<OUT_F32, EPI, PROF, 256>;
+    auto kern = gemm_pp_kernel<T, OUT_F32, EPI, PROF, 256>;
     int n_cu = 0;
     if (cap_kernel_setup((const void*)kern, LDS, &n_cu) != 0) return -1;
 #ifdef CAP_EXPERIMENTS
@@ -473,7 +526,7 @@ int launch_pp_t(const GemmParams& p, hipStream_t stream) {
     const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int rounds = ntiles / n_cu, tail = ntiles - rounds * n_cu;
     if (!PROF && rounds >= 1 && rounds <= 4 && tail > 0 && 2 * tail <= n_cu) {       // the tail round as half tiles: launch_big2
-        auto kern_h = gemm_pp_kernel<OUT_F32, EPI, PROF, 128>;
+        auto kern_h = gemm_pp_kernel<T, OUT_F32, EPI, PROF, 128>;
         if (cap_kernel_setup((const void*)kern_h, LDS_H, nullptr) != 0) return -1;
         GemmParams q = p;
         q.tile0 = 0; q.tile1 = rounds * n_cu;
@@ -489,27 +542,35 @@ int launch_pp_t(const GemmParams& p, hipStream_t stream) {
     return 0;
 }
 
-}  // namespace
-
-CAP_DEFINE_G8_CLAMP_READER(cap_g8_clamped_gemm_pp)
-
-// G8 operands only.  Returns -2 (nothing launched, no error set) when the shape or epilogue is not one this kernel takes:
-// the caller falls back to gemm_big2_kernel.  prof: cycle stamps to p.aux (-DCAP_EXPERIMENTS builds only).
-int launch_gemm_pp(const GemmParams& p, bool prof, hipStream_t stream) {
-    if (p.K < 64 || p.K % 32 != 0 || p.resid) return -2;
-    // 32-bit byte offsets inside A and W
-    if ((size_t)p.M * p.lda * 4 >= (1ull << 32) || (size_t)p.N * p.ldw * 4 >= (1ull << 32)) return -2;
+template <typename T>
+int launch_pp_type(const GemmParams& p, bool prof, hipStream_t stream) {
+    constexpr bool G8 = is_g8<T>;
 #ifdef CAP_EXPERIMENTS
     if (prof) {
-        if (p.epi == EPI_STORE && !p.out_f32) return launch_pp_t<false, EPI_STORE, true>(p, stream);
-        if (p.epi == EPI_STORE && p.out_f32) return launch_pp_t<true, EPI_STORE, true>(p, stream);
+        if (p.epi == EPI_STORE && !p.out_f32) return launch_pp_t<T, false, EPI_STORE, true>(p, stream);
+        if (p.epi == EPI_STORE && p.out_f32) return launch_pp_t<T, true, EPI_STORE, true>(p, stream);
         return -2;
     }
 #endif
     switch (p.epi) {
-        case EPI_STORE: return p.out_f32 ? launch_pp_t<true, EPI_STORE, false>(p, stream) : launch_pp_t<false, EPI_STORE, false>(p, stream);
-        case EPI_PATCH: return launch_pp_t<true, EPI_PATCH, false>(p, stream);
-        case EPI_CROSSKV: return launch_pp_t<true, EPI_CROSSKV, false>(p, stream);
+        case EPI_STORE: return p.out_f32 ? launch_pp_t<T, true, EPI_STORE, false>(p, stream) : launch_pp_t<T, false, EPI_STORE, false>(p, stream);
+        case EPI_PATCH: return launch_pp_t<T, true, EPI_PATCH, false>(p, stream);
+        case EPI_CROSSKV: return launch_pp_t<T, G8, EPI_CROSSKV, false>(p, stream);       // G8: fp32 rows or KV16; bf16: bf16 rows
         default: return -2;
     }
+}
+
+}  // namespace
+
+CAP_DEFINE_G8_CLAMP_READER(cap_g8_clamped_gemm_pp)
+
+// G8 or bf16 operands.  Returns -2 (nothing launched, no error set) when the shape or epilogue is not one this kernel takes:
+// the caller falls back to another 256x256 kernel.  prof: cycle stamps to p.aux (-DCAP_EXPERIMENTS builds only).
+int launch_gemm_pp(int dtype, const GemmParams& p, bool prof, hipStream_t stream) {
+    const int kstage = dtype == CAP_DT_G8 ? 32 : 64, esz = dtype == CAP_DT_G8 ? 4 : 2;
+    if ((dtype != CAP_DT_G8 && dtype != CAP_DT_BF16) || p.K < 2 * kstage || p.K % kstage != 0 || p.resid) return -2;
+    // 32-bit byte offsets inside A and W
+    if ((size_t)p.M * p.lda * esz >= (1ull << 32) || (size_t)p.N * p.ldw * esz >= (1ull << 32)) return -2;
+    if (dtype == CAP_DT_BF16 && !p.out_f32 && p.N % 8 != 0) return -2;              // 16-byte bf16 stores
+    return dtype == CAP_DT_G8 ? launch_pp_type<g8_t>(p, prof, stream) : launch_pp_type<bf16_t>(p, prof, stream);
 }

@@ -14,10 +14,13 @@ from embodied_captioning_amd import _native  # noqa: E402
 
 lib = _native.load_library()
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-SPLIT = 2
+BF16 = "--bf16" in sys.argv                   # bf16 operands: tile 20 against gemm_big3_kernel (tile 14; what K <= 1024 used) / gemm_big2 (tile 12)
+SPLIT = 1 if BF16 else 2
 
 
 def g8(x, w=False):
+    if BF16:
+        return x.to(torch.bfloat16)
     d = torch.empty_like(x)
     if w:
         assert lib.cap_op_convert_weight(SPLIT, C.c_void_p(x.data_ptr()), C.c_void_p(d.data_ptr()), x.shape[0], x.shape[1], s) == 0
@@ -70,24 +73,27 @@ if "--cycles" in sys.argv:
                           f"issue {g0[6] / nst:.0f} / {g1[6] / nst:.0f}  epilogue/tile {g0[4] / g0[5]:.0f} / {g1[4] / g1[5]:.0f} of which waiting for DMA {g0[7] / g0[5]:.0f} / {g1[7] / g1[5]:.0f}", flush=True)
     sys.exit(0)
 
+if BF16:
+    SHAPES = [x for x in SHAPES if x[3] % 64 == 0 and x[3] >= 128] + [("edgeb", 3333, 520, 192, 1, 0), ("edgef", 1000, 776, 128, 0, 1)]
 for name, M, N, K, gelu, f32out in SHAPES:
     A = g8(torch.randn(M, K, device="cuda"))
     W = g8(torch.randn(N, K, device="cuda") / K ** 0.5, True)
     bias = torch.randn(N, device="cuda")
     outs = {}
-    for tile in (10, 20):
+    REF = (14 if K <= 1024 else 12) if BF16 else 10
+    for tile in (REF, 20):
         out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32)
         gemm(A, W, bias, out, M, N, K, gelu, f32out, tile)
         torch.cuda.synchronize()
         outs[tile] = out
-    same = torch.equal(outs[10].view(torch.int32), outs[20].view(torch.int32))
+    same = torch.equal(outs[REF].view(torch.int32), outs[20].view(torch.int32))
     line = f"{name:6s} M={M} N={N} K={K}: identical={same}"
     if not same:
-        d = (outs[10] - outs[20]).abs()
-        line += f" maxdiff={d.max().item():.3e} nan20={torch.isnan(outs[20]).sum().item()} nan10={torch.isnan(outs[10]).sum().item()}"
-    out = outs[10]
+        d = (outs[REF] - outs[20]).abs()
+        line += f" maxdiff={d.max().item():.3e} nan20={torch.isnan(outs[20]).sum().item()} nanref={torch.isnan(outs[REF]).sum().item()}"
+    out = outs[REF]
     for rep in range(3):
-        for tile in (10, 20):
+        for tile in (REF, 20):
             for _ in range(3):
                 gemm(A, W, bias, out, M, N, K, gelu, f32out, tile)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
