@@ -38,11 +38,11 @@ struct GemmParams {
 // 6 = decode "rows" kernel (64x64 tile, the block's K range split over its four waves with private LDS-DMA pipelines; bf16 /
 // G8 with the plain-store or split-K epilogue - its sums are ordered differently from the other tiles': callers use it for
 // a given (N, K) at EVERY row count or not at all),
-// bf16: 10/11/12 = second generation with the compiler / iglp_opt(0) / iglp_opt(1) schedule, 14/15 = half-slab four-stage
-// structure (gemm_big3_kernel; what tile 3 picks for K <= 1024) without / with iglp_opt(1).  G8: tile 3 = gemm_pp.hip (20 = the
-// same, explicitly).  In a -DCAP_EXPERIMENTS build (python -m embodied_captioning_amd.build --experiments) also: 9 / 13 =
-// instrumented builds of the bf16 generations one / two, G8 10 / 13 = gemm_big2_kernel<g8_t> (the kernel gemm_pp.hip replaced) and
-// its instrumented build, 21 = instrumented gemm_pp_kernel (cycle stamps to GemmParams::aux; tools/gemm_cycles.py,
+// bf16 and G8: tile 3 = gemm_pp.hip (20 = the same, explicitly).  In a -DCAP_EXPERIMENTS build (python -m
+// embodied_captioning_amd.build --experiments) also the kernels it replaced and the instrumented builds: bf16 10/11/12 =
+// gemm_big2_kernel with the compiler / iglp_opt(0) / iglp_opt(1) schedule, 14/15 = gemm_big3_kernel (half-slab four-stage
+// structure) without / with iglp_opt(1), 9 / 13 = instrumented generations one / two; G8 10 / 13 = gemm_big2_kernel<g8_t> and its
+// instrumented build; 21 = instrumented gemm_pp_kernel (cycle stamps to GemmParams::aux; tools/gemm_cycles.py,
 // tools/bench_gemm_pp.py) - the default library does not contain them
 int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream);
 

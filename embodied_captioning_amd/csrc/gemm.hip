@@ -1063,10 +1063,10 @@ int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
         }
     }
 #endif
-    if constexpr (is_g8<T>) {
-        if (tile >= 10 && tile <= 15) tile = 3;
-    }
-    if (tile >= 10 && tile <= 15) {                     // second-generation kernel (bf16): A/B ids, 13 = instrumented
+#ifdef CAP_EXPERIMENTS
+    // bf16 second generation (gemm_big2_kernel) and the half-slab structure (gemm_big3_kernel): the kernels gemm_pp.hip replaced,
+    // experiments builds only - A/B partners of tools/bench_gemm_pp.py --bf16 (12 / 14) and tools/gemm_cycles.py, 13 = instrumented
+    if (tile >= 10 && tile <= 15) {
         if constexpr (sizeof(T) == 2) {
             if (p.K >= 128 && !p.resid) {
                 if (tile == 10) return launch_big2<T, OUT_F32, EPI, 0, false>(p, stream);
@@ -1074,13 +1074,12 @@ int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
                 if (tile == 12) return launch_big2<T, OUT_F32, EPI, 2, false>(p, stream);
                 if (tile == 14) return launch_big3<OUT_F32, EPI>(p, stream);
                 if (tile == 15) return launch_big3<OUT_F32, EPI, 1>(p, stream);
-#ifdef CAP_EXPERIMENTS
                 if constexpr (!OUT_F32 && EPI == EPI_STORE) return launch_big2<T, OUT_F32, EPI, 2, true>(p, stream);
-#endif
             }
         }
-        tile = 3;
     }
+#endif
+    if (tile >= 10 && tile <= 15) tile = 3;
     if (tile == 9) {                                    // instrumented main loop: per-wave cycle counts to p.aux
 #ifdef CAP_EXPERIMENTS
         if constexpr (sizeof(T) == 2 && !is_g8<T> && !OUT_F32 && EPI == EPI_STORE) return launch_big<T, OUT_F32, EPI, 4>(p, stream);
@@ -1093,11 +1092,9 @@ int launch_tile(const GemmParams& p, int tile, int nk, hipStream_t stream) {
     }
     if ((tile == 3 || tile == 5) && p.resid) tile = 4;  // the LDS-DMA kernels have no residual operand
     if (tile == 3) {
-        // bf16: second-generation kernel (16x16x32 MFMA, register-layout epilogue); iglp_opt(1) interleaves the ds_reads
-        // with the MFMAs (A/B: tools/gemm_cycles.py, profiles/)
+        // bf16: launch_gemm sends tile 3 to gemm_pp.hip; what that kernel does not take (K < 128, operands beyond 4 GB, an odd
+        // N) runs on the first-generation LDS-DMA kernel
         if constexpr (sizeof(T) == 2) {
-            if (p.K >= 128 && p.K <= 1024) return launch_big3<OUT_F32, EPI>(p, stream);   // short K: see gemm_big3_kernel
-            if (p.K >= 128) return launch_big2<T, OUT_F32, EPI, 2, false>(p, stream);
             return launch_big<T, OUT_F32, EPI, 3>(p, stream);
         } else if constexpr (is_g8<T>) {
             // split fp16: launch_gemm sends tile 3 to gemm_pp.hip; what that kernel does not take (K < 64, operands beyond 4 GB)
