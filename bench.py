@@ -174,9 +174,9 @@ def pooled(a, arch, sd, **kw):
     return pool
 
 
-KERNEL_NAME = {"bf16": "gemm_big3_kernel (K=768: qkv/proj/fc1) + gemm_big2_kernel (K=3072: fc2), 256x256 LDS-DMA, 16x16x32 bf16 MFMA",
+KERNEL_NAME = {"bf16": "gemm_pp_kernel<bf16> 256x256 LDS-DMA, wave groups half a stage apart, 16x16x32 bf16 MFMA (ViT qkv/proj/fc1/fc2)",
                "f32": "gemm_big_kernel 256x256 LDS-DMA, 32x32x2 fp32 MFMA (ViT qkv/proj/fc1/fc2 launches)",
-               "f32s": "gemm_pp_kernel 256x256 LDS-DMA, wave groups half a stage apart, split fp16: 3 x 16x16x32 f16 MFMA per product "
+               "f32s": "gemm_pp_kernel<g8_t> 256x256 LDS-DMA, wave groups half a stage apart, split fp16: 3 x 16x16x32 f16 MFMA per product "
                        "(ViT qkv/proj/fc1/fc2)"}
 
 
@@ -301,8 +301,8 @@ def pmc_summary(dtype):
             continue
     if d is None:
         return out
-    enc = (r"gemm_pp_kernel(ILb[01]ELi0E|<(true|false), 0,)|gemm_(big2|enc)_kernel(I4g8_tLb[01]ELi0E|<g8_t, (true|false), 0,)" if dtype == "f32s"
-           else r"gemm_big[23]_kernel(I(DF16b|u6__bf16)?Lb[01]ELi0E|ILb[01]ELi0E|<(__bf16, )?(true|false), 0,)")
+    enc = (r"gemm_pp_kernel<g8_t, (true|false), 0,|gemm_(big2|enc)_kernel(I4g8_tLb[01]ELi0E|<g8_t, (true|false), 0,)" if dtype == "f32s"
+           else r"gemm_pp_kernel(IDF16bLb[01]ELi0E|<bool _Accum, bool, E, 0,|<__bf16, (true|false), 0,)|gemm_big[23]_kernel(I(DF16b|u6__bf16)?Lb[01]ELi0E|ILb[01]ELi0E|<(__bf16, )?(true|false), 0,)")
     classes = {"enc_gemm": enc, "cross_attention": r"decode_attention_(online|shared)_kernel",
                "decode_gemm": r"gemm_(kernel|rows_kernel)<[^>]*, (true|false), 4>|gemm_rows_kernel|gemm_kernel<(g8_t|__bf16|float), 64, 64, 32, 32, 6, 3, false, 0>"}
     for cls, pat in classes.items():
@@ -397,7 +397,7 @@ def main_coca(a):
             "config": {"workload": f"CoCa ViT-L/14 encoder + attentional pooler + 29 KV-cached decode steps x {K} beam(s), {B} frames "
                                    "(SURVEY config 5's model and decode on ONE GPU; parity of this path is unpinned - DESIGN.md section 2)",
                        "streams": a.streams, "beams": K},
-            "roofline": {"bound": "mfma", "kernel": "gemm_big3_kernel / gemm_big2_kernel (ViT-L qkv/proj/fc1/fc2)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel (ViT-L qkv/proj/fc1/fc2)",
                          "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
                          "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_TFLOPS[a.dtype], 4), "traffic": None},
             "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:12]}}
@@ -490,7 +490,7 @@ def main_blip2(a):
             "unit": "captions/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "dtype": a.dtype, "data": "synthetic frames, procedural weights",
             "config": {"workload": f"ViT-g/14 + Q-Former + OPT-2.7b prefill (33 positions) + 19 cached decode steps, {B} frames", "streams": a.streams},
-            "roofline": {"bound": "mfma", "kernel": "gemm_big2/big3_kernel (ViT-g qkv/proj/fc1/fc2)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel (ViT-g qkv/proj/fc1/fc2)",
                          "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
                          "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_TFLOPS[a.dtype], 4), "traffic": None},
             "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:16]}}
