@@ -76,6 +76,21 @@ def beyond_fp16(sd, arch, value=1.0e5):
     return out
 
 
+def cross_kv_outliers(sd, arch, seed=0, factor=30.0, n=2):
+    """n of the 64 dimensions of every head of every cross-attention key and value projection are `factor` times the others:
+    the head rows of the KV16 cache (64 int16 with ONE scale) then quantise their ordinary dimensions `factor` times more
+    coarsely - 2^-16 * factor of their own size, i.e. about fp16's grid at factor 30."""
+    out = dict(sd)
+    r = _rng(seed, "kvout")
+    for k, v in sd.items():
+        if ".crossattention.self.key." in k or ".crossattention.self.value." in k:
+            m = torch.ones(v.shape[0])
+            for h in range(v.shape[0] // 64):
+                m[h * 64 + torch.from_numpy(r.choice(64, size=n, replace=False))] = factor
+            out[k] = v * (m[:, None] if v.dim() == 2 else m)
+    return out
+
+
 ILL_CONDITIONED = {"gamma_spread_raw": lambda sd, arch: gamma_spread(sd, 2, unit_rms=False)}
 
 FAMILIES = {
@@ -86,4 +101,5 @@ FAMILIES = {
     "massive_channels_1000": lambda sd, arch: massive_channels(sd, arch, 5, scale=1000.0),
     "small_gains": lambda sd, arch: small_gains(sd, 6),
     "heavy_tails+massive": lambda sd, arch: massive_channels(heavy_tails(sd, 7), arch, 7),
+    "cross_kv_outliers": lambda sd, arch: cross_kv_outliers(sd, arch, 8),          # the block-scaled KV16 cache's hard case
 }
