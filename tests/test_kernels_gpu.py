@@ -409,3 +409,24 @@ def test_gemm_partial_row_tile_writes_nothing_outside_c(lib, dtype, tile):
     assert (buf[:pad] == 12345.0).all() and (buf[pad + M * N:] == 12345.0).all()
     ref = A.double().cpu() @ W.double().cpu().T + bias.double().cpu()
     assert (Cv.cpu().double() - ref).abs().max().item() < 2e-4 * math.sqrt(K / 64)
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("geom", [(3, 197, 12, 2, 768), (2, 50, 2, 3, 128), (1, 197, 12, 1, 768)])
+def test_cross_kv_gemm_scatters_into_the_cache_layout(lib, dtype, geom):
+    """The cross-K/V GEMM (EPI_CROSSKV; bf16: gemm_pp.hip for >= 128 tiles, the register-staged tiles below) writes
+    [layer][k | v][image][head][token][64]: against the per-layer Linear calls it replaces (HF:modeling_blip_text.py:161-175)."""
+    n_img, tokens, heads, layers, K = geom
+    tag, tdt = DT[dtype]
+    M, N = n_img * tokens, layers * 2 * heads * 64
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).to(tdt)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(tdt)
+    bias = torch.randn(N, generator=g)
+    cache = torch.full((layers * 2 * n_img * heads * tokens, 64), float("nan"), dtype=tdt, device="cuda")
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()               # (named: a temporary would be freed before the kernel runs)
+    _check(lib, lib.cap_op_gemm_crosskv(tag, _p(Ad), _p(Wd), _p(bd), _p(cache), n_img, tokens, heads, layers, K, 0, _stream()))
+    torch.cuda.synchronize()
+    ref = (A.double() @ W.double().T + bias.double()).view(n_img, tokens, layers, 2, heads, 64).permute(2, 3, 0, 4, 1, 5)
+    got = cache.cpu().double().view(layers, 2, n_img, heads, tokens, 64)
+    tol = 2e-4 * math.sqrt(K / 64) if dtype == "f32" else 0.03
+    assert torch.isfinite(got).all() and (got - ref).abs().max().item() < tol
