@@ -129,14 +129,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(G
         int c = tid + i * NT, row = c >> 3, ch = c & 7;
         int gr = min(m0 + row, p.M - 1);
         ga[i] = (const u32x4*)(A + (size_t)gr * p.lda + (size_t)kz * Ks + ch * EPC);
-        da[i] = swz_off(row, ch);
+        da[i] = swz_off<is_g8<T>>(row, ch);
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
         int c = tid + i * NT, row = c >> 3, ch = c & 7;
         int gr = min(n0 + row, p.N - 1);
         gb[i] = (const u32x4*)(W + (size_t)gr * p.ldw + (size_t)kz * Ks + ch * EPC);
-        db[i] = BM * 128 + swz_off(row, ch);
+        db[i] = BM * 128 + swz_off<is_g8<T>>(row, ch);
     }
 
     constexpr bool G8 = is_g8<T>;
@@ -193,13 +193,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(G
                 vec ah[MI16], al[MI16], bh[NI16], bl[NI16];
 #pragma unroll
                 for (int i = 0; i < MI16; ++i) {
-                    ah[i] = *(const vec*)(a_s + swz_off(wm0 + i * 16 + r16, 2 * kg));
-                    al[i] = *(const vec*)(a_s + swz_off(wm0 + i * 16 + r16, 2 * kg + 1));
+                    ah[i] = *(const vec*)(a_s + swz_off<is_g8<T>>(wm0 + i * 16 + r16, 2 * kg));
+                    al[i] = *(const vec*)(a_s + swz_off<is_g8<T>>(wm0 + i * 16 + r16, 2 * kg + 1));
                 }
 #pragma unroll
                 for (int j = 0; j < NI16; ++j) {
-                    bh[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, 2 * kg));
-                    bl[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, 2 * kg + 1));
+                    bh[j] = *(const vec*)(b_s + swz_off<is_g8<T>>(wn0 + j * 16 + r16, 2 * kg));
+                    bl[j] = *(const vec*)(b_s + swz_off<is_g8<T>>(wn0 + j * 16 + r16, 2 * kg + 1));
                 }
 #pragma unroll
                 for (int i = 0; i < MI16; ++i)
@@ -214,9 +214,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(G
                 for (int ks = 0; ks < 2; ++ks) {
                     vec af[MI16], bf[NI16];
 #pragma unroll
-                    for (int i = 0; i < MI16; ++i) af[i] = *(const vec*)(a_s + swz_off(wm0 + i * 16 + r16, ks * 4 + kg));
+                    for (int i = 0; i < MI16; ++i) af[i] = *(const vec*)(a_s + swz_off<is_g8<T>>(wm0 + i * 16 + r16, ks * 4 + kg));
 #pragma unroll
-                    for (int j = 0; j < NI16; ++j) bf[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, ks * 4 + kg));
+                    for (int j = 0; j < NI16; ++j) bf[j] = *(const vec*)(b_s + swz_off<is_g8<T>>(wn0 + j * 16 + r16, ks * 4 + kg));
 #pragma unroll
                     for (int i = 0; i < MI16; ++i)
 #pragma unroll
@@ -227,9 +227,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, WPE) void gemm_kernel(G
                 for (int ks = 0; ks < 4; ++ks) {
                     vec af[MI], bf[NI];
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz_off(wm0 + i * 32 + r32, ks * 2 + h));
+                    for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz_off<is_g8<T>>(wm0 + i * 32 + r32, ks * 2 + h));
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz_off(wn0 + j * 32 + r32, ks * 2 + h));
+                    for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz_off<is_g8<T>>(wn0 + j * 32 + r32, ks * 2 + h));
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int rowbase = (wave * 4 + j) * 8, row = rowbase + prow;
-            const int gch = ppos ^ ((row >> 1) & 7);
+            const int gch = ppos ^ swz_key<is_g8<T>>(row);
             const int ga = min(tm * BM + row, p.M - 1), gb = min(tn * BN + row, p.N - 1);
             const T* sa = A + (size_t)ga * p.lda + (size_t)kt * SLAB + gch * EPC;
             const T* sb = W + (size_t)gb * p.ldw + (size_t)kt * SLAB + gch * EPC;
@@ -387,9 +387,9 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
                 for (int ks = 0; ks < 4; ++ks) {
                     vec af[MI], bf[NI];
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz_off(wm0 + i * 32 + r32, ks * 2 + h));
+                    for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz_off<is_g8<T>>(wm0 + i * 32 + r32, ks * 2 + h));
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz_off(wn0 + j * 32 + r32, ks * 2 + h));
+                    for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz_off<is_g8<T>>(wn0 + j * 32 + r32, ks * 2 + h));
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -504,14 +504,14 @@ __global__ __launch_bounds__(NWM * NWN * 64, NWM * NWN == 8 ? 2 : 1) void gemm_b
 #pragma unroll
         for (int j = 0; j < PPA; ++j) {
             const int row = (wave * PPA + j) * 8 + prow;
-            const int gch = ppos ^ ((row >> 1) & 7);
+            const int gch = ppos ^ swz_key<is_g8<T>>(row);
             const int ga = min(tm * 256 + sub * BM + row, p.M - 1);
             pa[j] = (const char*)((const T*)p.A + (size_t)ga * p.lda + gch * EPC);
         }
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             const int row = (wave * PPW + j) * 8 + prow;
-            const int gch = ppos ^ ((row >> 1) & 7);
+            const int gch = ppos ^ swz_key<is_g8<T>>(row);
             const int gb = min(tn * BN + row, p.N - 1);
             pb[j] = (const char*)((const T*)p.W + (size_t)gb * p.ldw + gch * EPC);
         }
@@ -587,13 +587,13 @@ __global__ __launch_bounds__(NWM * NWN * 64, NWM * NWN == 8 ? 2 : 1) void gemm_b
                 vec bh[NI], bl[NI];
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    bh[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, 2 * kg));
-                    bl[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, 2 * kg + 1));
+                    bh[j] = *(const vec*)(b_s + swz_off<is_g8<T>>(wn0 + j * 16 + r16, 2 * kg));
+                    bl[j] = *(const vec*)(b_s + swz_off<is_g8<T>>(wn0 + j * 16 + r16, 2 * kg + 1));
                 }
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
-                    const vec ah = *(const vec*)(a_s + swz_off(wm0 + i * 16 + r16, 2 * kg));
-                    const vec al = *(const vec*)(a_s + swz_off(wm0 + i * 16 + r16, 2 * kg + 1));
+                    const vec ah = *(const vec*)(a_s + swz_off<is_g8<T>>(wm0 + i * 16 + r16, 2 * kg));
+                    const vec al = *(const vec*)(a_s + swz_off<is_g8<T>>(wm0 + i * 16 + r16, 2 * kg + 1));
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
                         // three dependent MFMAs in a row on one accumulator: measured FASTER than three passes over j (the
@@ -608,9 +608,9 @@ __global__ __launch_bounds__(NWM * NWN * 64, NWM * NWN == 8 ? 2 : 1) void gemm_b
                 for (int ks = 0; ks < 2; ++ks) {
                     vec af[MI], bf[NI];
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz_off(wn0 + j * 16 + r16, ks * 4 + kg));
+                    for (int j = 0; j < NI; ++j) bf[j] = *(const vec*)(b_s + swz_off<is_g8<T>>(wn0 + j * 16 + r16, ks * 4 + kg));
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz_off(wm0 + i * 16 + r16, ks * 4 + kg));
+                    for (int i = 0; i < MI; ++i) af[i] = *(const vec*)(a_s + swz_off<is_g8<T>>(wm0 + i * 16 + r16, ks * 4 + kg));
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmParams p) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int row = q * 8 + prow;
-        const int gch = ppos ^ ((row >> 1) & 7);
+        const int gch = ppos ^ swz_key<is_g8<T>>(row);
         const int ga = min(m0 + row, p.M - 1), gb = min(n0 + row, p.N - 1);
         pa[q] = (const char*)((const T*)p.A + (size_t)ga * p.lda + (size_t)kz * (p.K / S) + gch * EPC);
         pb[q] = (const char*)((const T*)p.W + (size_t)gb * p.ldw + (size_t)kz * (p.K / S) + gch * EPC);
@@ -889,13 +889,13 @@ __global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmParams p) {
             vec ah[4], al[4], bh[4], bl[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                bh[j] = *(const vec*)(b_s + swz_off(j * 16 + r16, 2 * kg));
-                bl[j] = *(const vec*)(b_s + swz_off(j * 16 + r16, 2 * kg + 1));
+                bh[j] = *(const vec*)(b_s + swz_off<is_g8<T>>(j * 16 + r16, 2 * kg));
+                bl[j] = *(const vec*)(b_s + swz_off<is_g8<T>>(j * 16 + r16, 2 * kg + 1));
             }
 #pragma unroll
             for (int i = 0; i < MIA; ++i) {
-                ah[i] = *(const vec*)(a_s + swz_off(i * 16 + r16, 2 * kg));
-                al[i] = *(const vec*)(a_s + swz_off(i * 16 + r16, 2 * kg + 1));
+                ah[i] = *(const vec*)(a_s + swz_off<is_g8<T>>(i * 16 + r16, 2 * kg));
+                al[i] = *(const vec*)(a_s + swz_off<is_g8<T>>(i * 16 + r16, 2 * kg + 1));
             }
             // fragments are in registers: the buffer may take the slab after next
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -914,8 +914,8 @@ __global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmParams p) {
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    bf[ks][j] = *(const vec*)(b_s + swz_off(j * 16 + r16, ks * 4 + kg));
-                    if (j < MIA) af[ks][j] = *(const vec*)(a_s + swz_off(j * 16 + r16, ks * 4 + kg));
+                    bf[ks][j] = *(const vec*)(b_s + swz_off<is_g8<T>>(j * 16 + r16, ks * 4 + kg));
+                    if (j < MIA) af[ks][j] = *(const vec*)(a_s + swz_off<is_g8<T>>(j * 16 + r16, ks * 4 + kg));
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (t + 2 < n) issue(wave + 4 * (t + 2), ring + (t & 1) * BUF);

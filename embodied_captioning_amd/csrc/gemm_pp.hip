@@ -337,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < PQ; ++j) {
             const int row = (wq * PQ + j) * 8 + prow;    // row inside this group's half; WM % 16 == 0: both halves swizzle alike
-            const int gch = ppos ^ ((row >> 1) & 7);
+            const int gch = ppos ^ swz_key<G8>(row);
             const int ga = min(tm * 256 + sub * BM + wm0 + row, p.M - 1);
             oa[j] = ((unsigned)ga * (unsigned)p.lda + gch * EPC) * (unsigned)ESZ;
         }
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int row = (wq * 8 + j) * 8 + prow;
-                const int gch = ppos ^ ((row >> 1) & 7);
+                const int gch = ppos ^ swz_key<G8>(row);
                 const int gw = min(tn * BN + row, p.N - 1);
                 ow[j] = ((unsigned)gw * (unsigned)p.ldw + gch * EPC) * (unsigned)ESZ;
             }
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     vec bh[NI], bl[NI], ah[2], al[2];
     const unsigned lds0 = (unsigned)(size_t)CAP_LPTR(smem);
     // fragment 0 / 1 of a row (names: "h" / "l" after the G8 case); + 128 * (16-aligned row): same swizzle
-    const unsigned f_hi = swz_off(r16, G8 ? 2 * kg : kg), f_lo = swz_off(r16, G8 ? 2 * kg + 1 : 4 + kg);
+    const unsigned f_hi = swz_off<G8>(r16, G8 ? 2 * kg : kg), f_lo = swz_off<G8>(r16, G8 ? 2 * kg + 1 : 4 + kg);
     // G8: a_hi.w_lo, a_lo.w_hi, a_hi.w_hi per accumulator; bf16: k-step 0, k-step 1 - the order of every kernel of the type.  The
     // chains of two accumulators are interleaved, so that a wave that has the matrix pipe to itself never issues an MFMA that
     // waits for the one before it
