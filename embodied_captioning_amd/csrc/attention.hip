@@ -734,6 +734,10 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split(const g8_t* __rest
     const char* base = (const char*)(qkv + (size_t)b * N * ld + h * 64);      // byte address of (token 0, q dims of head h)
     const size_t rowb = (size_t)ld * 4;
     auto koff = [](int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); };
+    // V is read by ds_read_b64_tr_b16, served in two groups of 32 lanes: 4 consecutive keys x the 4 same-parity chunks of half a
+    // row x 8 bytes.  Key r & 15 folds those 16 pieces onto 8 slots (2-way conflict on every V read); keys {0, 1, 8, 9} by r & 3
+    // send the four rows' chunk sets to {0 2 4 6}, {1 3 5 7}, {8 ..}, {9 ..} (+ 8 for the other half): 16 slots, all 64 banks.
+    auto voff = [](int row, int chunk) { return row * 256 + ((chunk ^ ((row & 1) | ((row & 2) << 2))) << 4); };
     const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
     const int nqt = (N + 31) / 32, nkb = nqt;
     const float c1 = 0.125f * LOG2E;
@@ -761,9 +765,10 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split(const g8_t* __rest
         for (int p = wave; p < NP / 4; p += 8) {
             const int row = p * 4 + (lane >> 4);
             const int c = (lane & 15) ^ (row & 15);
-            const char* src = base + (size_t)min(c0 * 32 + row, N - 1) * rowb + c * 16;
-            __builtin_amdgcn_global_load_lds(CAP_GPTR(src + (size_t)D * 4), CAP_LPTR(Ks + p * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(CAP_GPTR(src + (size_t)2 * D * 4), CAP_LPTR(Vs + p * 1024), 16, 0, 0);
+            const int cv = (lane & 15) ^ ((row & 1) | ((row & 2) << 2));
+            const char* src = base + (size_t)min(c0 * 32 + row, N - 1) * rowb;
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(src + (size_t)D * 4 + c * 16), CAP_LPTR(Ks + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(src + (size_t)2 * D * 4 + cv * 16), CAP_LPTR(Vs + p * 1024), 16, 0, 0);
         }
         __syncthreads();                               // vmcnt(0) + barrier: every piece has landed
         if (!live) continue;
@@ -837,10 +842,10 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split(const g8_t* __rest
                     const int dcol = db * 32 + (tg & 1) * 16 + tp * 4;
                     const int key0 = kc * 32 + 16 * s2 + 4 * (tg >> 1) + tq;
                     const int ch = 2 * (dcol >> 3), sub = (dcol & 7) * 2;
-                    const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + koff(key0, ch) + sub));
-                    const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + koff(key0 + 8, ch) + sub));
-                    const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + koff(key0, ch + 1) + sub));
-                    const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + koff(key0 + 8, ch + 1) + sub));
+                    const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + voff(key0, ch) + sub));
+                    const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + voff(key0 + 8, ch) + sub));
+                    const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + voff(key0, ch + 1) + sub));
+                    const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + voff(key0 + 8, ch + 1) + sub));
                     const f16x8 vh = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
                     const f16x8 vl = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[db], 0, 0, 0);
