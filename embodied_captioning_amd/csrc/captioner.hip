@@ -105,6 +105,12 @@ struct CBlock {            // one CoCa text block: causal self-attention (unimod
 };
 
 constexpr bool kDeltaInT = false;
+// The ViT branch GEMMs (proj, fc2) of the MFMA-staged types add their output to the residual stream X IN PLACE (gemm_pp.hip's
+// residual epilogue: C = acc + bias + C) and the next LayerNorm reads X once.  The older scheme - branch output to `delta`, the
+// add+LayerNorm kernel reads delta and X and writes X back - moves 5 x M x D x 4 bytes per (GEMM, LayerNorm) pair against 4 here,
+// and stays for the exact fp32 mode, whose stream kernels have no residual operand.  Same fp32 add of the same two operands: the
+// residual stream has the same bits either way.
+inline bool vit_adds_in_place(int gdt) { return !kDeltaInT && gdt != CAP_DT_F32; }
 
 struct Captioner {
     CapConfig c;
@@ -413,7 +419,7 @@ int build_arena_coca(Captioner* m) {
     TRY(dev_alloc(m, &m->patches, Bm * m->P * m->Kpad * e));
     CAP_HIP_CHECK(hipMemset(m->patches, 0, Bm * m->P * m->Kpad * e));
     TRY(dev_alloc(m, (void**)&m->X, M * D * 4));
-    TRY(dev_alloc(m, (void**)&m->delta, M * D * (kDeltaInT ? m->esz : 4)));
+    if (!vit_adds_in_place(m->gdt)) TRY(dev_alloc(m, (void**)&m->delta, M * D * (kDeltaInT ? m->esz : 4)));
     TRY(dev_alloc(m, &m->ln, M * D * e));
     TRY(dev_alloc(m, &m->qkv, M * 3 * D * e));
     TRY(dev_alloc(m, &m->ctx, M * D * e));
@@ -452,7 +458,7 @@ int build_arena(Captioner* m) {
     TRY(dev_alloc(m, &m->patches, Bm * m->P * m->Kpad * e));
     CAP_HIP_CHECK(hipMemset(m->patches, 0, Bm * m->P * m->Kpad * e));
     TRY(dev_alloc(m, (void**)&m->X, M * D * 4));
-    TRY(dev_alloc(m, (void**)&m->delta, M * D * (kDeltaInT ? m->esz : 4)));
+    if (!vit_adds_in_place(m->gdt)) TRY(dev_alloc(m, (void**)&m->delta, M * D * (kDeltaInT ? m->esz : 4)));
     TRY(dev_alloc(m, &m->ln, M * D * e));
     TRY(dev_alloc(m, &m->qkv, M * 3 * D * e));
     TRY(dev_alloc(m, &m->ctx, M * D * e));
@@ -655,7 +661,7 @@ int build_blip2(Captioner* m) {
     TRY(dev_alloc(m, &m->patches, Bm * m->P * m->Kpad * e));
     CAP_HIP_CHECK(hipMemset(m->patches, 0, Bm * m->P * m->Kpad * e));
     TRY(dev_alloc(m, (void**)&m->X, M * D * 4));
-    TRY(dev_alloc(m, (void**)&m->delta, M * D * (kDeltaInT ? e : 4)));
+    if (!vit_adds_in_place(m->gdt)) TRY(dev_alloc(m, (void**)&m->delta, M * D * (kDeltaInT ? e : 4)));
     TRY(dev_alloc(m, &m->ln, M * D * e));
     TRY(dev_alloc(m, &m->qkv, M * 3 * D * e));
     TRY(dev_alloc(m, &m->ctx, M * D * e));
@@ -937,8 +943,10 @@ int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_emb
              m->Kpad, 0, 1, EPI_PATCH, m->P, 0, 0, 0, m->vpos));
     TRY(launch_cls_rows(m->cls, m->vpos, m->X, B, NT, D, s));
     if (coca) TRY(launch_layernorm(m->dt, m->X, D, m->ln_pre_g, m->ln_pre_b, c.v_eps, nullptr, m->X, M, D, s));
-    // Pre-LN blocks.  The two branch GEMMs (proj, fc2) write their output to `delta`; the next LayerNorm kernel folds it
-    // into the residual stream X (fp32) in the same pass that normalises it, so the GEMM epilogues are store-only.
+    // Pre-LN blocks.  Exact fp32 mode: the two branch GEMMs (proj, fc2) write their output to `delta`; the next LayerNorm kernel
+    // folds it into the residual stream X (fp32) in the same pass that normalises it, so the GEMM epilogues are store-only.
+    // Other modes: the branch GEMMs add into X themselves (vit_adds_in_place).
+    const bool in_place = vit_adds_in_place(m->gdt);
     bool pending = false;                                  // delta holds a branch output not yet added to X
     auto add_ln = [&](const float* g, const float* b, void* out_t, float* out_f) -> int {
         ProfScope ps(m, s, "layernorm", 0, (double)M * D * ((pending ? 8 + (kDeltaInT ? m->esz : 4) : 4) + m->esz + (out_f ? 4 : 0)));
@@ -958,11 +966,13 @@ int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_emb
             ProfScope ps(m, s, "vit_attention", 4.0 * B * H * (double)NT * NT * 64, (double)M * 4 * D * m->esz);
             TRY(launch_vit_attention(g8_attn ? CAP_DT_G8 : m->dt, m->qkv, m->ctx, B, NT, H, 0, s, D / H, 0, m->gdt));
         }
-        TRY(gemm(m, s, "gemm_proj", m->ctx, D, L.w_proj, D, m->delta, D, L.b_proj, nullptr, M, D, D, 0, kDeltaInT ? 0 : 1));
-        pending = true;
+        if (in_place) TRY(gemm(m, s, "gemm_proj", m->ctx, D, L.w_proj, D, m->X, D, L.b_proj, m->X, M, D, D, 0, 1));
+        else TRY(gemm(m, s, "gemm_proj", m->ctx, D, L.w_proj, D, m->delta, D, L.b_proj, nullptr, M, D, D, 0, kDeltaInT ? 0 : 1));
+        pending = !in_place;
         TRY(add_ln(L.ln2_g, L.ln2_b, m->ln, nullptr));
         TRY(gemm(m, s, "gemm_fc1", m->ln, D, L.w_fc1, D, m->mlp, c.v_mlp, L.b_fc1, nullptr, M, c.v_mlp, D, 1, 0));
-        TRY(gemm(m, s, "gemm_fc2", m->mlp, c.v_mlp, L.w_fc2, c.v_mlp, m->delta, D, L.b_fc2, nullptr, M, D, c.v_mlp, 0, kDeltaInT ? 0 : 1));
+        if (in_place) TRY(gemm(m, s, "gemm_fc2", m->mlp, c.v_mlp, L.w_fc2, c.v_mlp, m->X, D, L.b_fc2, m->X, M, D, c.v_mlp, 0, 1));
+        else TRY(gemm(m, s, "gemm_fc2", m->mlp, c.v_mlp, L.w_fc2, c.v_mlp, m->delta, D, L.b_fc2, nullptr, M, D, c.v_mlp, 0, kDeltaInT ? 0 : 1));
     }
     if (coca) TRY(add_ln(m->lnk_g, m->lnk_b, m->emb_t, nullptr));
     else TRY(add_ln(m->post_g, m->post_b, m->emb_t, out_embeds ? out_embeds : m->emb_f));

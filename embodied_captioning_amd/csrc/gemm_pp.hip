@@ -16,8 +16,8 @@
 //     (vmcnt(0)) right before the barrier at which it starts the stage they belong to - one whole stage time after issuing them;
 //   * A fragments are double buffered in registers (block i+1 is read under block i's 12 MFMAs); fragment reads and their
 //     counted lgkmcnt waits are asm statements (hipcc waits lgkmcnt(0), i.e. also for the block it has just requested);
-//   * epilogue without LDS: fp32 output is the accumulator layout as it is (16 bytes per lane); G8 output pairs lanes with
-//     v_permlane16_swap_b32 (pp_epilogue_body).
+//   * epilogue through two LDS strips per wave slot, whole 128-byte lines per store (pp_epilogue_body); with a residual operand
+//     (fp32 output: C = acc + bias + resid, resid may be C) the ViT branch GEMMs add into the residual stream in place.
 // Hazards (buffers S & 1):
 //   RAW  upper A / W of stage S+1: issued by group 0 in step 2S, confirmed by group 0 before the barrier of step 2S+2 (their first
 //        reader; group 1 reads W in step 2S+3).  Lower A of stage S+1: issued by group 1 in step 2S+1, confirmed before the barrier
@@ -82,13 +82,14 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 //     (FULL) store unguarded through two running pointers, clamped groups are counted in a register and added to the
 //     translation unit's counter once per tile;
 //   * a G8 output piece is the strip row image [8 hi | 8 lo] per 8 columns: two 8-byte writes per four values.
-template <typename T, bool OUT_F32, int EPI, int MI, int NI, int ACT, bool FULL>
+template <typename T, bool OUT_F32, int EPI, int MI, int NI, int ACT, bool FULL, bool RESID>
 __device__ __forceinline__ void pp_epilogue_body(const GemmParams& p, const f32x4 (&acc)[MI][NI], const f32x4 (&biasv)[NI], char* strip2,
                                                  int row0, int col0, int lane) {
     constexpr bool G8 = is_g8<T>;
     constexpr bool F32OUT = OUT_F32 || EPI == EPI_PARTIAL || EPI == EPI_PATCH;
     static_assert(F32OUT || !G8 || EPI == EPI_STORE, "G8 output exists for plain row-major stores only");
     static_assert(NI == 4, "two 32-column pieces per row block");
+    static_assert(!RESID || (OUT_F32 && EPI == EPI_STORE), "the residual operand exists for fp32 row-major stores only");
     if constexpr (!G8 && !F32OUT) {
         // bf16 output: a strip row is the row block's whole 64 columns (128 bytes): one piece per row block
         constexpr int SPITCH = 144, SBYTES = 16 * SPITCH;
@@ -177,10 +178,38 @@ __device__ __forceinline__ void pp_epilogue_body(const GemmParams& p, const f32x
         ptr1 = ptr0 + (size_t)p.ldc * 32;
         step = (size_t)p.ldc * 64;
     }
+    // RESID: C = f(acc + bias) + resid (resid may be C itself: the ViT branch GEMMs add into the residual stream in place).  The
+    // two 16-byte pieces of residual a lane needs for piece n + 1 are requested before piece n is drained (one piece of memory
+    // latency under a piece of epilogue); a lane loads exactly the addresses it stores, load first: aliasing is safe.
+    const char* rp0 = nullptr;
+    const char* rp1 = nullptr;
+    size_t rstep = 0;
+    f32x4 q0[2], q1[2];
+    if constexpr (RESID) {
+        rp0 = (const char*)p.resid + ((size_t)(row0 + srow) * p.ldr + col0 + spiece * 4) * 4;
+        rp1 = rp0 + (size_t)p.ldr * 32;
+        rstep = (size_t)p.ldr * 64;
+    }
+    auto fetch = [&](int n) __attribute__((always_inline)) {
+        if constexpr (RESID) {
+            const int i = n >> 1, jp = n & 1;
+            const int col = col0 + jp * 32 + spiece * 4;
+            const int rowa = row0 + i * 16 + srow, rowb = rowa + 8;
+            const bool cok = FULL || col < p.N;
+            q0[n & 1] = 0.f; q1[n & 1] = 0.f;
+            if (FULL || (cok && rowa < p.M)) q0[n & 1] = *(const f32x4*)(rp0 + jp * 128);
+            if (FULL || (cok && rowb < p.M)) q1[n & 1] = *(const f32x4*)(rp1 + jp * 128);
+            if (jp == 1) { rp0 += rstep; rp1 += rstep; }
+        }
+    };
     auto drain = [&](int n) __attribute__((always_inline)) {
         const int i = n >> 1, jp = n & 1;
         const char* st = strip2 + (n & 1) * SBYTES + srow * SPITCH + spiece * 16;
-        const u32x4 r0 = *(const u32x4*)st, r1 = *(const u32x4*)(st + 8 * SPITCH);
+        u32x4 r0 = *(const u32x4*)st, r1 = *(const u32x4*)(st + 8 * SPITCH);
+        if constexpr (RESID) {
+            r0 = __builtin_bit_cast(u32x4, __builtin_bit_cast(f32x4, r0) + q0[n & 1]);
+            r1 = __builtin_bit_cast(u32x4, __builtin_bit_cast(f32x4, r1) + q1[n & 1]);
+        }
         const int col = col0 + jp * 32 + spiece * 4;
         const int rowa = row0 + i * 16 + srow, rowb = rowa + 8;
         const bool cok = FULL || col < p.N;
@@ -193,10 +222,14 @@ __device__ __forceinline__ void pp_epilogue_body(const GemmParams& p, const f32x
             if (FULL || (cok && rowb < p.M)) epi_store_f32<EPI>(p, rowb, col, __builtin_bit_cast(f32x4, r1));
         }
     };
+    fetch(0);
     compute(0);
 #pragma unroll
     for (int n = 0; n < NP; ++n) {
-        if (n + 1 < NP) compute(n + 1);
+        if (n + 1 < NP) {
+            fetch(n + 1);
+            compute(n + 1);
+        }
         drain(n);
     }
     if constexpr (!F32OUT) {
@@ -261,7 +294,7 @@ __device__ __forceinline__ void pp_epilogue_kv16(const GemmParams& p, const f32x
     }
 }
 
-template <typename T, bool OUT_F32, int EPI, int MI, int NI>
+template <typename T, bool OUT_F32, int EPI, int MI, int NI, bool RESID>
 __device__ __forceinline__ void pp_epilogue(const GemmParams& p, const f32x4 (&acc)[MI][NI], const char* bias_w, char* strip2, int row0,
                                             int col0, int lane) {
     const int kg = lane >> 4;
@@ -276,15 +309,15 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, const f32x4 (&a
     }
     const int act = EPI != EPI_PARTIAL ? p.gelu : 0;
     if (row0 + MI * 16 <= p.M && col0 + NI * 16 <= p.N) {
-        if (act == 0) pp_epilogue_body<T, OUT_F32, EPI, MI, NI, 0, true>(p, acc, biasv, strip2, row0, col0, lane);
-        else if (act == 1) pp_epilogue_body<T, OUT_F32, EPI, MI, NI, 1, true>(p, acc, biasv, strip2, row0, col0, lane);
-        else pp_epilogue_body<T, OUT_F32, EPI, MI, NI, 2, true>(p, acc, biasv, strip2, row0, col0, lane);
+        if (act == 0) pp_epilogue_body<T, OUT_F32, EPI, MI, NI, 0, true, RESID>(p, acc, biasv, strip2, row0, col0, lane);
+        else if (act == 1) pp_epilogue_body<T, OUT_F32, EPI, MI, NI, 1, true, RESID>(p, acc, biasv, strip2, row0, col0, lane);
+        else pp_epilogue_body<T, OUT_F32, EPI, MI, NI, 2, true, RESID>(p, acc, biasv, strip2, row0, col0, lane);
     } else {
-        pp_epilogue_body<T, OUT_F32, EPI, MI, NI, -1, false>(p, acc, biasv, strip2, row0, col0, lane);
+        pp_epilogue_body<T, OUT_F32, EPI, MI, NI, -1, false, RESID>(p, acc, biasv, strip2, row0, col0, lane);
     }
 }
 
-template <typename T, bool OUT_F32, int EPI, bool PROF, int BM = 256>
+template <typename T, bool OUT_F32, int EPI, bool PROF, int BM = 256, bool RESID = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     // T = g8_t: 32 k values per 128-byte stage row, chunks [H0 L0 H1 L1 ..]: fragment 0 / 1 = the hi / lo chunk of k-group kg,
     // three MFMAs per product.  T = bf16_t: 64 k values per row, fragment 0 / 1 = k-step 0 / 1 (chunks kg / 4 + kg), one MFMA each.
@@ -421,6 +454,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         CAP_RAW_BARRIER();
         if constexpr (PROF) { prof_vm += t1 - t0; prof_bar += clock64() - t1; }
     };
+    int c_kt = 0, c_x = 0;
     auto half0 = [&](int S) __attribute__((always_inline)) {
         const unsigned sa = lds0 + (S & 1) * STAGE;
         const unsigned aH = sa + wm0 * 128 + f_hi, aL = sa + wm0 * 128 + f_lo;
@@ -449,7 +483,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
             mma_block(i);
         });
     };
-    int c_kt = 0, c_x = 0;
     auto half1 = [&](int S) __attribute__((always_inline)) {
         const unsigned sa = lds0 + (S & 1) * STAGE;
         const unsigned aH = sa + wm0 * 128 + f_hi, aL = sa + wm0 * 128 + f_lo;
@@ -473,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
             const int item = first + c_x * nl;
             const int t = tile0 + item / SUB, sub = item % SUB;
             const int tm = t / ntn, tn = t - tm * ntn;
-            pp_epilogue<T, OUT_F32, EPI, MI, NI>(p, acc, has_bias ? bias_rows + (c_x & 1) * 1024 + wq * 256 : nullptr, strips + wq * (2 * 16 * 144),
+            pp_epilogue<T, OUT_F32, EPI, MI, NI, RESID>(p, acc, has_bias ? bias_rows + (c_x & 1) * 1024 + wq * 256 : nullptr, strips + wq * (2 * 16 * 144),
                                               tm * 256 + sub * BM + wm0, tn * BN + wn0, lane);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -515,11 +548,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     }
 }
 
-template <typename T, bool OUT_F32, int EPI, bool PROF>
+template <typename T, bool OUT_F32, int EPI, bool PROF, bool RESID = false>
 int launch_pp_t(const GemmParams& p, hipStream_t stream) {
     constexpr int EXTRA = 2 * 1024 + 4 * 2 * 16 * 144;   // bias rows + epilogue strips
     constexpr int LDS = 2 * 512 * 128 + EXTRA, LDS_H = 2 * 384 * 128 + EXTRA;
-    auto kern = gemm_pp_kernel<T, OUT_F32, EPI, PROF, 256>;
+    auto kern = gemm_pp_kernel<T, OUT_F32, EPI, PROF, 256, RESID>;
     int n_cu = 0;
     if (cap_kernel_setup((const void*)kern, LDS, &n_cu) != 0) return -1;
 #ifdef CAP_EXPERIMENTS
@@ -528,7 +561,7 @@ int launch_pp_t(const GemmParams& p, hipStream_t stream) {
     const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int rounds = ntiles / n_cu, tail = ntiles - rounds * n_cu;
     if (!PROF && rounds >= 1 && rounds <= 4 && tail > 0 && 2 * tail <= n_cu) {       // the tail round as half tiles: launch_big2
-        auto kern_h = gemm_pp_kernel<T, OUT_F32, EPI, PROF, 128>;
+        auto kern_h = gemm_pp_kernel<T, OUT_F32, EPI, PROF, 128, RESID>;
         if (cap_kernel_setup((const void*)kern_h, LDS_H, nullptr) != 0) return -1;
         GemmParams q = p;
         q.tile0 = 0; q.tile1 = rounds * n_cu;
@@ -555,7 +588,9 @@ int launch_pp_type(const GemmParams& p, bool prof, hipStream_t stream) {
     }
 #endif
     switch (p.epi) {
-        case EPI_STORE: return p.out_f32 ? launch_pp_t<T, true, EPI_STORE, false>(p, stream) : launch_pp_t<T, false, EPI_STORE, false>(p, stream);
+        case EPI_STORE:
+            if (p.resid) return launch_pp_t<T, true, EPI_STORE, false, true>(p, stream);
+            return p.out_f32 ? launch_pp_t<T, true, EPI_STORE, false>(p, stream) : launch_pp_t<T, false, EPI_STORE, false>(p, stream);
         case EPI_PATCH: return launch_pp_t<T, true, EPI_PATCH, false>(p, stream);
         case EPI_CROSSKV: return launch_pp_t<T, G8, EPI_CROSSKV, false>(p, stream);       // G8: fp32 rows or KV16; bf16: bf16 rows
         default: return -2;
@@ -570,7 +605,8 @@ CAP_DEFINE_G8_CLAMP_READER(cap_g8_clamped_gemm_pp)
 // the caller falls back to another 256x256 kernel.  prof: cycle stamps to p.aux (-DCAP_EXPERIMENTS builds only).
 int launch_gemm_pp(int dtype, const GemmParams& p, bool prof, hipStream_t stream) {
     const int kstage = dtype == CAP_DT_G8 ? 32 : 64, esz = dtype == CAP_DT_G8 ? 4 : 2;
-    if ((dtype != CAP_DT_G8 && dtype != CAP_DT_BF16) || p.K < 2 * kstage || p.K % kstage != 0 || p.resid) return -2;
+    if ((dtype != CAP_DT_G8 && dtype != CAP_DT_BF16) || p.K < 2 * kstage || p.K % kstage != 0) return -2;
+    if (p.resid && (prof || p.epi != EPI_STORE || !p.out_f32)) return -2;            // residual operand: fp32 row-major output only
     // 32-bit byte offsets inside A and W
     if ((size_t)p.M * p.lda * esz >= (1ull << 32) || (size_t)p.N * p.ldw * esz >= (1ull << 32)) return -2;
     if (dtype == CAP_DT_BF16 && !p.out_f32 && p.N % 8 != 0) return -2;              // 16-byte bf16 stores

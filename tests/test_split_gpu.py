@@ -124,6 +124,38 @@ def test_split_gemm_g8_output_is_bit_identical_across_kernels(lib, shape, act):
 
 
 @gpu
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("shape", [(52000, 776, 64), (1000, 520, 128), (66000, 768, 192), (300, 2304, 768), (50432, 768, 768)])
+def test_branch_gemm_adds_into_the_residual_stream_in_place(lib, shape, bf16):
+    """The ViT branch GEMMs (proj, fc2) add their output to the residual stream in place: C = (acc + bias) + C with C aliasing the
+    residual operand (gemm_pp.hip's residual epilogue: a lane loads the 16 bytes it is about to store, one piece ahead).  Against
+    the same kernel without the operand followed by one fp32 add (what the add+LayerNorm kernel used to do): the same bits, on
+    interior and ragged edge tiles, with the half-tile tail launch ((66000, 768): 774 tiles) and on the register-staged tile 4;
+    and a second residual buffer (not aliased) is left untouched."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    if bf16:
+        dt, Ad, Wd = 1, A.to(torch.bfloat16).cuda(), W.to(torch.bfloat16).cuda()
+    else:
+        dt, Ad, Wd = SPLIT, _g8(A), _g8(W, G8_WSCALE)
+    bd = torch.randn(N, generator=g).cuda()
+    X0 = torch.randn(M, N, generator=g).cuda()
+    plain = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    _check(lib, lib.cap_op_gemm(dt, _p(Ad), _p(Wd), _p(bd), _p(None), _p(plain), M, N, K, 0, 1, 3, _stream()))
+    want = (plain + X0).view(torch.int32)
+    for tile in (3, 4):
+        X = X0.clone()
+        _check(lib, lib.cap_op_gemm(dt, _p(Ad), _p(Wd), _p(bd), _p(X), _p(X), M, N, K, 0, 1, tile, _stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(X.view(torch.int32), want), tile
+    R, out = X0.clone(), torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    _check(lib, lib.cap_op_gemm(dt, _p(Ad), _p(Wd), _p(bd), _p(R), _p(out), M, N, K, 0, 1, 3, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int32), want) and torch.equal(R, X0)
+
+
+@gpu
 @pytest.mark.parametrize("tile", [0, 2, 3, 6])
 def test_split_gemm_gelu_into_g8_output(lib, tile):
     M, N, K = 600, 3072, 256
