@@ -339,6 +339,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     const int tile0 = p.tile1 > 0 ? p.tile0 : 0;
     const int nitems = ((p.tile1 > 0 ? p.tile1 : ((p.M + 255) / 256) * ntn) - tile0) * SUB;
     const int nk = p.K / (8 * EPC);
+    // Tile t -> (row tile tm, column tile tn).  The 32 workgroups of an XCD work on 32 consecutive tiles at a time and share what
+    // they fetch through that XCD's L2.  Row-major numbering makes those 32 tiles one strip of 32 / ntn rows x ntn columns - fine
+    // up to ntn ~ 12 (qkv: 3.6 rows + 9 column tiles of operands per 32 output tiles), but for the cross-K/V GEMM (ntn = 72) it is
+    // half a row: ONE A tile and 32 different W tiles, every work item pulls its own 0.8 MB of W through the fabric (11.8 GB per
+    // launch by FETCH_SIZE against 0.2 GB of operands).  Wide problems are therefore numbered in bands of 4 tile rows, column by
+    // column inside a band: 32 consecutive tiles = 4 rows x 8 columns, 12 operand tiles instead of 33.
+    const int ntm_all = (p.M + 255) / 256;
+    const bool banded = ntn > 16;
+    auto tile_coords = [&](int t, int& tm, int& tn) __attribute__((always_inline)) {
+        if (!banded) {
+            tm = t / ntn;
+            tn = t - tm * ntn;
+        } else {
+            const int band = t / (4 * ntn), r = t - band * 4 * ntn;
+            const int h = min(4, ntm_all - band * 4);    // rows of this band (the last one may be short)
+            tn = r / h;
+            tm = band * 4 + (r - tn * h);
+        }
+    };
 
     // XCD-aware walk, as in gemm_big2_kernel: XCD x owns the contiguous run [c0, c1) of work items
     const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
@@ -366,7 +385,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     auto set_ptrs = [&](int x) __attribute__((always_inline)) {
         const int item = first + x * nl;
         const int t = tile0 + item / SUB, sub = item % SUB;
-        const int tm = t / ntn, tn = t - tm * ntn;
+        int tm, tn;
+        tile_coords(t, tm, tn);
 #pragma unroll
         for (int j = 0; j < PQ; ++j) {
             const int row = (wq * PQ + j) * 8 + prow;    // row inside this group's half; WM % 16 == 0: both halves swizzle alike
@@ -505,7 +525,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
             if constexpr (PROF) prof_ew += clock64() - e0;
             const int item = first + c_x * nl;
             const int t = tile0 + item / SUB, sub = item % SUB;
-            const int tm = t / ntn, tn = t - tm * ntn;
+            int tm, tn;
+        tile_coords(t, tm, tn);
             pp_epilogue<T, OUT_F32, EPI, MI, NI, RESID>(p, acc, has_bias ? bias_rows + (c_x & 1) * 1024 + wq * 256 : nullptr, strips + wq * (2 * 16 * 144),
                                               tm * 256 + sub * BM + wm0, tn * BN + wn0, lane);
 #pragma unroll

@@ -97,12 +97,13 @@ def test_split_gemm_tiles_are_bit_identical(lib, shape):
 
 @gpu
 @pytest.mark.parametrize("act", [0, 1, 2])
-@pytest.mark.parametrize("shape", [(52000, 776, 64), (1000, 520, 96), (66000, 768, 192), (300, 2304, 768)])
+@pytest.mark.parametrize("shape", [(52000, 776, 64), (1000, 520, 96), (66000, 768, 192), (300, 2304, 768), (1500, 4360, 64)])
 def test_split_gemm_g8_output_is_bit_identical_across_kernels(lib, shape, act):
     """The 256x256 kernel with the skewed wave groups (gemm_pp.hip: what tile 3 selects for G8 operands; its epilogue builds the
     [8 hi | 8 lo] row image in LDS strips and stores whole 128-byte lines) against the register-staged tiles: G8 output with
     bias and no activation / GELU / ReLU, ragged M and N edges, a half-tile tail launch ((66000, 768): 774 tiles), clamped groups
-    counted alike.  (gemm_big2_kernel<g8_t>, the kernel it replaced, exists in experiments builds only: tools/bench_gemm_pp.py
+    counted alike; (1500, 4360): more than 16 column tiles, numbered in bands of four tile rows (the last band has two).
+    (gemm_big2_kernel<g8_t>, the kernel it replaced, exists in experiments builds only: tools/bench_gemm_pp.py
     checks bit-identity against it there.)"""
     M, N, K = shape
     g = torch.Generator().manual_seed(M + N + K + act)

@@ -21,7 +21,7 @@ python3 tools/summarize_prof.py stats "$OUT/stats" "$OUT/kernel_stats.md"
 if [ "${PMC:-1}" = "1" ]; then
   cd /tmp
   i=0
-  for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+  for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS"; do
     i=$((i+1))
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$OUT/pmc/p$i" -- python3 $ROOT/bench.py --steps 1 --warmup 1 --lite --streams 1 "$@" > "$OUT/pmc_p$i.json" 2> "$OUT/pmc_p$i.err"
     echo "pmc pass $i ($ctr) done"

@@ -50,6 +50,8 @@ def pmc(src, dst):
             e["hbm_read_bytes_corrected"] = e["FETCH_SIZE"] * 1024 * 2
         if "WRITE_SIZE" in e:
             e["hbm_write_bytes"] = e["WRITE_SIZE"] * 1024
+        if e.get("SQ_LDS_IDX_ACTIVE"):                # share of the LDS array's cycles that are bank-conflict replays
+            e["lds_conflict_share"] = e.get("SQ_LDS_BANK_CONFLICT", 0.0) / e["SQ_LDS_IDX_ACTIVE"]
         out[k] = e
     json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
     print("wrote", dst, len(out), "kernels")
