@@ -508,7 +508,7 @@ int gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, int lda, c
     p.p0 = p0; p.p1 = p1; p.p2 = p2; p.p3 = p3; p.aux = aux; p.C2 = C2; p.splitk = 1;
     p.kv16 = epi == EPI_CROSSKV && m->kv16 ? 1 : 0;
     const double osz = out_f32 ? 4.0 : (double)m->esz;
-    ProfScope ps(m, s, tag, 2.0 * M * N * K, ((double)M * K + (double)N * K) * m->esz + (double)M * N * osz);
+    ProfScope ps(m, s, tag, 2.0 * M * N * K, ((double)M * K + (double)N * K) * m->esz + (double)M * N * (osz + (resid ? 4.0 : 0.0)));
     return launch_gemm(m->gdt, p, 0, s);   // tile 0 = auto (stream kernel for encoder-sized problems without residual)
 }
 
