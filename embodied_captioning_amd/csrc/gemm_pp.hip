@@ -581,7 +581,11 @@ int launch_pp_t(const GemmParams& p, hipStream_t stream) {
 #endif
     const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int rounds = ntiles / n_cu, tail = ntiles - rounds * n_cu;
-    if (!PROF && rounds >= 1 && rounds <= 4 && tail > 0 && 2 * tail <= n_cu) {       // the tail round as half tiles: launch_big2
+    // The last, partial round of tiles of a SHORT launch runs as half tiles (128 rows) in a second launch (proj / fc2: 2.31 rounds;
+    // a row's sums do not depend on the tile height).  Not for long launches, and not as quarter tiles either: fc1 (9.23 rounds; its
+    // 60 leftover tiles as 240 workgroups of 64 rows) measured level both ways, 632-640 us against 629-638 (tools/ab_gemm_libs.py) -
+    // a round that fills a quarter of the chip runs with the clock and the memory system to itself and is much shorter than a full one.
+    if (!PROF && rounds >= 1 && rounds <= 4 && tail > 0 && 2 * tail <= n_cu) {
         auto kern_h = gemm_pp_kernel<T, OUT_F32, EPI, PROF, 128, RESID>;
         if (cap_kernel_setup((const void*)kern_h, LDS_H, nullptr) != 0) return -1;
         GemmParams q = p;

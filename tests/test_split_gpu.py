@@ -97,12 +97,13 @@ def test_split_gemm_tiles_are_bit_identical(lib, shape):
 
 @gpu
 @pytest.mark.parametrize("act", [0, 1, 2])
-@pytest.mark.parametrize("shape", [(52000, 776, 64), (1000, 520, 96), (66000, 768, 192), (300, 2304, 768), (1500, 4360, 64)])
+@pytest.mark.parametrize("shape", [(52000, 776, 64), (1000, 520, 96), (66000, 768, 192), (300, 2304, 768), (1500, 4360, 64), (9500, 2040, 64)])
 def test_split_gemm_g8_output_is_bit_identical_across_kernels(lib, shape, act):
     """The 256x256 kernel with the skewed wave groups (gemm_pp.hip: what tile 3 selects for G8 operands; its epilogue builds the
     [8 hi | 8 lo] row image in LDS strips and stores whole 128-byte lines) against the register-staged tiles: G8 output with
     bias and no activation / GELU / ReLU, ragged M and N edges, a half-tile tail launch ((66000, 768): 774 tiles), clamped groups
-    counted alike; (1500, 4360): more than 16 column tiles, numbered in bands of four tile rows (the last band has two).
+    counted alike; (1500, 4360): more than 16 column tiles, numbered in bands of four tile rows (the last band has two);
+    (9500, 2040): 304 tiles with ragged edges both ways, the 48 of the partial round as half tiles.
     (gemm_big2_kernel<g8_t>, the kernel it replaced, exists in experiments builds only: tools/bench_gemm_pp.py
     checks bit-identity against it there.)"""
     M, N, K = shape
@@ -126,12 +127,12 @@ def test_split_gemm_g8_output_is_bit_identical_across_kernels(lib, shape, act):
 
 @gpu
 @pytest.mark.parametrize("bf16", [False, True])
-@pytest.mark.parametrize("shape", [(52000, 776, 64), (1000, 520, 128), (66000, 768, 192), (300, 2304, 768), (50432, 768, 768)])
+@pytest.mark.parametrize("shape", [(52000, 776, 64), (1000, 520, 128), (66000, 768, 192), (300, 2304, 768), (50432, 768, 768), (9500, 2040, 128)])
 def test_branch_gemm_adds_into_the_residual_stream_in_place(lib, shape, bf16):
     """The ViT branch GEMMs (proj, fc2) add their output to the residual stream in place: C = (acc + bias) + C with C aliasing the
     residual operand (gemm_pp.hip's residual epilogue: a lane loads the 16 bytes it is about to store, one piece ahead).  Against
     the same kernel without the operand followed by one fp32 add (what the add+LayerNorm kernel used to do): the same bits, on
-    interior and ragged edge tiles, with the half-tile tail launch ((66000, 768): 774 tiles) and on the register-staged tile 4;
+    interior and ragged edge tiles, with the half-tile tail launch ((66000, 768): 774 tiles; (9500, 2040): 304 tiles, ragged both ways) and on the register-staged tile 4;
     and a second residual buffer (not aliased) is left untouched."""
     M, N, K = shape
     g = torch.Generator().manual_seed(M + N + K)
