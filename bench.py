@@ -233,7 +233,8 @@ def roofline_pass(eng, px, L, dtype, arch, batch):
             "mfma_products_per_mac": k, "executed_tflops": round(k * alg, 2), "frac_executed": round(k * alg / peak, 4),
             "mfma_busy_pmc": pm["enc_gemm"].get("mfma_busy"), "frac_vs_fp32_mfma": round(alg / FP32_MFMA_PEAK, 3),
             "traffic_source": pm["source"],
-            "note": "achieved = 2MNK of the ViT Linear layers per launch / HIP-event launch time; frac = achieved / dense peak of "
+            "note": "achieved = 2MNK of the ViT Linear layers per launch / HIP-event launch time (the proj / fc2 launches also add their "
+                    "output into the fp32 residual stream in place: +155 MB read each, counted in algorithmic_bytes_per_launch); frac = achieved / dense peak of "
                     "the MFMA pipe the kernel runs on (MI355X_MICROARCH.md).  executed_tflops counts the MFMA products the "
                     "algorithm spends per MAC (split mode: hi.hi + hi.lo + lo.hi = 3); mfma_busy_pmc = SQ_VALU_MFMA_BUSY_CYCLES / "
                     "(GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of the same launches in the committed counter pass; frac_vs_fp32_mfma = "
@@ -313,7 +314,7 @@ def pmc_summary(dtype):
                 w = v["launches_per_pass"]
                 # a Linear layer whose last tile round is cut runs as TWO launches (256-row tiles, then the 128-row halves of the
                 # tail round): bytes and cycles of both count, the layer counts once
-                n += 0 if (cls == "enc_gemm" and re.search(r", 128>|Li128E", k)) else w
+                n += 0 if (cls == "enc_gemm" and re.search(r", 128(, (true|false))?>|Li128E", k)) else w
                 b += w * (v["hbm_read_bytes_corrected"] + v.get("hbm_write_bytes", 0.0))
                 busy += w * v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
                 act += w * v.get("GRBM_GUI_ACTIVE", 0.0)
