@@ -181,6 +181,9 @@ __device__ __forceinline__ void pp_epilogue_body(const GemmParams& p, const f32x
     // RESID: C = f(acc + bias) + resid (resid may be C itself: the ViT branch GEMMs add into the residual stream in place).  The
     // two 16-byte pieces of residual a lane needs for piece n + 1 are requested before piece n is drained (one piece of memory
     // latency under a piece of epilogue); a lane loads exactly the addresses it stores, load first: aliasing is safe.
+    // (The loads cost 20-25 us per launch: every workgroup wants its block at the same moment.  Touching the block ahead of time
+    // with 4-byte LDS-DMA into a sink - all of it two stages early, or a quarter every other stage over the last nine - measured
+    // the same or worse, tools/bench_branch_add.py.)
     const char* rp0 = nullptr;
     const char* rp1 = nullptr;
     size_t rstep = 0;
