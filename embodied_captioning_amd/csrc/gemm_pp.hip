@@ -183,7 +183,10 @@ __device__ __forceinline__ void pp_epilogue_body(const GemmParams& p, const f32x
     // latency under a piece of epilogue); a lane loads exactly the addresses it stores, load first: aliasing is safe.
     // (The loads cost 20-25 us per launch: every workgroup wants its block at the same moment.  Touching the block ahead of time
     // with 4-byte LDS-DMA into a sink - all of it two stages early, or a quarter every other stage over the last nine - measured
-    // the same or worse, tools/bench_branch_add.py.)
+    // the same or worse, tools/bench_branch_add.py.  What the waits say: vmcnt counts loads and stores in one in-order queue, so
+    // the wait for piece n's residual is also a wait for the stores of piece n - 2; requesting two or more pieces ahead - also with
+    // the look-ahead growing as accumulator registers fall free - pushes the kernel from 256 registers into scratch INSIDE the stage
+    // loop (the DMA offsets go first): fc2 557 -> 823 us.)
     const char* rp0 = nullptr;
     const char* rp1 = nullptr;
     size_t rstep = 0;
