@@ -200,6 +200,9 @@ HBM_PEAK_GBPS = 8000.0                                                 # MI355X_
 FP32_MFMA_PEAK = 157.3                                                 # the pipe the reference's fp32 arithmetic would need
 
 
+POWER_LIMITED_MFMA = {"f32s": 1960.0}     # v_mfma_f32_16x16x32_f16, tools/mfma_power_probe.sh (measured, one box)
+
+
 def roofline_pass(eng, px, L, dtype, arch, batch):
     """Per-kernel HIP-event timing (events recorded on the launch stream inside the library).
 
@@ -232,6 +235,10 @@ def roofline_pass(eng, px, L, dtype, arch, batch):
             "algorithmic_bytes_per_launch": round(sum(rep[t]["bytes"] for t in ENC_GEMM_TAGS if t in rep) / n),
             "mfma_products_per_mac": k, "executed_tflops": round(k * alg, 2), "frac_executed": round(k * alg / peak, 4),
             "mfma_busy_pmc": pm["enc_gemm"].get("mfma_busy"), "frac_vs_fp32_mfma": round(alg / FP32_MFMA_PEAK, 3),
+            # what a register-only loop of the same MFMA instruction sustains on this board with RANDOM fp16 operands: the socket
+            # power limit (~1.3 kW) holds the clock at 2.0 GHz (profiles/r03_mfma_power.txt; 2 390 TFLOP/s with one constant pair)
+            "power_limited_mfma_tflops": POWER_LIMITED_MFMA.get(dtype), "frac_executed_vs_power_limited":
+            round(k * alg / POWER_LIMITED_MFMA[dtype], 4) if POWER_LIMITED_MFMA.get(dtype) else None,
             "traffic_source": pm["source"],
             "note": "achieved = 2MNK of the ViT Linear layers per launch / HIP-event launch time (the proj / fc2 launches also add their "
                     "output into the fp32 residual stream in place: +155 MB read each, counted in algorithmic_bytes_per_launch); frac = achieved / dense peak of "

@@ -584,6 +584,11 @@ int launch_pp_t(const GemmParams& p, hipStream_t stream) {
     if (cap_kernel_setup((const void*)kern, LDS, &n_cu) != 0) return -1;
 #ifdef CAP_EXPERIMENTS
     if (const char* e = getenv("CAP_EXP_CUS")) n_cu = std::min(n_cu, std::max(8, atoi(e)));
+    if (getenv("CAP_EXP_NONPERSIST")) {                  // one tile per workgroup: workgroups retire all the time (tools/stagger_experiment.py)
+        hipLaunchKernelGGL(kern, dim3(((p.M + 255) / 256) * ((p.N + 255) / 256)), dim3(512), LDS, stream, p);
+        CAP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
 #endif
     const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const int rounds = ntiles / n_cu, tail = ntiles - rounds * n_cu;
