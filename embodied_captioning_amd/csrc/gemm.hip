@@ -1179,6 +1179,10 @@ int launch_gemm(int dtype, const GemmParams& p, int tile, hipStream_t stream) {
         const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
         tile = (t256 >= 256 || (t256 >= 128 && p.M >= 256)) ? 3 : (t128 >= 256 ? 1 : 2);   // few rows: a 256-row tile is mostly padding
+        // split fp16 with a long K (the OPT prefill's out_proj / fc2: 1056 x 2560 x 2560 / 10240 with the residual operand): the
+        // 128x128 tile already pays at half a round of workgroups - 84 / 271 us against 97 / 371 for the 64x64 tile; at K <= 1024
+        // and for bf16 the small tile stays level or ahead (tools/bench_prefill_gemm.py).  Same bits either way.
+        if (dtype == CAP_DT_G8 && tile == 2 && t128 >= 128 && p.K >= 2048) tile = 1;
     }
     if (p.epi == EPI_CROSSKV && p.kv16) {               // int16 rows with one scale each: only gemm_pp.hip's epilogue builds them
         const int rc = dtype == CAP_DT_G8 ? launch_gemm_pp(dtype, p, false, stream) : -2;
