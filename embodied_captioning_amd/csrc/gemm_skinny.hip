@@ -35,7 +35,9 @@ struct SkinnyParams {
 // wave's LDS-DMA instruction moves 8 rows x 128 bytes (whole lines) into a wave-private ring of 64-wide slabs instead, and
 // the fragments are read back through the XOR swizzle.  No workgroup barrier in the stream: a wave only reads what it
 // fetched itself, ordered by counted s_waitcnt vmcnt.
-__device__ __forceinline__ int skl_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// (key: the bf16 one of gemm_tile.h::swz_key - conflict-free for the lane groups gfx950 serves a ds_read_b128 in)
+__device__ __forceinline__ int skl_key(int row) { const int t = (row >> 1) & 7; return t ^ (((t >> 1) ^ (t >> 2)) & 1); }
+__device__ __forceinline__ int skl_swz(int row, int chunk) { return row * 128 + ((chunk ^ skl_key(row)) << 4); }
 #define SKL_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define SKL_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(SkinnyParams p) {
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
         const int row = q * 8 + (lane >> 3);
-        wsrc[q] = p.W + (size_t)(n0 + row) * p.ldw + kw + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+        wsrc[q] = p.W + (size_t)(n0 + row) * p.ldw + kw + (((lane & 7) ^ skl_key(row)) << 3);
     }
     auto issue = [&](int sl) {
         char* dst = ring + (sl % SKL_RING) * SLAB;
