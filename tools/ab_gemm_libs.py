@@ -7,7 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from embodied_captioning_amd import _native
 new = _native.load_library()
-old = C.CDLL(os.path.join(ROOT, "embodied_captioning_amd", "lib", "libcaptioner_old.so"))
+OLD = os.path.join(ROOT, "embodied_captioning_amd", "lib", "libcaptioner_old.so")
+if not os.path.exists(OLD):
+    sys.exit(f"{OLD} is missing: build the earlier revision and copy its libcaptioner_hip.so there first")
+old = C.CDLL(OLD)
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 BF16 = "--bf16" in sys.argv
 DT = 1 if BF16 else 2
