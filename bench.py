@@ -75,6 +75,7 @@ def parse():
                     "golden's weights; larger values end every caption early)")
     ap.add_argument("--lite", action="store_true", help="timed steps only (profiler counter passes): no roofline / "
                     "encoder-only / parity / fp32 / CPU legs")
+    ap.add_argument("--latency-only", action="store_true", help="print only the small-batch `latency` block (B = 1, 8, 64)")
     ap.add_argument("--image-size", type=int, default=224, help="coca: 224 or 336 (SURVEY config 5); blip: 224 (the "
                     "BASELINE config) or 384 (what the published BLIP checkpoints ship - extra line, no golden)")
     return ap.parse_args()
@@ -552,6 +553,77 @@ def golden_parity(ids, g, arch, L, B, tau):
             "reference": "HF transformers 5.15 BlipForConditionalGeneration greedy, fp32 CPU (tests/golden/blip_base256.npz)"}
 
 
+LAYER_STEP_TAGS = ("dec_gemm_qkv", "dec_self_attn", "dec_gemm_so", "dec_reduce_ln", "dec_gemm_cq", "dec_cross_attn", "dec_gemm_co",
+                   "dec_gemm_f1", "dec_gemm_f2", "dec_small_qkv", "dec_small_so", "dec_small_cross", "dec_small_co", "dec_small_f1",
+                   "dec_small_f2")
+
+
+def latency_block(arch, sd, dev, dtype, L, batches=(1, 8, 64), reps=7):
+    """The reference's real call pattern: ONE crop per call (coca.py:27-33, blip2.py:24-29, goal_exploration.py:95-105,
+    pseudolabeler.py:673-676); BASELINE config 1 is 8 crops.  Per batch size: median wall time of one `cap_generate` on one
+    stream (frames resident, host synchronised after each call), with HF's stopping rule off (all L-1 steps) and on (the plugin's
+    poll every 4 steps), and how many kernel launches one decoder layer-step takes (per-tag launch counts of the library's own
+    profile pass over the tags of one text layer / (layers x steps)).  `forward_pil_ms`: `BLIP.forward(PIL.Image)` end to end -
+    resize on the host, upload, generate with per-step logits, detokenise - at batch 1."""
+    import statistics
+    out = {"unit": "ms", "max_length": L, "dtype": dtype, "reps": reps, "batches": {}}
+    for B in batches:
+        eng = CaptionerEngine(arch, dtype=dtype, max_batch=B, max_beams=1, max_len=L, device=dev)
+        eng.load_state_dict(sd)
+        px = synthetic_pixels(B, arch.image_size, seed=0).to(dev)
+        rec = {}
+        for key, poll in (("generate_ms", 0), ("generate_early_exit_ms", 4)):
+            eng.set_early_exit(poll)
+            for _ in range(2):
+                eng.generate(px, max_length=L)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                o = eng.generate(px, max_length=L)
+                torch.cuda.synchronize()
+                ts.append(1e3 * (time.perf_counter() - t0))
+            rec[key] = round(statistics.median(ts), 3)
+            rec[key.replace("_ms", "_steps")] = eng.last_decode_steps
+        eng.set_early_exit(0)
+        rec["mean_caption_tokens"] = round(float(o["lengths"].float().mean()), 2)
+        eng.profile(True)
+        eng.generate(px, max_length=L)
+        rep = eng.profile_report()
+        eng.profile(False)
+        n = sum(r["launches"] for t, r in rep.items() if t in LAYER_STEP_TAGS)
+        rec["launches_per_layer_step"] = round(n / (arch.t_layers * (L - 1)), 2)
+        rec["tagged_launches_per_generate"] = sum(r["launches"] for r in rep.values())
+        rec["decode_kernel_ms"] = round(sum(r["ms"] for t, r in rep.items() if t.startswith("dec_") or t == "greedy_select"), 3)
+        rec["image_side_kernel_ms"] = round(sum(r["ms"] for t, r in rep.items() if not (t.startswith("dec_") or t == "greedy_select")), 3)
+        rec["ms_per_caption"] = round(rec["generate_ms"] / B, 3)
+        out["batches"][str(B)] = rec
+        eng.close()
+    try:
+        from PIL import Image
+        from embodied_captioning_amd.captioner.models.blip.blip import BLIP
+        from embodied_captioning_amd.captioner.utils.utils import CaptionerField
+        model = BLIP(CaptionerField(arch_name="blip", model_name="procedural:0:9", height=arch.image_size, width=arch.image_size,
+                                    dtype=dtype, batch_size=1, max_length=L, device=str(dev)))
+        rng = np.random.default_rng(0)
+        im = Image.fromarray(rng.integers(0, 256, (480, 640, 3), dtype=np.uint8))
+        for _ in range(2):
+            model.forward(im)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            model.forward(im)
+            torch.cuda.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t0))
+        out["forward_pil_ms"] = round(statistics.median(ts), 3)
+        out["forward_pil_note"] = ("BLIP.forward(PIL 640x480): host bicubic resize + upload + cap_generate with per-step logits "
+                                   "(early-exit poll 4, the plugin default) + detokenise")
+        model.engine.close()
+    except Exception as e:  # noqa: BLE001
+        out["forward_pil_error"] = repr(e)
+    return out
+
+
 def main_strong(a, arch, sd, dev, rank, world):
     """Strong scaling (north_star: >= 6x at 8 GPUs; SURVEY config 4): --frames in total, contiguous shards, micro-batches of
     --batch rotating over the stream pool, ONE caption all-gather at the end, consensus grouping on rank 0's table."""
@@ -629,6 +701,9 @@ def main():
         if world > 1:
             torch.distributed.barrier()
             torch.distributed.destroy_process_group()
+        return
+    if a.latency_only:
+        print(json.dumps({"latency": latency_block(arch, sd, dev, a.dtype, L)}))
         return
     px = synthetic_pixels(B, arch.image_size, seed=0, first=rank * B).to(dev)
 
@@ -714,6 +789,9 @@ def main():
                            for k, v in kernels.items()}
         line["kernel_ms_per_step"] = round(kernel_ms, 3)           # sum of ONE stream's kernel durations (see single_stream)
         line["encoder_only"] = encoder_only(eng, px, arch)
+        eng.close()
+        log("latency block: B = 1, 8, 64")
+        line["latency"] = latency_block(arch, sd, dev, a.dtype, L)
         golden = None
         try:
             from tests._util import load_golden
@@ -721,7 +799,6 @@ def main():
             line["parity"] = golden_parity(ids, golden, arch, L, B, 0.3 if a.dtype == "bf16" else 0.0)
         except Exception as e:  # noqa: BLE001
             line["parity"] = {"error": repr(e)}
-        eng.close()
         if world == 1 and not (a.no_strict or a.no_extra_modes):
             for other, key in (("bf16", "bf16"), ("f32", "f32_exact"), ("f32s", "f32s")):
                 if other == a.dtype:
