@@ -53,6 +53,8 @@ _SIGNATURES = {
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "cap_set_early_exit": (C.c_int, [C.c_void_p, C.c_int]),
     "cap_last_decode_steps": (C.c_int, [C.c_void_p]),
+    "cap_set_decode_path": (C.c_int, [C.c_void_p, C.c_int]),
+    "cap_last_decode_path": (C.c_int, [C.c_void_p]),
     "cap_device_bytes": (C.c_size_t, [C.c_void_p]),
     "cap_g8_saturations": (C.c_longlong, [C.c_int]),
     "cap_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

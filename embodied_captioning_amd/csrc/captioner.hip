@@ -17,6 +17,7 @@
 #include "../../include/captioner_hip.h"
 #include "gemm.h"
 #include "ops.h"
+#include "decode_small.h"
 
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local char g_err[2048] = "";
@@ -132,6 +133,9 @@ struct Captioner {
     // early exit of the decode loop (cap_set_early_exit): poll every `poll` steps through a host-mapped word
     int poll = 0; int* host_flag = nullptr; int* host_flag_dev = nullptr;
     int last_steps = 0;          // decode steps the last cap_generate ran (cap_last_decode_steps)
+    int decode_path = 0;         // cap_set_decode_path: 0 = by row count (<= SMALL_MAX_ROWS rows: the fused small-batch kernels),
+                                 // 1 = always the batch kernels, 2 = always the small-batch kernels (an error beyond their row limit)
+    int last_path = 0;           // what the last cap_generate's decode steps ran on (cap_last_decode_path): 1 batch, 2 small-batch
     // vision weights
     float *cls, *vpos, *b_patch, *post_g, *post_b;
     void* w_patch;
@@ -148,6 +152,7 @@ struct Captioner {
                                  // of bf16 captions token-identical to the fp32 mode's - not worth it, so off)
     int *seq, *finished, *lens, *anc;
     float *dx, *dy, *logits, *dpart;
+    float* dx2 = nullptr;        // small-batch decode path: second fp32 LayerNorm row buffer (ping-pong with dx), SMALL_MAX_ROWS rows
     void *dx_t, *dq, *dctx, *dh;
     void* beam = nullptr;
     size_t cache_layer_bytes = 0;
@@ -472,6 +477,7 @@ int build_arena(Captioner* m) {
     TRY(dev_alloc(m, (void**)&m->anc, 2 * R * Lm * 4));
     TRY(dev_alloc(m, (void**)&m->dx, R * T * 4));
     TRY(dev_alloc(m, (void**)&m->dy, R * T * 4));
+    TRY(dev_alloc(m, (void**)&m->dx2, (size_t)SMALL_MAX_ROWS * T * 4));
     TRY(dev_alloc(m, (void**)&m->dpart, 12 * R * T * 4));      // split-K slabs: 8 x [R,T] (ffn) or 4 x [R,3T] (qkv)
     TRY(dev_alloc(m, &m->dx_t, R * T * e));
     TRY(dev_alloc(m, &m->dq, R * T * e));
@@ -1007,6 +1013,7 @@ int run_coca_pool(Captioner* m, int B, float* tokens_out, hipStream_t s) {
 struct Dec {
     int b0, B, R, Btot;
     float *dx, *dy, *logits, *dpart;
+    float* dx2;           // (the whole-batch slice only: the small-batch path's second LayerNorm row buffer)
     char *dx_t, *dq, *dctx, *dh;
     int *seq, *finished, *lens, *anc;
     void* beam;
@@ -1019,6 +1026,7 @@ Dec make_slice(Captioner* m, int b0, int B, int Btot, int K, int Lm) {
     const size_t r0 = (size_t)b0 * K;
     Dec d;
     d.b0 = b0; d.B = B; d.R = B * K; d.Btot = Btot;
+    d.dx2 = b0 == 0 ? m->dx2 : nullptr;
     d.dx = m->dx + r0 * T; d.dy = m->dy + r0 * T; d.logits = m->logits + r0 * m->ldl; d.dpart = m->dpart + 12 * r0 * T;
     d.dx_t = (char*)m->dx_t + r0 * T * e; d.dq = (char*)m->dq + r0 * T * e; d.dctx = (char*)m->dctx + r0 * T * e;
     d.dh = (char*)m->dh + r0 * F * e;
@@ -1152,6 +1160,131 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------- small-batch decoder step
+// Up to SMALL_MAX_ROWS rows (the reference calls the captioner with ONE crop, BASELINE config 1 with 8): the same step as
+// run_decoder_step in 6 launches per layer instead of 11 - every split-K consumer / LayerNorm and the self-attention run in the
+// prologue of the kernel that needs their result, the cross-attention block (LayerNorm, query projection, attention) is one
+// kernel per (row, head) - decode_small.hip.  The sums are those of the batch kernels (same K-slice plan, same chains, same
+// LayerNorm / attention arithmetic): logits and tokens have the same bits on either path (tests/test_small_decode_gpu.py).
+// The fp32 LayerNorm rows (the batch path's dx) alternate between d.dx and d.dx2: the one workgroup that writes a row never
+// writes the buffer the others are still reading.
+bool small_path_takes(const Captioner* m, const Dec& d, int t) {
+    const CapConfig& c = m->c;
+    if (m->gdt == CAP_DT_F32 || c.arch != CAP_ARCH_BLIP || !d.dx2) return false;
+    if (d.R > SMALL_MAX_ROWS || t + 1 > 32) return false;
+    const int T = c.t_hidden, F = c.t_ffn, slab = m->gdt == CAP_DT_BF16 ? 64 : 32;
+    if (T > 1024 || T != c.t_heads * 64 || T % 16 != 0 || F % 16 != 0 || T % slab != 0 || F % slab != 0) return false;
+    // q|k|v partial sums sit beside the [<= 4][R][T] slabs of the other GEMMs in dpart (12 R T floats): at most 2 K slices
+    return decode_splitk(m, 3 * T, T, 4) <= 2;
+}
+
+int run_decoder_step_small(Captioner* m, const Dec& d, const int* tokens, int tok_ld, int t, int K, const int* anc, int Lm,
+                           hipStream_t s) {
+    const CapConfig& c = m->c;
+    const int T = c.t_hidden, F = c.t_ffn, H = c.t_heads, R = d.R, NT = m->NT;
+    const size_t e = m->esz;
+    const int* skip = K == 1 ? d.finished : nullptr;
+    float* xb[2] = {d.dx, d.dx2};
+    int cur = 0;                                   // xb[cur]: the LayerNorm row the next consumer adds as its residual
+    float* qkvp = d.dpart + (size_t)4 * R * T;     // q|k|v partial sums, beside the [<= 4][R][T] slabs of the other GEMMs
+    const int S_qkv = decode_splitk(m, 3 * T, T, 4), S_tt = decode_splitk(m, T, T, 4), S_f2 = decode_splitk(m, T, F, 4);
+    const int kv_kind = m->kv16 ? SMALL_KV_KV16 : (m->dt == CAP_DT_BF16 ? SMALL_KV_BF16 : SMALL_KV_F32);
+    TRY(launch_embed(m->gdt, tokens, tok_ld, t, m->word_f32, m->tpos, m->emb_g, m->emb_b, c.t_eps, d.dx_t, xb[0], R, T, s));
+    SmallLN pend;                                  // the consumer the next kernel's prologue runs
+    memset(&pend, 0, sizeof(pend));
+    auto base = [&](const void* W, int N, int Kk, int S, int pro, int epi) {
+        SmallGemm g;
+        memset(&g, 0, sizeof(g));
+        g.W = W; g.R = R; g.N = N; g.K = Kk; g.S = S; g.pro = pro; g.epi = epi; g.nchain = 4;
+        return g;
+    };
+    auto consume = [&](SmallLN ln, bool keep) {    // bind the pending consumer to the current residual row / the other buffer
+        ln.resid = xb[cur];
+        ln.x_out = keep ? xb[cur ^ 1] : nullptr;
+        if (keep) cur ^= 1;
+        return ln;
+    };
+    for (int i = 0; i < c.t_layers; ++i) {
+        const TLayer& L = m->tl[i];
+        char* kc = (char*)L.self_cache + d.cache_off;
+        char* vc = kc + (size_t)R * H * Lm * 64 * e;
+        {
+            SmallGemm g = base(L.w_qkv, 3 * T, T, S_qkv, i == 0 ? SMALL_PRO_GLOBAL : SMALL_PRO_LN, SMALL_EPI_PARTIAL);
+            if (i == 0) g.A = d.dx_t; else g.ln = consume(pend, true);
+            g.out_part = qkvp;
+            ProfScope ps(m, s, "dec_small_qkv", 2.0 * R * 3 * T * T, ((double)R * T + 3.0 * T * T) * e + (double)S_qkv * R * 3 * T * 4);
+            TRY(launch_small_gemm(m->gdt, g, s));
+        }
+        {
+            SmallGemm g = base(L.w_so, T, T, S_tt, SMALL_PRO_SELFATTN, SMALL_EPI_PARTIAL);
+            g.sa.qkv_part = qkvp; g.sa.qkv_bias = L.b_qkv; g.sa.qkv_S = S_qkv; g.sa.kc = kc; g.sa.vc = vc; g.sa.anc = anc; g.sa.anc_ld = Lm;
+            g.sa.kv_ld = Lm; g.sa.n_keys = t + 1; g.sa.H = H; g.sa.skip = skip;
+            g.out_part = d.dpart;
+            ProfScope ps(m, s, "dec_small_so", 2.0 * R * T * T + 4.0 * R * H * (t + 1) * 64, ((double)R * T + (double)T * T) * e + (double)S_tt * R * T * 4);
+            TRY(launch_small_gemm(m->gdt, g, s));
+        }
+        {
+            SmallCross x;
+            memset(&x, 0, sizeof(x));
+            x.W = L.w_cq; x.bias = L.b_cq; x.R = R; x.D = T; x.H = H; x.S = S_tt;
+            SmallLN ln;
+            memset(&ln, 0, sizeof(ln));
+            ln.part = d.dpart; ln.S = S_tt; ln.bias = L.b_so; ln.gamma = L.so_g; ln.beta = L.so_b; ln.eps = c.t_eps;
+            x.ln = consume(ln, true);
+            const size_t blk = m->cross_block((size_t)d.Btot * H * NT);
+            x.kbase = (char*)m->cross + ((size_t)i * 2 + 0) * blk;
+            x.vbase = (char*)m->cross + ((size_t)i * 2 + 1) * blk;
+            x.kv_row0 = (size_t)d.b0 * H * NT;
+            x.rows_per_kv = K; x.kv_ld = NT; x.n_keys = NT; x.kv_kind = kv_kind; x.skip = skip; x.out = d.dctx;
+            ProfScope ps(m, s, "dec_small_cross", 2.0 * R * T * T + 4.0 * R * H * NT * 64, (double)T * T * e + 2.0 * R * H * NT * m->kvrow);
+            TRY(launch_small_cross(m->gdt, x, s));
+        }
+        {
+            SmallGemm g = base(L.w_co, T, T, S_tt, SMALL_PRO_GLOBAL, SMALL_EPI_PARTIAL);
+            g.A = d.dctx; g.out_part = d.dpart;
+            ProfScope ps(m, s, "dec_small_co", 2.0 * R * T * T, ((double)R * T + (double)T * T) * e + (double)S_tt * R * T * 4);
+            TRY(launch_small_gemm(m->gdt, g, s));
+        }
+        {
+            SmallGemm g = base(L.w_f1, F, T, 1, SMALL_PRO_LN, SMALL_EPI_ACT_T);
+            SmallLN ln;
+            memset(&ln, 0, sizeof(ln));
+            ln.part = d.dpart; ln.S = S_tt; ln.bias = L.b_co; ln.gamma = L.co_g; ln.beta = L.co_b; ln.eps = c.t_eps;
+            g.ln = consume(ln, true);
+            g.bias = L.b_f1; g.act = 1; g.out = d.dh; g.ldc = F;
+            ProfScope ps(m, s, "dec_small_f1", 2.0 * R * F * T, ((double)R * T + (double)F * T + (double)R * F) * e);
+            TRY(launch_small_gemm(m->gdt, g, s));
+        }
+        {
+            SmallGemm g = base(L.w_f2, T, F, S_f2, SMALL_PRO_GLOBAL, SMALL_EPI_PARTIAL);
+            g.A = d.dh; g.out_part = d.dpart;
+            ProfScope ps(m, s, "dec_small_f2", 2.0 * R * T * F, ((double)R * F + (double)T * F) * e + (double)S_f2 * R * T * 4);
+            TRY(launch_small_gemm(m->gdt, g, s));
+        }
+        memset(&pend, 0, sizeof(pend));
+        pend.part = d.dpart; pend.S = S_f2; pend.bias = L.b_f2; pend.gamma = L.f_g; pend.beta = L.f_b; pend.eps = c.t_eps;
+    }
+    {   // prediction head transform: LayerNorm of the last layer's FFN in the prologue, bias + GELU -> fp32
+        SmallGemm g = base(m->w_tr, T, T, 1, SMALL_PRO_LN, SMALL_EPI_ACT_F32);
+        g.nchain = 1;
+        g.ln = consume(pend, false);
+        g.bias = m->b_tr; g.act = 1; g.out = d.dy; g.ldc = T;
+        ProfScope ps(m, s, "dec_small_tr", 2.0 * R * T * T, ((double)R * T + (double)T * T) * e + (double)R * T * 4);
+        TRY(launch_small_gemm(m->gdt, g, s));
+    }
+    {   // vocabulary GEMM with the transform's LayerNorm in the prologue
+        SmallGemm g = base(m->word_t, c.vocab, T, 1, SMALL_PRO_LN, SMALL_EPI_ACT_F32);
+        g.nchain = 1;
+        memset(&g.ln, 0, sizeof(g.ln));
+        g.ln.part = d.dy; g.ln.S = 1; g.ln.gamma = m->tr_g; g.ln.beta = m->tr_b; g.ln.eps = c.t_eps;
+        g.bias = m->b_vocab; g.act = 0; g.out = d.logits; g.ldc = m->ldl;
+        ProfScope ps(m, s, "dec_small_vocab", 2.0 * R * c.vocab * T, ((double)R * T + (double)c.vocab * T) * e + (double)R * c.vocab * 4);
+        TRY(launch_small_gemm(m->gdt, g, s));
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- CoCa decoder
 // One KV-cached step through the unimodal text tower (t_layers causal blocks) and the multimodal decoder (mm_layers x
 // [causal self-attention block, cross-attention block]).  Every block is pre-LN: the residual stream x stays fp32 in
@@ -1254,8 +1387,20 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
         m->last_steps = t + 1;
         const int* tokens = greedy ? d.seq : beam_running_tokens_p(d.beam, B, K, Lm, cur_len & 1);
         const int* anc = greedy ? nullptr : d.anc + (size_t)(cur_len & 1) * R * Lm;
-        if (coca) TRY(run_coca_step(m, d, tokens, Lm, t, K, anc, Lm, s));
-        else TRY(run_decoder_step(m, d, tokens, Lm, t, K, anc, Lm, s));
+        if (coca) {
+            TRY(run_coca_step(m, d, tokens, Lm, t, K, anc, Lm, s));
+        } else {
+            const bool can = small_path_takes(m, d, t);
+            if (m->decode_path == 2 && !can) {
+                cap_set_error("cap_generate: the small-batch decode path was forced (cap_set_decode_path 2) but does not take this call "
+                              "(%d rows, step %d, compute type %d): at most %d rows, 32 positions, split or bf16 mode, BLIP", R, t, m->gdt, SMALL_MAX_ROWS);
+                return -1;
+            }
+            const bool small = can && m->decode_path != 1;
+            m->last_path = small ? 2 : 1;
+            if (small) TRY(run_decoder_step_small(m, d, tokens, Lm, t, K, anc, Lm, s));
+            else TRY(run_decoder_step(m, d, tokens, Lm, t, K, anc, Lm, s));
+        }
         if (out_step_logits) {
             hipLaunchKernelGGL(copy_logits_kernel, dim3(1024), dim3(256), 0, s, d.logits, m->ldl,
                                out_step_logits + (size_t)t * R * c.vocab, R, c.vocab);
@@ -1435,6 +1580,15 @@ int cap_set_early_exit(CapHandle h, int poll_steps) {
 
 int cap_last_decode_steps(CapHandle h) { return h ? ((Captioner*)h)->last_steps : -1; }
 
+int cap_set_decode_path(CapHandle h, int path) {
+    Captioner* m = (Captioner*)h;
+    if (!m) { cap_set_error("cap_set_decode_path: null handle"); return -1; }
+    if (path < 0 || path > 2) { cap_set_error("cap_set_decode_path: path must be 0 (by row count), 1 (batch kernels) or 2 (small-batch kernels), got %d", path); return -1; }
+    m->decode_path = path;
+    return 0;
+}
+int cap_last_decode_path(CapHandle h) { return h ? ((Captioner*)h)->last_path : -1; }
+
 size_t cap_device_bytes(CapHandle h) { return h ? ((Captioner*)h)->dev_bytes : 0; }
 
 int cap_load_weight(CapHandle h, const char* name, const float* data, int on_device, int ndim, const int64_t* shape,
@@ -1584,7 +1738,7 @@ long long cap_g8_saturations(int reset) {
     if (hipDeviceSynchronize() != hipSuccess) { cap_set_error("cap_g8_saturations: device synchronisation failed"); return -1; }
     unsigned long long total = 0;
     if (cap_g8_clamped_gemm(&total, reset) != 0 || cap_g8_clamped_gemm_pp(&total, reset) != 0 || cap_g8_clamped_elementwise(&total, reset) != 0 ||
-        cap_g8_clamped_attention(&total, reset) != 0)
+        cap_g8_clamped_attention(&total, reset) != 0 || cap_g8_clamped_decode_small(&total, reset) != 0)
         return -1;
     return (long long)total;
 }

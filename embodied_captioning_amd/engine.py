@@ -121,6 +121,18 @@ class CaptionerEngine:
     def last_decode_steps(self) -> int:
         return int(self.lib.cap_last_decode_steps(self._h))
 
+    DECODE_PATHS = {"auto": 0, "batch": 1, "small": 2}
+
+    def set_decode_path(self, path: str) -> None:
+        """Kernels of the decode steps (BLIP, "f32s" / "bf16"): "auto" = the fused small-batch kernels for images x beams <= 16
+        rows (6 launches per layer-step instead of 11; same bits), the batch kernels above; "batch" / "small" force one
+        (forcing "small" makes generate fail for calls those kernels do not take)."""
+        N.check(self.lib.cap_set_decode_path(self._h, self.DECODE_PATHS[path]), "cap_set_decode_path")
+
+    @property
+    def last_decode_path(self) -> str:
+        return {0: "none", 1: "batch", 2: "small"}[int(self.lib.cap_last_decode_path(self._h))]
+
     # ------------------------------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> Dict[str, object]:
         """HF BLIP key names or an open_clip CoCa state dict (derived tensors are added here).

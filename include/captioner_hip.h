@@ -115,6 +115,17 @@ int cap_set_early_exit(CapHandle h, int poll_steps);
 /* Decode steps the last cap_generate on this handle ran (max_len - 1 without early exit; diagnostics and tests). */
 int cap_last_decode_steps(CapHandle h);
 
+/* Which kernels the decode steps of cap_generate run on (CAP_ARCH_BLIP, split and bf16 modes).  The reference calls its captioner
+ * with ONE crop per call (captioner/models/coca/coca.py:27-33, blip2/blip2.py:24-29, agents/goal_exploration/goal_exploration.py:
+ * 95-105; BASELINE config 1: 8 crops): for images x beams <= 16 rows a decoder layer-step runs as 6 fused launches
+ * (csrc/decode_small.hip) instead of the batch path's 11.  Both paths form the same sums in the same order: tokens, logits and
+ * scores have the same bits (tests/test_small_decode_gpu.py).
+ *   path 0 (default): by row count;  1: always the batch kernels;  2: always the small-batch kernels - cap_generate then fails for
+ *   calls they do not take (more than 16 rows, more than 32 positions, CAP_F32, other architectures). */
+int cap_set_decode_path(CapHandle h, int path);
+/* 1 = batch kernels, 2 = small-batch kernels: what the last decode step of the last cap_generate ran on (0 before any). */
+int cap_last_decode_path(CapHandle h);
+
 /* Object crops of one frame, resized for the captioner ON THE DEVICE, bit-exact with Pillow's
  * `Image.crop(box).resize((S, S), Image.BICUBIC)` - what the reference does to every detected box on the host before the
  * captioner sees it (detector/pseudolabeler.py:670-675 expand + crop, BGR->RGB at :670; HF BlipImageProcessor.resize).

@@ -1,0 +1,171 @@
+"""GPU: the small-batch decode path (csrc/decode_small.hip; images x beams <= 16 rows - the reference calls its captioner with
+ONE crop per call: captioner/models/coca/coca.py:27-33, blip2/blip2.py:24-29, agents/goal_exploration/goal_exploration.py:95-105;
+BASELINE config 1 is 8 crops) against the batch path, the HF goldens and itself.
+
+The bar: the fused kernels form the same sums in the same order as the batch kernels, so tokens AND per-step logits have the
+same bits on either path (`torch.equal`, no tolerance), a frame decodes to the same bits alone and in a batch of 8, and config
+1's batch (tests/golden/blip_base.npz IS that batch) is token-identical to HF through this path."""
+import numpy as np
+import pytest
+import torch
+
+from _util import golden_inputs, pad_to
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(arch, dtype, batch, beams, max_len, path="auto"):
+    from embodied_captioning_amd.engine import CaptionerEngine
+    eng = CaptionerEngine(arch, dtype=dtype, max_batch=batch, max_beams=beams, max_len=max_len)
+    eng.set_decode_path(path)
+    return eng
+
+
+def _live_mask(seq, arch, steps):
+    """[steps, B] True where row b's logits of step t are still looked at (the row had not ended before step t)."""
+    B, L = seq.shape
+    live = np.ones((steps, B), dtype=bool)
+    for b in range(B):
+        row = list(seq[b, 1:])
+        if arch.eos in row:
+            live[row.index(arch.eos) + 1:, b] = False
+    return live
+
+
+@pytest.mark.parametrize("dtype", ["f32s", "bf16"])
+@pytest.mark.parametrize("name", ["blip_tiny", "blip_tiny_eos", "blip_base"])
+def test_small_path_has_the_bits_of_the_batch_path(name, dtype):
+    g, meta, arch, sd, px = golden_inputs(name)
+    B, L = meta["batch"], meta["max_length"]
+    assert B <= 16
+    outs = {}
+    for path in ("small", "batch"):
+        eng = _engine(arch, dtype, B, 1, L, path)
+        eng.load_state_dict(sd)
+        outs[path] = eng.generate(px.cuda(), num_beams=1, max_length=L, output_logits=True)
+        assert eng.last_decode_path == path
+        if dtype == "f32s":
+            assert eng.saturations() == 0
+        eng.close()
+    a, b = outs["small"], outs["batch"]
+    assert torch.equal(a["sequences"], b["sequences"])
+    assert torch.equal(a["lengths"], b["lengths"])
+    live = torch.from_numpy(_live_mask(a["sequences"].cpu().numpy(), arch, L - 1))
+    la, lb = a["logits"].cpu(), b["logits"].cpu()
+    assert torch.equal(la[live], lb[live]), float((la[live] - lb[live]).abs().max())
+
+
+@pytest.mark.parametrize("dtype", ["f32s", "bf16"])
+@pytest.mark.parametrize("name", ["blip_tiny", "blip_base"])
+def test_small_path_beams_have_the_bits_of_the_batch_path(name, dtype):
+    g, meta, arch, sd, px = golden_inputs(name)
+    L, K = meta["max_length"], meta["beams"]
+    B = min(meta["batch"], 16 // K)
+    outs = {}
+    for path in ("small", "batch"):
+        eng = _engine(arch, dtype, B, K, L, path)
+        eng.load_state_dict(sd)
+        outs[path] = eng.generate(px[:B].cuda(), num_beams=K, max_length=L)
+        assert eng.last_decode_path == path
+        eng.close()
+    a, b = outs["small"], outs["batch"]
+    assert torch.equal(a["sequences"], b["sequences"])
+    assert torch.equal(a["sequences_scores"], b["sequences_scores"])
+
+
+@pytest.mark.parametrize("dtype", ["f32s", "f32"])
+def test_config1_batch_of_8_is_token_identical_to_hf(dtype):
+    """BASELINE config 1: 8 frames, greedy, max_length 20 - tests/golden/blip_base.npz is that batch through the real HF loop.
+    "f32s" takes the small-batch path by row count; the exact-product "f32" mode has no fused kernels and stays on the batch
+    path (same tokens)."""
+    g, meta, arch, sd, px = golden_inputs("blip_base")
+    B, L = meta["batch"], meta["max_length"]
+    assert B == 8
+    eng = _engine(arch, dtype, B, 1, L)
+    eng.load_state_dict(sd)
+    out = eng.generate(px.cuda(), num_beams=1, max_length=L, output_logits=True)
+    assert eng.last_decode_path == ("small" if dtype == "f32s" else "batch")
+    seq = out["sequences"].cpu().numpy()
+    ref = pad_to(g["greedy_sequences"], L, arch.pad)
+    assert np.array_equal(seq, ref), (seq, ref)
+    T = g["greedy_top8_ids"].shape[0]
+    top = torch.topk(out["logits"].cpu()[:T], 8, dim=-1)
+    live = _live_mask(ref, arch, T)
+    assert np.array_equal(top.indices.numpy()[live], g["greedy_top8_ids"][live])
+    np.testing.assert_allclose(top.values.numpy()[live], g["greedy_top8_vals"][live], rtol=0, atol=1e-3)
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32s", "bf16"])
+def test_one_frame_alone_equals_its_row_in_a_batch_of_8_and_of_64(dtype):
+    """Batch invariance across the path switch: frame 0 alone (small path), inside config 1's 8 (small path) and inside 64 frames
+    (batch path) - same tokens, same logits bits while the row is open."""
+    g, meta, arch, sd, px = golden_inputs("blip_base64")
+    L = meta["max_length"]
+    res = {}
+    for B in (1, 8, 16, 64):
+        eng = _engine(arch, dtype, B, 1, L)
+        eng.load_state_dict(sd)
+        out = eng.generate(px[:B].cuda(), num_beams=1, max_length=L, output_logits=True)
+        assert eng.last_decode_path == ("small" if B <= 16 else "batch")
+        res[B] = (out["sequences"][0].cpu(), out["logits"][:, 0].cpu())
+        eng.close()
+    n = _live_mask(res[1][0][None].numpy(), arch, L - 1)[:, 0]
+    for B in (8, 16, 64):
+        assert torch.equal(res[B][0], res[1][0]), B
+        assert torch.equal(res[B][1][n], res[1][1][n]), B
+
+
+@pytest.mark.parametrize("rows", [1, 2, 3, 5, 13, 16])
+def test_ragged_row_counts(rows):
+    """Row counts that do not fill the 16-row MFMA block or the waves of the LayerNorm prologue: row r of a batch of `rows` equals
+    row r of the 16-row batch (tokens and live logits)."""
+    g, meta, arch, sd, px = golden_inputs("blip_tiny")
+    from embodied_captioning_amd.weights import synthetic_pixels
+    px = synthetic_pixels(16, arch.image_size, seed=meta["seed"])
+    L = meta["max_length"]
+    ref = None
+    for B in (16, rows):
+        eng = _engine(arch, "f32s", 16, 1, L, "small")
+        eng.load_state_dict(sd)
+        out = eng.generate(px[:B].cuda(), num_beams=1, max_length=L, output_logits=True)
+        cur = (out["sequences"].cpu(), out["logits"].cpu())
+        eng.close()
+        if ref is None:
+            ref = cur
+    live = torch.from_numpy(_live_mask(cur[0].numpy(), arch, L - 1))
+    assert torch.equal(cur[0], ref[0][:rows])
+    assert torch.equal(cur[1][live], ref[1][:, :rows][live])
+
+
+def test_six_launches_per_layer_step_and_early_exit():
+    g, meta, arch, sd, px = golden_inputs("blip_base")
+    B, L = meta["batch"], meta["max_length"]
+    eng = _engine(arch, "f32s", B, 1, L)
+    eng.load_state_dict(sd)
+    eng.profile(True)
+    full = eng.generate(px.cuda(), num_beams=1, max_length=L)
+    rep = eng.profile_report()
+    eng.profile(False)
+    per = sum(r["launches"] for t, r in rep.items() if t.startswith("dec_small_") and t not in ("dec_small_tr", "dec_small_vocab"))
+    assert per == 6 * arch.t_layers * (L - 1), rep
+    assert not any(t.startswith("dec_gemm_") or t in ("dec_reduce_ln", "dec_self_attn", "dec_cross_attn") for t in rep), rep
+    eng.set_early_exit(2)
+    early = eng.generate(px.cuda(), num_beams=1, max_length=L)
+    assert torch.equal(early["sequences"], full["sequences"])
+    eng.close()
+
+
+def test_forcing_the_small_path_beyond_its_row_limit_fails_by_name():
+    from embodied_captioning_amd._native import CaptionerHipError
+    g, meta, arch, sd, px = golden_inputs("blip_tiny")
+    from embodied_captioning_amd.weights import synthetic_pixels
+    px = synthetic_pixels(17, arch.image_size, seed=1)
+    eng = _engine(arch, "f32s", 17, 1, meta["max_length"], "small")
+    eng.load_state_dict(sd)
+    with pytest.raises(CaptionerHipError, match="small-batch decode path was forced"):
+        eng.generate(px.cuda(), num_beams=1, max_length=meta["max_length"])
+    eng.set_decode_path("auto")
+    eng.generate(px.cuda(), num_beams=1, max_length=meta["max_length"])
+    assert eng.last_decode_path == "batch"
+    eng.close()
