@@ -997,6 +997,7 @@ __global__ __launch_bounds__(256, 2) void decode_attention_shared_kernel(const T
                                                                       const T* __restrict__ vbase, int kv_ld, int n_keys,
                                                                       TO* __restrict__ out, int n_img, int H, QSource qs,
                                                                       const int* __restrict__ skip, size_t ri0 = 0) {
+#pragma clang fp contract(off)      // the online unit's arithmetic exactly as written there (decode_attn.h): same bits per row
     constexpr int CH = 8 * G;
     const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (unit >= n_img * H) return;
@@ -1046,11 +1047,7 @@ __global__ __launch_bounds__(256, 2) void decode_attention_shared_kernel(const T
             float sc[G], cm = -INFINITY;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                float sv = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sv = fmaf(qv[b][e], kr[g].get(e), sv);
-                if constexpr (Raw8<TKV>::scaled) sv *= kr[g].scale();
-                sv += __shfl_xor(sv, 1, 64); sv += __shfl_xor(sv, 2, 64); sv += __shfl_xor(sv, 4, 64);
+                const float sv = decode_key_score<TKV>(qv[b], kr[g]);
                 sc[g] = (k0 + g * 8 + ksub < n_keys) ? sv : -INFINITY;
                 cm = fmaxf(cm, sc[g]);
             }

@@ -29,8 +29,8 @@ struct QSource {
 };
 
 // Split-K partials of 8 consecutive columns: issue() puts every slice's loads (and the bias) in flight without a
-// dependent add between them; finish() sums them in slice order.  Slices beyond S re-read slice 0 with weight 0, so
-// there is no branch between the loads (up to 4 slices unrolled, which is what the decode GEMMs produce).
+// dependent add between them; finish() sums them in slice order.  Up to 4 slices are unrolled (what the decode GEMMs produce);
+// a slice beyond S enters as slice 0 with weight 0 (S is uniform: one scalar branch per slice, no load).
 struct Part8 {
     f32x4 a[4], b[4], ba, bb;
     const float* p;
@@ -40,13 +40,18 @@ struct Part8 {
         zs = (size_t)R * qs.part_ld;
 #pragma unroll
         for (int z = 0; z < 4; ++z) {
-            const float* pz = p + (z < qs.S ? (size_t)z * zs : 0);
-            a[z] = *(const f32x4*)pz; b[z] = *(const f32x4*)(pz + 4);
+            if (z < qs.S) {
+                const float* pz = p + (size_t)z * zs;
+                a[z] = *(const f32x4*)pz; b[z] = *(const f32x4*)(pz + 4);
+            } else {
+                a[z] = a[0]; b[z] = b[0];
+            }
         }
         ba = *(const f32x4*)(qs.bias + col); bb = *(const f32x4*)(qs.bias + col + 4);
     }
     template <typename T>
     __device__ __forceinline__ void finish(const QSource& qs, float (&v)[8]) {
+#pragma clang fp contract(off)
         f32x4 sa = a[0], sb = b[0];
 #pragma unroll
         for (int z = 1; z < 4; ++z) {
@@ -119,6 +124,7 @@ __device__ __forceinline__ void decode_attention_wave_unit(const T* __restrict__
                                                            const int* __restrict__ anc, int anc_ld, int rows_per_kv, int kv_ld,
                                                            int n_keys, TO* out_row, int R, int H, const QSource& qs, int row, int h,
                                                            int lane, bool write_kv, const float* q_ready = nullptr) {
+#pragma clang fp contract(off)      // as written, wherever it is inlined (batch kernel / small-batch prologue): same bits
     const int Dh = H * 64;
     const int ksub = lane >> 3, dch = lane & 7;
     const bool fused_kv = qs.part != nullptr && qs.append_kv;
@@ -209,18 +215,65 @@ __device__ __forceinline__ void decode_attention_wave_unit(const T* __restrict__
     }
 }
 
+// score of one key for the 8 lanes that hold its row: q . k over the lane's 8 dimensions (q already scaled), the cache's row scale,
+// then the sum over the 8 lanes - every lane of the key ends with the same value.  The one place this arithmetic is written.
+template <typename TKV>
+__device__ __forceinline__ float decode_key_score(const float (&qv)[8], const Raw8<TKV>& kr) {
+#pragma clang fp contract(off)      // as written, wherever it is inlined: callers on different paths must agree bit for bit
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf(qv[e], kr.get(e), s);
+    if constexpr (Raw8<TKV>::scaled) s *= kr.scale();
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    return s;
+}
+
+// Scores of the key groups g_first, g_first + g_stride, ... (8 keys each) of one (row, head) into sc_out[key]: the part of the
+// online unit below that does not depend on the running softmax state, so several waves can share it (small-batch path: one
+// (row, head) per workgroup, the chain of shuffles per key group is what the single wave would otherwise walk alone).
+template <typename TKV>
+__device__ __forceinline__ void decode_attention_scores(const void* kbase, size_t ri_base, int n_keys, const float* q_ready,
+                                                        float* sc_out, int lane, int g_first, int g_stride) {
+#pragma clang fp contract(off)
+    const int ksub = lane >> 3, dch = lane & 7;
+    float qv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = q_ready[dch * 8 + e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] *= 0.125f;
+    const int ng = (n_keys + 7) / 8;
+    for (int g0 = g_first; g0 < ng; g0 += 4 * g_stride) {
+        Raw8<TKV> kr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = (g0 + i * g_stride) * 8 + ksub;
+            if (key < n_keys) kr[i].load_row(kbase, ri_base + key, dch); else kr[i].zero();
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = (g0 + i * g_stride) * 8 + ksub;
+            const float s = decode_key_score<TKV>(qv, kr[i]);
+            if (dch == 0 && key < n_keys) sc_out[key] = s;
+        }
+    }
+}
+
 // ---- long history (cross-attention over the image tokens): the history walked in chunks of 8 G keys.  A chunk's K loads and
 // V loads (16 B per lane, one 128-byte key row per 8 lanes) are all issued into raw registers before any arithmetic.  Online
 // softmax across chunks (fp32).  DB: two register buffers, the next chunk's loads are in flight while the current one is consumed.
 // ri_base: K/V row index of key 0 of this (row, head) when there is no ancestry (kbase / vbase + row index -> Raw8::load_row);
 // with ancestry the rows are ri0 + (anc[row][key] * H + h) * kv_ld + key.
 // q_ready: when non-null the 8 query values of this lane (already summed over the split-K partials, bias added, NOT yet scaled)
-// are read from q_ready[dch * 8 ..] instead of qs / q.
-template <typename T, int G, bool DB, bool NT, typename TO, typename TKV>
+// are read from q_ready[dch * 8 ..] instead of qs / q.  sc_ready: when non-null the scores come from sc_ready[key]
+// (decode_attention_scores) and K is not read here.
+template <typename T, int G, bool DB, bool NT, typename TO, typename TKV, bool SCR = false>
 __device__ __forceinline__ void decode_attention_online_unit(const T* __restrict__ q, const void* kbase, const void* vbase,
                                                              const int* __restrict__ anc, int anc_ld, int kv_ld, int n_keys,
                                                              TO* out_row, int R, int H, const QSource& qs, int row, int h, int lane,
-                                                             size_t ri0, size_t ri_base, const float* q_ready) {
+                                                             size_t ri0, size_t ri_base, const float* q_ready,
+                                                             const float* sc_ready = nullptr) {
+#pragma clang fp contract(off)      // as written, wherever it is inlined: same bits on every path
+    // SCR (compile time): the scores come from sc_ready
     constexpr int CH = 8 * G;
     const int Dh = H * 64;
     const int ksub = lane >> 3, dch = lane & 7;
@@ -235,7 +288,7 @@ __device__ __forceinline__ void decode_attention_online_unit(const T* __restrict
             if (key < n_keys) {
                 const size_t ri = anc ? ri0 + ((size_t)anc[(size_t)row * anc_ld + key] * H + h) * kv_ld + key : ri_base + key;
                 if constexpr (NT) { kr[g].load_row_nt(kbase, ri, dch); vr[g].load_row_nt(vbase, ri, dch); }
-                else { kr[g].load_row(kbase, ri, dch); vr[g].load_row(vbase, ri, dch); }
+                else { if constexpr (!SCR) kr[g].load_row(kbase, ri, dch); else kr[g].zero(); vr[g].load_row(vbase, ri, dch); }
             } else {
                 kr[g].zero(); vr[g].zero();
             }
@@ -245,12 +298,11 @@ __device__ __forceinline__ void decode_attention_online_unit(const T* __restrict
         float sc[G], cm = -INFINITY;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s = fmaf(qv[e], kr[g].get(e), s);
-            if constexpr (Raw8<TKV>::scaled) s *= kr[g].scale();
-            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-            sc[g] = (k0 + g * 8 + ksub < n_keys) ? s : -INFINITY;
+            const int key = k0 + g * 8 + ksub;
+            float s;
+            if constexpr (SCR) s = sc_ready[min(key, n_keys - 1)];
+            else s = decode_key_score<TKV>(qv, kr[g]);
+            sc[g] = (key < n_keys) ? s : -INFINITY;
             cm = fmaxf(cm, sc[g]);
         }
         cm = fmaxf(cm, __shfl_xor(cm, 8, 64)); cm = fmaxf(cm, __shfl_xor(cm, 16, 64)); cm = fmaxf(cm, __shfl_xor(cm, 32, 64));

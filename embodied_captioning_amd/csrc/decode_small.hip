@@ -29,10 +29,36 @@
 #include "ops.h"
 #include "decode_small.h"
 
+#ifdef CAP_EXPERIMENTS
+// cycle stamps of workgroup 0 of the LAST launch (tools/bench_small_decode.py --stamps): [kernel][2 i] = s_memtime (shader clock),
+// [kernel][2 i + 1] = the 100 MHz wall clock; kernel 0 = cross, 1 = GEMM
+__device__ unsigned long long g_small_stamps[2][32];
+#define SMALL_STAMP(k, i, cond)                                                                          \
+    do {                                                                                                 \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (cond)) {                                      \
+            g_small_stamps[k][2 * (i)] = __builtin_readcyclecounter();                                   \
+            g_small_stamps[k][2 * (i) + 1] = wall_clock64();                                             \
+        }                                                                                                \
+    } while (0)
+#else
+#define SMALL_STAMP(k, i, cond) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int PRO_GLOBAL = SMALL_PRO_GLOBAL, PRO_LN = SMALL_PRO_LN, PRO_SELFATTN = SMALL_PRO_SELFATTN;
 constexpr int SEPI_PARTIAL = SMALL_EPI_PARTIAL, SEPI_ACT_T = SMALL_EPI_ACT_T, SEPI_ACT_F32 = SMALL_EPI_ACT_F32;
+
+// Pointers that arrive inside a by-value struct are generic to the compiler (flat_load: both counters, no global addressing
+// modes); every one of them points to global memory, and a round trip through address space 1 tells it so.
+template <typename P> __device__ __forceinline__ P* glob(P* p) {
+    return (P*)(__attribute__((address_space(1))) P*)p;
+}
+__device__ __forceinline__ SmallLN glob_ln(SmallLN ln) {
+    ln.part = glob(ln.part); ln.bias = glob(ln.bias); ln.resid = glob(ln.resid); ln.gamma = glob(ln.gamma); ln.beta = glob(ln.beta);
+    ln.x_out = glob(ln.x_out);
+    return ln;
+}
 
 template <typename T> struct AttT { using type = T; };
 template <> struct AttT<g8_t> { using type = float; };        // split mode: q|k|v, the K/V caches are fp32
@@ -67,43 +93,83 @@ template <typename T> __device__ __forceinline__ void mma_slab(f32x4& acc, const
 
 // ---- split-K consumer + LayerNorm of up to RPW rows per wave (rows wave, wave + NWV, ...): y = sum_z part[z] + bias + resid in
 // the order of reduce_layernorm_row_kernel, LayerNorm in ln_row's order; the operand-type row goes to the LDS image `img`
-// (row pitch `pitch` bytes), the fp32 row to x_out when this workgroup is the designated writer.
-template <typename T, int RPW>
+// (row pitch `pitch` bytes), the fp32 row to x_out when this workgroup is the designated writer.  EVERY load - the slabs and
+// residual rows of all the wave's rows, bias, gamma, beta - is issued before the first add: the slabs were written by the
+// previous kernel on other XCDs, a dependent round trip to them costs 2-3 us, and this way there is one.
+// NV: float4 per lane and row (3 for rows up to 768 wide, 4 up to 1024).
+// (Loads are unconditional 16-byte vector loads from clamped addresses under wave-uniform branches only: a per-lane
+// `cond ? *p : 0` becomes a select between a global and a private address, i.e. flat loads in dword pieces.)
+struct LnCols { f32x4 g, be, bb; };
+template <int NV>
+__device__ __forceinline__ void ln_load_cols(const SmallLN& ln, int D, int lane, LnCols (&k)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int cc = min(lane * 4 + i * 256, D - 4);
+        k[i].g = *(const f32x4*)(ln.gamma + cc);
+        k[i].be = *(const f32x4*)(ln.beta + cc);
+        k[i].bb = 0.f;
+        if (ln.bias) k[i].bb = *(const f32x4*)(ln.bias + cc);
+    }
+}
+struct LnRow { f32x4 pz[4], rs; };
+template <int NV>
+__device__ __forceinline__ void ln_load_row(const SmallLN& ln, int R, int D, int row, int lane, LnRow (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int cc = min(lane * 4 + i * 256, D - 4);
+#pragma unroll
+        for (int z = 0; z < 4; ++z) {
+            v[i].pz[z] = 0.f;
+            if (z < ln.S) v[i].pz[z] = *(const f32x4*)(ln.part + ((size_t)z * R + row) * D + cc);
+        }
+        v[i].rs = 0.f;
+        if (ln.resid) v[i].rs = *(const f32x4*)(ln.resid + (size_t)row * D + cc);
+    }
+}
+// y = slabs in order, + bias, + residual (reduce_layernorm_row_kernel's order), then the LayerNorm
+template <typename T, int NV>
+__device__ __forceinline__ void ln_finish_row(const SmallLN& ln, int R, int D, int row, int lane, const LnRow (&v)[NV],
+                                              const LnCols (&k)[NV], T* out_t, float* out_f) {
+    float4 a[NV], g[NV], be[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int cc = min(lane * 4 + i * 256, D - 4);
+        f32x4 s = v[i].pz[0];
+#pragma unroll
+        for (int z = 1; z < 4; ++z)
+            if (z < ln.S) s += v[i].pz[z];
+        for (int z = 4; z < ln.S; ++z) s += *(const f32x4*)(ln.part + ((size_t)z * R + row) * D + cc);
+        if (ln.bias) s += k[i].bb;
+        if (ln.resid) s += v[i].rs;
+        a[i] = make_float4(s[0], s[1], s[2], s[3]);
+        g[i] = make_float4(k[i].g[0], k[i].g[1], k[i].g[2], k[i].g[3]);
+        be[i] = make_float4(k[i].be[0], k[i].be[1], k[i].be[2], k[i].be[3]);
+    }
+    ln_row_regs<T, NV>(a, NV, lane, D, g, be, ln.eps, out_t, out_f);
+}
+
+template <typename T, int RPW, int NV>
 __device__ __forceinline__ void ln_rows_prologue(const SmallLN& ln, int R, int D, char* img, int pitch, int wave, int nwv, int lane,
                                                  bool write_x) {
-    const int nv = (D + 255) / 256;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int RB = RPW < 2 ? RPW : 2;                   // rows of a wave in flight at once (registers: 20 NV per row)
+    LnCols k[NV];
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-        const int row = wave + rr * nwv;
-        if (row >= R) break;
-        float4 a[4];
+    for (int r0 = 0; r0 < RPW; r0 += RB) {
+        if (wave + r0 * nwv >= R) break;
+        LnRow v[RB][NV];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = lane * 4 + i * 256;
-            a[i] = z4;
-            if (i < nv && c < D) {
-                float4 pz[4];
-#pragma unroll
-                for (int z = 0; z < 4; ++z) pz[z] = z < ln.S ? *(const float4*)(ln.part + ((size_t)z * R + row) * D + c) : z4;
-                float4 bb = z4, rs = z4;
-                if (ln.bias) bb = *(const float4*)(ln.bias + c);
-                if (ln.resid) rs = *(const float4*)(ln.resid + (size_t)row * D + c);
-                float4 s = pz[0];
-#pragma unroll
-                for (int z = 1; z < 4; ++z)
-                    if (z < ln.S) { s.x += pz[z].x; s.y += pz[z].y; s.z += pz[z].z; s.w += pz[z].w; }
-                for (int z = 4; z < ln.S; ++z) {
-                    const float4 b = *(const float4*)(ln.part + ((size_t)z * R + row) * D + c);
-                    s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
-                }
-                if (ln.bias) { s.x += bb.x; s.y += bb.y; s.z += bb.z; s.w += bb.w; }
-                if (ln.resid) { s.x += rs.x; s.y += rs.y; s.z += rs.z; s.w += rs.w; }
-                a[i] = s;
-            }
+        for (int rr = 0; rr < RB; ++rr) {
+            const int row = wave + (r0 + rr) * nwv;
+            ln_load_row<NV>(ln, R, D, min(row, R - 1), lane, v[rr]);
         }
-        ln_row<T, 4>(a, nv, lane, D, ln.gamma, ln.beta, ln.eps, (T*)(img + (size_t)row * pitch),
-                     write_x && ln.x_out ? ln.x_out + (size_t)row * D : nullptr);
+        if (r0 == 0) ln_load_cols<NV>(ln, D, lane, k);
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const int row = wave + (r0 + rr) * nwv;
+            if (row >= R) break;
+            ln_finish_row<T, NV>(ln, R, D, row, lane, v[rr], k, (T*)(img + (size_t)row * pitch),
+                                 write_x && ln.x_out ? ln.x_out + (size_t)row * D : nullptr);
+        }
     }
 }
 
@@ -117,12 +183,16 @@ __device__ __forceinline__ void ln_rows_prologue(const SmallLN& ln, int R, int D
 // NW: waves per workgroup (the self-attention prologue uses 8: its units are spread over all of them).
 template <typename T, int PRO, int EPI, int NCHAIN, int NW, int RPW>
 __global__ __launch_bounds__(NW * 64, 1) void dec_small_gemm_kernel(SmallGemm p) {
+    p.W = glob(p.W); p.A = glob(p.A); p.out_part = glob(p.out_part); p.bias = glob(p.bias); p.out = glob(p.out);
+    p.ln = glob_ln(p.ln);
+    p.sa.qkv_part = glob(p.sa.qkv_part); p.sa.qkv_bias = glob(p.sa.qkv_bias); p.sa.kc = glob(p.sa.kc); p.sa.vc = glob(p.sa.vc);
+    p.sa.anc = glob(p.sa.anc); p.sa.skip = glob(p.sa.skip);
     constexpr int SLAB = is_g8<T> ? 32 : 64;
     constexpr int ESZ = is_g8<T> ? 4 : 2;
     constexpr int CT = NCHAIN == 4 ? 16 : 64;
     // slabs per register batch; two batches in flight.  (The self-attention prologue's 8-wave workgroup has 256 registers per
     // lane and its units need ~190: a K slice of a few heads is 1-2 slabs per chain anyway.)
-    constexpr int NF = PRO == PRO_SELFATTN ? 2 : 6;
+    constexpr int NF = PRO == PRO_SELFATTN ? 2 : (NCHAIN == 1 && RPW < 4 ? 12 : 6);
     using TA = typename AttT<T>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -160,29 +230,29 @@ __global__ __launch_bounds__(NW * 64, 1) void dec_small_gemm_kernel(SmallGemm p)
             }
         }
     };
+    SMALL_STAMP(1, 0, wave == 0);
     if (live) {
         load_batch(0, wq[0], aq[0]);
         if (n > NF) load_batch(1, wq[1], aq[1]);
     }
+    SMALL_STAMP(1, 1, wave == 0);
 
     // ---- prologue: the A rows of this slice as an LDS image
     if constexpr (PRO == PRO_LN) {
-        ln_rows_prologue<T, RPW>(p.ln, p.R, p.K, img, pitch, wave, NW, lane, blockIdx.x == 0);
+        if (p.K <= 768) ln_rows_prologue<T, RPW, 3>(p.ln, p.R, p.K, img, pitch, wave, NW, lane, blockIdx.x == 0);
+        else ln_rows_prologue<T, RPW, 4>(p.ln, p.R, p.K, img, pitch, wave, NW, lane, blockIdx.x == 0);
         __syncthreads();
     } else if constexpr (PRO == PRO_SELFATTN) {
         const int hps = Ks / 64, h0 = kz * hps, units = hps * p.R;
         QSource qs;
         qs.part = p.sa.qkv_part; qs.bias = p.sa.qkv_bias; qs.S = p.sa.qkv_S; qs.part_ld = 3 * p.sa.H * 64; qs.col0 = 0; qs.append_kv = 1;
         const int ng8 = (p.sa.n_keys + 7) / 8;
+        // (rows of ended captions are computed like the others: 16 rows at most, and no branch between the units of a wave)
+        TA* kc = (TA*)p.sa.kc; TA* vc = (TA*)p.sa.vc;
+        const bool wr = tn == 0;
         for (int u = wave; u < units; u += NW) {
             const int row = u / hps, h = h0 + u % hps;
             T* out_row = (T*)(img + (size_t)row * pitch) - h0 * 64;
-            if (p.sa.skip && p.sa.skip[row]) {                // ended caption: a defined (zero) context, nothing appended
-                if (lane < 16) store4(out_row, h * 64 + lane * 4, make_float4(0.f, 0.f, 0.f, 0.f));
-                continue;
-            }
-            TA* kc = (TA*)p.sa.kc; TA* vc = (TA*)p.sa.vc;
-            const bool wr = tn == 0;
             if (ng8 <= 1)
                 decode_attention_wave_unit<TA, 1, T>(nullptr, kc, vc, p.sa.anc, p.sa.anc_ld, 1, p.sa.kv_ld, p.sa.n_keys, out_row, p.R, p.sa.H, qs, row, h, lane, wr);
             else if (ng8 <= 2)
@@ -193,6 +263,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dec_small_gemm_kernel(SmallGemm p)
         __syncthreads();
     }
 
+    SMALL_STAMP(1, 2, wave == 0);
     // ---- the chains
     f32x4 acc = 0.f;
     if (live) {
@@ -218,6 +289,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dec_small_gemm_kernel(SmallGemm p)
         }
     }
 
+    SMALL_STAMP(1, 3, wave == 0 && acc[0] == acc[0]);
     // ---- epilogue.  acc[e] = C[row r16][n0 + 4 kg + e]
     f32x4 v = acc;
     int row = r16, col = n0 + 4 * kg;
@@ -237,6 +309,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dec_small_gemm_kernel(SmallGemm p)
             v += *(const f32x4*)(src + 768);
         }
     }
+    SMALL_STAMP(1, 4, wave == 0);
     if (!store || row >= p.R || col >= p.N) return;
     if constexpr (is_g8<T>) v *= (1.0f / G8_WSCALE);
     if constexpr (EPI == SEPI_PARTIAL) {
@@ -258,12 +331,17 @@ __global__ __launch_bounds__(NW * 64, 1) void dec_small_gemm_kernel(SmallGemm p)
 // ------------------------------------------------------------------------------------------------------------------
 // Cross-attention block of one (row, head): LayerNorm of the row (split-K consumer of the self-attention output projection),
 // the head's 64 query columns (the sums of the batch path's cq GEMM: S slices x 4 chains), attention over the image's K/V.
-// The (row, head) K/V block - 197 rows: 50 KB of KV16 groups, K and V - is copied into LDS by LDS-DMA while the LayerNorm and
-// the query projection run, then one wave walks it with decode_attn.h's online unit (the arithmetic of
-// decode_attention_online_kernel with the same chunking: same bits), reading LDS instead of waiting for HBM chunk by chunk.
-// KV_LDS false: blocks that do not fit (577-token checkpoints): the unit reads global memory as in the batch path.
-template <typename T, typename TKV, int G, bool KV_LDS>
-__global__ __launch_bounds__(256, 1) void dec_small_cross_kernel(SmallCross p) {
+// Eight waves.  What the kernel waits for is memory round trips (2-3 us each for data the previous kernel wrote), so everything
+// is requested at once: wave 7 puts the row's slabs / residual / gamma / beta in flight first, every wave its share of the
+// head's query weights (wave = K slice x half of the 64 columns), waves 0-6 the LDS-DMA copy of the (row, head) K/V block -
+// 197 rows: 50 KB of KV16 groups, K and V.  Then LayerNorm (wave 7) -> query chains (all waves) -> scores of the 25 key groups
+// (all waves, decode_attn.h) -> one wave walks the softmax / P.V with the arithmetic and chunking of
+// decode_attention_online_kernel, reading V from LDS: same bits as the batch path.
+// KV_LDS false: blocks that do not fit (577-token checkpoints) or short histories: global memory as in the batch path.
+template <typename T, typename TKV, int G, bool KV_LDS, int NV>
+__global__ __launch_bounds__(512, 1) void dec_small_cross_kernel(SmallCross p) {
+    p.W = glob(p.W); p.bias = glob(p.bias); p.kbase = glob(p.kbase); p.vbase = glob(p.vbase); p.skip = glob(p.skip); p.out = glob(p.out);
+    p.ln = glob_ln(p.ln);
     constexpr int SLAB = is_g8<T> ? 32 : 64;
     constexpr int ESZ = is_g8<T> ? 4 : 2;
     constexpr int NF = 6;
@@ -275,11 +353,13 @@ __global__ __launch_bounds__(256, 1) void dec_small_cross_kernel(SmallCross p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kg = lane >> 4;
+    SMALL_STAMP(0, 0, wave == 0);
 
     char* xrow = smem;                                       // the LayerNorm row as a GEMM operand: D * ESZ bytes
     float* qpart = (float*)(smem + ((D * ESZ + 255) & ~255));   // [4][64] slice sums
     float* qfin = qpart + 256;                               // [64]
-    char* kimg = (char*)(qfin + 64);
+    float* scl = qfin + 64;                                  // [n_keys rounded up to 64] scores
+    char* kimg = (char*)(scl + ((p.n_keys + 63) & ~63));
     // ---- K/V block of (image of this row, head): row indices [rb, rb + n_keys) of the layer's k / v block
     const size_t rb = p.kv_row0 + ((size_t)(row / p.rows_per_kv) * H + h) * p.kv_ld;
     size_t src_off, n16, ri_lds;
@@ -290,99 +370,88 @@ __global__ __launch_bounds__(256, 1) void dec_small_cross_kernel(SmallCross p) {
         src_off = rb * 64 * sizeof(TKV); n16 = (size_t)p.n_keys * 64 * sizeof(TKV) / 16; ri_lds = 0;
     }
     char* vimg = kimg + n16 * 16;
-    if constexpr (KV_LDS) {
-        const char* ks = (const char*)p.kbase + src_off;
-        const char* vs = (const char*)p.vbase + src_off;
-        for (size_t i = (size_t)wave * 64; i < n16; i += 256) {          // 1 KiB per wave-instruction, lane-linear in LDS
-            if (i + lane < n16) {
-                __builtin_amdgcn_global_load_lds(CAP_GPTR(ks + (i + lane) * 16), CAP_LPTR(kimg + i * 16), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(CAP_GPTR(vs + (i + lane) * 16), CAP_LPTR(vimg + i * 16), 16, 0, 0);
-            }
-        }
+
+    // ---- wave 7: the LayerNorm row's loads go first
+    const SmallLN& ln = p.ln;
+    LnRow lv[NV];
+    LnCols lk[NV];
+    if (wave == 7) {
+        ln_load_row<NV>(ln, p.R, D, row, lane, lv);
+        ln_load_cols<NV>(ln, D, lane, lk);
     }
-    // ---- W of this head's query columns: wave = K slice, its slabs x 4 column blocks
+    // ---- W of this head's query columns: wave = (K slice sl, column half ch): the slice's slabs x 2 column blocks
     const int S = p.S, Ks = D / S, nkb = Ks / SLAB;
-    const bool gw = wave < S;
-    const char* wbase = (const char*)p.W + ((size_t)(h * 64 + r16) * D + (size_t)wave * Ks) * ESZ;
-    Frag wq[NF][4];
+    const int sl = wave & 3, ch = wave >> 2;
+    const bool gw = sl < S;
+    const char* wbase = (const char*)p.W + ((size_t)(h * 64 + ch * 32 + r16) * D + (size_t)sl * Ks) * ESZ;
+    Frag wq[NF][2];
     if (gw) {
 #pragma unroll
         for (int j = 0; j < NF; ++j)
             if (j < nkb) {
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) wq[j][cb] = load_frag<T>(wbase + (size_t)cb * 16 * D * ESZ + (size_t)j * 128, kg);
+                for (int cb = 0; cb < 2; ++cb) wq[j][cb] = load_frag<T>(wbase + (size_t)cb * 16 * D * ESZ + (size_t)j * 128, kg);
             }
     }
-    // ---- LayerNorm of the row (one wave), operand row to LDS; the head-0 workgroup writes the fp32 row
-    if (wave == 3) {
-        // (the last wave: with S < 4 it has no query slice)
-        const SmallLN& ln = p.ln;
-        const int nv = (D + 255) / 256;
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 a[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = lane * 4 + i * 256;
-            a[i] = z4;
-            if (i < nv && c < D) {
-                float4 pz[4];
-#pragma unroll
-                for (int z = 0; z < 4; ++z) pz[z] = z < ln.S ? *(const float4*)(ln.part + ((size_t)z * p.R + row) * D + c) : z4;
-                float4 bb = z4, rs = z4;
-                if (ln.bias) bb = *(const float4*)(ln.bias + c);
-                if (ln.resid) rs = *(const float4*)(ln.resid + (size_t)row * D + c);
-                float4 s = pz[0];
-#pragma unroll
-                for (int z = 1; z < 4; ++z)
-                    if (z < ln.S) { s.x += pz[z].x; s.y += pz[z].y; s.z += pz[z].z; s.w += pz[z].w; }
-                for (int z = 4; z < ln.S; ++z) {
-                    const float4 b = *(const float4*)(ln.part + ((size_t)z * p.R + row) * D + c);
-                    s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    if constexpr (KV_LDS) {
+        if (wave < 7) {
+            const char* ks = (const char*)p.kbase + src_off;
+            const char* vs = (const char*)p.vbase + src_off;
+            for (size_t i = (size_t)wave * 64; i < n16; i += 7 * 64) {      // 1 KiB per wave-instruction, lane-linear in LDS
+                if (i + lane < n16) {
+                    __builtin_amdgcn_global_load_lds(CAP_GPTR(ks + (i + lane) * 16), CAP_LPTR(kimg + i * 16), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(CAP_GPTR(vs + (i + lane) * 16), CAP_LPTR(vimg + i * 16), 16, 0, 0);
                 }
-                if (ln.bias) { s.x += bb.x; s.y += bb.y; s.z += bb.z; s.w += bb.w; }
-                if (ln.resid) { s.x += rs.x; s.y += rs.y; s.z += rs.z; s.w += rs.w; }
-                a[i] = s;
             }
         }
-        ln_row<T, 4>(a, nv, lane, D, ln.gamma, ln.beta, ln.eps, (T*)xrow, h == 0 && ln.x_out ? ln.x_out + (size_t)row * D : nullptr);
+    }
+    SMALL_STAMP(0, 1, wave == 0);
+    // ---- LayerNorm of the row (wave 7), operand row to LDS; the head-0 workgroup writes the fp32 row
+    if (wave == 7) {
+        SMALL_STAMP(0, 7, lv[0].pz[0][0] == lv[0].pz[0][0]);
+        ln_finish_row<T, NV>(ln, p.R, D, row, lane, lv, lk, (T*)xrow, h == 0 && ln.x_out ? ln.x_out + (size_t)row * D : nullptr);
+        SMALL_STAMP(0, 8, true);
     }
     __syncthreads();
-    // ---- the query columns: chain c of slice `wave` = slabs c, c + 4, ...; the row sits in MFMA column 0
+    SMALL_STAMP(0, 2, wave == 0);
+    // ---- the query columns: chain c of slice sl = slabs c, c + 4, ...; the row sits in MFMA column 0
     if (gw) {
-        f32x4 acc[4][4];
+        f32x4 acc[4][2];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[c][cb] = 0.f;
+            for (int cb = 0; cb < 2; ++cb) acc[c][cb] = 0.f;
 #pragma unroll
         for (int j = 0; j < NF; ++j)
             if (j < nkb) {
-                const Frag af = r16 == 0 ? load_frag<T>(xrow + ((size_t)wave * nkb + j) * 128, kg) : zero_frag();
+                const Frag af = r16 == 0 ? load_frag<T>(xrow + ((size_t)sl * nkb + j) * 128, kg) : zero_frag();
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) mma_slab<T>(acc[j & 3][cb], wq[j][cb], af);
+                for (int cb = 0; cb < 2; ++cb) mma_slab<T>(acc[j & 3][cb], wq[j][cb], af);
             }
         for (int j = NF; j < nkb; ++j) {                      // longer slices than the register batch: one slab at a time
-            const Frag af = r16 == 0 ? load_frag<T>(xrow + ((size_t)wave * nkb + j) * 128, kg) : zero_frag();
+            const Frag af = r16 == 0 ? load_frag<T>(xrow + ((size_t)sl * nkb + j) * 128, kg) : zero_frag();
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
+            for (int cb = 0; cb < 2; ++cb) {
                 const Frag w = load_frag<T>(wbase + (size_t)cb * 16 * D * ESZ + (size_t)j * 128, kg);
-                f32x4 t;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) if ((j & 3) == c) { t = acc[c][cb]; mma_slab<T>(t, w, af); acc[c][cb] = t; }
+                for (int c = 0; c < 4; ++c)
+                    if ((j & 3) == c) { f32x4 t = acc[c][cb]; mma_slab<T>(t, w, af); acc[c][cb] = t; }
             }
         }
         if (r16 == 0) {
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
+            for (int cb = 0; cb < 2; ++cb) {
                 f32x4 v = acc[0][cb];
                 v += acc[1][cb]; v += acc[2][cb]; v += acc[3][cb];
                 if constexpr (is_g8<T>) v *= (1.0f / G8_WSCALE);
-                *(f32x4*)(qpart + wave * 64 + cb * 16 + 4 * kg) = v;
+                *(f32x4*)(qpart + sl * 64 + ch * 32 + cb * 16 + 4 * kg) = v;
             }
         }
     }
+    SMALL_STAMP(0, 3, wave == 0);
     if constexpr (KV_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    SMALL_STAMP(0, 4, wave == 0);
     // ---- q = slices in order + bias, through the attention's value type (Part8::finish)
     if (tid < 64) {
         float s = qpart[tid];
@@ -395,28 +464,32 @@ __global__ __launch_bounds__(256, 1) void dec_small_cross_kernel(SmallCross p) {
         qfin[tid] = to_f32(from_f32<TA>(s));
     }
     __syncthreads();
-    if (wave != 0) return;
+    SMALL_STAMP(0, 5, wave == 0);
     QSource qs;
     qs.part = nullptr; qs.bias = nullptr; qs.S = 0; qs.part_ld = 0; qs.col0 = 0; qs.append_kv = 0;
     T* out_row = (T*)p.out + (size_t)row * H * 64;
-    if constexpr (KV_LDS) {
-        decode_attention_online_unit<TA, G, false, false, T, TKV>(nullptr, kimg, vimg, nullptr, 0, p.kv_ld, p.n_keys, out_row, p.R, H, qs,
-                                                                  row, h, lane, 0, ri_lds, qfin);
-    } else {
-        if constexpr (!std::is_same<TKV, kv16_t>::value) {
-            if (p.n_keys <= 32) {      // short histories (fixture-sized image towers): the batch path's one-round-trip wave kernel
-                TA* kb = (TA*)p.kbase + p.kv_row0 * 64;
-                TA* vb = (TA*)p.vbase + p.kv_row0 * 64;
-                const int ng8 = (p.n_keys + 7) / 8;
-                if (ng8 <= 1) decode_attention_wave_unit<TA, 1, T>(nullptr, kb, vb, nullptr, 0, p.rows_per_kv, p.kv_ld, p.n_keys, out_row, p.R, H, qs, row, h, lane, false, qfin);
-                else if (ng8 <= 2) decode_attention_wave_unit<TA, 2, T>(nullptr, kb, vb, nullptr, 0, p.rows_per_kv, p.kv_ld, p.n_keys, out_row, p.R, H, qs, row, h, lane, false, qfin);
-                else decode_attention_wave_unit<TA, 4, T>(nullptr, kb, vb, nullptr, 0, p.rows_per_kv, p.kv_ld, p.n_keys, out_row, p.R, H, qs, row, h, lane, false, qfin);
-                return;
-            }
+    if constexpr (!std::is_same<TKV, kv16_t>::value) {
+        if (p.n_keys <= 32) {      // short histories (fixture-sized image towers): the batch path's one-round-trip wave kernel
+            if (wave != 0) return;
+            TA* kb = (TA*)p.kbase + p.kv_row0 * 64;
+            TA* vb = (TA*)p.vbase + p.kv_row0 * 64;
+            const int ng8 = (p.n_keys + 7) / 8;
+            if (ng8 <= 1) decode_attention_wave_unit<TA, 1, T>(nullptr, kb, vb, nullptr, 0, p.rows_per_kv, p.kv_ld, p.n_keys, out_row, p.R, H, qs, row, h, lane, false, qfin);
+            else if (ng8 <= 2) decode_attention_wave_unit<TA, 2, T>(nullptr, kb, vb, nullptr, 0, p.rows_per_kv, p.kv_ld, p.n_keys, out_row, p.R, H, qs, row, h, lane, false, qfin);
+            else decode_attention_wave_unit<TA, 4, T>(nullptr, kb, vb, nullptr, 0, p.rows_per_kv, p.kv_ld, p.n_keys, out_row, p.R, H, qs, row, h, lane, false, qfin);
+            return;
         }
-        decode_attention_online_unit<TA, G, false, false, T, TKV>(nullptr, p.kbase, p.vbase, nullptr, 0, p.kv_ld, p.n_keys, out_row, p.R, H,
-                                                                  qs, row, h, lane, 0, rb, qfin);
     }
+    const void* kb = KV_LDS ? (const void*)kimg : p.kbase;
+    const void* vb = KV_LDS ? (const void*)vimg : p.vbase;
+    const size_t rib = KV_LDS ? ri_lds : rb;
+    decode_attention_scores<TKV>(kb, rib, p.n_keys, qfin, scl, lane, wave, 8);
+    __syncthreads();
+    SMALL_STAMP(0, 9, wave == 0);
+    if (wave != 0) return;
+    decode_attention_online_unit<TA, G, false, false, T, TKV, true>(nullptr, kb, vb, nullptr, 0, p.kv_ld, p.n_keys, out_row, p.R, H, qs, row,
+                                                                    h, lane, 0, rib, qfin, scl);
+    SMALL_STAMP(0, 6, true);
 }
 
 template <typename T, int PRO, int EPI, int NCHAIN, int NW, int RPW>
@@ -463,6 +536,14 @@ int launch_small_t(const SmallGemm& p, hipStream_t s) {
 
 CAP_DEFINE_G8_CLAMP_READER(cap_g8_clamped_decode_small)
 
+#ifdef CAP_EXPERIMENTS
+extern "C" int cap_debug_small_stamps(unsigned long long* out64) {
+    CAP_HIP_CHECK(hipDeviceSynchronize());
+    CAP_HIP_CHECK(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_small_stamps), sizeof(unsigned long long) * 64));
+    return 0;
+}
+#endif
+
 int launch_small_gemm(int dtype, const SmallGemm& p, hipStream_t s) {
     const int slab = dtype == CAP_DT_BF16 ? 64 : 32;
     if (dtype != CAP_DT_G8 && dtype != CAP_DT_BF16) { cap_set_error("launch_small_gemm: G8 or bf16 operands only (dtype %d)", dtype); return -1; }
@@ -498,27 +579,27 @@ int launch_small_cross(int dtype, const SmallCross& p, hipStream_t s) {
     size_t kvb;
     if (p.kv_kind == SMALL_KV_KV16) kvb = ((size_t)p.n_keys + 62) / 32 * KV16_GROUP_BYTES;
     else kvb = (size_t)p.n_keys * 64 * (p.kv_kind == SMALL_KV_BF16 ? 2 : 4);
-    const size_t fixed = ((p.D * esz + 255) & ~255) + 256 * 4 + 64 * 4;
+    const size_t fixed = ((p.D * esz + 255) & ~255) + 256 * 4 + 64 * 4 + (((size_t)p.n_keys + 63) & ~(size_t)63) * 4;
     const bool fits = p.n_keys > 32 && fixed + 2 * kvb <= 150 * 1024;     // (<= 32 keys: the one-round-trip wave unit reads global memory)
     const int lds = (int)(fixed + (fits ? 2 * kvb : 0));
     const int grid = p.R * p.H;
+#define CAP_SMALL_CROSS_NV(TT, TKV, GG, LDSB, NVV)                                                                      \
+    do {                                                                                                                \
+        auto kern = dec_small_cross_kernel<TT, TKV, GG, LDSB, NVV>;                                                     \
+        if (cap_kernel_setup((const void*)kern, lds, nullptr) != 0) return -1;                                          \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);                                                     \
+    } while (0)
 #define CAP_SMALL_CROSS(TT, TKV, GG)                                                                                    \
     do {                                                                                                                \
-        if (fits) {                                                                                                     \
-            auto kern = dec_small_cross_kernel<TT, TKV, GG, true>;                                                      \
-            if (cap_kernel_setup((const void*)kern, lds, nullptr) != 0) return -1;                                      \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);                                                 \
-        } else {                                                                                                        \
-            auto kern = dec_small_cross_kernel<TT, TKV, GG, false>;                                                     \
-            if (cap_kernel_setup((const void*)kern, lds, nullptr) != 0) return -1;                                      \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);                                                 \
-        }                                                                                                               \
+        if (fits) { if (p.D <= 768) CAP_SMALL_CROSS_NV(TT, TKV, GG, true, 3); else CAP_SMALL_CROSS_NV(TT, TKV, GG, true, 4); }   \
+        else { if (p.D <= 768) CAP_SMALL_CROSS_NV(TT, TKV, GG, false, 3); else CAP_SMALL_CROSS_NV(TT, TKV, GG, false, 4); }      \
     } while (0)
     // chunking (G) of the batch path's kernels for the same cache type (attention.hip::launch_decode_attention)
     if (dtype == CAP_DT_BF16 && p.kv_kind == SMALL_KV_BF16) CAP_SMALL_CROSS(bf16_t, bf16_t, 5);
     else if (dtype == CAP_DT_G8 && p.kv_kind == SMALL_KV_KV16) CAP_SMALL_CROSS(g8_t, kv16_t, 5);
     else if (dtype == CAP_DT_G8 && p.kv_kind == SMALL_KV_F32) CAP_SMALL_CROSS(g8_t, float, 7);
     else { cap_set_error("launch_small_cross: cache kind %d does not go with operand type %d", p.kv_kind, dtype); return -1; }
+#undef CAP_SMALL_CROSS_NV
 #undef CAP_SMALL_CROSS
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
