@@ -214,9 +214,12 @@ def roofline_pass(eng, px, L, dtype, arch, batch):
     eng.profile(True)
     reps = 2
     for _ in range(reps):
-        eng.generate(px, num_beams=1, max_length=L)
+        gen = eng.generate(px, num_beams=1, max_length=L)
     rep = eng.profile_report()
     eng.profile(False)
+    # rows a decode step still reads: a caption of n tokens (BOS .. EOS) is open for its first n - 1 steps; the attention
+    # kernels skip a row from the step after its EOS on
+    live_row_steps = float(torch.clamp(gen["lengths"].float() - 1, max=L - 1).sum())
     kernels = {}
     for tag, r in rep.items():
         kernels[tag] = {"launches_per_step": r["launches"] // reps, "ms_per_step": r["ms"] / reps,
@@ -229,7 +232,11 @@ def roofline_pass(eng, px, L, dtype, arch, batch):
     k = MFMA_PER_PRODUCT[dtype]
     alg = fl / (ms * 1e-3) / 1e12                    # 2 M N K / t
     peak = PEAK_TFLOPS[dtype]
-    pm = pmc_summary(dtype)
+    def _avg_us(tags):
+        ms_ = sum(rep[t]["ms"] for t in tags if t in rep); n_ = sum(rep[t]["launches"] for t in tags if t in rep)
+        return 1e3 * ms_ / n_ if n_ else None
+    pm = pmc_summary(dtype, {"enc_gemm": 1e3 * ms / n if n else None, "cross_attention": _avg_us(("dec_cross_attn",)),
+                             "decode_gemm": _avg_us(DEC_GEMM_TAGS)})
     roof = {"bound": "mfma", "kernel": KERNEL_NAME[dtype], "achieved": round(alg, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(alg / peak, 4), "traffic": pm["enc_gemm"].get("traffic"),
             "algorithmic_flops_per_launch": fl / n, "avg_launch_us": round(1e3 * ms / n, 2), "launches_per_step": n // reps,
@@ -240,7 +247,7 @@ def roofline_pass(eng, px, L, dtype, arch, batch):
             # power limit (~1.3 kW) holds the clock at 2.0 GHz (profiles/r03_mfma_power.txt; 2 390 TFLOP/s with one constant pair)
             "power_limited_mfma_tflops": POWER_LIMITED_MFMA.get(dtype), "frac_executed_vs_power_limited":
             round(k * alg / POWER_LIMITED_MFMA[dtype], 4) if POWER_LIMITED_MFMA.get(dtype) else None,
-            "traffic_source": pm["source"],
+            "traffic_source": pm["source"], "pmc_stale": pm["pmc_stale"], "pmc_stale_why": pm["pmc_stale_why"],
             "note": "achieved = 2MNK of the ViT Linear layers per launch / HIP-event launch time (the proj / fc2 launches also add their "
                     "output into the fp32 residual stream in place: +155 MB read each, counted in algorithmic_bytes_per_launch); frac = achieved / dense peak of "
                     "the MFMA pipe the kernel runs on (MI355X_MICROARCH.md).  executed_tflops counts the MFMA products the "
@@ -252,14 +259,21 @@ def roofline_pass(eng, px, L, dtype, arch, batch):
     dec = {}
     if "dec_cross_attn" in rep:
         r = rep["dec_cross_attn"]
-        g = r["bytes"] / (r["ms"] * 1e-3) / 1e9
+        all_rows = r["bytes"] / r["launches"]                              # K and V blocks of every row of the batch
+        per_row = all_rows / batch
+        layers = arch.t_layers
+        live = per_row * live_row_steps * layers * reps                    # what the launches of the pass actually had to read
+        g = live / (r["ms"] * 1e-3) / 1e9
         dec["cross_attention"] = {"bound": "hbm", "achieved": round(g, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                   "frac": round(g / HBM_PEAK_GBPS, 4), "traffic": pm["cross_attention"].get("traffic"),
-                                  "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"]),
+                                  "algorithmic_bytes_per_launch": round(live / r["launches"]),
+                                  "bytes_per_launch_if_every_row_were_open": round(all_rows),
+                                  "live_row_steps": int(live_row_steps), "row_steps": batch * (L - 1),
                                   "avg_launch_us": round(1e3 * r["ms"] / r["launches"], 2), "launches_per_step": r["launches"] // reps,
                                   "ms_per_step": round(r["ms"] / reps, 3),
-                                  "note": "algorithmic bytes = K and V blocks of every row (ended captions are skipped by the kernel "
-                                          "but counted here, so achieved overstates the stream once captions end; traffic is the PMC figure)"}
+                                  "note": "algorithmic bytes = KV16 K and V blocks (132 bytes per 64-wide head row) of the rows still OPEN at each "
+                                          "step (a caption of n tokens is read for n - 1 steps; ended rows are skipped by the kernel), "
+                                          "counted from this run's caption lengths; traffic = the counter file's bytes per launch"}
     tags = [t for t in DEC_GEMM_TAGS if t in rep]
     if tags:
         by = sum(rep[t]["bytes"] for t in tags); ms_d = sum(rep[t]["ms"] for t in tags); nl = sum(rep[t]["launches"] for t in tags)
@@ -290,46 +304,74 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-PMC_FILES = {"f32s": "r03_bench_pmc.json", "bf16": "r03_bench_bf16_pmc.json"}
-PMC_FALLBACK = {"f32s": "r02_bench_pmc.json", "bf16": "r02_bench_bf16_pmc.json"}
+PMC_FILES = {"f32s": "r04_bench_pmc.json", "bf16": "r04_bench_bf16_pmc.json"}
 
 
-def pmc_summary(dtype):
+def _kernel_in_build(name: str, lib_bytes: bytes) -> bool:
+    """Is a kernel of this (demangled) name compiled into the library of THIS run?  Kernels are templates in an anonymous
+    namespace: their mangled symbols carry <length><identifier>."""
+    m = re.match(r"(?:void )?([A-Za-z_][A-Za-z0-9_]*)", name)
+    return bool(m) and f"{len(m.group(1))}{m.group(1)}".encode() in lib_bytes
+
+
+def pmc_summary(dtype, live_avg_us=None):
     """Counter figures of the committed rocprofv3 --pmc passes of THIS command (tools/profile_round.sh -> profiles/<file>) -
     NOT measured by this process: rocprofv3 cannot run inside the bench.  Per kernel class, weighted by launches:
     traffic = FETCH_SIZE x 2 (the gfx950 correction) + WRITE_SIZE in bytes per launch; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES /
-    (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs).  Empty entries when there is no file for the mode."""
-    out = {"enc_gemm": {}, "cross_attention": {}, "decode_gemm": {}, "source": None}
-    d = None
-    for fn in (PMC_FILES.get(dtype), PMC_FALLBACK.get(dtype)):
-        try:
-            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
-            out["source"] = f"profiles/{fn} (committed rocprofv3 --pmc passes of this command, not this run)"
-            break
-        except Exception:  # noqa: BLE001
-            continue
-    if d is None:
+    (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs).
+    The file is a record of an earlier run, so it can go stale: `pmc_stale` is true - and `pmc_stale_why` says what - when
+    the file is missing, a kernel class matches no entry of it, a matched kernel's name is not compiled into the library this
+    run loaded, or (live_avg_us given: class -> this run's HIP-event microseconds per launch) the file's average launch duration
+    of a class differs from this run's by more than a third."""
+    out = {"enc_gemm": {}, "cross_attention": {}, "decode_gemm": {}, "source": None, "pmc_stale": False, "pmc_stale_why": []}
+    fn = PMC_FILES.get(dtype)
+    if fn is None:
+        out["pmc_stale_why"].append(f"no counter pass is kept for mode {dtype}")
         return out
-    enc = (r"gemm_pp_kernel<g8_t, (true|false), 0,|gemm_(big2|enc)_kernel(I4g8_tLb[01]ELi0E|<g8_t, (true|false), 0,)" if dtype == "f32s"
-           else r"gemm_pp_kernel(IDF16bLb[01]ELi0E|<bool _Accum, bool, E, 0,|<__bf16, (true|false), 0,)|gemm_big[23]_kernel(I(DF16b|u6__bf16)?Lb[01]ELi0E|ILb[01]ELi0E|<(__bf16, )?(true|false), 0,)")
-    classes = {"enc_gemm": enc, "cross_attention": r"decode_attention_(online|shared)_kernel",
-               "decode_gemm": r"gemm_(kernel|rows_kernel)<[^>]*, (true|false), 4>|gemm_rows_kernel|gemm_kernel<(g8_t|__bf16|float), 64, 64, 32, 32, 6, 3, false, 0>"}
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", fn)))
+        out["source"] = f"profiles/{fn} (committed rocprofv3 --pmc passes of this command, not this run)"
+    except Exception as e:  # noqa: BLE001
+        out["pmc_stale"] = True
+        out["pmc_stale_why"].append(f"no counter file for mode {dtype} ({fn}): {e!r}")
+        return out
+    try:
+        from embodied_captioning_amd.build import LIB
+        lib_bytes = open(LIB, "rb").read()
+    except Exception:  # noqa: BLE001
+        lib_bytes = None
+    enc = r"gemm_pp_kernel<g8_t, (true|false), 0," if dtype == "f32s" else r"gemm_pp_kernel<__bf16, (true|false), 0,"
+    classes = {"enc_gemm": enc, "cross_attention": r"decode_attention_(online|shared)_kernel", "decode_gemm": r"gemm_rows_kernel"}
     for cls, pat in classes.items():
-        n = b = busy = act = 0.0
+        n = b = busy = act = us = nl = 0.0
         names = []
         for k, v in d.items():
             if re.search(pat, k) and "hbm_read_bytes_corrected" in v:
                 w = v["launches_per_pass"]
                 # a Linear layer whose last tile round is cut runs as TWO launches (256-row tiles, then the 128-row halves of the
                 # tail round): bytes and cycles of both count, the layer counts once
-                n += 0 if (cls == "enc_gemm" and re.search(r", 128(, (true|false))?>|Li128E", k)) else w
+                n += 0 if (cls == "enc_gemm" and re.search(r", 128(, (true|false))?>", k)) else w
                 b += w * (v["hbm_read_bytes_corrected"] + v.get("hbm_write_bytes", 0.0))
                 busy += w * v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
                 act += w * v.get("GRBM_GUI_ACTIVE", 0.0)
+                us += w * v.get("avg_us", 0.0); nl += w
                 names.append(k.split("(")[0][:80])
-        if n:
-            out[cls] = {"traffic": round(b / n), "mfma_busy": round(busy / (act / 8 * 1024), 4) if act else None,
-                        "kernel": "; ".join(sorted(set(names)))[:240]}
+                if lib_bytes is not None and not _kernel_in_build(k, lib_bytes):
+                    out["pmc_stale"] = True
+                    out["pmc_stale_why"].append(f"{cls}: kernel {k.split('(')[0][:60]} of the counter file is not in this build")
+        if not n:
+            out["pmc_stale"] = True
+            out["pmc_stale_why"].append(f"{cls}: no kernel of the counter file matches /{pat}/")
+            continue
+        out[cls] = {"traffic": round(b / n), "mfma_busy": round(busy / (act / 8 * 1024), 4) if act else None,
+                    "kernel": "; ".join(sorted(set(names)))[:240], "pmc_avg_launch_us": round(us / n, 2)}
+        if live_avg_us and live_avg_us.get(cls):
+            r = out[cls]["pmc_avg_launch_us"] / live_avg_us[cls]
+            out[cls]["pmc_over_live_launch_time"] = round(r, 3)
+            if not (0.67 <= r <= 1.5):
+                out["pmc_stale"] = True
+                out["pmc_stale_why"].append(f"{cls}: {out[cls]['pmc_avg_launch_us']} us per launch in the counter file, "
+                                            f"{round(live_avg_us[cls], 2)} us in this run")
     return out
 
 
@@ -365,7 +407,7 @@ def cpu_baseline(sd, arch, L, sample):
     big, small = runs[f"batch_{sample}_frames"], runs["config1_8_frames"]
     best = max(big, small, key=lambda r: r["captions_per_s"])       # the CPU's better figure is the baseline (small batches fit its caches)
     return {"value": best["captions_per_s"], "unit": "captions/s", "cores": host_cores(), "torch_threads": torch.get_num_threads(),
-            "os_cpu_count": os.cpu_count(), "cpu_model": cpu_model(), "kind": "port",
+            "os_cpu_count": os.cpu_count(), "cpu_model": cpu_model(), "kind": "port", "baseline_batch": best["frames"],
             "sample": f"config 1 (8 frames) and {sample} frames 224x224, encoder + greedy max_length={L}, fp32, oracle/blip_ref.py on "
                       f"{torch.get_num_threads()} threads: 1 warm-up + median of 5 runs each; value = the better of the two "
                       f"({best['frames']} frames, median {best['median_s']} s)",
@@ -742,15 +784,19 @@ def main():
     if rank == 0:
         value = world * B * a.steps / dt
         S = arch.image_size
-        mode = {"f32s": "f32 (every GEMM operand split into two fp16 halves, 3 fp16 MFMA products per MAC, fp32 accumulate)",
-                "bf16": "bf16", "f32": "f32"}[a.dtype]
+        mode = {"f32s": "f32 carried as split fp16: every GEMM operand = two fp16 halves, 3 fp16 MFMA products per MAC, fp32 accumulate; "
+                        "cross-attention K/V cache = KV16 (int16 + one fp32 scale per 64-wide head row: 15 value bits); LayerNorm / softmax / "
+                        "residual stream / self-attention cache fp32.  The exact-product fp32 MFMA mode of the same run is the `f32_exact` key",
+                "bf16": "bf16 operands and K/V caches, fp32 accumulate / LayerNorm / softmax / residual stream", "f32": "f32 (fp32 MFMA, exact products)"}[a.dtype]
         line = {"metric": f"captions/sec ({S}x{S}, beam={a.beams})", "value": round(value, 2), "unit": "captions/s",
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": mode,
                 "data": "synthetic frames (PCG64, seed = frame index), procedural weights (no checkpoint offline)",
                 "config": {"workload": f"BLIP-base ViT-B/16 encoder + {'greedy' if a.beams == 1 else f'beam-{a.beams}'} decode, {B} frames/GPU {S}x{S}, "
                                        f"max_length={L}, caption all-gather", "global_batch": world * B,
-                           "parallelism": f"dp{world}", "streams": a.streams, "compute_mode": a.dtype}}
+                           "parallelism": f"dp{world}", "streams": a.streams, "compute_mode": a.dtype,
+                           "value_is": (f"consecutive batches overlapped on {a.streams} engines / HIP streams of one GPU (EnginePool); one batch at a "
+                                        f"time on one stream is the `single_stream` key") if a.streams > 1 else "one batch at a time on one stream"}}
         ln = lens[:B].float()
         line["caption_tokens"] = {"mean": round(float(ln.mean()), 2), "max": int(ln.max()), "of": L}
         pw = getattr(timed_steps, "power", None)

@@ -2,12 +2,12 @@
 # rocprofv3 passes of a bench command for profiles/: kernel-trace stats, then (PMC=1) hardware counters in SEPARATE passes
 # (never combined with other trace domains) of the same workload's timed steps only.  The program comes directly after `--`.
 # Run on the GPU box from the repo root:
-#   bash tools/profile_round.sh r03_bench                          # default bench command (f32s headline), stats + PMC
-#   PMC=0 bash tools/profile_round.sh r03_bench_beam3 --beams 3 --batch 64
-#   bash tools/profile_round.sh r03_bench_bf16 --dtype bf16
+#   bash tools/profile_round.sh r04_bench                          # default bench command (f32s headline), stats + PMC
+#   PMC=0 bash tools/profile_round.sh r04_bench_beam3 --beams 3 --batch 64
+#   bash tools/profile_round.sh r04_bench_bf16 --dtype bf16
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r03_bench}; shift || true
+TAG=${1:-r04_bench}; shift || true
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
