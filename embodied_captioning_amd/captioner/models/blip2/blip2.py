@@ -10,9 +10,16 @@ Arithmetic: libcaptioner_hip.so (`CaptionerEngine` with a `Blip2Arch`: ViT-g/14,
     captions come back as space-separated token ids);
   * a BLIP(-base) captioning checkpoint selected with ``arch_name: blip2`` still runs through the BLIP path (compatibility
     with configs written before this class existed).
-The reference loads 8-bit weights / fp16 activations (``blip2.py:19-22``).  Here ``dtype`` is "f32s" by default: fp32-grade
-split-fp16 GEMMs, token-identical to HF's fp32 CPU model on the committed golden (tests/test_blip2_gpu.py) - the parity
-clause's mode; "bf16" halves the decoder's weight stream (about 2x the captions/s, near-tie token flips), "f32" is exact.
+The reference loads 8-bit weights / fp16 activations (``blip2.py:19-22``: ``load_in_8bit=True, torch_dtype=float16``).  Policy
+here: the checkpoint's tensors are taken at the precision they are STORED in - an fp16-stored
+checkpoint enters fp32 / the split format exactly (every fp16 value is a hi half with a zero lo half) - and the arithmetic is
+``dtype``: "f32s" by default (fp32-grade split-fp16 GEMMs, token-identical to HF's fp32 CPU model on the committed golden,
+tests/test_blip2_gpu.py - the parity clause's mode), "bf16" (halves the decoder's weight stream, about 2x the captions/s,
+near-tie token flips), "f32" (exact).  bitsandbytes' LLM.int8 quantisation is NOT implemented: ``load_in_8bit`` is rejected by
+name rather than silently replaced by another arithmetic.
+``checkpoint_name`` (optional): a PEFT LoRA adapter directory (``adapter_config.json`` + ``adapter_model.safetensors``) - what
+the reference's fine-tuned BLIP-2 is (``scripts/evaluate_finetuned_model.py:147-148``: ``PeftModel.from_pretrained``) - merged
+into the base weights at load (weights.merge_peft_lora), or a state-dict file that overrides tensors of the base checkpoint.
 """
 from __future__ import annotations
 
@@ -27,7 +34,7 @@ import torch
 from ...captioning_predictor import CaptioningPredictor
 from ....config import Blip2Arch
 from ....engine import CaptionerEngine
-from ....weights import load_state_dict_file, procedural_blip2_state_dict, resolve_hf_dir
+from ....weights import is_peft_adapter, load_state_dict_file, merge_peft_lora, procedural_blip2_state_dict, resolve_hf_dir
 from ..blip.blip import BLIP
 
 logger = logging.getLogger(__name__)
@@ -91,6 +98,13 @@ class BLIP2(BLIP):
             super().__init__(cfg)                       # a BLIP captioning checkpoint under arch_name blip2
             return
         CaptioningPredictor.__init__(self, cfg)
+        if getattr(cfg, "load_in_8bit", None) or getattr(cfg, "load_in_4bit", None):
+            raise ValueError("BLIP2(cfg): load_in_8bit / load_in_4bit (bitsandbytes quantisation, reference blip2.py:19-22) is not "
+                             "implemented by the MI355X captioner library - drop the key: the checkpoint's tensors are used at their "
+                             "stored precision and the arithmetic is cfg.dtype ('f32s' default | 'bf16' | 'f32')")
+        td = getattr(cfg, "torch_dtype", None)
+        if td is not None and str(td).replace("torch.", "") not in ("float16", "half", "bfloat16", "float32", "float"):
+            raise ValueError(f"BLIP2(cfg): torch_dtype={td!r} is not a floating type a checkpoint is stored in")
         self.num_beams = 1
         self.batch_size = int(getattr(cfg, "batch_size", 8) or 8)
         dtype = getattr(cfg, "dtype", None) or "f32s"      # parity-grade default: tokens identical to HF fp32 on the golden
@@ -110,6 +124,15 @@ class BLIP2(BLIP):
                 self.tokenizer = AutoTokenizer.from_pretrained(model_dir)
             except Exception as e:  # noqa: BLE001
                 logger.warning("no tokenizer under %s (%s): captions are returned as space-separated token ids", model_dir, e)
+        ck = getattr(cfg, "checkpoint_name", None)
+        self.adapter_report = None
+        if ck:
+            if is_peft_adapter(ck):
+                sd, self.adapter_report = merge_peft_lora(sd, ck)
+                logger.info("PEFT LoRA adapter %s merged into %d modules", ck, self.adapter_report["merged"])
+            else:
+                sd.update(load_state_dict_file(ck))
+                logger.info("Captioner model checkpoint loaded successfully from %s", ck)
         # the reference passes no length: HF then generates 20 new tokens; the optional config key `max_new_tokens` (HF's
         # name) overrides that.  The plugin's `max_length` key is BLIP's / CoCa's TOTAL length and is not read here.
         self.max_length = int(getattr(cfg, "max_new_tokens", 0) or self.arch.max_new_tokens)

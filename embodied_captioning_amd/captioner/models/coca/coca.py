@@ -40,6 +40,13 @@ class CoCa(CaptioningPredictor):
         self.num_beam_groups = int(g) if g else None
         if self.num_beam_groups and self.num_beams % self.num_beam_groups:
             raise ValueError(f"num_beams ({self.num_beams}) must be a multiple of num_beam_groups ({self.num_beam_groups})")
+        # the other generation options of the reference's model (coca_model.py:205-224): off, or rejected by name
+        from ...generation_options import reject_unsupported_generation_options
+        self.generation_options = {k: getattr(cfg, k) for k in ("generation_type", "top_k", "top_p", "temperature", "repetition_penalty")
+                                   if getattr(cfg, k, None) is not None}
+        reject_unsupported_generation_options(self.generation_options, "CoCa(cfg)")
+        if self.generation_options.get("generation_type") == "beam_search" and self.num_beams < 2:
+            raise ValueError("CoCa(cfg): generation_type='beam_search' needs num_beams >= 2 (the reference's default is 6 in 3 groups)")
         dtype = getattr(cfg, "dtype", None) or "f32s"      # fp32-grade default (token-identical to the fp32 restatement); "bf16" is ~2x faster
         if int(getattr(cfg, "streams", 1) or 1) > 1:
             logger.warning("captioner.streams > 1 is implemented for arch_name 'blip' only: running one engine")
@@ -124,6 +131,31 @@ class CoCa(CaptioningPredictor):
             return self.bpe.caption(ids)
         a = self.arch
         return " ".join(str(i) for i in ids if i not in (a.sot, a.eos, a.pad))
+
+    @torch.no_grad()
+    def generate(self, image, **options) -> torch.Tensor:
+        """The reference model's `generate(image, ...)` entry (coca_model.py:205-224) on preprocessed frames: token ids [B, seq_len].
+        generation_type "top_k" with top_k=1 (the reference wrapper's call, coca.py:29) or "beam_search" with num_beams /
+        num_beam_groups; every other option must be at its neutral value or the call raises ValueError naming it."""
+        from ...generation_options import reject_unsupported_generation_options
+        opts = dict(options)
+        gt = opts.pop("generation_type", "top_k" if self.num_beams == 1 else "beam_search")
+        beams = int(opts.pop("num_beams", self.num_beams if gt == "beam_search" else 1))
+        groups = opts.pop("num_beam_groups", self.num_beam_groups if gt == "beam_search" else None)
+        seq_len = int(opts.pop("seq_len", self.arch.seq_len))
+        reject_unsupported_generation_options({"generation_type": gt, **opts}, "CoCa.generate")
+        extra = sorted(set(opts) - {"top_k", "top_p", "temperature", "repetition_penalty", "stopping_criteria", "text", "max_seq_len",
+                                     "pad_token_id", "eos_token_id", "sot_token_id", "min_seq_len", "fixed_output_length"})
+        if extra:
+            raise TypeError(f"CoCa.generate() got unexpected keyword argument(s) {extra}")
+        if gt == "top_k":
+            beams, groups = 1, None
+        if beams > self.engine.max_beams or seq_len > self.engine.max_len:
+            raise ValueError(f"CoCa.generate: num_beams={beams} / seq_len={seq_len} exceed what this captioner was built for "
+                             f"(cfg.num_beams={self.engine.max_beams}, seq_len={self.engine.max_len})")
+        px = self.preprocess(image)
+        out = self.engine.generate(px.to(self._device), num_beams=beams, max_length=seq_len, num_beam_groups=groups)
+        return out["sequences"]
 
     @torch.no_grad()
     def generate_batch(self, images) -> dict:

@@ -7,7 +7,9 @@ generate, HF's name; None = 20 as HF's generate default - `max_length` is BLIP's
 BLIP-2).  dtype: "f32s" (default for BLIP: fp32-grade split-fp16 GEMMs, token-identical to the fp32 reference), "bf16",
 "f32"; None = the architecture's default.  CoCa: num_beam_groups (the model's beam groups, coca_model.py:218-219; None = one
 group), tokenizer_dir (directory holding the CLIP BPE vocabulary - vocab.json / merges.txt / bpe_simple_vocab_16e6.txt.gz -
-when it is not next to the checkpoint and open_clip is not installed)."""
+when it is not next to the checkpoint and open_clip is not installed); generation_type / top_k / top_p / temperature /
+repetition_penalty (the reference model's other `generate` options, coca_model.py:205-224): accepted at their neutral values
+("top_k" with top_k=1 = greedy, "beam_search"), rejected by name otherwise - sampling is not implemented."""
 
 
 class Configuration:
@@ -19,7 +21,9 @@ class Configuration:
 class CaptionerField:
     def __init__(self, arch_name=None, model_name=None, checkpoint_name=None, height=None, width=None,
                  num_beams=1, max_length=20, dtype=None, batch_size=8, device="cuda:0", image_size=None, streams=1,
-                 early_exit_poll=None, max_new_tokens=None, num_beam_groups=None, tokenizer_dir=None):
+                 early_exit_poll=None, max_new_tokens=None, num_beam_groups=None, tokenizer_dir=None,
+                 generation_type=None, top_k=None, top_p=None, temperature=None, repetition_penalty=None,
+                 load_in_8bit=None, load_in_4bit=None, torch_dtype=None):
         self.arch_name = arch_name
         self.model_name = model_name
         self.checkpoint_name = checkpoint_name
@@ -36,3 +40,15 @@ class CaptionerField:
         self.max_new_tokens = max_new_tokens
         self.num_beam_groups = num_beam_groups
         self.tokenizer_dir = tokenizer_dir
+        # the reference model's other generation options (coca_model.py:205-224): None = not asked for; anything but the neutral
+        # value is rejected by name when the captioner is built (captioner/generation_options.py)
+        self.generation_type = generation_type
+        self.top_k = top_k
+        self.top_p = top_p
+        self.temperature = temperature
+        self.repetition_penalty = repetition_penalty
+        # the reference's BLIP-2 load options (blip2.py:19-22): load_in_8bit is rejected by name (no int8 arithmetic here),
+        # torch_dtype only names the precision the checkpoint is stored in
+        self.load_in_8bit = load_in_8bit
+        self.load_in_4bit = load_in_4bit
+        self.torch_dtype = torch_dtype

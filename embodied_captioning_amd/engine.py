@@ -205,13 +205,23 @@ class CaptionerEngine:
         return out
 
     def generate(self, pixels: torch.Tensor, num_beams: int = 1, max_length: Optional[int] = None,
-                 length_penalty: float = 1.0, output_logits: bool = False, num_beam_groups: Optional[int] = None) -> Dict[str, torch.Tensor]:
+                 length_penalty: float = 1.0, output_logits: bool = False, num_beam_groups: Optional[int] = None,
+                 **sampling_options) -> Dict[str, torch.Tensor]:
         """Returns device tensors: sequences int32 [B, max_length] (incl. BOS), lengths int32 [B],
         sequences_scores fp32 [B] (beams only), logits fp32 [max_length-1, B*num_beams, vocab] (optional).
         BLIP-2: max_length counts NEW tokens (HF max_new_tokens); sequences are those new tokens only (no image
         placeholders / BOS), logits [max_length, B, vocab].
         num_beam_groups (CoCa): the reference's `_generate_beamsearch` with that many beam groups (coca_model.py:335-482;
-        its `generate()` defaults are 6 beams in 3 groups) - cap_generate_groups; no per-step logits in that mode."""
+        its `generate()` defaults are 6 beams in 3 groups) - cap_generate_groups; no per-step logits in that mode.
+        sampling_options: anything else a caller of the reference's / HF's `generate` may pass (top_p, top_k, temperature,
+        repetition_penalty, do_sample, ...): accepted at their neutral values, rejected BY NAME otherwise - never ignored."""
+        if sampling_options:
+            from .captioner.generation_options import reject_unsupported_generation_options, _NEUTRAL
+            known = set(_NEUTRAL) | {"generation_type", "top_k", "top_p"}
+            unknown = sorted(set(sampling_options) - known)
+            if unknown:
+                raise TypeError(f"generate() got unexpected keyword argument(s) {unknown}")
+            reject_unsupported_generation_options(sampling_options, "CaptionerEngine.generate")
         pixels, fmt = self._pixels(pixels)
         B = pixels.shape[0]
         L = max_length or self.max_len

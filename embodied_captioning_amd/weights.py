@@ -349,6 +349,102 @@ def load_state_dict_file(path: str) -> Dict[str, torch.Tensor]:
     return _strip_prefixes(sd, ("module.",))
 
 
+def _peft_pattern_value(pattern: dict, module: str, default):
+    """PEFT's rank_pattern / alpha_pattern: keys are module-name suffixes or regular expressions (peft.utils.get_pattern_key)."""
+    import re
+    for key, val in (pattern or {}).items():
+        if module == key or module.endswith("." + key) or re.fullmatch(key, module) or re.search(rf"(^|\.){key}$", module):
+            return val
+    return default
+
+
+def merge_peft_lora(sd: Dict[str, torch.Tensor], adapter: str, strict: bool = True) -> Tuple[Dict[str, torch.Tensor], Dict[str, object]]:
+    """Fold a PEFT LoRA adapter into a base state dict - what `PeftModel.from_pretrained(model, ckpt_path)` + the adapted
+    forward compute (reference: scripts/evaluate_finetuned_model.py:147-148, the fine-tuned BLIP-2 of the paper):
+
+        W' = W + scaling * (lora_B @ lora_A),   scaling = lora_alpha / r   (lora_alpha / sqrt(r) with use_rslora)
+
+    in fp32, per adapted module (transposed when the config says fan_in_fan_out).  `adapter`: a PEFT output directory
+    (adapter_config.json + adapter_model.safetensors | adapter_model.bin) or the weight file itself with the config beside it.
+    Keys: `base_model.model.<module path>.lora_A[.<adapter name>].weight` / `lora_B...`; `modules_to_save` copies
+    (`<module>.modules_to_save[.<name>].<param>`) replace the base tensor.  Anything the merge does not implement - DoRA
+    magnitude vectors, non-LoRA PEFT types, LoRA on embeddings, trained LoRA biases - is rejected by name.
+    Returns (new state dict, {"merged": n, "replaced": n, "scaling": {module: s}})."""
+    import json
+    cfg_dir = adapter if os.path.isdir(adapter) else os.path.dirname(adapter)
+    cfg_path = os.path.join(cfg_dir, "adapter_config.json")
+    if not os.path.exists(cfg_path):
+        raise RuntimeError(f"PEFT adapter: no adapter_config.json under {cfg_dir}")
+    cfg = json.load(open(cfg_path))
+    ptype = str(cfg.get("peft_type", "LORA")).upper()
+    if ptype != "LORA":
+        raise RuntimeError(f"PEFT adapter of type {ptype} is not supported (LoRA only)")
+    if cfg.get("use_dora"):
+        raise RuntimeError("PEFT adapter: use_dora (weight-decomposed LoRA) is not supported")
+    if str(cfg.get("bias", "none")) != "none":
+        raise RuntimeError(f"PEFT adapter: bias='{cfg.get('bias')}' (trained biases stored with the adapter) is not supported")
+    if os.path.isdir(adapter):
+        for fn in ("adapter_model.safetensors", "adapter_model.bin"):
+            if os.path.exists(os.path.join(adapter, fn)):
+                ad = load_state_dict_file(os.path.join(adapter, fn))
+                break
+        else:
+            raise RuntimeError(f"PEFT adapter: no adapter_model.safetensors / adapter_model.bin under {adapter}")
+    else:
+        ad = load_state_dict_file(adapter)
+    r0, a0 = int(cfg.get("r", 8)), float(cfg.get("lora_alpha", 8))
+    out = dict(sd)
+    report = {"merged": 0, "replaced": 0, "scaling": {}}
+    import re
+    pat = re.compile(r"^(?:base_model\.model\.)?(?P<mod>.+?)\.lora_(?P<ab>[AB])(?:\.[^.]+)?\.weight$")
+    pairs: Dict[str, Dict[str, torch.Tensor]] = {}
+    for k, v in ad.items():
+        m = pat.match(k)
+        if m:
+            pairs.setdefault(m.group("mod"), {})[m.group("ab")] = v
+            continue
+        ms = re.match(r"^(?:base_model\.model\.)?(?P<mod>.+?)\.modules_to_save(?:\.[^.]+)?\.(?P<par>weight|bias)$", k)
+        if ms:
+            key = f"{ms.group('mod')}.{ms.group('par')}"
+            if key not in out and strict:
+                raise RuntimeError(f"PEFT adapter: modules_to_save tensor {k} has no counterpart {key} in the base checkpoint")
+            out[key] = v.float()
+            report["replaced"] += 1
+            continue
+        if "lora_embedding" in k or "lora_magnitude" in k:
+            raise RuntimeError(f"PEFT adapter: tensor {k} (LoRA on embeddings / DoRA) is not supported")
+        if strict:
+            raise RuntimeError(f"PEFT adapter: tensor {k} is not a LoRA A/B matrix nor a modules_to_save copy")
+    for mod, ab in pairs.items():
+        if "A" not in ab or "B" not in ab:
+            raise RuntimeError(f"PEFT adapter: module {mod} has only one of lora_A / lora_B")
+        key = mod + ".weight"
+        if key not in out:
+            raise RuntimeError(f"PEFT adapter: adapted module {mod} has no weight {key} in the base checkpoint")
+        A, B = ab["A"].float(), ab["B"].float()            # [r, in], [out, r]
+        r = int(_peft_pattern_value(cfg.get("rank_pattern"), mod, r0))
+        if A.shape[0] != r or B.shape[1] != r:
+            r = A.shape[0]                                   # the tensors are what was trained; the config's pattern did not name them
+        alpha = float(_peft_pattern_value(cfg.get("alpha_pattern"), mod, a0))
+        scaling = alpha / (r ** 0.5) if cfg.get("use_rslora") else alpha / r
+        delta = (B @ A) * scaling
+        if cfg.get("fan_in_fan_out"):
+            delta = delta.t()
+        W = out[key].float()
+        if delta.shape != W.shape:
+            raise RuntimeError(f"PEFT adapter: {mod}: B @ A is {tuple(delta.shape)}, the base weight {tuple(W.shape)}")
+        out[key] = W + delta
+        report["merged"] += 1
+        report["scaling"][mod] = scaling
+    if not report["merged"] and not report["replaced"]:
+        raise RuntimeError(f"PEFT adapter {adapter}: no LoRA matrices found")
+    return out, report
+
+
+def is_peft_adapter(path: str) -> bool:
+    return bool(path) and os.path.exists(os.path.join(path if os.path.isdir(path) else os.path.dirname(path), "adapter_config.json"))
+
+
 def load_hf_blip_checkpoint(model_dir: str) -> Tuple[BlipArch, Dict[str, torch.Tensor]]:
     """HF ``from_pretrained`` directory layout: config.json + model.safetensors | pytorch_model.bin."""
     arch = BlipArch.from_hf_config(model_dir)

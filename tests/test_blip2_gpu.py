@@ -100,3 +100,70 @@ def test_blip2_early_exit_leaves_the_loop():
     assert sx == a.max_new_tokens and sy < sx, (sx, sy)
     assert int(x["lengths"].max()) < a.max_new_tokens // 2
     assert torch.equal(x["sequences"], y["sequences"]) and torch.equal(x["lengths"], y["lengths"])
+
+
+def _opt_massive_channels(sd, arch, seed=0, scale=300.0, n=3):
+    """Trained OPT decoders carry 'massive activations': a handful of residual-stream channels hundreds of times larger than the
+    rest, from the first layers on (pre-LN: nothing normalises the stream itself).  Here the bias of layer 0's fc2 gets +-scale on
+    n channels: every later LayerNorm (layer 1, the final one) squeezes the other 2557 channels by ~sqrt(2560 / n) / scale, the
+    G8 lo halves of those rows go subnormal, and the fp32 residual adds mix 1e2 with 1e-1."""
+    from _families import _rng
+    out = dict(sd)
+    r = _rng(seed, "opt-massive")
+    key = "language_model.model.decoder.layers.0.fc2.bias"
+    b = sd[key].clone()
+    ch = r.choice(arch.t_hidden, size=n, replace=False)
+    b[torch.from_numpy(ch)] += torch.from_numpy((scale * r.choice([-1.0, 1.0], size=n)).astype(np.float32))
+    out[key] = b
+    return out
+
+
+_WIDE = {}
+
+
+def _wide_blip2():
+    """(arch, state dict) of the production-width, two-layer model: 340 M seeded parameters, drawn once per test session."""
+    import dataclasses
+    from embodied_captioning_amd.config import Blip2Arch
+    from embodied_captioning_amd.weights import procedural_blip2_state_dict
+    if not _WIDE:
+        a = dataclasses.replace(Blip2Arch(), v_layers=2, q_layers=2, t_layers=2, max_new_tokens=8)
+        _WIDE["a"], _WIDE["sd"] = a, procedural_blip2_state_dict(a, 6, eos_boost=0.3)
+    return _WIDE["a"], _WIDE["sd"]
+
+
+@pytest.mark.parametrize("family", ["gaussian", "massive_channels"])
+@pytest.mark.parametrize("dtype", ["f32s", "f32"])
+def test_blip2_production_width_reduced_depth_against_restatement(dtype, family):
+    """The production GEOMETRY of `Salesforce/blip2-opt-2.7b` (reference blip2.py:19-22) at full width - ViT-g/14 1408 wide, 16
+    heads of 88, 257 tokens at 224 px; Q-Former 768 / 32 queries; OPT 2560 wide, 32 heads of 80, FFN 10240, the real 50272-token
+    vocabulary - with two layers per tower so that the CPU restatement (oracle/blip2_ref.py, held to HF by the tiny golden)
+    finishes in seconds.  Split mode and exact fp32: tokens identical, logits of every live step within 1e-3, nothing clamped;
+    also with OPT-style massive residual channels."""
+    from embodied_captioning_amd.weights import synthetic_pixels
+    from oracle import blip2_ref as R
+    a, sd = _wide_blip2()
+    assert (a.v_hidden, a.v_heads, a.t_hidden, a.t_heads, a.t_ffn, a.vocab, a.n_tokens) == (1408, 16, 2560, 32, 10240, 50272, 257)
+    if family == "massive_channels":
+        sd = _opt_massive_channels(sd, a, 6)
+    B = 2
+    px = synthetic_pixels(B, a.image_size, seed=6)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = R.greedy_generate(sd, a, px)
+    eng = _engine(a, dtype, B)
+    eng.load_state_dict(sd)
+    eng.saturations(reset=True)
+    out = eng.generate(px.cuda(), max_length=a.max_new_tokens, output_logits=True)
+    assert eng.saturations(reset=True) == 0
+    new = ref["sequences"][:, a.num_query_tokens + 1:].numpy()
+    want = np.full((B, a.max_new_tokens), a.pad, dtype=np.int64)
+    want[:, : new.shape[1]] = new
+    got = out["sequences"].cpu().numpy()
+    assert np.array_equal(got, want), (got, want)
+    lg = out["logits"].cpu()
+    rl = torch.stack(ref["logits"], 0)                              # [steps, B, V]
+    for b in range(B):
+        n = int((new[b] == a.eos).argmax()) + 1 if (new[b] == a.eos).any() else new.shape[1]
+        err = (lg[:n, b] - rl[:n, b]).abs().max().item()
+        assert err < 1e-3, (b, err)
+    eng.close()
