@@ -150,17 +150,11 @@ def timed_steps(eng, px, L, steps, warmup, world, gather, beams=1):
         for out in outs:
             res = gather(out["sequences"], out["lengths"])
         return res
+    from embodied_captioning_amd.distributed import timed_region
     run(max(warmup, len(pool)) if pool is not None else warmup)       # every engine of a pool runs once untimed
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
     with PowerSampler(torch.cuda.current_device()) as ps:
-        t0 = time.perf_counter()
-        res = run(steps)
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        dt = time.perf_counter() - t0
+        # barrier + synchronise, the K steps, synchronise + barrier, MAX over ranks (distributed.timed_region)
+        dt, res = timed_region(lambda: run(steps), world, torch.device("cuda", torch.cuda.current_device()))
     timed_steps.power = ps
     return dt, res
 
@@ -669,7 +663,7 @@ def latency_block(arch, sd, dev, dtype, L, batches=(1, 8, 64), reps=7):
 def main_strong(a, arch, sd, dev, rank, world):
     """Strong scaling (north_star: >= 6x at 8 GPUs; SURVEY config 4): --frames in total, contiguous shards, micro-batches of
     --batch rotating over the stream pool, ONE caption all-gather at the end, consensus grouping on rank 0's table."""
-    from embodied_captioning_amd.distributed import caption_shard, captions_frequency, group_captions, shard_range
+    from embodied_captioning_amd.distributed import shard_range, strong_scaling_job
     from embodied_captioning_amd.engine import EnginePool
     L, B = a.max_length, a.batch
     pool = EnginePool(arch, n=max(a.streams, 1), device=dev, dtype=a.dtype, max_batch=B, max_beams=1, max_len=L)
@@ -681,24 +675,11 @@ def main_strong(a, arch, sd, dev, rank, world):
         return torch.randint(0, 256, (count, arch.image_size, arch.image_size, 3), dtype=torch.uint8, device=dev, generator=gen)
 
     pool.generate_many([frames_of(0, B)] * len(pool), threads=True, max_length=L)      # warm-up: every engine once
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ids, lens = caption_shard(lambda f: pool.submit(f, max_length=L), frames_of, a.frames, B, L, arch.pad, join=pool.join)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t.item())
+    job = strong_scaling_job(lambda f: pool.submit(f, max_length=L), frames_of, a.frames, B, L, arch.pad, join=pool.join,
+                             keys_of=lambda i: (i // 500, (i // 10) % 50), device=dev,
+                             range_check=(lambda: pool.engines[0].saturations()) if a.dtype == "f32s" else None)
+    dt = job["seconds"]
     if rank == 0:
-        t1 = time.perf_counter()
-        ids_h, lens_h = ids.cpu().numpy(), lens.cpu().numpy()
-        caps = [" ".join(str(x) for x in row[1:n - 1]) for row, n in zip(ids_h, lens_h)]
-        freq = captions_frequency(group_captions([(i // 500, (i // 10) % 50) for i in range(a.frames)], caps, apply_filter=False))
         first, last, per = shard_range(a.frames, 0, world)
         S = arch.image_size
         print(json.dumps({"metric": f"captions/sec ({S}x{S}, beam=1)", "value": round(a.frames / dt, 2), "unit": "captions/s",
@@ -708,8 +689,8 @@ def main_strong(a, arch, sd, dev, rank, world):
                           "config": {"workload": f"BLIP-base encoder + greedy decode over {a.frames} frames in total, contiguous shards of "
                                                  f"{per}, micro-batches of {B} on {len(pool)} streams, one caption all-gather, consensus grouping",
                                      "global_batch": world * B, "parallelism": f"dp{world}", "streams": len(pool), "frames": a.frames},
-                          "job_s": round(dt, 3), "grouping_s": round(time.perf_counter() - t1, 3), "objects": len(freq),
-                          "mean_caption_tokens": round(float(lens_h.mean()), 2)}))
+                          "job_s": round(dt, 3), "grouping_s": round(job["grouping_s"], 3), "objects": job["objects"],
+                          "range_clamps": job.get("range_clamps"), "mean_caption_tokens": round(job["mean_caption_tokens"], 2)}))
     pool.close()
 
 
@@ -749,17 +730,8 @@ def main():
         return
     px = synthetic_pixels(B, arch.image_size, seed=0, first=rank * B).to(dev)
 
-    if world > 1:
-        ids_all = torch.empty((world * B, L), dtype=torch.int32, device=dev)
-        len_all = torch.empty((world * B,), dtype=torch.int32, device=dev)
-
-        def gather(ids, lens):
-            torch.distributed.all_gather_into_tensor(ids_all, ids)
-            torch.distributed.all_gather_into_tensor(len_all, lens)
-            return ids_all, len_all
-    else:
-        def gather(ids, lens):
-            return ids, lens
+    from embodied_captioning_amd.distributed import make_step_gather
+    gather = make_step_gather(world, B, L, dev)       # the per-step caption all-gather into buffers allocated once
 
     log(f"rank {rank}/{world}: weights + {B} frames ready, host cores usable: {host_cores()}")
     eng = CaptionerEngine(arch, dtype=a.dtype, max_batch=B, max_beams=a.beams, max_len=L, device=dev)
@@ -775,11 +747,7 @@ def main():
     decode_steps = (runner.engines[0] if a.streams > 1 else eng).last_decode_steps
     if a.streams > 1:
         runner.close()
-    log(f"timed region: {dt:.3f}s for {a.steps} steps")
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t.item())
+    log(f"timed region: {dt:.3f}s for {a.steps} steps (max over ranks)")
 
     if rank == 0:
         value = world * B * a.steps / dt

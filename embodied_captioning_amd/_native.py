@@ -30,6 +30,7 @@ class CapConfig(C.Structure):
         ("min_len", C.c_int32),
         ("q_hidden", C.c_int32), ("q_layers", C.c_int32), ("q_heads", C.c_int32), ("q_ffn", C.c_int32),
         ("q_cross_freq", C.c_int32), ("num_query_tokens", C.c_int32), ("q_eps", C.c_float),
+        ("cross_kv_fp32", C.c_int32),
     ]
 
 
@@ -55,6 +56,7 @@ _SIGNATURES = {
     "cap_last_decode_steps": (C.c_int, [C.c_void_p]),
     "cap_set_decode_path": (C.c_int, [C.c_void_p, C.c_int]),
     "cap_last_decode_path": (C.c_int, [C.c_void_p]),
+    "cap_cross_cache_kind": (C.c_int, [C.c_void_p]),
     "cap_device_bytes": (C.c_size_t, [C.c_void_p]),
     "cap_g8_saturations": (C.c_longlong, [C.c_int]),
     "cap_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

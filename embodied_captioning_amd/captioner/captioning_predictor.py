@@ -35,6 +35,33 @@ class CaptioningPredictor(_Base):
         # the pool of a wrapper (cfg.streams > 1) is attached to the engine's weight store: one load serves every replica
         return self.engine.load_state_dict(sd, strict=strict)
 
+    # ---- range of the split mode ("f32s", the wrappers' default): a GEMM input beyond +-65000 is clamped AND counted by the
+    # library (cap_g8_saturations).  The wrappers look at the counter after their FIRST call and every `range_check_every`-th
+    # call after it (each look synchronises the device), and `check_range()` can be called at the end of a job; a non-zero
+    # count is logged as an error naming the remedy, or raised when cfg.strict_range is set.  The counter is per process and
+    # GPU, not per handle: engines of one pool share it, which is the conservative side.
+    range_check_every = 256
+
+    def check_range(self, reset: bool = False) -> int:
+        eng = getattr(self, "engine", None)
+        if eng is None or getattr(eng, "dtype", None) not in ("f32s", "split", "f32_split"):
+            return 0
+        n = eng.saturations(reset=reset)
+        if n:
+            msg = (f"{n} GEMM-input values left the range of dtype 'f32s' (|x| > 65000) and were clamped: captions of this "
+                   f"checkpoint are NOT fp32-grade in this mode - use dtype 'f32' (exact) or 'bf16' (INTEGRATION.md 6a)")
+            if getattr(self, "strict_range", False):
+                raise RuntimeError(msg)
+            import logging
+            logging.getLogger(__name__).error(msg)
+        return n
+
+    def _range_tick(self) -> None:
+        k = getattr(self, "_range_calls", 0)
+        self._range_calls = k + 1
+        if k == 0 or (k + 1) % self.range_check_every == 0:
+            self.check_range()
+
     def pre_process_input(self, inputs):
         pass
 

@@ -67,12 +67,14 @@ class BLIP(CaptioningPredictor):
             sd.update(over)
             logger.info("Captioner model checkpoint loaded successfully from %s", cfg.checkpoint_name)
         self.engine = CaptionerEngine(self.arch, dtype=dtype, max_batch=self.batch_size, max_beams=self.num_beams,
-                                      max_len=self.max_length, device=self._device)
+                                      max_len=self.max_length, device=self._device,
+                                      cross_cache=getattr(cfg, "cross_cache", None) or "auto")
         # HF generate stops once every caption has its EOS; look every few steps (cfg early_exit_poll, 0 = never)
         poll = getattr(cfg, "early_exit_poll", None)
         poll = 4 if poll is None else int(poll)
         self.engine.set_early_exit(poll)
         self.engine.load_state_dict(sd)
+        self.strict_range = bool(getattr(cfg, "strict_range", False))
         # cfg.streams > 1: micro-batches of one generate_batch call rotate over that many engines / HIP streams and overlap
         # (engine.EnginePool; same captions; one arena per engine, ONE copy of the weights: the pool's engines attach to
         # this engine's weight store)
@@ -81,7 +83,8 @@ class BLIP(CaptioningPredictor):
         if n_streams > 1:
             from ....engine import EnginePool
             self.pool = EnginePool(self.arch, n=n_streams, device=self._device, dtype=dtype, max_batch=self.batch_size,
-                                   max_beams=getattr(self, "num_beams", 1), max_len=self.engine.max_len, weights_of=self.engine)
+                                   max_beams=getattr(self, "num_beams", 1), max_len=self.engine.max_len, weights_of=self.engine,
+                                   cross_cache=self.engine.cross_cache)
             self.pool.set_early_exit(poll)
 
     # nn.Module surface the callers use; weights live in the engine, so .to() only re-targets host-side tensors
@@ -149,6 +152,7 @@ class BLIP(CaptioningPredictor):
                 logits.append(out["logits"])
         seq = torch.cat(seqs).cpu()
         ln = torch.cat(lens).cpu()
+        self._range_tick()
         for r, n in zip(seq.tolist(), ln.tolist()):
             texts.append(self.decode(r[:n]))
         res = {"texts": texts, "sequences": seq, "lengths": ln}
@@ -165,6 +169,7 @@ class BLIP(CaptioningPredictor):
                                    output_logits=True)
         n = int(out["lengths"][0])
         ids = out["sequences"][0, :n].tolist()
+        self._range_tick()
         # new objects every call: callers keep references to outputs["logits"] across calls
         # (reference generate_pseudo_caption_from_file.py:152)
         self.outputs = {"text": self.decode(ids),

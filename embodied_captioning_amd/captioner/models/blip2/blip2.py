@@ -137,11 +137,12 @@ class BLIP2(BLIP):
         # name) overrides that.  The plugin's `max_length` key is BLIP's / CoCa's TOTAL length and is not read here.
         self.max_length = int(getattr(cfg, "max_new_tokens", 0) or self.arch.max_new_tokens)
         self.engine = CaptionerEngine(self.arch, dtype=dtype, max_batch=self.batch_size, max_beams=1, max_len=self.max_length,
-                                      device=self._device)
+                                      device=self._device, cross_cache=getattr(cfg, "cross_cache", None) or "auto")
         # HF generate stops once every caption has its EOS; look every few steps (cfg early_exit_poll, 0 = never)
         poll = getattr(cfg, "early_exit_poll", None)
         self.engine.set_early_exit(4 if poll is None else int(poll))
         self.engine.load_state_dict(sd)
+        self.strict_range = bool(getattr(cfg, "strict_range", False))
 
     def decode(self, ids: Sequence[int]) -> str:
         if not hasattr(self.arch, "num_query_tokens"):
@@ -159,6 +160,7 @@ class BLIP2(BLIP):
         px = self.preprocess(inputs)[:1]
         out = self.engine.generate(px.to(self._device), max_length=self.max_length, output_logits=True)
         n = int(out["lengths"][0])
+        self._range_tick()
         # HF's `logits` tuple has one entry per generated token; new objects every call (callers keep references)
         self.outputs = {"text": self.decode(out["sequences"][0, :n].tolist()), "logits": tuple(out["logits"][t] for t in range(n))}
         return self.outputs

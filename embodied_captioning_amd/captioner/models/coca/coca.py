@@ -85,11 +85,13 @@ class CoCa(CaptioningPredictor):
                 logger.warning("no CLIP BPE vocabulary (vocab.json / merges.txt / bpe_simple_vocab_16e6.txt.gz) next to the "
                                "checkpoint and open_clip is not installed: captions are returned as space-separated token ids")
         self.engine = CaptionerEngine(self.arch, dtype=dtype, max_batch=self.batch_size, max_beams=self.num_beams,
-                                      max_len=self.arch.seq_len, device=self._device)
+                                      max_len=self.arch.seq_len, device=self._device,
+                                      cross_cache=getattr(cfg, "cross_cache", None) or "auto")
         # HF generate stops once every caption has its EOS; look every few steps (cfg early_exit_poll, 0 = never)
         poll = getattr(cfg, "early_exit_poll", None)
         self.engine.set_early_exit(4 if poll is None else int(poll))
         self.engine.load_state_dict(sd)
+        self.strict_range = bool(getattr(cfg, "strict_range", False))
 
     @property
     def device(self):
@@ -166,6 +168,7 @@ class CoCa(CaptioningPredictor):
                                        num_beam_groups=self.num_beam_groups)
             seqs.append(out["sequences"]); lens.append(out["lengths"])
         seq, ln = torch.cat(seqs).cpu(), torch.cat(lens).cpu()
+        self._range_tick()
         return {"texts": [self.decode(r[:n]) for r, n in zip(seq.tolist(), ln.tolist())], "sequences": seq, "lengths": ln}
 
     @torch.no_grad()
@@ -175,6 +178,7 @@ class CoCa(CaptioningPredictor):
         out = self.engine.generate(px.to(self._device), max_length=a.seq_len, output_logits=True)
         n = int(out["lengths"][0])
         ids = out["sequences"][0, :n].tolist()
+        self._range_tick()
         steps: List[torch.Tensor] = []
         for t in range(n - 1):                       # one entry per generated token, like the reference's loop
             lg = out["logits"][t].clone()

@@ -23,7 +23,7 @@ class CaptionerField:
                  num_beams=1, max_length=20, dtype=None, batch_size=8, device="cuda:0", image_size=None, streams=1,
                  early_exit_poll=None, max_new_tokens=None, num_beam_groups=None, tokenizer_dir=None,
                  generation_type=None, top_k=None, top_p=None, temperature=None, repetition_penalty=None,
-                 load_in_8bit=None, load_in_4bit=None, torch_dtype=None):
+                 load_in_8bit=None, load_in_4bit=None, torch_dtype=None, cross_cache=None, strict_range=False):
         self.arch_name = arch_name
         self.model_name = model_name
         self.checkpoint_name = checkpoint_name
@@ -52,3 +52,7 @@ class CaptionerField:
         self.load_in_8bit = load_in_8bit
         self.load_in_4bit = load_in_4bit
         self.torch_dtype = torch_dtype
+        # "f32s" only: cross_cache "fp32" keeps fp32 rows in the cross-attention K/V cache instead of KV16 (None / "auto": KV16);
+        # strict_range: a value that leaves the mode's range (clamped and counted by the library) raises instead of being logged
+        self.cross_cache = cross_cache
+        self.strict_range = strict_range

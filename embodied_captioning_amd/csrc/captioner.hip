@@ -1530,7 +1530,8 @@ static int create_impl(const CapConfig* cfg, Captioner* share, CapHandle* out) {
     const int g = text_only ? 0 : cfg->image_size / cfg->patch_size;
     // (the KV16 layout is read by the chunked cross-attention kernels: more than 32 keys per image - every real geometry; the
     // fixture-sized ones keep fp32 rows)
-    m->kv16 = m->gdt == CAP_DT_G8 && ((cfg->arch == CAP_ARCH_BLIP && g * g + 1 > 32) || (cfg->arch == CAP_ARCH_COCA && cfg->pool_queries - 1 > 32));
+    m->kv16 = m->gdt == CAP_DT_G8 && !cfg->cross_kv_fp32 &&
+              ((cfg->arch == CAP_ARCH_BLIP && g * g + 1 > 32) || (cfg->arch == CAP_ARCH_COCA && cfg->pool_queries - 1 > 32));
     m->kvrow = m->kv16 ? 132 : 64 * m->esz;
     m->P = g * g; m->NT = m->P + 1;
     m->Kpatch = text_only ? 0 : 3 * cfg->patch_size * cfg->patch_size;
@@ -1588,6 +1589,11 @@ int cap_set_decode_path(CapHandle h, int path) {
     return 0;
 }
 int cap_last_decode_path(CapHandle h) { return h ? ((Captioner*)h)->last_path : -1; }
+int cap_cross_cache_kind(CapHandle h) {
+    const Captioner* m = (const Captioner*)h;
+    if (!m) return -1;
+    return m->kv16 ? 2 : (m->dt == CAP_DT_BF16 ? 1 : 0);
+}
 
 size_t cap_device_bytes(CapHandle h) { return h ? ((Captioner*)h)->dev_bytes : 0; }
 

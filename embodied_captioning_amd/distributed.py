@@ -67,6 +67,82 @@ def gather_caption_records(ids: torch.Tensor, lens: torch.Tensor, n_pad: int, pa
     return ids_all, lens_all
 
 
+def _sync(device) -> None:
+    if device is not None and torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def make_step_gather(world: int, rows: int, max_len: int, device) -> Callable[[torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]:
+    """The per-step collective of the weak-scaling bench: every rank contributes `rows` caption records (ids int32 [rows,
+    max_len], lens int32 [rows]) and receives all world * rows of them, rank-major, in buffers allocated ONCE here (no
+    allocation inside the timed region).  world == 1: the records themselves.  Reference analogue: train_helpers.py:218-246."""
+    if world <= 1:
+        return lambda ids, lens: (ids, lens)
+    ids_all = torch.empty((world * rows, max_len), dtype=torch.int32, device=device)
+    len_all = torch.empty((world * rows,), dtype=torch.int32, device=device)
+
+    def gather(ids: torch.Tensor, lens: torch.Tensor):
+        if tuple(ids.shape) != (rows, max_len) or tuple(lens.shape) != (rows,):
+            raise ValueError(f"step gather was built for [{rows}, {max_len}] records, got {tuple(ids.shape)} / {tuple(lens.shape)}")
+        dist.all_gather_into_tensor(ids_all, ids.contiguous())
+        dist.all_gather_into_tensor(len_all, lens.contiguous())
+        return ids_all, len_all
+    return gather
+
+
+def timed_region(run: Callable[[], object], world: int, device=None):
+    """The bench contract's bracket: barrier + device synchronise, `run()`, device synchronise + barrier, wall time; then the
+    MAX over ranks (one all-reduce) - every rank returns (seconds of the slowest rank, run()'s result)."""
+    import time
+    if world > 1:
+        dist.barrier()
+    _sync(device)
+    t0 = time.perf_counter()
+    res = run()
+    _sync(device)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, res
+
+
+def strong_scaling_job(submit: Callable[[torch.Tensor], Dict[str, torch.Tensor]], frames_of: Callable[[int, int], torch.Tensor],
+                       n_frames: int, micro_batch: int, max_len: int, pad_id: int = 0, join: Callable[[], None] | None = None,
+                       keys_of: Callable[[int], Tuple[int, int]] | None = None, detokenise: Callable[[Sequence[int]], str] | None = None,
+                       device=None, range_check: Callable[[], int] | None = None) -> Dict[str, object]:
+    """SURVEY config 4 / north_star's strong-scaling shape as ONE function: a FIXED total of frames, contiguous shards
+    (`caption_shard`), ONE caption all-gather at the end, then - on rank 0 - the consensus grouping of the gathered table
+    (`group_captions` / `captions_frequency` under the key `keys_of(frame index)`).  Timed with `timed_region` (max over ranks).
+    Returns {"seconds", "ids", "lens"} on every rank, plus {"grouping_s", "objects", "frequencies", "mean_caption_tokens"} on
+    rank 0.  `range_check` (optional, e.g. engine.saturations): called after the job; a non-zero count is reported under
+    "range_clamps" and warned about (split mode: values clamped to its range)."""
+    import time
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    dt, (ids, lens) = timed_region(lambda: caption_shard(submit, frames_of, n_frames, micro_batch, max_len, pad_id, join=join), world, device)
+    out: Dict[str, object] = {"seconds": dt, "ids": ids, "lens": lens}
+    if range_check is not None:
+        n = int(range_check())
+        out["range_clamps"] = n
+        if n:
+            import warnings
+            warnings.warn(f"strong_scaling_job: {n} GEMM-input values were clamped to the split mode's range (|x| > 65000)")
+    if rank == 0:
+        t1 = time.perf_counter()
+        ids_h, lens_h = ids.cpu().numpy(), lens.cpu().numpy()
+        detok = detokenise or (lambda row: " ".join(str(int(x)) for x in row))
+        caps = [detok(row[1:max(int(n) - 1, 1)]) for row, n in zip(ids_h, lens_h)]
+        keys = [keys_of(i) for i in range(n_frames)] if keys_of is not None else [(0, i) for i in range(n_frames)]
+        freq = captions_frequency(group_captions(keys, caps, apply_filter=False))
+        out.update(grouping_s=time.perf_counter() - t1, objects=len(freq), frequencies=freq,
+                   mean_caption_tokens=float(lens_h.mean()) if len(lens_h) else 0.0)
+    return out
+
+
 def _fp_hash(fingerprint: str) -> str:
     import hashlib
     return hashlib.sha256(fingerprint.encode()).hexdigest()[:12]

@@ -31,8 +31,12 @@ class CaptionerEngine:
     """One handle = one model replica on one GPU, bound to torch's current stream of `device` at each call."""
 
     def __init__(self, arch: BlipArch, dtype: str = "bf16", max_batch: int = 8, max_beams: int = 1,
-                 max_len: int = 20, device: str | torch.device = "cuda:0", share_weights_with: "CaptionerEngine | None" = None):
-        """share_weights_with: an engine of the same model / dtype / GPU whose (read-only) weights this one uses instead of
+                 max_len: int = 20, device: str | torch.device = "cuda:0", share_weights_with: "CaptionerEngine | None" = None,
+                 cross_cache: str = "auto"):
+        """cross_cache: "auto" = the mode's own cross-attention K/V cache ("f32s": KV16 - int16 + one scale per 64-wide head row,
+        the decode side's HBM stream at half the bytes; "bf16": bf16 rows; "f32": fp32 rows); "fp32" = fp32 rows in "f32s" too
+        (`cross_cache_kind` tells what the handle uses).
+        share_weights_with: an engine of the same model / dtype / GPU whose (read-only) weights this one uses instead of
         holding a copy - it gets its own arena only (cap_create_shared); load_state_dict through either is seen by both."""
         if not torch.cuda.is_available():
             raise N.CaptionerHipError("CaptionerEngine needs a GPU (torch.cuda.is_available() is False); "
@@ -74,6 +78,10 @@ class CaptionerEngine:
             cfg.vocab, cfg.max_pos, cfg.t_eps = arch.vocab, arch.max_pos, arch.t_eps
             cfg.bos, cfg.eos, cfg.pad = arch.bos, arch.eos, arch.pad
         cfg.max_batch, cfg.max_beams, cfg.max_len = max_batch, max_beams, max_len
+        if cross_cache not in ("auto", "fp32"):
+            raise ValueError(f"cross_cache must be 'auto' or 'fp32', got {cross_cache!r}")
+        cfg.cross_kv_fp32 = int(cross_cache == "fp32")
+        self.cross_cache = cross_cache
         for i in range(3):
             cfg.pix_mean[i] = OPENAI_CLIP_MEAN[i]
             cfg.pix_std[i] = OPENAI_CLIP_STD[i]
@@ -120,6 +128,11 @@ class CaptionerEngine:
     @property
     def last_decode_steps(self) -> int:
         return int(self.lib.cap_last_decode_steps(self._h))
+
+    @property
+    def cross_cache_kind(self) -> str:
+        """Layout of this handle's cross-attention K/V cache: "fp32", "bf16" or "kv16"."""
+        return {0: "fp32", 1: "bf16", 2: "kv16"}[int(self.lib.cap_cross_cache_kind(self._h))]
 
     DECODE_PATHS = {"auto": 0, "batch": 1, "small": 2}
 

@@ -44,9 +44,12 @@ enum { CAP_ARCH_BLIP = 0, CAP_ARCH_COCA = 1, CAP_ARCH_MINILM = 2, CAP_ARCH_BLIP2
  *   CAP_BF16       bf16 operands on the bf16 MFMA pipe - fastest, but not token-identical to an fp32 reference
  *   CAP_F32_SPLIT  fp32 values carried into every GEMM as two fp16 halves (hi + lo = x to 2^-23), each product formed as
  *                  hi.hi + hi.lo + lo.hi on the fp16 MFMA pipe: products good to ~2^-21 (fp32: 2^-24, bf16: 2^-9) at 3/16
- *                  of the fp32 pipe's cost; LayerNorm, softmax, attention, residual stream and K/V caches are fp32 as in
- *                  CAP_F32.  Token-identical to the fp32 reference on every golden fixture; the default of the plugin and
- *                  of bench.py.  Every captioner architecture (BLIP, BLIP-2, CoCa); not the sentence encoder.  The mode has a
+ *                  of the fp32 pipe's cost; LayerNorm, softmax, attention, residual stream and the self-attention K/V cache are
+ *                  fp32 as in CAP_F32.  The CROSS-attention K/V cache (the decode side's HBM stream) is KV16 - per token and
+ *                  head 64 int16 and one fp32 scale, 15 value bits relative to the row's largest element - whenever an image has
+ *                  more than 32 tokens (every real BLIP / CoCa geometry); CapConfig.cross_kv_fp32 = 1 keeps fp32 rows instead
+ *                  (1.9x the bytes), cap_cross_cache_kind() reports what a handle uses.  Token-identical to the fp32 reference
+ *                  on every golden fixture; the default of the plugin and of bench.py.  Every captioner architecture (BLIP, BLIP-2, CoCa); not the sentence encoder.  The mode has a
  *                  finite range - see cap_g8_saturations. */
 enum { CAP_F32 = 0, CAP_BF16 = 1, CAP_F32_SPLIT = 2 };
 enum { CAP_PIX_F32_NCHW = 0, CAP_PIX_U8_NHWC = 1 }; /* normalised fp32 [B,3,H,W] | raw RGB uint8 [B,H,W,3] */
@@ -77,6 +80,9 @@ typedef struct CapConfig {
      * bos/eos/pad = OPT ids as generate() uses them. */
     int32_t q_hidden, q_layers, q_heads, q_ffn, q_cross_freq, num_query_tokens;
     float q_eps;
+    /* CAP_F32_SPLIT only: 1 = the cross-attention K/V cache keeps fp32 rows (as CAP_F32 does) instead of KV16.  0 (default): KV16
+     * for images of more than 32 tokens.  Ignored by the other modes (bf16 rows / fp32 rows). */
+    int32_t cross_kv_fp32;
 } CapConfig;
 
 const char* cap_last_error(void);
@@ -125,6 +131,9 @@ int cap_last_decode_steps(CapHandle h);
 int cap_set_decode_path(CapHandle h, int path);
 /* 1 = batch kernels, 2 = small-batch kernels: what the last decode step of the last cap_generate ran on (0 before any). */
 int cap_last_decode_path(CapHandle h);
+/* Layout of the handle's cross-attention K/V cache: 0 = fp32 rows, 1 = bf16 rows, 2 = KV16 (int16 + one fp32 scale per 64-wide
+ * head row; CAP_F32_SPLIT unless CapConfig.cross_kv_fp32).  -1 for a null handle. */
+int cap_cross_cache_kind(CapHandle h);
 
 /* Object crops of one frame, resized for the captioner ON THE DEVICE, bit-exact with Pillow's
  * `Image.crop(box).resize((S, S), Image.BICUBIC)` - what the reference does to every detected box on the host before the

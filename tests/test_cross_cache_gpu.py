@@ -1,0 +1,79 @@
+"""GPU: the split mode's cross-attention K/V cache (KV16: 64 int16 + one fp32 scale per head row) against the SAME engine with
+fp32 rows (`cross_cache="fp32"`, CapConfig.cross_kv_fp32) at the production geometries whose caches the tiny fixtures never
+build: BLIP at 384 px (577 image tokens - what the published checkpoints ship) and CoCa ViT-L/14 (255 pooled tokens), plain
+weights and weights whose key / value heads carry OUTLIER dimensions (x30: the block-scaled format's hard case - the row's other
+62 dimensions are quantised 30 times more coarsely).  Stated bound: every live step's logits within 1e-3 of the fp32-cache
+engine (the parity bar of north_star), tokens identical.  Reference arithmetic: HF modeling_blip_text.py:130-198 (fp32 K/V)."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from _families import _rng, cross_kv_outliers
+
+pytestmark = pytest.mark.gpu
+BOUND = 1e-3
+
+
+def _compare(arch, sd, px, L, beams=1):
+    from embodied_captioning_amd.engine import CaptionerEngine
+    outs = {}
+    for cc, kind in (("auto", "kv16"), ("fp32", "fp32")):
+        eng = CaptionerEngine(arch, dtype="f32s", max_batch=px.shape[0], max_beams=beams, max_len=L, cross_cache=cc)
+        assert eng.cross_cache_kind == kind
+        eng.load_state_dict(sd)
+        eng.saturations(reset=True)
+        outs[kind] = eng.generate(px.cuda(), num_beams=1, max_length=L, output_logits=True)
+        assert eng.saturations(reset=True) == 0
+        eng.close()
+    a, b = outs["kv16"], outs["fp32"]
+    assert torch.equal(a["sequences"], b["sequences"])
+    seq = a["sequences"].cpu().numpy()
+    steps = a["logits"].shape[0]
+    err = 0.0
+    for r in range(seq.shape[0]):
+        row = list(seq[r, 1:])
+        n = min(row.index(arch.eos) + 1 if arch.eos in row else steps, steps)
+        err = max(err, float((a["logits"][:n, r] - b["logits"][:n, r]).abs().max()))
+    return err
+
+
+@pytest.mark.parametrize("family", ["gaussian", "outlier_heads"])
+def test_blip_384px_kv16_cache_against_fp32_rows(family):
+    from embodied_captioning_amd.config import BlipArch
+    from embodied_captioning_amd.weights import procedural_blip_state_dict, synthetic_pixels
+    arch = BlipArch()
+    arch.image_size = 384
+    assert arch.n_tokens == 577
+    sd = procedural_blip_state_dict(arch, 0, eos_boost=5.0)
+    if family == "outlier_heads":
+        sd = cross_kv_outliers(sd, arch, 8)
+    px = synthetic_pixels(4, arch.image_size, seed=31)
+    err = _compare(arch, sd, px, 20)
+    assert err < BOUND, err
+
+
+@pytest.mark.parametrize("family", ["gaussian", "outlier_heads"])
+def test_coca_vit_l14_kv16_cache_against_fp32_rows_unpinned(family):
+    """CoCa's cross-attention reads the 255 pooled image tokens (Q - 1); parity of the CoCa path itself is unpinned (no open_clip
+    offline) - this test compares the library's two cache layouts with each other, which needs no oracle."""
+    from embodied_captioning_amd.config import CocaArch
+    from embodied_captioning_amd.weights import procedural_coca_state_dict, synthetic_pixels
+    arch = CocaArch()
+    assert arch.pool_queries - 1 == 255
+    sd = procedural_coca_state_dict(arch, 2)
+    if family == "outlier_heads":
+        sd = dict(sd)
+        E = arch.embed_dim
+        r = _rng(9, "coca-kvout")
+        for i in range(arch.mm_layers):
+            for key in (f"text_decoder.cross_attn.{i}.attn.in_proj_weight", f"text_decoder.cross_attn.{i}.attn.in_proj_bias"):
+                v = sd[key].clone()
+                m = torch.ones(v.shape[0])
+                for h in range(2 * E // 64):                 # the k and v rows (E .. 3E), 64-wide heads
+                    m[E + h * 64 + torch.from_numpy(r.choice(64, size=2, replace=False))] = 30.0
+                sd[key] = v * (m[:, None] if v.dim() == 2 else m)
+    px = synthetic_pixels(2, arch.image_size, seed=33)
+    err = _compare(arch, sd, px, arch.seq_len)
+    assert err < BOUND, err

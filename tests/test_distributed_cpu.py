@@ -139,3 +139,70 @@ def test_caption_shard_resume_ignores_records_of_another_job(tmp_path):
     with pytest.raises(RuntimeError, match="not written by this job"):
         D.caption_shard(make(5), frames_of, 10, micro_batch=4, max_len=L, resume_dir=d, record_every=1, fingerprint=fb)
     assert np.load(os.path.join(d, name_b))["fingerprint"] == fa
+
+
+def _bench_worker(rank, world, port, n_frames, q):
+    """What bench.py's N > 1 branches run, on gloo with a fake captioner: the per-step gather into buffers allocated once, the
+    timed bracket with its max-over-ranks all-reduce, and the strong-scaling job (shards, one gather, grouping on rank 0)."""
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from embodied_captioning_amd import distributed as D
+    B, L = 5, 6
+
+    def generate(frames):
+        ids = torch.stack([(frames * 7 + j) % 1000 for j in range(L)], dim=1).int()
+        return {"sequences": ids, "lengths": (frames % (L - 1) + 2).int()}
+
+    # weak scaling: every rank captions its own B frames per step, one all-gather per step
+    gather = D.make_step_gather(world, B, L, "cpu")
+    mine = torch.arange(rank * B, rank * B + B, dtype=torch.int32)
+
+    def steps():
+        for _ in range(3):
+            out = generate(mine)
+            res = gather(out["sequences"], out["lengths"])
+        time.sleep(0.05 * (rank + 1))                     # ranks finish at different times: everyone must report the slowest
+        return res
+    dt, (ids_all, len_all) = D.timed_region(steps, world, None)
+    want = generate(torch.arange(world * B, dtype=torch.int32))
+    assert torch.equal(ids_all, want["sequences"]) and torch.equal(len_all, want["lengths"])
+    assert dt >= 0.05 * world
+    try:
+        gather(want["sequences"], want["lengths"])           # a record block of another shape is refused, not mis-gathered
+        raise AssertionError("shape check missing")
+    except ValueError:
+        pass
+    # strong scaling: a fixed total of frames
+    clamps = []
+    job = D.strong_scaling_job(generate, lambda first, n: torch.arange(first, first + n, dtype=torch.int32), n_frames, micro_batch=4,
+                               max_len=L, keys_of=lambda i: (i // 6, i % 3), range_check=lambda: clamps.append(1) or 0)
+    assert clamps == [1] and job["range_clamps"] == 0
+    q.put((rank, dt, job["seconds"], job["ids"].clone(), job["lens"].clone(), job.get("objects"), job.get("frequencies")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_multi_rank_paths_world2():
+    n_frames = 13
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    frames = torch.arange(n_frames, dtype=torch.int32)
+    want_ids = torch.stack([(frames * 7 + j) % 1000 for j in range(6)], dim=1).int()
+    want_len = (frames % 5 + 2).int()
+    (r0, dt0, job0, ids0, lens0, objects, freq), (r1, dt1, job1, ids1, lens1, obj1, freq1) = res
+    assert dt0 == dt1 and job0 == job1                       # the max over ranks, on every rank
+    for ids, lens in ((ids0, lens0), (ids1, lens1)):
+        assert torch.equal(ids, want_ids) and torch.equal(lens, want_len)
+    assert obj1 is None and freq1 is None                    # grouping runs on rank 0 only
+    keys = {(i // 6, i % 3) for i in range(n_frames)}
+    assert objects == len(keys) and set(freq) == keys
+    assert sum(n for fl in freq.values() for n, _ in fl) == n_frames

@@ -77,6 +77,20 @@ int main(void) {
     EXPECT(cap_op_gemm(CAP_F32, w, w, NULL, NULL, w, 64, 62, 64, 0, 1, 3, NULL) != 0);
     EXPECT(cap_op_gemm(CAP_F32_SPLIT, w, w, NULL, NULL, w, 64, 68, 96, 0, 0, 0, NULL) != 0);
     EXPECT(cap_op_gemm(CAP_BF16, w, w, NULL, NULL, w, 0, 64, 64, 0, 1, 0, NULL) != 0);
+    /* round 3 / 4 entry points: bad shapes and null handles are refused before any HIP call */
+    EXPECT(cap_op_gemm_partial(CAP_F32_SPLIT, w, w, w, 64, 64, 96, 4, 6, NULL) != 0);        /* K not a multiple of 4 slabs */
+    EXPECT(cap_op_gemm_partial(CAP_BF16, w, w, w, 64, 62, 128, 1, 6, NULL) != 0);            /* N % 4 */
+    EXPECT(cap_op_gemm_crosskv(CAP_F32_SPLIT, w, w, NULL, w, 1, 40, 1, 1, 48, 1, NULL) != 0);  /* K below two stages: no KV16 epilogue */
+    EXPECT(cap_op_gemm_crosskv(CAP_F32, w, w, NULL, w, 1, 40, 1, 1, 64, 1, NULL) != 0);      /* KV16 needs G8 operands */
+    EXPECT(cap_set_decode_path(NULL, 0) != 0);
+    EXPECT(cap_last_decode_path(NULL) == -1);
+    EXPECT(cap_cross_cache_kind(NULL) == -1);
+    {
+        long long sat = cap_g8_saturations(0);                                                /* no GPU: a clean error, or a count */
+        EXPECT(sat >= -1);
+        int rcp = cap_op_pack_kv16(w, w, 0, NULL);                                            /* zero rows: nothing to launch */
+        EXPECT(rcp == 0 || strlen(cap_last_error()) > 0);
+    }
     printf(failures ? "asan host check: %d FAILED\n" : "asan host check: all calls returned cleanly (%d failures)\n", failures);
     return failures ? 1 : 0;
 }
