@@ -62,6 +62,24 @@ class CaptioningPredictor(_Base):
         if k == 0 or (k + 1) % self.range_check_every == 0:
             self.check_range()
 
+    @staticmethod
+    def _cross_cache_for(cfg, sd, dtype) -> str:
+        """The engine's cross-attention cache layout: cfg.cross_cache when given; otherwise "auto" (split mode: KV16) unless the
+        checkpoint's key / value heads have outlier dimensions beyond what KV16 holds the parity bar for - then fp32 rows."""
+        asked = getattr(cfg, "cross_cache", None)
+        if asked:
+            return asked
+        if dtype in ("f32s", "split", "f32_split"):
+            from ..weights import KV16_MAX_HEAD_SPREAD, cross_kv_head_spread
+            sp = cross_kv_head_spread(sd)
+            if sp > KV16_MAX_HEAD_SPREAD:
+                import logging
+                logging.getLogger(__name__).warning(
+                    "cross-attention K/V heads of this checkpoint spread %.1fx around their median: keeping fp32 rows in the cross "
+                    "cache instead of KV16 (1.9x the decode side's K/V bytes)", sp)
+                return "fp32"
+        return "auto"
+
     def pre_process_input(self, inputs):
         pass
 

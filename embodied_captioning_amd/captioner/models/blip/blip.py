@@ -68,7 +68,7 @@ class BLIP(CaptioningPredictor):
             logger.info("Captioner model checkpoint loaded successfully from %s", cfg.checkpoint_name)
         self.engine = CaptionerEngine(self.arch, dtype=dtype, max_batch=self.batch_size, max_beams=self.num_beams,
                                       max_len=self.max_length, device=self._device,
-                                      cross_cache=getattr(cfg, "cross_cache", None) or "auto")
+                                      cross_cache=self._cross_cache_for(cfg, sd, dtype))
         # HF generate stops once every caption has its EOS; look every few steps (cfg early_exit_poll, 0 = never)
         poll = getattr(cfg, "early_exit_poll", None)
         poll = 4 if poll is None else int(poll)

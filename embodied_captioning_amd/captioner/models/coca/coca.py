@@ -86,7 +86,7 @@ class CoCa(CaptioningPredictor):
                                "checkpoint and open_clip is not installed: captions are returned as space-separated token ids")
         self.engine = CaptionerEngine(self.arch, dtype=dtype, max_batch=self.batch_size, max_beams=self.num_beams,
                                       max_len=self.arch.seq_len, device=self._device,
-                                      cross_cache=getattr(cfg, "cross_cache", None) or "auto")
+                                      cross_cache=self._cross_cache_for(cfg, sd, dtype))
         # HF generate stops once every caption has its EOS; look every few steps (cfg early_exit_poll, 0 = never)
         poll = getattr(cfg, "early_exit_poll", None)
         self.engine.set_early_exit(4 if poll is None else int(poll))

@@ -166,6 +166,18 @@ class CaptionerEngine:
             raise N.CaptionerHipError(f"state dict lacks {e}: this architecture derives tensors from the checkpoint at load "
                                       f"and needs the complete dict (keys with a 'model.' / 'module.' prefix? see "
                                       f"weights.strip_wrapper_prefixes)") from e
+        # the KV16 cross-attention cache has ONE scale per 64-wide head row: a checkpoint whose key / value heads carry outlier
+        # dimensions is refused here (measured bound: weights.KV16_MAX_HEAD_SPREAD), never served with coarser logits
+        if not getattr(self, "_skip_kv16_guard", False) and hasattr(self.lib, "cap_cross_cache_kind") \
+                and not isinstance(self, TextEncoderEngine) and self.cross_cache_kind == "kv16":
+            from .weights import KV16_MAX_HEAD_SPREAD, cross_kv_head_spread
+            spread = cross_kv_head_spread(sd)
+            if spread > KV16_MAX_HEAD_SPREAD:
+                raise N.CaptionerHipError(
+                    f"the cross-attention key / value heads of this checkpoint have dimensions {spread:.1f}x their head's median "
+                    f"magnitude; the split mode's KV16 cache (one scale per 64-wide head row) holds the 1e-3 logit bar up to "
+                    f"{KV16_MAX_HEAD_SPREAD:.0f}x - create the engine with cross_cache='fp32' (captioner.cross_cache: fp32; the "
+                    f"wrappers choose it themselves), or use dtype 'f32' / 'bf16'")
         matched, unknown = 0, []
         with torch.cuda.device(self.device):
             s = _stream_ptr(self.device)

@@ -349,6 +349,46 @@ def load_state_dict_file(path: str) -> Dict[str, torch.Tensor]:
     return _strip_prefixes(sd, ("module.",))
 
 
+# Largest spread of the 64 dimensions of one cross-attention key / value head that the KV16 cache (int16 + ONE scale per head row)
+# takes: measured on the GPU with two dimensions per head `factor` times the others (tests/probe_kv16_outliers.py,
+# profiles/r04_kv16_outlier_probe.txt), the logits move by 1.5e-4 at factor 8, 3.0e-4 at 12, 5.4e-4 at 16 and 2.3e-3 at 30 against
+# the same engine with fp32 rows - the parity bar is 1e-3.  Beyond this spread the cache must keep fp32 rows (cross_cache="fp32").
+KV16_MAX_HEAD_SPREAD = 12.0
+
+
+def cross_kv_head_spread(sd: Dict[str, torch.Tensor]) -> float:
+    """max over the key / value heads of every cross-attention layer of (largest / median) magnitude of the head's 64 output
+    dimensions, a dimension's magnitude being sqrt(|W row|^2 + b^2) - what its values are sized like on LayerNorm'ed inputs.
+    BLIP (`...crossattention.self.{key,value}.*`), CoCa (`text_decoder.cross_attn.<i>.attn.in_proj_*`, k and v rows, with
+    `ln_1_kv` folded in as the library does) or the library's own `derived.cross_kv.*`.  1.0 when the dict has no such tensors."""
+    mags = []
+    if "derived.cross_kv.weight" in sd:
+        w, b = sd["derived.cross_kv.weight"].float(), sd["derived.cross_kv.bias"].float()
+        mags.append((w.pow(2).sum(1) + b.pow(2)).sqrt())
+    else:
+        for k, w in sd.items():
+            if k.endswith(".weight") and (".crossattention.self.key." in k or ".crossattention.self.value." in k):
+                b = sd.get(k[:-6] + "bias")
+                w = w.float()
+                mags.append((w.pow(2).sum(1) + (b.float().pow(2) if b is not None else 0.0)).sqrt())
+            elif k.startswith("text_decoder.cross_attn.") and k.endswith(".attn.in_proj_weight"):
+                pre = k[: -len("attn.in_proj_weight")]
+                w, b = w.float(), sd[pre + "attn.in_proj_bias"].float()
+                E = w.shape[1]
+                g, beta = sd.get(pre + "ln_1_kv.weight"), sd.get(pre + "ln_1_kv.bias")
+                wkv, bkv = w[E:], b[E:]
+                if g is not None:
+                    bkv = bkv + wkv @ beta.float()
+                    wkv = wkv * g.float()[None, :]
+                mags.append((wkv.pow(2).sum(1) + bkv.pow(2)).sqrt())
+    spread = 1.0
+    for m in mags:
+        h = m.reshape(-1, 64)
+        med = h.median(dim=1).values.clamp_min(1e-30)
+        spread = max(spread, float((h.max(dim=1).values / med).max()))
+    return spread
+
+
 def _peft_pattern_value(pattern: dict, module: str, default):
     """PEFT's rank_pattern / alpha_pattern: keys are module-name suffixes or regular expressions (peft.utils.get_pattern_key)."""
     import re
