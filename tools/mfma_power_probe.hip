@@ -35,14 +35,44 @@ __global__ __launch_bounds__(512) void mfma_loop(float* out, int iters) {
     if (s == 12345.678f) out[0] = s;
 }
 
+// The same loop on v_mfma_f32_32x32x16_f16 (round 4: does the larger block - 16 MACs per operand element read from the register
+// file against 8 - sustain more under the power limit?): four 32x32 accumulators, 4 x 2 random fragments, 32768 flop per MFMA.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <bool RANDOM>
+__global__ __launch_bounds__(512) void mfma_loop_32(float* out, int iters) {
+    f16x8 a[4], b[2];
+    unsigned x = 0x9E3779B9u * (threadIdx.x + 1) + blockIdx.x;
+    for (int r = 0; r < 4; ++r)
+        for (int i = 0; i < 8; ++i) {
+            x = x * 1664525u + 1013904223u;
+            const float v = RANDOM ? ((int)(x >> 8) - (1 << 23)) * (1.0f / (1 << 23)) : 0.001f * (threadIdx.x + i);
+            a[r][i] = (_Float16)v;
+            if (r < 2) b[r][i] = (_Float16)(RANDOM ? 0.37f * v - 0.11f * (float)a[r][(i + 3) & 7] : 0.002f * (threadIdx.x - i));
+        }
+    f32x16 acc[4];
+    for (int j = 0; j < 4; ++j) acc[j] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[RANDOM ? j : 0], b[RANDOM ? (u & 1) : 0], acc[j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int j = 0; j < 4; ++j)
+        for (int e = 0; e < 16; ++e) s += acc[j][e];
+    if (s == 12345.678f) out[0] = s;
+}
+
 int main(int argc, char** argv) {
     const bool rnd = argc > 1 && argv[1][0] == 'r';
-    auto kern = rnd ? mfma_loop<true> : mfma_loop<false>;
-    printf("operands: %s\n", rnd ? "random fp16, 32 pairs" : "one constant pair");
+    const bool big = argc > 2 && argv[2][0] == '3';                    // "32": the 32x32x16 shape (same flops per iteration)
+    auto kern = big ? (rnd ? mfma_loop_32<true> : mfma_loop_32<false>) : (rnd ? mfma_loop<true> : mfma_loop<false>);
+    printf("shape: %s, operands: %s\n", big ? "v_mfma_f32_32x32x16_f16" : "v_mfma_f32_16x16x32_f16", rnd ? "random fp16" : "one constant pair");
     int n_cu = 0;
     hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, 0);
     float* out; hipMalloc(&out, 4);
-    const int iters = 20000;                                   // 32 MFMAs per iteration per wave
+    const int iters = 20000;                                   // 32 MFMAs of 16x16x32 (16 of 32x32x16) per iteration per wave: same flops
     const double flop = (double)n_cu * 8 * iters * 32 * 16384.0;
     hipLaunchKernelGGL(kern, dim3(n_cu), dim3(512), 0, 0, out, iters);
     hipDeviceSynchronize();
