@@ -443,6 +443,7 @@ int build_arena_coca(Captioner* m) {
     TRY(dev_alloc(m, (void**)&m->anc, 2 * R * Lm * 4 + 256));    // beam ancestry of the self-attention caches (beam.hip)
     TRY(dev_alloc(m, (void**)&m->dx, R * E * 4));
     TRY(dev_alloc(m, (void**)&m->dy, R * E * 4));
+    TRY(dev_alloc(m, (void**)&m->dx2, (size_t)SMALL_MAX_ROWS * E * 4));
     TRY(dev_alloc(m, (void**)&m->dpart, 12 * R * E * 4));
     TRY(dev_alloc(m, &m->dx_t, R * E * e));
     TRY(dev_alloc(m, &m->dq, R * E * e));
@@ -1171,9 +1172,9 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
 // writes the buffer the others are still reading.
 bool small_path_takes(const Captioner* m, const Dec& d, int t) {
     const CapConfig& c = m->c;
-    if (m->gdt == CAP_DT_F32 || c.arch != CAP_ARCH_BLIP || !d.dx2) return false;
+    if (m->gdt == CAP_DT_F32 || (c.arch != CAP_ARCH_BLIP && c.arch != CAP_ARCH_COCA) || !d.dx2) return false;
     if (d.R > SMALL_MAX_ROWS || t + 1 > 32) return false;
-    const int T = c.t_hidden, F = c.t_ffn, slab = m->gdt == CAP_DT_BF16 ? 64 : 32;
+    const int T = c.arch == CAP_ARCH_COCA ? m->E : c.t_hidden, F = c.t_ffn, slab = m->gdt == CAP_DT_BF16 ? 64 : 32;
     if (T > 1024 || T != c.t_heads * 64 || T % 16 != 0 || F % 16 != 0 || T % slab != 0 || F % slab != 0) return false;
     // q|k|v partial sums sit beside the [<= 4][R][T] slabs of the other GEMMs in dpart (12 R T floats): at most 2 K slices
     return decode_splitk(m, 3 * T, T, 4) <= 2;
@@ -1332,6 +1333,110 @@ int run_coca_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, int
     return 0;
 }
 
+
+// The same step for up to SMALL_MAX_ROWS rows (the reference calls CoCa with ONE crop, coca.py:27-33): 4 launches per block instead
+// of 7 - [consumer + LayerNorm] q|k|v GEMM, [self-attention] output projection, [consumer + LayerNorm] c_fc, c_proj; a
+// cross-attention block starts with the (row, head) kernel (LayerNorm, query columns, attention) instead of the first two.  CoCa
+// is pre-LN: the consumer's SUM is the new residual row (SmallLN::x_is_sum), its LayerNorm only feeds the next GEMM.  Same sums
+// as run_coca_step (tests/test_small_decode_gpu.py).
+int run_coca_step_small(Captioner* m, const Dec& d, const int* tokens, int tok_ld, int t, int K, const int* anc, int Lm, hipStream_t s) {
+    const CapConfig& c = m->c;
+    const int E = m->E, F = c.t_ffn, H = c.t_heads, R = d.R, Q = m->Q;
+    const size_t e = m->esz;
+    const int nb = (int)m->cb.size();
+    float* xb[2] = {d.dx, d.dx2};
+    int cur = 0;
+    float* qkvp = d.dpart + (size_t)4 * R * E;
+    const int S_qkv = decode_splitk(m, 3 * E, E, 4), S_ee = decode_splitk(m, E, E, 4), S_pr = decode_splitk(m, E, F, 4);
+    const int kv_kind = m->kv16 ? SMALL_KV_KV16 : (m->dt == CAP_DT_BF16 ? SMALL_KV_BF16 : SMALL_KV_F32);
+    TRY(launch_embed(m->gdt, tokens, tok_ld, t, m->tok_emb, m->tpos, m->cb[0].ln1_g, m->cb[0].ln1_b, c.t_eps, d.dx_t, nullptr, R, E, s,
+                     xb[0]));
+    SmallLN pend;
+    memset(&pend, 0, sizeof(pend));
+    auto base = [&](const void* W, int N, int Kk, int S, int pro, int epi) {
+        SmallGemm g;
+        memset(&g, 0, sizeof(g));
+        g.W = W; g.R = R; g.N = N; g.K = Kk; g.S = S; g.pro = pro; g.epi = epi; g.nchain = 4;
+        return g;
+    };
+    auto consume = [&](SmallLN ln, const float* gam, const float* bet, bool keep) {
+        ln.gamma = gam; ln.beta = bet; ln.eps = c.t_eps; ln.x_is_sum = 1;
+        ln.resid = xb[cur];
+        ln.x_out = keep ? xb[cur ^ 1] : nullptr;
+        if (keep) cur ^= 1;
+        return ln;
+    };
+    for (int bi = 0; bi < nb; ++bi) {
+        const CBlock& b = m->cb[bi];
+        if (!b.cross) {
+            char* kc = (char*)m->ccache[b.cache] + d.cache_off;
+            char* vc = kc + (size_t)R * H * Lm * 64 * e;
+            {
+                SmallGemm g = base(b.w_in, 3 * E, E, S_qkv, bi == 0 ? SMALL_PRO_GLOBAL : SMALL_PRO_LN, SMALL_EPI_PARTIAL);
+                if (bi == 0) g.A = d.dx_t; else g.ln = consume(pend, b.ln1_g, b.ln1_b, true);
+                g.out_part = qkvp;
+                ProfScope ps(m, s, "coca_small_qkv", 2.0 * R * 3 * E * E, ((double)R * E + 3.0 * E * E) * e + (double)S_qkv * R * 3 * E * 4);
+                TRY(launch_small_gemm(m->gdt, g, s));
+            }
+            {
+                SmallGemm g = base(b.w_o, E, E, S_ee, SMALL_PRO_SELFATTN, SMALL_EPI_PARTIAL);
+                g.sa.qkv_part = qkvp; g.sa.qkv_bias = b.b_in; g.sa.qkv_S = S_qkv; g.sa.kc = kc; g.sa.vc = vc; g.sa.anc = anc; g.sa.anc_ld = Lm;
+                g.sa.kv_ld = Lm; g.sa.n_keys = t + 1; g.sa.H = H; g.sa.skip = nullptr;
+                g.out_part = d.dpart;
+                ProfScope ps(m, s, "coca_small_o", 2.0 * R * E * E + 4.0 * R * H * (t + 1) * 64, ((double)R * E + (double)E * E) * e + (double)S_ee * R * E * 4);
+                TRY(launch_small_gemm(m->gdt, g, s));
+            }
+        } else {
+            {
+                SmallCross x;
+                memset(&x, 0, sizeof(x));
+                x.W = b.w_in; x.bias = b.b_in; x.R = R; x.D = E; x.H = H; x.S = S_ee;
+                x.ln = consume(pend, b.ln1_g, b.ln1_b, true);
+                const size_t blk = m->cross_block((size_t)d.Btot * H * Q);
+                x.kbase = (char*)m->cross + ((size_t)b.cross_idx * 2 + 0) * blk;
+                x.vbase = (char*)m->cross + ((size_t)b.cross_idx * 2 + 1) * blk;
+                x.kv_row0 = (size_t)d.b0 * H * Q + 1;                 // token 0 (the pooled token) is skipped
+                x.rows_per_kv = K; x.kv_ld = Q; x.n_keys = Q - 1; x.kv_kind = kv_kind; x.skip = nullptr; x.out = d.dctx;
+                ProfScope ps(m, s, "coca_small_cross", 2.0 * R * E * E + 4.0 * R * H * (Q - 1) * 64, (double)E * E * e + 2.0 * R * H * (Q - 1) * m->kvrow);
+                TRY(launch_small_cross(m->gdt, x, s));
+            }
+            {
+                SmallGemm g = base(b.w_o, E, E, S_ee, SMALL_PRO_GLOBAL, SMALL_EPI_PARTIAL);
+                g.A = d.dctx; g.out_part = d.dpart;
+                ProfScope ps(m, s, "coca_small_o", 2.0 * R * E * E, ((double)R * E + (double)E * E) * e + (double)S_ee * R * E * 4);
+                TRY(launch_small_gemm(m->gdt, g, s));
+            }
+        }
+        {
+            SmallGemm g = base(b.w_fc, F, E, 1, SMALL_PRO_LN, SMALL_EPI_ACT_T);
+            SmallLN ln;
+            memset(&ln, 0, sizeof(ln));
+            ln.part = d.dpart; ln.S = S_ee; ln.bias = b.b_o;
+            g.ln = consume(ln, b.ln2_g, b.ln2_b, true);
+            g.bias = b.b_fc; g.act = 1; g.out = d.dh; g.ldc = F;
+            ProfScope ps(m, s, "coca_small_fc", 2.0 * R * F * E, ((double)R * E + (double)F * E + (double)R * F) * e);
+            TRY(launch_small_gemm(m->gdt, g, s));
+        }
+        {
+            SmallGemm g = base(b.w_pr, E, F, S_pr, SMALL_PRO_GLOBAL, SMALL_EPI_PARTIAL);
+            g.A = d.dh; g.out_part = d.dpart;
+            ProfScope ps(m, s, "coca_small_pr", 2.0 * R * E * F, ((double)R * F + (double)E * F) * e + (double)S_pr * R * E * 4);
+            TRY(launch_small_gemm(m->gdt, g, s));
+        }
+        memset(&pend, 0, sizeof(pend));
+        pend.part = d.dpart; pend.S = S_pr; pend.bias = b.b_pr;
+    }
+    {
+        SmallGemm g = base(m->w_cvocab, c.vocab, E, 1, SMALL_PRO_LN, SMALL_EPI_ACT_F32);
+        g.nchain = 1;
+        g.ln = consume(pend, m->lnf_g, m->lnf_b, false);
+        g.bias = nullptr; g.act = 0; g.out = d.logits; g.ldc = m->ldl;
+        ProfScope ps(m, s, "coca_small_vocab", 2.0 * R * c.vocab * E, ((double)R * E + (double)c.vocab * E) * e + (double)R * c.vocab * 4);
+        TRY(launch_small_gemm(m->gdt, g, s));
+    }
+    return 0;
+}
+
 __global__ void iota_rows_kernel(int* anc, int R, int L) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * R * L; i += gridDim.x * blockDim.x) anc[i] = (i / L) % R;
 }
@@ -1387,19 +1492,22 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
         m->last_steps = t + 1;
         const int* tokens = greedy ? d.seq : beam_running_tokens_p(d.beam, B, K, Lm, cur_len & 1);
         const int* anc = greedy ? nullptr : d.anc + (size_t)(cur_len & 1) * R * Lm;
-        if (coca) {
-            TRY(run_coca_step(m, d, tokens, Lm, t, K, anc, Lm, s));
-        } else {
+        {
             const bool can = small_path_takes(m, d, t);
             if (m->decode_path == 2 && !can) {
                 cap_set_error("cap_generate: the small-batch decode path was forced (cap_set_decode_path 2) but does not take this call "
-                              "(%d rows, step %d, compute type %d): at most %d rows, 32 positions, split or bf16 mode, BLIP", R, t, m->gdt, SMALL_MAX_ROWS);
+                              "(%d rows, step %d, compute type %d): at most %d rows, 32 positions, split or bf16 mode, BLIP / CoCa", R, t, m->gdt, SMALL_MAX_ROWS);
                 return -1;
             }
             const bool small = can && m->decode_path != 1;
             m->last_path = small ? 2 : 1;
-            if (small) TRY(run_decoder_step_small(m, d, tokens, Lm, t, K, anc, Lm, s));
-            else TRY(run_decoder_step(m, d, tokens, Lm, t, K, anc, Lm, s));
+            if (coca) {
+                if (small) TRY(run_coca_step_small(m, d, tokens, Lm, t, K, anc, Lm, s));
+                else TRY(run_coca_step(m, d, tokens, Lm, t, K, anc, Lm, s));
+            } else {
+                if (small) TRY(run_decoder_step_small(m, d, tokens, Lm, t, K, anc, Lm, s));
+                else TRY(run_decoder_step(m, d, tokens, Lm, t, K, anc, Lm, s));
+            }
         }
         if (out_step_logits) {
             hipLaunchKernelGGL(copy_logits_kernel, dim3(1024), dim3(256), 0, s, d.logits, m->ldl,

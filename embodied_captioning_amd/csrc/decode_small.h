@@ -17,7 +17,9 @@ struct SmallLN {
     const float* bias;                // [D] or null
     const float* resid;               // fp32 [R][D] or null: the row the batch path keeps in `dx`
     const float* gamma; const float* beta; float eps;
-    float* x_out;                     // fp32 [R][D] or null: LayerNorm output, written by ONE workgroup (must not alias resid)
+    float* x_out;                     // fp32 [R][D] or null: written by ONE workgroup (must not alias resid) - the LayerNorm output
+    int x_is_sum;                     // (post-LN decoders: BLIP), or with x_is_sum the un-normalised sum y itself (pre-LN: CoCa,
+                                      // whose residual stream is the running sum)
 };
 struct SmallSA {
     const float* qkv_part; const float* qkv_bias; int qkv_S;   // fp32 [qkv_S][R][3 H 64] partial sums of q|k|v, bias [3 H 64]

@@ -144,8 +144,9 @@ __device__ __forceinline__ void ln_finish_row(const SmallLN& ln, int R, int D, i
         a[i] = make_float4(s[0], s[1], s[2], s[3]);
         g[i] = make_float4(k[i].g[0], k[i].g[1], k[i].g[2], k[i].g[3]);
         be[i] = make_float4(k[i].be[0], k[i].be[1], k[i].be[2], k[i].be[3]);
+        if (out_f && ln.x_is_sum && lane * 4 + i * 256 < D) *(f32x4*)(out_f + lane * 4 + i * 256) = s;   // pre-LN: the stream is y
     }
-    ln_row_regs<T, NV>(a, NV, lane, D, g, be, ln.eps, out_t, out_f);
+    ln_row_regs<T, NV>(a, NV, lane, D, g, be, ln.eps, out_t, ln.x_is_sum ? nullptr : out_f);
 }
 
 template <typename T, int RPW, int NV>

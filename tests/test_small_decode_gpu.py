@@ -169,3 +169,67 @@ def test_forcing_the_small_path_beyond_its_row_limit_fails_by_name():
     eng.generate(px.cuda(), num_beams=1, max_length=meta["max_length"])
     assert eng.last_decode_path == "batch"
     eng.close()
+
+
+# ---- CoCa (pre-LN decoder, 36 blocks: the reference's production captioner, called with ONE crop - coca.py:27-33).  Parity of
+# the CoCa path against open_clip is unpinned; what is held here needs no oracle: the fused kernels against the batch kernels.
+
+def _coca_outs(arch, sd, px, dtype, beams, groups=None):
+    from embodied_captioning_amd.engine import CaptionerEngine
+    outs = {}
+    for path in ("small", "batch"):
+        eng = CaptionerEngine(arch, dtype=dtype, max_batch=px.shape[0], max_beams=beams, max_len=arch.seq_len)
+        eng.set_decode_path(path)
+        eng.load_state_dict(sd)
+        outs[path] = eng.generate(px.cuda(), num_beams=beams, max_length=arch.seq_len, output_logits=beams == 1 and groups is None,
+                                  num_beam_groups=groups)
+        assert eng.last_decode_path == path
+        eng.close()
+    return outs["small"], outs["batch"]
+
+
+@pytest.mark.parametrize("dtype", ["f32s", "bf16"])
+@pytest.mark.parametrize("boost", [0.0, 4.0])
+def test_coca_tiny_small_path_has_the_bits_of_the_batch_path_unpinned(boost, dtype):
+    from embodied_captioning_amd.config import CocaArch
+    from embodied_captioning_amd.weights import procedural_coca_state_dict, synthetic_pixels
+    a = CocaArch.tiny()
+    sd = procedural_coca_state_dict(a, 1, eos_boost=boost)
+    px = synthetic_pixels(5, a.image_size, seed=1)
+    s, b = _coca_outs(a, sd, px, dtype, 1)
+    assert torch.equal(s["sequences"], b["sequences"]) and torch.equal(s["lengths"], b["lengths"])
+    seq = s["sequences"].cpu().numpy()
+    steps = s["logits"].shape[0]
+    live = np.ones((steps, seq.shape[0]), dtype=bool)
+    for r in range(seq.shape[0]):
+        row = list(seq[r, 1:])
+        ends = [i for i, tk in enumerate(row) if tk in (a.eos, a.pad)]
+        if ends:
+            live[ends[0] + 1:, r] = False
+    live = torch.from_numpy(live)
+    assert torch.equal(s["logits"].cpu()[live], b["logits"].cpu()[live])
+    # beams (the reference's _generate_beamsearch) and beam groups
+    for beams, groups in ((3, None), (5, None), (6, 3)):
+        s, b = _coca_outs(a, sd, px[: 16 // beams], dtype, beams, groups)
+        assert torch.equal(s["sequences"], b["sequences"]) and torch.equal(s["sequences_scores"], b["sequences_scores"]), (beams, groups)
+
+
+@pytest.mark.parametrize("dtype", ["f32s", "bf16"])
+def test_coca_vit_l14_small_path_has_the_bits_of_the_batch_path_unpinned(dtype):
+    """Production geometry (ViT-L/14, 12 + 12 text layers, vocabulary 49408, 255 cross-attention keys in the KV16 cache): one
+    crop and two crops, greedy, every step's live logits."""
+    from embodied_captioning_amd.config import CocaArch
+    from embodied_captioning_amd.weights import procedural_coca_state_dict, synthetic_pixels
+    a = CocaArch()
+    sd = procedural_coca_state_dict(a, 2, eos_boost=3.0)
+    px = synthetic_pixels(2, a.image_size, seed=5)
+    s, b = _coca_outs(a, sd, px, dtype, 1)
+    assert torch.equal(s["sequences"], b["sequences"])
+    seq = s["sequences"].cpu().numpy()
+    for r in range(2):
+        row = list(seq[r, 1:])
+        ends = [i for i, tk in enumerate(row) if tk in (a.eos, a.pad)]
+        n = ends[0] + 1 if ends else len(row)
+        assert torch.equal(s["logits"][:n, r], b["logits"][:n, r]), r
+    s1, _ = _coca_outs(a, sd, px[:1], dtype, 1)
+    assert torch.equal(s1["sequences"][0], s["sequences"][0])
