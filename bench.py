@@ -75,6 +75,8 @@ def parse():
                     "golden's weights; larger values end every caption early)")
     ap.add_argument("--lite", action="store_true", help="timed steps only (profiler counter passes): no roofline / "
                     "encoder-only / parity / fp32 / CPU legs")
+    ap.add_argument("--no-latency", action="store_true", help="skip the small-batch `latency` block (profiler passes: its B = 1 / 8 / 64 "
+                    "launches would be averaged into the headline workload's kernel durations)")
     ap.add_argument("--latency-only", action="store_true", help="print only the small-batch `latency` block (B = 1, 8, 64)")
     ap.add_argument("--image-size", type=int, default=224, help="coca: 224 or 336 (SURVEY config 5); blip: 224 (the "
                     "BASELINE config) or 384 (what the published BLIP checkpoints ship - extra line, no golden)")
@@ -804,8 +806,9 @@ def main():
         line["kernel_ms_per_step"] = round(kernel_ms, 3)           # sum of ONE stream's kernel durations (see single_stream)
         line["encoder_only"] = encoder_only(eng, px, arch)
         eng.close()
-        log("latency block: B = 1, 8, 64")
-        line["latency"] = latency_block(arch, sd, dev, a.dtype, L)
+        if not a.no_latency:
+            log("latency block: B = 1, 8, 64")
+            line["latency"] = latency_block(arch, sd, dev, a.dtype, L)
         golden = None
         try:
             from tests._util import load_golden

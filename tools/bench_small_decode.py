@@ -26,11 +26,19 @@ def main():
     ap.add_argument("--dtype", default="f32s")
     ap.add_argument("--batches", default="1,8,16")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--model", default="blip", choices=["blip", "coca"], help="coca: ViT-L/14, 12 + 12 text layers, seq_len 30 (parity unpinned)")
     ap.add_argument("--stamps", action="store_true", help="experiments build (python -m embodied_captioning_amd.build --experiments): "
                     "cycle stamps of workgroup 0 of the last cross / GEMM launch")
     a = ap.parse_args()
-    arch, L = BlipArch(), 20
-    sd = procedural_blip_state_dict(arch, 0, eos_boost=9.0)
+    if a.model == "coca":
+        from embodied_captioning_amd.config import CocaArch
+        from embodied_captioning_amd.weights import procedural_coca_state_dict
+        arch = CocaArch()
+        L = arch.seq_len
+        sd = procedural_coca_state_dict(arch, 0)
+    else:
+        arch, L = BlipArch(), 20
+        sd = procedural_blip_state_dict(arch, 0, eos_boost=9.0)
     out = {}
     for B in [int(x) for x in a.batches.split(",")]:
         px = synthetic_pixels(B, arch.image_size, seed=0).cuda()
@@ -53,7 +61,7 @@ def main():
             rep = eng.profile_report()
             eng.profile(False)
             tags = {t: {"n": r["launches"], "us": round(1e3 * r["ms"] / r["launches"], 2), "ms": round(r["ms"], 3)}
-                    for t, r in sorted(rep.items()) if t.startswith("dec_") or t == "greedy_select"}
+                    for t, r in sorted(rep.items()) if t.startswith(("dec_", "coca_")) and "gemm_crosskv" not in t or t == "greedy_select"}
             if a.stamps and path == "small":
                 import ctypes as C
                 buf = (C.c_ulonglong * 64)()

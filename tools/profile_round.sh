@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 # one stream: with the default stream pool kernels of different batches co-run and share the GPU, so their durations in the
 # trace are not those of the kernel alone (vit_attention_split: 963 us pooled, 228 us alone) - the bench's roofline pass, which
 # these averages must agree with, also runs one engine on one stream
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $ROOT/bench.py --steps 3 --warmup 1 --streams 1 --no-extra-modes --no-cpu-baseline "$@" > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $ROOT/bench.py --steps 3 --warmup 1 --streams 1 --no-extra-modes --no-cpu-baseline --no-latency "$@" > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 echo "stats pass done"
 cd "$ROOT"
 python3 tools/summarize_prof.py stats "$OUT/stats" "$OUT/kernel_stats.md"
