@@ -379,6 +379,7 @@ __global__ __launch_bounds__(512, 1) void dec_small_cross_kernel(SmallCross p) {
     if (wave == 7) {
         ln_load_row<NV>(ln, p.R, D, row, lane, lv);
         ln_load_cols<NV>(ln, D, lane, lk);
+        SMALL_STAMP(0, 10, true);
     }
     // ---- W of this head's query columns: wave = (K slice sl, column half ch): the slice's slabs x 2 column blocks
     const int S = p.S, Ks = D / S, nkb = Ks / SLAB;
@@ -394,6 +395,8 @@ __global__ __launch_bounds__(512, 1) void dec_small_cross_kernel(SmallCross p) {
                 for (int cb = 0; cb < 2; ++cb) wq[j][cb] = load_frag<T>(wbase + (size_t)cb * 16 * D * ESZ + (size_t)j * 128, kg);
             }
     }
+    SMALL_STAMP(0, 11, wave == 0);
+    SMALL_STAMP(0, 12, wave == 7);
     if constexpr (KV_LDS) {
         if (wave < 7) {
             const char* ks = (const char*)p.kbase + src_off;
@@ -415,6 +418,7 @@ __global__ __launch_bounds__(512, 1) void dec_small_cross_kernel(SmallCross p) {
     }
     __syncthreads();
     SMALL_STAMP(0, 2, wave == 0);
+    SMALL_STAMP(0, 13, wave == 0 && wq[0][0].x[0][0] == wq[0][0].x[0][0]);
     // ---- the query columns: chain c of slice sl = slabs c, c + 4, ...; the row sits in MFMA column 0
     if (gw) {
         f32x4 acc[4][2];

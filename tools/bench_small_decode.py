@@ -71,8 +71,8 @@ def main():
                 for k, name in ((0, "cross"), (1, "gemm")):
                     cyc = [buf[k * 32 + 2 * i] for i in range(16)]
                     wal = [buf[k * 32 + 2 * i + 1] for i in range(16)]
-                    tags.setdefault("_stamps", {})[name] = {"cycles_from_0": [int(c - cyc[0]) if c else None for c in cyc[:9]],
-                                                            "wall_ns_from_0": [int(w - wal[0]) * 10 if w else None for w in wal[:9]]}
+                    tags.setdefault("_stamps", {})[name] = {"cycles_from_0": [int(c - cyc[0]) if c else None for c in cyc[:14]],
+                                                            "wall_ns_from_0": [int(w - wal[0]) * 10 if w else None for w in wal[:14]]}
             rec[path] = {"generate_ms": round(statistics.median(ts), 3), "decode_kernel_ms": round(sum(v["ms"] for k, v in tags.items() if k != "_stamps"), 3),
                          "tags": tags}
         out[str(B)] = rec
