@@ -233,3 +233,47 @@ def test_coca_vit_l14_small_path_has_the_bits_of_the_batch_path_unpinned(dtype):
         assert torch.equal(s["logits"][:n, r], b["logits"][:n, r]), r
     s1, _ = _coca_outs(a, sd, px[:1], dtype, 1)
     assert torch.equal(s1["sequences"][0], s["sequences"][0])
+
+
+@pytest.mark.parametrize("dtype,cross_cache", [("f32s", "auto"), ("f32s", "fp32"), ("bf16", "auto")])
+def test_577_token_checkpoints_small_path_has_the_bits_of_the_batch_path(dtype, cross_cache):
+    """BLIP at 384 px (what the published checkpoints ship): the (row, head) K/V block no longer fits the cross kernel's LDS copy
+    (2 x 80 KB of KV16 groups), so the block is read from global memory - same arithmetic, same bits; also with fp32 rows."""
+    from embodied_captioning_amd.config import BlipArch
+    from embodied_captioning_amd.engine import CaptionerEngine
+    from embodied_captioning_amd.weights import procedural_blip_state_dict, synthetic_pixels
+    arch = BlipArch()
+    arch.image_size = 384
+    sd = procedural_blip_state_dict(arch, 0, eos_boost=6.0)
+    px = synthetic_pixels(3, arch.image_size, seed=41)
+    L = 20
+    outs = {}
+    for path in ("small", "batch"):
+        eng = CaptionerEngine(arch, dtype=dtype, max_batch=3, max_beams=1, max_len=L, cross_cache=cross_cache)
+        eng.set_decode_path(path)
+        eng.load_state_dict(sd)
+        outs[path] = eng.generate(px.cuda(), max_length=L, output_logits=True)
+        assert eng.last_decode_path == path
+        eng.close()
+    a, b = outs["small"], outs["batch"]
+    assert torch.equal(a["sequences"], b["sequences"])
+    live = torch.from_numpy(_live_mask(a["sequences"].cpu().numpy(), arch, L - 1))
+    assert torch.equal(a["logits"].cpu()[live], b["logits"].cpu()[live])
+
+
+def test_engine_pool_and_a_large_arena_take_the_small_path_for_small_calls():
+    """An engine sized for 256 frames that is handed 3, and the engines of a stream pool: the row count of the CALL selects the path."""
+    from embodied_captioning_amd.engine import CaptionerEngine, EnginePool
+    g, meta, arch, sd, px = golden_inputs("blip_base")
+    L = meta["max_length"]
+    ref = pad_to(g["greedy_sequences"], L, arch.pad)
+    eng = CaptionerEngine(arch, dtype="f32s", max_batch=64, max_beams=1, max_len=L)
+    eng.load_state_dict(sd)
+    out = eng.generate(px[:3].cuda(), max_length=L)
+    assert eng.last_decode_path == "small" and np.array_equal(out["sequences"].cpu().numpy(), ref[:3])
+    pool = EnginePool(arch, n=2, dtype="f32s", max_batch=8, max_beams=1, max_len=L, weights_of=eng)
+    outs = pool.generate_many([px[i:i + 4].cuda() for i in (0, 4)], threads=True, max_length=L)
+    assert np.array_equal(torch.cat([o["sequences"] for o in outs]).cpu().numpy(), ref)
+    assert all(e.last_decode_path == "small" for e in pool.engines)
+    pool.close()
+    eng.close()
