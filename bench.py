@@ -306,7 +306,7 @@ PMC_FILES = {"f32s": "r04_bench_pmc.json", "bf16": "r04_bench_bf16_pmc.json"}
 def _kernel_in_build(name: str, lib_bytes: bytes) -> bool:
     """Is a kernel of this (demangled) name compiled into the library of THIS run?  Kernels are templates in an anonymous
     namespace: their mangled symbols carry <length><identifier>."""
-    m = re.match(r"(?:void )?([A-Za-z_][A-Za-z0-9_]*)", name)
+    m = re.match(r"(?:void )?\d*([A-Za-z_][A-Za-z0-9_]*?)(?=I[A-Z0-9]|<|\(|$)", name)     # (bf16 names reach rocprofv3 half-mangled: 14gemm_pp_kernelIDF16b...)
     return bool(m) and f"{len(m.group(1))}{m.group(1)}".encode() in lib_bytes
 
 
@@ -336,7 +336,10 @@ def pmc_summary(dtype, live_avg_us=None):
         lib_bytes = open(LIB, "rb").read()
     except Exception:  # noqa: BLE001
         lib_bytes = None
-    enc = r"gemm_pp_kernel<g8_t, (true|false), 0," if dtype == "f32s" else r"gemm_pp_kernel<__bf16, (true|false), 0,"
+    # (the demangler of rocprofv3 does not know __bf16: its kernels arrive as `14gemm_pp_kernelIDF16bLb0ELi0E...` or as
+    # `gemm_pp_kernel<bool _Accum, bool, E, 0, ...>`; template arguments: operand type, OUT_F32, EPI = 0 (plain store), ...)
+    enc = (r"gemm_pp_kernel<g8_t, (true|false), 0," if dtype == "f32s"
+           else r"gemm_pp_kernel(IDF16bLb[01]ELi0E|<bool _Accum, bool, E, 0,|<__bf16, (true|false), 0,)")
     classes = {"enc_gemm": enc, "cross_attention": r"decode_attention_(online|shared)_kernel", "decode_gemm": r"gemm_rows_kernel"}
     for cls, pat in classes.items():
         n = b = busy = act = us = nl = 0.0
