@@ -18,6 +18,11 @@
  *                       minus the 32 image placeholders and BOS), logits as HF's `output_logits`
  *   caption embedding   agents/goal_exploration/goal_exploration.py:57,102 and                cap_embed_text
  *                       detector/pseudolabeler.py:568,677 `SentenceTransformer("all-MiniLM-L6-v2").encode(caption)`  (CAP_ARCH_MINILM handle)
+ *   one crop per call   coca.py:27-33, blip2.py:24-29, goal_exploration.py:95-105,     cap_generate (rows <= 16: fused
+ *                       pseudolabeler.py:673-676 (the callers hand over ONE image)      launches), cap_set_decode_path
+ *   load options        blip2.py:19-22 `load_in_8bit=True, torch_dtype=float16`;       CapConfig.compute_dtype,
+ *                       evaluate_finetuned_model.py:147-148 `PeftModel.from_pretrained`  CapConfig.cross_kv_fp32 (host side:
+ *                                                                                      weights.merge_peft_lora)
  *   device move/free    predictor_utils.py:187 `.to(...)`; object lifetime            cap_destroy
  *   errors              Python exceptions (utils_captioner.py:6, factory.py:231,309)  int return codes + cap_last_error
  *
