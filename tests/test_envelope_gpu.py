@@ -97,3 +97,46 @@ def test_ill_conditioned_weights_split_mode_is_no_worse_than_exact_fp32(base):
     es = (emb_s - ref["image_embeds"]).abs().max().item()
     ex = (emb_x - ref["image_embeds"]).abs().max().item()
     assert sat == 0 and es < 4 * ex + 1e-3, (es, ex)
+
+
+def test_wrappers_read_the_clamp_counter(base, tmp_path):
+    """The split mode's promise is that leaving its range is never silent: the plugin wrapper itself looks at the clamp counter
+    after its first call - an error in the log, or an exception with `strict_range` - instead of leaving that to the caller
+    (advisor, round 3).  Weights: the fc1 unit driven to 1e5 of the test above, handed over as a checkpoint override."""
+    import logging
+    from PIL import Image
+    from embodied_captioning_amd.captioner.models.blip.blip import BLIP
+    from embodied_captioning_amd.captioner.utils.utils import Configuration
+    arch, sd0, px = base
+    sd = beyond_fp16(sd0, arch)
+    path = str(tmp_path / "beyond.pt")
+    torch.save({"model": {k: v for k, v in sd.items() if k == "vision_model.encoder.layers.2.mlp.fc1.bias"}}, path)
+    im = Image.fromarray(np.random.default_rng(0).integers(0, 256, (224, 224, 3), dtype=np.uint8))
+    cfg = Configuration(arch_name="blip", model_name="procedural:0:5", checkpoint_name=path, height=224, width=224, batch_size=2).captioner
+    model = BLIP(cfg)
+    model.engine.saturations(reset=True)
+    records = []
+    handler = logging.Handler()
+    handler.emit = records.append
+    logging.getLogger("embodied_captioning_amd.captioner.captioning_predictor").addHandler(handler)
+    try:
+        model.forward(im)                                   # first call: the wrapper reads the counter
+    finally:
+        logging.getLogger("embodied_captioning_amd.captioner.captioning_predictor").removeHandler(handler)
+    assert any("left the range" in r.getMessage() for r in records), [r.getMessage() for r in records]
+    assert model.check_range() > 0
+    model.engine.close()
+    cfg = Configuration(arch_name="blip", model_name="procedural:0:5", checkpoint_name=path, height=224, width=224, batch_size=2,
+                        strict_range=True).captioner
+    model = BLIP(cfg)
+    model.engine.saturations(reset=True)
+    with pytest.raises(RuntimeError, match="left the range"):
+        model.forward(im)
+    model.engine.close()
+    # inside the envelope: silent, and zero
+    cfg = Configuration(arch_name="blip", model_name="procedural:0:5", height=224, width=224, batch_size=2, strict_range=True).captioner
+    model = BLIP(cfg)
+    model.engine.saturations(reset=True)
+    model.forward(im)
+    assert model.check_range() == 0
+    model.engine.close()
