@@ -38,3 +38,25 @@ def test_restatement_matches_hf_golden():
         assert np.abs(lg[:n, b] - ref[:n, b]).max() < 5e-5
     # the fixture exercises both endings
     assert (new == a.eos).any() and not (new == a.eos).any(axis=1).all()
+
+
+def test_restatement_matches_hf_golden_at_production_width():
+    """The production GEOMETRY of `Salesforce/blip2-opt-2.7b` (reference captioner/models/blip2/blip2.py:19-28): ViT-g/14 1408 wide
+    / 16 heads of 88 / 257 tokens, Q-Former 768 / 32 queries, OPT 2560 wide / 32 heads of 80 / FFN 10240, the real 50272-token
+    vocabulary - two layers per tower.  The golden is HF Blip2ForConditionalGeneration itself on these weights
+    (tools/make_goldens_blip2.py --width); it pins the restatement at the widths the tiny golden cannot reach."""
+    g, meta, a, sd, px = load_blip2("blip2_width")
+    assert (a.v_hidden, a.v_heads, a.q_hidden, a.t_hidden, a.t_heads, a.t_ffn, a.vocab, a.n_tokens) == (1408, 16, 768, 2560, 32, 10240, 50272, 257)
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+    out = R.greedy_generate(sd, a, px)
+    emb = out["image_embeds"]
+    assert np.abs(emb[:, :, :16].numpy() - g["image_embeds_head"]).max() < 1e-4
+    assert np.abs(emb.norm(dim=-1).numpy() - g["image_embeds_norm"]).max() < 1e-3 * float(g["image_embeds_norm"].max())
+    assert np.abs(out["query_output"].numpy() - g["query_output"]).max() < 5e-5
+    seq = out["sequences"].numpy()
+    assert np.array_equal(seq, g["sequences"][:, : seq.shape[1]]) and (g["sequences"][:, seq.shape[1]:] == a.pad).all()
+    lg = torch.stack(out["logits"], 0)                                     # [steps, B, V]
+    assert lg.shape[0] == g["top8_ids"].shape[0]
+    got = torch.gather(lg, 2, torch.from_numpy(g["top8_ids"]).long()).numpy()
+    assert np.abs(got - g["top8_values"]).max() < 1e-4
+    assert np.array_equal(torch.topk(lg, 8, dim=-1).indices.numpy(), g["top8_ids"])

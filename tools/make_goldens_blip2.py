@@ -1,8 +1,11 @@
 #!/usr/bin/env python
 """Golden vectors for the BLIP-2 OPT path: the REAL HuggingFace Blip2ForConditionalGeneration (imported only in the build
-container) on the seeded weights / frames of embodied_captioning_amd.weights.  Writes tests/golden/blip2_tiny.npz.
+container) on the seeded weights / frames of embodied_captioning_amd.weights.  Writes tests/golden/blip2_tiny.npz and, with --width,
+tests/golden/blip2_width.npz: the production GEOMETRY of `Salesforce/blip2-opt-2.7b` (reference captioner/models/blip2/blip2.py:
+19-28) at full width - ViT-g/14 1408 / 16 heads of 88, Q-Former 768 / 32 queries, OPT 2560 / 32 heads of 80 / FFN 10240, the
+real 50272-token vocabulary - with two layers per tower (340 M seeded parameters; HF itself on the CPU of the build container).
 
-    python tools/make_goldens_blip2.py
+    python tools/make_goldens_blip2.py [--width]
 """
 import dataclasses
 import json
@@ -37,26 +40,44 @@ def build_hf(a: Blip2Arch, sd):
     return m
 
 
-def run(a: Blip2Arch, seed: int, batch: int, eos_boost: float):
+def run(a: Blip2Arch, seed: int, batch: int, eos_boost: float, compact: bool = False):
     sd = procedural_blip2_state_dict(a, seed, eos_boost=eos_boost)
     m = build_hf(a, sd)
     px = synthetic_pixels(batch, a.image_size, seed=seed)
+    kw = {"max_new_tokens": a.max_new_tokens} if compact else {}
     with torch.no_grad():
-        out = m.generate(pixel_values=px, output_logits=True, return_dict_in_generate=True)
+        out = m.generate(pixel_values=px, output_logits=True, return_dict_in_generate=True, **kw)
         emb = m.vision_model(px).last_hidden_state
         qo = m.qformer(query_embeds=m.query_tokens.expand(batch, -1, -1), encoder_hidden_states=emb).last_hidden_state
     logits = torch.stack(list(out.logits), 0)                               # [T, B, V]
     top = torch.topk(logits, 2, dim=-1).values
     print("sequences", out.sequences[:, a.num_query_tokens:].tolist())
+    if compact:
+        # the full-width fixture keeps what a parity check reads: every step's 8 largest logits (ids + values) and top-1 / top-2
+        # margin, the tokens, the Q-Former output and a checksum view of the 257 x 1408 image embeddings (first 16 columns of
+        # every token + every token's L2 norm) - 0.4 MB instead of 20
+        t8 = torch.topk(logits, 8, dim=-1)
+        return {"sequences": out.sequences.numpy().astype(np.int32), "top8_ids": t8.indices.numpy().astype(np.int32),
+                "top8_values": t8.values.numpy(), "margin": (top[..., 0] - top[..., 1]).numpy(),
+                "image_embeds_head": emb[:, :, :16].numpy(), "image_embeds_norm": emb.norm(dim=-1).numpy(), "query_output": qo.numpy(),
+                "meta": np.array(json.dumps(dict(seed=seed, batch=batch, eos_boost=eos_boost, arch=dataclasses.asdict(a),
+                                                 transformers=__import__("transformers").__version__)))}
     return {"sequences": out.sequences.numpy().astype(np.int32), "logits": logits.numpy(), "margin": (top[..., 0] - top[..., 1]).numpy(),
             "image_embeds": emb.numpy(), "query_output": qo.numpy(),
             "meta": np.array(json.dumps(dict(seed=seed, batch=batch, eos_boost=eos_boost, arch=dataclasses.asdict(a),
                                              transformers=__import__("transformers").__version__)))}
 
 
+def width_arch() -> Blip2Arch:
+    return dataclasses.replace(Blip2Arch(), v_layers=2, q_layers=2, t_layers=2, max_new_tokens=8)
+
+
 def main():
     gold = os.path.join(ROOT, "tests", "golden")
-    np.savez_compressed(os.path.join(gold, "blip2_tiny.npz"), **run(Blip2Arch.tiny(), seed=11, batch=4, eos_boost=0.5))
+    if "--width" in sys.argv:
+        np.savez_compressed(os.path.join(gold, "blip2_width.npz"), **run(width_arch(), seed=6, batch=2, eos_boost=0.3, compact=True))
+    else:
+        np.savez_compressed(os.path.join(gold, "blip2_tiny.npz"), **run(Blip2Arch.tiny(), seed=11, batch=4, eos_boost=0.5))
     print("done")
 
 
