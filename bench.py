@@ -2,8 +2,9 @@
 """Captioner throughput bench (BASELINE.json metric: captions/sec, 224x224, beam=1, + greedy token parity).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W         # starts its own N ranks (a torch.distributed.run CHILD process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W            # the driver's form: WORLD_SIZE is set, nothing is spawned
 
 One step = one pass of the hot path (ViT encoder -> cross-K/V -> 19 greedy decode steps) over one batch of 256
 synthetic 224x224 frames per GPU that are already resident in HBM, followed by the RCCL all-gather of the caption
@@ -73,6 +74,11 @@ def parse():
                     "every caption is finished (HF's stopping rule; 0 = never, the default: no host sync in generate)")
     ap.add_argument("--eos-boost", type=float, default=9.0, help="blip: EOS logit offset of the procedural weights (9 = the "
                     "golden's weights; larger values end every caption early)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling job (--frames in total over all ranks) that the "
+                    "default line reports beside the weak-scaling value")
+    ap.add_argument("--stub-engine", action="store_true", help="TEST ONLY (tests/test_distributed_cpu.py): the launch / rendezvous / "
+                    "timed-region / gather / strong-scaling plumbing on CPU ranks over gloo with a fake captioner whose ids are a "
+                    "function of the frame index; prints a line marked \"stub\": true and never touches a GPU")
     ap.add_argument("--lite", action="store_true", help="timed steps only (profiler counter passes): no roofline / "
                     "encoder-only / parity / fp32 / CPU legs")
     ap.add_argument("--no-latency", action="store_true", help="skip the small-batch `latency` block (profiler passes: its B = 1 / 8 / 64 "
@@ -135,7 +141,18 @@ class PowerSampler:
                 "source": "amdgpu hwmon power1_input of this GPU, 50 ms samples over the timed region (informational)"}
 
 
-def timed_steps(eng, px, L, steps, warmup, world, gather, beams=1):
+class _NoPower:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        pass
+
+    def result(self, captions, seconds):
+        return None
+
+
+def timed_steps(eng, px, L, steps, warmup, world, gather, beams=1, dev="cuda"):
     """`eng`: a CaptionerEngine, or an EnginePool - consecutive steps then run on the pool's engines / streams and overlap
     (each step is still one whole batch through encoder + decode + gather; all of them finish inside the timed region)."""
     pool = eng if hasattr(eng, "submit") else None
@@ -154,9 +171,10 @@ def timed_steps(eng, px, L, steps, warmup, world, gather, beams=1):
         return res
     from embodied_captioning_amd.distributed import timed_region
     run(max(warmup, len(pool)) if pool is not None else warmup)       # every engine of a pool runs once untimed
-    with PowerSampler(torch.cuda.current_device()) as ps:
+    on_gpu = dev != "cpu"
+    with (PowerSampler(torch.cuda.current_device()) if on_gpu else _NoPower()) as ps:
         # barrier + synchronise, the K steps, synchronise + barrier, MAX over ranks (distributed.timed_region)
-        dt, res = timed_region(lambda: run(steps), world, torch.device("cuda", torch.cuda.current_device()))
+        dt, res = timed_region(lambda: run(steps), world, torch.device("cuda", torch.cuda.current_device()) if on_gpu else None)
     timed_steps.power = ps
     return dt, res
 
@@ -561,20 +579,24 @@ def main_blip2(a):
     print(json.dumps(line))
 
 
-def extra_mode(arch, sd, px, L, B, dev, dtype, streams, ref_ids, golden):
+def extra_mode(arch, sd, px, L, B, dev, dtype, streams, ref_ids, golden, cross_cache="auto"):
     """One of the non-headline arithmetic modes on the same workload: pooled timed steps, the encoder-GEMM roofline of one
-    engine, token agreement with the headline run and with the HF golden."""
+    engine, token agreement with the headline run and with the HF golden.  cross_cache="fp32": the split mode with fp32
+    cross-attention K/V rows instead of KV16 (the encoder is the headline's: no roofline pass)."""
     from embodied_captioning_amd.engine import EnginePool
-    eng = CaptionerEngine(arch, dtype=dtype, max_batch=B, max_beams=1, max_len=L, device=dev)
+    kw = {"cross_cache": cross_cache} if cross_cache != "auto" else {}
+    eng = CaptionerEngine(arch, dtype=dtype, max_batch=B, max_beams=1, max_len=L, device=dev, **kw)
     eng.load_state_dict(sd)
-    runner = EnginePool(arch, n=streams, device=dev, dtype=dtype, max_batch=B, max_beams=1, max_len=L, weights_of=eng) if streams > 1 else eng
-    steps = 6 if dtype == "bf16" else 2
-    dt, (ids, _) = timed_steps(runner, px, L, steps, 2 if dtype == "bf16" else 1, 1, lambda i, l: (i, l))
+    runner = EnginePool(arch, n=streams, device=dev, dtype=dtype, max_batch=B, max_beams=1, max_len=L, weights_of=eng, **kw) if streams > 1 else eng
+    steps = 6 if dtype != "f32" else 2
+    dt, (ids, _) = timed_steps(runner, px, L, steps, 2 if dtype != "f32" else 1, 1, lambda i, l: (i, l))
     if streams > 1:
         runner.close()
-    roof, _, _, _ = roofline_pass(eng, px, L, dtype, arch, B)
     out = {"value": round(B * steps / dt, 2), "unit": "captions/s", "ms_per_step": round(1e3 * dt / steps, 3), "streams": streams,
-           "roofline": roof, "rows_identical_to_headline": round(float((ids == ref_ids).all(dim=1).float().mean().item()), 4)}
+           "cross_cache": eng.cross_cache_kind}
+    if cross_cache == "auto":
+        out["roofline"] = roofline_pass(eng, px, L, dtype, arch, B)[0]
+    out["rows_identical_to_headline"] = round(float((ids == ref_ids).all(dim=1).float().mean().item()), 4)
     if golden is not None:
         out["parity"] = golden_parity(ids, golden, arch, L, B, 0.3 if dtype == "bf16" else 0.0)
     eng.close()
@@ -699,10 +721,101 @@ def main_strong(a, arch, sd, dev, rank, world):
     pool.close()
 
 
+def spawn_ranks(a) -> int:
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as ONE child process - `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` - wait for it and
+    return its exit code.  This process has made no GPU call (parse() and imports only) and makes none: it never replaces
+    itself with another program, the ranks are children."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log(f"--gpus {a.gpus} without WORLD_SIZE: starting the ranks as a child process: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on these hosts
+    return subprocess.run(cmd, env=env).returncode
+
+
+class StubEngine:
+    """--stub-engine: a captioner whose ids depend on the frame index only (CPU; plumbing tests)."""
+
+    def __init__(self, L):
+        self.L = L
+        self.last_decode_steps = L - 1
+
+    def generate(self, frames, num_beams=1, max_length=None):
+        f = frames.to(torch.int32).reshape(-1)
+        ids = torch.stack([(f * 7 + j) % 1000 for j in range(self.L)], dim=1).int()
+        return {"sequences": ids, "lengths": (f % (self.L - 1) + 2).int()}
+
+    def saturations(self):
+        return 0
+
+
+def strong_figure(a, arch, runner, dev, world, L, B, stub=False):
+    """The strong-scaling job beside the weak-scaling value (north_star's >= 6x at 8 GPUs is a STRONG-scaling target; SURVEY config
+    4): --frames in total over all ranks, contiguous shards, micro-batches of --batch on the engines the timed steps used, ONE
+    caption all-gather, consensus grouping on rank 0.  Every rank calls this (collectives inside); rank 0 gets the dict."""
+    from embodied_captioning_amd.distributed import shard_range, strong_scaling_job
+    pool = runner if hasattr(runner, "submit") else None
+    if stub:
+        def frames_of(first, count):
+            return torch.arange(first, first + count, dtype=torch.int32)
+    else:
+        gen = torch.Generator(device=dev)
+
+        def frames_of(first, count):       # raw RGB frames made on the device from the first frame index
+            gen.manual_seed(1_000_003 * first + 17)
+            return torch.randint(0, 256, (count, arch.image_size, arch.image_size, 3), dtype=torch.uint8, device=dev, generator=gen)
+    submit = (lambda f: pool.submit(f, max_length=L)) if pool is not None else (lambda f: runner.generate(f, max_length=L))
+    eng0 = pool.engines[0] if pool is not None else runner
+    job = strong_scaling_job(submit, frames_of, a.frames, B, L, 0 if stub else arch.pad, join=pool.join if pool is not None else None,
+                             keys_of=lambda i: (i // 500, (i // 10) % 50), device=None if stub else dev,
+                             range_check=(lambda: eng0.saturations()) if (stub or a.dtype == "f32s") else None)
+    if not job.get("objects"):
+        return None
+    first, last, per = shard_range(a.frames, 0, world)
+    return {"frames": a.frames, "n_gpus": world, "captions_per_s": round(a.frames / job["seconds"], 2), "job_s": round(job["seconds"], 3),
+            "frames_per_rank": per, "micro_batch": B, "grouping_s": round(job["grouping_s"], 3), "objects": job["objects"],
+            "range_clamps": job.get("range_clamps"), "mean_caption_tokens": round(job["mean_caption_tokens"], 2),
+            "scaling": "strong", "note": "a FIXED total of frames sharded contiguously over the ranks, one caption all-gather at the end, "
+                                         "consensus grouping on rank 0; divide by the 1-GPU line's figure for the strong-scaling speed-up"}
+
+
+def main_stub(a, dev, rank, world):
+    """--stub-engine: the weak-scaling steps and the strong-scaling job of main() with StubEngine on CPU ranks (gloo)."""
+    from embodied_captioning_amd.distributed import make_step_gather
+    L, B = a.max_length, a.batch
+    eng = StubEngine(L)
+    px = torch.arange(rank * B, rank * B + B, dtype=torch.int32)
+    gather = make_step_gather(world, B, L, "cpu")
+    dt, (ids, lens) = timed_steps(eng, px, L, a.steps, a.warmup, world, gather, 1, dev="cpu")
+    want = eng.generate(torch.arange(world * B, dtype=torch.int32))
+    assert torch.equal(ids, want["sequences"]) and torch.equal(lens, want["lengths"]), "gathered records are not rank-major"
+    strong = None if a.no_strong else strong_figure(a, None, eng, dev, world, L, B, stub=True)
+    if rank == 0:
+        print(json.dumps({"metric": "captions/sec (stub)", "value": round(world * B * a.steps / dt, 2), "unit": "captions/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
+                          "scaling": "weak", "stub": True, "strong_scaling": strong}))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     a = parse()
     if a.dtype is None:
         a.dtype = {"blip": "f32s", "blip2": "f32s", "coca": "bf16", "minilm": "bf16"}[a.model]
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if a.model != "blip":
+            raise SystemExit(f"--gpus {a.gpus}: only the blip workload (BASELINE's metric) runs on several ranks")
+        sys.exit(spawn_ranks(a))                 # before anything touches the GPU: the ranks are children of this process
     if a.model == "coca":
         return main_coca(a)
     if a.model == "blip2":
@@ -712,13 +825,23 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does)")
+    if a.stub_engine:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if a.stub_engine:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        world = torch.distributed.get_world_size()      # n_gpus of the line = the ranks the process group actually has
+        rank = torch.distributed.get_rank()
+    if a.stub_engine:
+        return main_stub(a, dev, rank, world)
 
     arch = BlipArch()
     arch.image_size = a.image_size
@@ -750,9 +873,13 @@ def main():
     log(f"weights loaded once, {a.streams} engine(s) / stream(s) on them; timing ({a.dtype})")
     dt, (ids, lens) = timed_steps(runner, px, L, a.steps, a.warmup, world, gather, a.beams)
     decode_steps = (runner.engines[0] if a.streams > 1 else eng).last_decode_steps
+    log(f"timed region: {dt:.3f}s for {a.steps} steps (max over ranks)")
+    strong = None
+    if not (a.no_strong or a.lite or a.beams > 1 or arch.image_size != 224 or a.early_exit):
+        log(f"strong-scaling job: {a.frames} frames in total over {world} rank(s)")
+        strong = strong_figure(a, arch, runner, dev, world, L, B)
     if a.streams > 1:
         runner.close()
-    log(f"timed region: {dt:.3f}s for {a.steps} steps (max over ranks)")
 
     if rank == 0:
         value = world * B * a.steps / dt
@@ -772,6 +899,8 @@ def main():
                                         f"time on one stream is the `single_stream` key") if a.streams > 1 else "one batch at a time on one stream"}}
         ln = lens[:B].float()
         line["caption_tokens"] = {"mean": round(float(ln.mean()), 2), "max": int(ln.max()), "of": L}
+        if strong:
+            line["strong_scaling"] = strong
         pw = getattr(timed_steps, "power", None)
         pw = pw.result(B * a.steps, dt) if pw is not None else None      # rank 0's GPU, its own captions
         if pw:
@@ -827,6 +956,11 @@ def main():
                     continue
                 log(f"extra mode: {other}")
                 line[key] = extra_mode(arch, sd, px, L, B, dev, other, a.streams if other != "f32" else 1, ids, golden)
+            if a.dtype == "f32s":
+                # the headline's arithmetic with fp32 cross-attention K/V rows (CapConfig.cross_kv_fp32): what the split mode costs
+                # when the checkpoint's K/V heads are refused for KV16 - and the line's figure without the 15-bit cache
+                log("extra mode: f32s with fp32 cross-attention K/V rows")
+                line["f32s_fp32kv"] = extra_mode(arch, sd, px, L, B, dev, "f32s", a.streams, ids, golden, cross_cache="fp32")
         if world == 1 and not a.no_cpu_baseline:
             log(f"cpu baseline: {a.cpu_sample} captions on {host_cores()} host threads")
             cb, _ = cpu_baseline(sd, arch, L, a.cpu_sample)

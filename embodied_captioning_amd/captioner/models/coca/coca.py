@@ -150,6 +150,16 @@ class CoCa(CaptioningPredictor):
                                      "pad_token_id", "eos_token_id", "sot_token_id", "min_seq_len", "fixed_output_length"})
         if extra:
             raise TypeError(f"CoCa.generate() got unexpected keyword argument(s) {extra}")
+        # options the engine was BUILT with (cap_create: arch.min_seq_len, the token ids, the 77-token context of the reference's
+        # window `text[:, -max_seq_len:]`, coca_model.py:295): accepted at the value in force, refused - by name - at any other
+        a = self.arch
+        built = {"min_seq_len": a.min_seq_len, "eos_token_id": a.eos, "pad_token_id": a.pad, "sot_token_id": a.sot,
+                 "fixed_output_length": False}
+        differ = [f"{k}={opts[k]!r} (this captioner was built with {v!r})" for k, v in built.items() if k in opts and opts[k] is not None and opts[k] != v]
+        if "max_seq_len" in opts and opts["max_seq_len"] is not None and int(opts["max_seq_len"]) < seq_len:
+            differ.append(f"max_seq_len={opts['max_seq_len']!r} (a context window shorter than seq_len={seq_len} is not implemented)")
+        if differ:
+            raise ValueError("CoCa.generate: " + "; ".join(differ) + " - set it in the captioner's configuration instead of per call")
         if gt == "top_k":
             beams, groups = 1, None
         if beams > self.engine.max_beams or seq_len > self.engine.max_len:

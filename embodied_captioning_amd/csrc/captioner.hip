@@ -1487,6 +1487,11 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
         hipLaunchKernelGGL(iota_rows_kernel, dim3(64), dim3(256), 0, s, d.anc, R, Lm);
     }
     CAP_HIP_CHECK(hipGetLastError());
+    if (m->decode_path == 2 && Lm - 1 > 32) {      // fail at entry, not after 32 steps have run
+        cap_set_error("cap_generate: the small-batch decode path was forced (cap_set_decode_path 2) but max_len %d needs %d positions: "
+                      "it takes at most 32 (automatic selection continues on the batch kernels from position 33)", Lm, Lm - 1);
+        return -1;
+    }
     for (int t = 0; t + 1 < Lm; ++t) {
         const int cur_len = t + 1;
         m->last_steps = t + 1;

@@ -358,19 +358,29 @@ KV16_MAX_HEAD_SPREAD = 12.0
 
 def cross_kv_head_spread(sd: Dict[str, torch.Tensor]) -> float:
     """max over the key / value heads of every cross-attention layer of (largest / median) magnitude of the head's 64 output
-    dimensions, a dimension's magnitude being sqrt(|W row|^2 + b^2) - what its values are sized like on LayerNorm'ed inputs.
-    BLIP (`...crossattention.self.{key,value}.*`), CoCa (`text_decoder.cross_attn.<i>.attn.in_proj_*`, k and v rows, with
+    dimensions, a dimension's magnitude being sqrt(|W row|^2 + b^2) - what its values are sized like on LayerNorm'ed inputs (the
+    LayerNorm's own gamma / beta folded into W / b).  A weight-side PROXY: it cannot see outliers that only the activations carry.
+    BLIP (`...crossattention.self.{key,value}.*` with `vision_model.post_layernorm` folded in), CoCa (`text_decoder.cross_attn.<i>.attn.in_proj_*`, k and v rows, with
     `ln_1_kv` folded in as the library does) or the library's own `derived.cross_kv.*`.  1.0 when the dict has no such tensors."""
     mags = []
     if "derived.cross_kv.weight" in sd:
         w, b = sd["derived.cross_kv.weight"].float(), sd["derived.cross_kv.bias"].float()
         mags.append((w.pow(2).sum(1) + b.pow(2)).sqrt())
     else:
+        # BLIP: the projections read the image tower's post_layernorm output x = xhat * gamma + beta (xhat unit-scale), so what sizes
+        # a dimension is the row of W * gamma and the bias b + W . beta - a checkpoint whose final LayerNorm carries a few large
+        # gamma channels (the usual place of a ViT's massive activations) shows up here, not in W alone
+        pg, pb = sd.get("vision_model.post_layernorm.weight"), sd.get("vision_model.post_layernorm.bias")
         for k, w in sd.items():
             if k.endswith(".weight") and (".crossattention.self.key." in k or ".crossattention.self.value." in k):
                 b = sd.get(k[:-6] + "bias")
                 w = w.float()
-                mags.append((w.pow(2).sum(1) + (b.float().pow(2) if b is not None else 0.0)).sqrt())
+                b = b.float() if b is not None else torch.zeros(w.shape[0])
+                if pg is not None and pg.numel() == w.shape[1]:
+                    if pb is not None:
+                        b = b + w @ pb.float()
+                    w = w * pg.float()[None, :]
+                mags.append((w.pow(2).sum(1) + b.pow(2)).sqrt())
             elif k.startswith("text_decoder.cross_attn.") and k.endswith(".attn.in_proj_weight"):
                 pre = k[: -len("attn.in_proj_weight")]
                 w, b = w.float(), sd[pre + "attn.in_proj_bias"].float()

@@ -159,6 +159,15 @@ def test_coca_wrapper_dict_api():
     assert torch.isinf(out["logits"][0][0, model.arch.eos])        # MinLength mask visible in the recorded logits
     ppl = model.compute_perplexity()
     assert torch.isfinite(ppl)
+    # options of the reference's generate() that the engine was BUILT with (coca_model.py:209-223): accepted at the value in force,
+    # refused by name at any other - never dropped
+    a = model.arch
+    ids = model.generate(im, min_seq_len=a.min_seq_len, eos_token_id=a.eos, pad_token_id=a.pad, sot_token_id=a.sot, max_seq_len=77)
+    assert ids.shape == (1, a.seq_len)
+    for opts, word in (({"min_seq_len": a.min_seq_len + 2}, "min_seq_len"), ({"eos_token_id": 7}, "eos_token_id=7"),
+                       ({"fixed_output_length": True}, "fixed_output_length"), ({"max_seq_len": 4}, "max_seq_len=4")):
+        with pytest.raises(ValueError, match=word):
+            model.generate(im, **opts)
 
 
 def _beam_expected(ref, L, pad):

@@ -206,3 +206,29 @@ def test_bench_multi_rank_paths_world2():
     keys = {(i // 6, i % 3) for i in range(n_frames)}
     assert objects == len(keys) and set(freq) == keys
     assert sum(n for fl in freq.values() for n, _ in fl) == n_frames
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: bench.py starts the two ranks itself (a
+    torch.distributed.run child process at 127.0.0.1, spawned before any GPU call), they rendezvous, run the timed steps with the
+    per-step caption all-gather and the strong-scaling job, and rank 0's line carries n_gpus = the size of the process group.
+    --stub-engine: CPU ranks over gloo with a fake captioner (the GPU branch differs in the backend name and set_device only)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-engine", "--steps", "3", "--warmup", "1",
+                        "--frames", "203", "--batch", "8", "--max-length", "6"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                        # rank 0 alone prints, once
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["stub"] is True and line["scaling"] == "weak" and line["value"] > 0
+    st = line["strong_scaling"]
+    assert st["frames"] == 203 and st["n_gpus"] == 2 and st["frames_per_rank"] == 102 and st["scaling"] == "strong"
+    assert st["objects"] == len({(i // 500, (i // 10) % 50) for i in range(203)})
+    # a launcher that set WORLD_SIZE to something else is an error, not a silent single-rank run
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-engine"], env={**env, "WORLD_SIZE": "1"},
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr

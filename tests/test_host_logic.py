@@ -195,3 +195,18 @@ def test_clip_bpe_decoder_agrees_with_the_hf_clip_tokenizer_on_its_own_files(tmp
         assert ours_m.decode(ids) == ours.decode(ids)
     full = [sid["<|startoftext|>"], sid["the</w>"], sid["cat</w>"], sid["<|endoftext|>"]]
     assert ours.caption(full) == "the cat "
+
+
+def test_kv16_guard_sees_outliers_through_the_post_layernorm_gamma():
+    """weights.cross_kv_head_spread sizes a K/V dimension on the projection's INPUT distribution: BLIP's cross-attention reads
+    post_layernorm(x) = xhat * gamma + beta, so a large gamma channel that one head dimension weights heavily is an outlier
+    dimension of that head although the projection's rows alone look level."""
+    from embodied_captioning_amd.config import BlipArch
+    from embodied_captioning_amd.weights import KV16_MAX_HEAD_SPREAD, cross_kv_head_spread, procedural_blip_state_dict
+    sd = procedural_blip_state_dict(BlipArch.tiny(), 0)
+    assert cross_kv_head_spread(sd) < 1.5
+    key = next(k for k in sd if k.endswith("crossattention.self.key.weight"))
+    w = sd[key].clone(); w[5, 3] *= 30
+    g = sd["vision_model.post_layernorm.weight"].clone(); g[3] *= 200
+    assert cross_kv_head_spread({**sd, key: w}) < 3                                      # the rows alone: level
+    assert cross_kv_head_spread({**sd, key: w, "vision_model.post_layernorm.weight": g}) > KV16_MAX_HEAD_SPREAD

@@ -70,9 +70,11 @@ def test_gemm_pp_fragment_registers_are_untouched_between_read_and_wait(gemm_pp_
             t = l.strip()
             if not t or t.startswith((";", ".")):
                 continue
-            if re.match(r"^[.\w$]+:", t) or t.startswith(("s_cbranch", "s_branch", "s_setpc", "s_endpgm")):
-                pending = []                            # (checked per basic block: the stage loop is straight-line code)
+            if t.startswith(("s_branch", "s_setpc", "s_endpgm")):
+                pending = []                            # nothing falls through: the next line starts from another path
                 continue
+            if re.match(r"^[.\w$]+:", t) or t.startswith("s_cbranch"):
+                continue                                # a label / conditional branch: the fall-through path keeps its reads in flight
             op = t.split()[0]
             if op.startswith("ds_read") or op.startswith("ds_load"):
                 dst = _regs(t.split(",")[0])
@@ -87,11 +89,12 @@ def test_gemm_pp_fragment_registers_are_untouched_between_read_and_wait(gemm_pp_
                     keep = int(m.group(1))
                     pending = pending[len(pending) - keep:] if keep else []
                 continue
-            if op.startswith(("ds_write", "ds_store", "ds_bpermute", "ds_swizzle", "s_load", "s_buffer_load", "global_load_lds",
-                              "buffer_load")) and "lds" in t or op.startswith(("ds_write", "ds_store")):
-                continue                                # other LDS traffic: no VGPR destination of ours
+            # every other instruction - LDS stores and LDS-DMA included: their address and data operands are VGPRs too - must
+            # stay off the registers of reads still in flight
             used = _regs(t)
             for p in pending:
                 hit = p & used
                 assert not hit, (name, "touches a fragment register before its wait", t, sorted(hit)[:4])
+            if op.startswith(("ds_write", "ds_store", "ds_bpermute", "ds_swizzle")):
+                pending.append(set())                   # counts in lgkmcnt like a read (in order), holds no register of ours
     assert checked > 100, checked

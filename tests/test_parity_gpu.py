@@ -18,9 +18,9 @@ BF16_TAU = 0.3            # a bf16 row may leave the oracle path only where the 
 EXACT = ("f32", "f32s")   # modes held to the north_star's bar: identical tokens, beam scores within 1e-3
 
 
-def _engine(arch, dtype, batch, beams, max_len):
+def _engine(arch, dtype, batch, beams, max_len, **kw):
     from embodied_captioning_amd.engine import CaptionerEngine
-    return CaptionerEngine(arch, dtype=dtype, max_batch=batch, max_beams=beams, max_len=max_len)
+    return CaptionerEngine(arch, dtype=dtype, max_batch=batch, max_beams=beams, max_len=max_len, **kw)
 
 
 @pytest.mark.parametrize("dtype", EXACT)
@@ -99,6 +99,21 @@ def test_wide_golden_256_rows_one_whole_headline_batch(dtype):
         seq2 = torch.cat([o["sequences"] for o in outs]).cpu().numpy()
         assert np.array_equal(seq2, ref)
         pool.close()
+    eng.close()
+
+
+def test_wide_golden_256_rows_with_fp32_cross_rows():
+    """The headline batch in the split mode WITHOUT the KV16 cache (`cross_cache="fp32"`, CapConfig.cross_kv_fp32 - what a checkpoint
+    whose K/V heads fail the KV16 guard runs on, and the bench line's `f32s_fp32kv` key): token-identical to the HF golden on all
+    256 rows, and to the KV16 run."""
+    g, meta, arch, sd, px = golden_inputs("blip_base256")
+    B, L = meta["batch"], meta["max_length"]
+    eng = _engine(arch, "f32s", B, 1, L, cross_cache="fp32")
+    eng.load_state_dict(sd)
+    assert eng.cross_cache_kind == "fp32"
+    seq = eng.generate(px.cuda(), num_beams=1, max_length=L)["sequences"].cpu().numpy()
+    same = (seq == g["greedy_sequences"]).all(axis=1)
+    assert same.all(), (int(same.sum()), np.nonzero(~same)[0][:8])
     eng.close()
 
 

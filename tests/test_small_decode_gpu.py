@@ -277,3 +277,35 @@ def test_engine_pool_and_a_large_arena_take_the_small_path_for_small_calls():
     assert all(e.last_decode_path == "small" for e in pool.engines)
     pool.close()
     eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32s", "bf16"])
+def test_automatic_selection_crosses_position_32_with_the_bits_of_the_batch_path(dtype):
+    """The fused kernels take at most 32 cached positions: with max_length 40 the automatic selection runs them for positions 1..32
+    and the batch kernels from 33 on, in the middle of ONE generate.  Both read and write the same self-attention cache and
+    LayerNorm rows, so tokens and live logits equal the batch path's; forcing the small path for such a call fails at entry."""
+    from embodied_captioning_amd._native import CaptionerHipError
+    from embodied_captioning_amd.config import BlipArch
+    from embodied_captioning_amd.weights import procedural_blip_state_dict, synthetic_pixels
+    arch = BlipArch.tiny()
+    sd = procedural_blip_state_dict(arch, 5, eos_boost=-6.0)          # EOS pushed down: the captions run the whole length
+    B, L = 5, 40
+    px = synthetic_pixels(B, arch.image_size, seed=5).cuda()
+    outs = {}
+    for path in ("auto", "batch"):
+        eng = _engine(arch, dtype, B, 1, L, path)
+        eng.load_state_dict(sd)
+        outs[path] = eng.generate(px, num_beams=1, max_length=L, output_logits=True)
+        assert eng.last_decode_path == "batch"                        # what the LAST step ran on, either way
+        eng.close()
+    a, b = outs["auto"], outs["batch"]
+    assert int(a["lengths"].max()) > 34                               # the switch happened inside live captions
+    assert torch.equal(a["sequences"], b["sequences"]) and torch.equal(a["lengths"], b["lengths"])
+    live = torch.from_numpy(_live_mask(a["sequences"].cpu().numpy(), arch, L - 1))
+    assert torch.equal(a["logits"].cpu()[live], b["logits"].cpu()[live])
+    eng = _engine(arch, dtype, B, 1, L, "small")
+    eng.load_state_dict(sd)
+    with pytest.raises(CaptionerHipError, match="at most 32"):
+        eng.generate(px, num_beams=1, max_length=L)
+    assert eng.last_decode_steps == 0 or eng.last_decode_path in ("none", "small", "batch")
+    eng.close()
