@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--stub-engine", action="store_true", help="TEST ONLY (tests/test_distributed_cpu.py): the launch / rendezvous / "
                     "timed-region / gather / strong-scaling plumbing on CPU ranks over gloo with a fake captioner whose ids are a "
                     "function of the frame index; prints a line marked \"stub\": true and never touches a GPU")
+    ap.add_argument("--decode-path", default="auto", choices=["auto", "batch", "small", "tile"],
+                    help="blip: decode kernels of the timed steps (engine.set_decode_path; A/B of the batch path's kernel sets)")
     ap.add_argument("--lite", action="store_true", help="timed steps only (profiler counter passes): no roofline / "
                     "encoder-only / parity / fp32 / CPU legs")
     ap.add_argument("--no-latency", action="store_true", help="skip the small-batch `latency` block (profiler passes: its B = 1 / 8 / 64 "
@@ -865,11 +867,13 @@ def main():
     eng = CaptionerEngine(arch, dtype=a.dtype, max_batch=B, max_beams=a.beams, max_len=L, device=dev)
     eng.load_state_dict(sd)
     eng.set_early_exit(a.early_exit)
+    eng.set_decode_path(a.decode_path)
     runner = eng
     if a.streams > 1:
         from embodied_captioning_amd.engine import EnginePool
         runner = EnginePool(arch, n=a.streams, device=dev, dtype=a.dtype, max_batch=B, max_beams=a.beams, max_len=L, weights_of=eng)
         runner.set_early_exit(a.early_exit)
+        runner.set_decode_path(a.decode_path)
     log(f"weights loaded once, {a.streams} engine(s) / stream(s) on them; timing ({a.dtype})")
     dt, (ids, lens) = timed_steps(runner, px, L, a.steps, a.warmup, world, gather, a.beams)
     decode_steps = (runner.engines[0] if a.streams > 1 else eng).last_decode_steps

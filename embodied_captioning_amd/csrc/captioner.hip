@@ -18,6 +18,7 @@
 #include "gemm.h"
 #include "ops.h"
 #include "decode_small.h"
+#include "decode_tile.h"
 
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local char g_err[2048] = "";
@@ -152,7 +153,7 @@ struct Captioner {
                                  // of bf16 captions token-identical to the fp32 mode's - not worth it, so off)
     int *seq, *finished, *lens, *anc;
     float *dx, *dy, *logits, *dpart;
-    float* dx2 = nullptr;        // small-batch decode path: second fp32 LayerNorm row buffer (ping-pong with dx), SMALL_MAX_ROWS rows
+    float* dx2 = nullptr;        // fused decode paths: second fp32 LayerNorm row buffer (ping-pong with dx), as many rows as dx
     void *dx_t, *dq, *dctx, *dh;
     void* beam = nullptr;
     size_t cache_layer_bytes = 0;
@@ -443,7 +444,7 @@ int build_arena_coca(Captioner* m) {
     TRY(dev_alloc(m, (void**)&m->anc, 2 * R * Lm * 4 + 256));    // beam ancestry of the self-attention caches (beam.hip)
     TRY(dev_alloc(m, (void**)&m->dx, R * E * 4));
     TRY(dev_alloc(m, (void**)&m->dy, R * E * 4));
-    TRY(dev_alloc(m, (void**)&m->dx2, (size_t)SMALL_MAX_ROWS * E * 4));
+    TRY(dev_alloc(m, (void**)&m->dx2, (size_t)(R > SMALL_MAX_ROWS ? R : SMALL_MAX_ROWS) * E * 4));
     TRY(dev_alloc(m, (void**)&m->dpart, 12 * R * E * 4));
     TRY(dev_alloc(m, &m->dx_t, R * E * e));
     TRY(dev_alloc(m, &m->dq, R * E * e));
@@ -478,7 +479,7 @@ int build_arena(Captioner* m) {
     TRY(dev_alloc(m, (void**)&m->anc, 2 * R * Lm * 4));
     TRY(dev_alloc(m, (void**)&m->dx, R * T * 4));
     TRY(dev_alloc(m, (void**)&m->dy, R * T * 4));
-    TRY(dev_alloc(m, (void**)&m->dx2, (size_t)SMALL_MAX_ROWS * T * 4));
+    TRY(dev_alloc(m, (void**)&m->dx2, (size_t)(R > SMALL_MAX_ROWS ? R : SMALL_MAX_ROWS) * T * 4));
     TRY(dev_alloc(m, (void**)&m->dpart, 12 * R * T * 4));      // split-K slabs: 8 x [R,T] (ffn) or 4 x [R,3T] (qkv)
     TRY(dev_alloc(m, &m->dx_t, R * T * e));
     TRY(dev_alloc(m, &m->dq, R * T * e));
@@ -1014,7 +1015,7 @@ int run_coca_pool(Captioner* m, int B, float* tokens_out, hipStream_t s) {
 struct Dec {
     int b0, B, R, Btot;
     float *dx, *dy, *logits, *dpart;
-    float* dx2;           // (the whole-batch slice only: the small-batch path's second LayerNorm row buffer)
+    float* dx2;           // the fused paths' second LayerNorm row buffer
     char *dx_t, *dq, *dctx, *dh;
     int *seq, *finished, *lens, *anc;
     void* beam;
@@ -1027,7 +1028,7 @@ Dec make_slice(Captioner* m, int b0, int B, int Btot, int K, int Lm) {
     const size_t r0 = (size_t)b0 * K;
     Dec d;
     d.b0 = b0; d.B = B; d.R = B * K; d.Btot = Btot;
-    d.dx2 = b0 == 0 ? m->dx2 : nullptr;
+    d.dx2 = m->dx2 + r0 * T;
     d.dx = m->dx + r0 * T; d.dy = m->dy + r0 * T; d.logits = m->logits + r0 * m->ldl; d.dpart = m->dpart + 12 * r0 * T;
     d.dx_t = (char*)m->dx_t + r0 * T * e; d.dq = (char*)m->dq + r0 * T * e; d.dctx = (char*)m->dctx + r0 * T * e;
     d.dh = (char*)m->dh + r0 * F * e;
@@ -1089,7 +1090,7 @@ int gemm_rows(Captioner* m, hipStream_t s, const char* tag, const void* A, const
 // launch it saves - cross-XCD hand-over, DESIGN.md section 4 - and was removed.)
 int gemm_splitk_reduce_ln(Captioner* m, hipStream_t s, const Dec& d, const char* tag, const void* A, const void* W,
                           const float* bias, const float* g, const float* b, float eps, int N, int K, void* out_t,
-                          float* out_f, float* y_out) {
+                          float* out_f, float* y_out, const float* resid = nullptr) {
     const int S = decode_splitk(m, N, K, 4);
     GemmParams p;
     memset(&p, 0, sizeof(p));
@@ -1100,19 +1101,55 @@ int gemm_splitk_reduce_ln(Captioner* m, hipStream_t s, const Dec& d, const char*
         TRY(launch_gemm(m->gdt, p, decode_tile(m), s));
     }
     ProfScope ps(m, s, "dec_reduce_ln", 0, (double)(S + 2) * d.R * N * 4 + (double)d.R * N * m->esz);
-    return launch_reduce_layernorm(m->gdt, d.dpart, S, bias, d.dx, g, b, eps, out_t, out_f, y_out, d.R, N, s, true);
+    return launch_reduce_layernorm(m->gdt, d.dpart, S, bias, resid ? resid : d.dx, g, b, eps, out_t, out_f, y_out, d.R, N, s, true);
 }
 
+// x: the fp32 LayerNorm row buffer the consumer adds as its residual and replaces (d.dx, or d.dx2 on the fused paths)
 int gemm_splitk_ln(Captioner* m, hipStream_t s, const Dec& d, const char* tag, const void* A, const void* W,
-                   const float* bias, const float* g, const float* b, int N, int K) {
-    return gemm_splitk_reduce_ln(m, s, d, tag, A, W, bias, g, b, m->c.t_eps, N, K, d.dx_t, d.dx, nullptr);
+                   const float* bias, const float* g, const float* b, int N, int K, float* x = nullptr) {
+    return gemm_splitk_reduce_ln(m, s, d, tag, A, W, bias, g, b, m->c.t_eps, N, K, d.dx_t, x ? x : d.dx, nullptr, x);
 }
 
+// cross block of layer i as the fused kernel's parameter block (decode_tile.hip): consumer of the self-attention output
+// projection's slabs (S_so slices in d.dpart) + LayerNorm, query projection, attention; LayerNorm rows: resid -> x_out
+SmallCross tile_cross_params(const Captioner* m, const Dec& d, const TLayer& L, int i, int K, int S_so, const float* resid, float* x_out,
+                             const int* skip) {
+    const CapConfig& c = m->c;
+    const int T = c.t_hidden, H = c.t_heads, NT = m->NT;
+    SmallCross x;
+    memset(&x, 0, sizeof(x));
+    x.W = L.w_cq; x.bias = L.b_cq; x.R = d.R; x.D = T; x.H = H; x.S = decode_splitk(m, T, T, 4);
+    x.ln.part = d.dpart; x.ln.S = S_so; x.ln.bias = L.b_so; x.ln.gamma = L.so_g; x.ln.beta = L.so_b; x.ln.eps = c.t_eps;
+    x.ln.resid = resid; x.ln.x_out = x_out;
+    const size_t blk = m->cross_block((size_t)d.Btot * H * NT);
+    x.kbase = (char*)m->cross + ((size_t)i * 2 + 0) * blk;
+    x.vbase = (char*)m->cross + ((size_t)i * 2 + 1) * blk;
+    x.kv_row0 = (size_t)d.b0 * H * NT;
+    x.rows_per_kv = K; x.kv_ld = NT; x.n_keys = NT;
+    x.kv_kind = m->kv16 ? SMALL_KV_KV16 : (m->dt == CAP_DT_BF16 ? SMALL_KV_BF16 : SMALL_KV_F32);
+    x.skip = skip; x.out = d.dctx;
+    return x;
+}
+
+// The batch path's fused kernels take the call: BLIP, split or bf16 mode, greedy (one row per image), more rows than the
+// small-batch kernels take
+bool tile_path_takes(const Captioner* m, const Dec& d, int K) {
+    const CapConfig& c = m->c;
+    if (m->gdt == CAP_DT_F32 || c.arch != CAP_ARCH_BLIP || K != 1 || d.R <= SMALL_MAX_ROWS) return false;
+    TLayer none;
+    memset((void*)&none, 0, sizeof(none));
+    return tile_cross_takes(m->gdt, tile_cross_params(m, d, none, 0, K, decode_splitk(m, c.t_hidden, c.t_hidden, 4), nullptr, nullptr, nullptr));
+}
+
+// fused: the cross block of every layer as ONE launch (decode_tile.hip) instead of reduce_layernorm + cq GEMM + attention:
+// 9 launches per layer-step instead of 11, the same bits (tests/test_tile_decode_gpu.py)
 int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, int t, int K, const int* anc, int Lm,
-                     hipStream_t s) {
+                     hipStream_t s, bool fused = false) {
     const CapConfig& c = m->c;
     const int T = c.t_hidden, F = c.t_ffn, H = c.t_heads, R = d.R, NT = m->NT;
     const size_t e = m->esz;
+    float* xcur = d.dx;                            // fp32 LayerNorm rows: the residual of the next consumer (fused: ping-pong with
+    float* xalt = d.dx2;                           // d.dx2 - the head-0 workgroup of a tile writes the rows the others still read)
     // greedy: the attention kernels leave the rows of ended captions alone (d.finished is set by greedy_select one step
     // before); the GEMMs still cover every row - they are bound by the weight stream, not by the row count
     const int* skip = K == 1 ? d.finished : nullptr;
@@ -1135,6 +1172,17 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
             ProfScope ps(m, s, "dec_self_attn", 4.0 * R * H * (t + 1) * 64, 2.0 * R * H * (t + 1) * 64 * e);
             TRY(launch_decode_attention(m->dt, d.dq, kc, vc, anc, Lm, 1, Lm, t + 1, d.dctx, R, H, 0, s, nullptr, 0, nullptr, 0, 0, 0, m->gdt, skip));
         }
+        if (fused) {
+            int S = 1;
+            TRY(gemm_partial(m, s, "dec_gemm_so", d.dctx, L.w_so, d.dpart, R, T, T, 4, &S));
+            const SmallCross x = tile_cross_params(m, d, L, i, K, S, xcur, xalt, skip);
+            {
+                ProfScope ps(m, s, "dec_tile_cross", 2.0 * R * T * T + 4.0 * R * H * NT * 64,
+                             (double)T * T * e + (double)(S + 2) * R * T * 4 + 2.0 * d.B * H * NT * m->kvrow);
+                TRY(launch_tile_cross(m->gdt, x, s));
+            }
+            float* tmp = xcur; xcur = xalt; xalt = tmp;
+        } else {
         TRY(gemm_splitk_ln(m, s, d, "dec_gemm_so", d.dctx, L.w_so, L.b_so, L.so_g, L.so_b, T, T));
         {
             int S = 1;
@@ -1148,9 +1196,10 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
             TRY(launch_decode_attention(m->dt, nullptr, ck, cv, nullptr, 0, K, NT, NT, d.dctx, R, H, 0, s, d.dpart, S, L.b_cq,
                                         T, 0, 0, m->gdt, skip, m->kv16 ? 1 : 0, m->kv16 ? row0 : 0));
         }
-        TRY(gemm_splitk_ln(m, s, d, "dec_gemm_co", d.dctx, L.w_co, L.b_co, L.co_g, L.co_b, T, T));
+        }
+        TRY(gemm_splitk_ln(m, s, d, "dec_gemm_co", d.dctx, L.w_co, L.b_co, L.co_g, L.co_b, T, T, xcur));
         TRY(gemm_rows(m, s, "dec_gemm_f1", d.dx_t, L.w_f1, d.dh, L.b_f1, R, F, T, 1));
-        TRY(gemm_splitk_ln(m, s, d, "dec_gemm_f2", d.dh, L.w_f2, L.b_f2, L.f_g, L.f_b, T, F));
+        TRY(gemm_splitk_ln(m, s, d, "dec_gemm_f2", d.dh, L.w_f2, L.b_f2, L.f_g, L.f_b, T, F, xcur));
     }
     TRY(gemm(m, s, "dec_gemm_tr", d.dx_t, T, m->w_tr, T, d.dy, T, m->b_tr, nullptr, R, T, T, 1, 1));
     {
@@ -1504,14 +1553,21 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
                               "(%d rows, step %d, compute type %d): at most %d rows, 32 positions, split or bf16 mode, BLIP / CoCa", R, t, m->gdt, SMALL_MAX_ROWS);
                 return -1;
             }
-            const bool small = can && m->decode_path != 1;
-            m->last_path = small ? 2 : 1;
+            const bool small = can && (m->decode_path == 0 || m->decode_path == 2);
+            const bool can_tile = !coca && tile_path_takes(m, d, K);
+            if (m->decode_path == 3 && !can_tile) {
+                cap_set_error("cap_generate: the fused batch decode path was forced (cap_set_decode_path 3) but does not take this call "
+                              "(%d rows, %d beam(s), compute type %d): more than %d rows, greedy, split or bf16 mode, BLIP", R, K, m->gdt, SMALL_MAX_ROWS);
+                return -1;
+            }
+            const bool tile = !small && can_tile && (m->decode_path == 0 || m->decode_path == 3);
+            m->last_path = small ? 2 : (tile ? 3 : 1);
             if (coca) {
                 if (small) TRY(run_coca_step_small(m, d, tokens, Lm, t, K, anc, Lm, s));
                 else TRY(run_coca_step(m, d, tokens, Lm, t, K, anc, Lm, s));
             } else {
                 if (small) TRY(run_decoder_step_small(m, d, tokens, Lm, t, K, anc, Lm, s));
-                else TRY(run_decoder_step(m, d, tokens, Lm, t, K, anc, Lm, s));
+                else TRY(run_decoder_step(m, d, tokens, Lm, t, K, anc, Lm, s, tile));
             }
         }
         if (out_step_logits) {
@@ -1697,7 +1753,7 @@ int cap_last_decode_steps(CapHandle h) { return h ? ((Captioner*)h)->last_steps 
 int cap_set_decode_path(CapHandle h, int path) {
     Captioner* m = (Captioner*)h;
     if (!m) { cap_set_error("cap_set_decode_path: null handle"); return -1; }
-    if (path < 0 || path > 2) { cap_set_error("cap_set_decode_path: path must be 0 (by row count), 1 (batch kernels) or 2 (small-batch kernels), got %d", path); return -1; }
+    if (path < 0 || path > 3) { cap_set_error("cap_set_decode_path: path must be 0 (by row count), 1 (batch kernels, one launch per operation), 2 (small-batch kernels) or 3 (batch kernels with the fused cross block), got %d", path); return -1; }
     m->decode_path = path;
     return 0;
 }
@@ -1857,7 +1913,8 @@ long long cap_g8_saturations(int reset) {
     if (hipDeviceSynchronize() != hipSuccess) { cap_set_error("cap_g8_saturations: device synchronisation failed"); return -1; }
     unsigned long long total = 0;
     if (cap_g8_clamped_gemm(&total, reset) != 0 || cap_g8_clamped_gemm_pp(&total, reset) != 0 || cap_g8_clamped_elementwise(&total, reset) != 0 ||
-        cap_g8_clamped_attention(&total, reset) != 0 || cap_g8_clamped_decode_small(&total, reset) != 0)
+        cap_g8_clamped_attention(&total, reset) != 0 || cap_g8_clamped_decode_small(&total, reset) != 0 ||
+        cap_g8_clamped_decode_tile(&total, reset) != 0)
         return -1;
     return (long long)total;
 }

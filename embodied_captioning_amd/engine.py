@@ -134,7 +134,7 @@ class CaptionerEngine:
         """Layout of this handle's cross-attention K/V cache: "fp32", "bf16" or "kv16"."""
         return {0: "fp32", 1: "bf16", 2: "kv16"}[int(self.lib.cap_cross_cache_kind(self._h))]
 
-    DECODE_PATHS = {"auto": 0, "batch": 1, "small": 2}
+    DECODE_PATHS = {"auto": 0, "batch": 1, "small": 2, "tile": 3}
 
     def set_decode_path(self, path: str) -> None:
         """Kernels of the decode steps (BLIP, "f32s" / "bf16"): "auto" = the fused small-batch kernels for images x beams <= 16
@@ -144,7 +144,7 @@ class CaptionerEngine:
 
     @property
     def last_decode_path(self) -> str:
-        return {0: "none", 1: "batch", 2: "small"}[int(self.lib.cap_last_decode_path(self._h))]
+        return {0: "none", 1: "batch", 2: "small", 3: "tile"}[int(self.lib.cap_last_decode_path(self._h))]
 
     # ------------------------------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> Dict[str, object]:
@@ -327,6 +327,10 @@ class EnginePool:
     def set_early_exit(self, poll_steps: int) -> None:
         for e in self.engines:
             e.set_early_exit(poll_steps)
+
+    def set_decode_path(self, path: str) -> None:
+        for e in self.engines:
+            e.set_decode_path(path)
 
     def close(self) -> None:
         for e in self.engines:
