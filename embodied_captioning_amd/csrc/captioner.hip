@@ -1560,7 +1560,7 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
                               "(%d rows, %d beam(s), compute type %d): more than %d rows, greedy, split or bf16 mode, BLIP", R, K, m->gdt, SMALL_MAX_ROWS);
                 return -1;
             }
-            const bool tile = !small && can_tile && (m->decode_path == 0 || m->decode_path == 3);
+            const bool tile = !small && can_tile && m->decode_path == 3;      // (measured level with the batch kernels: not the automatic choice)
             m->last_path = small ? 2 : (tile ? 3 : 1);
             if (coca) {
                 if (small) TRY(run_coca_step_small(m, d, tokens, Lm, t, K, anc, Lm, s));

@@ -78,17 +78,17 @@ def test_fused_cross_block_ragged_tiles_and_short_image_towers(dtype, rows):
     _same_bits(a, b, arch, L)
 
 
-def test_fused_cross_block_whole_headline_batch_and_the_automatic_selection():
-    """256 frames = the bench's batch: the automatic selection takes the fused kernels above 16 rows (greedy, BLIP, split mode) and
-    the tokens are HF's on all 256 rows; the same bits as the one-launch-per-operation kernels."""
+def test_fused_cross_block_whole_headline_batch():
+    """256 frames = the bench's batch on the fused kernels: the tokens are HF's on all 256 rows, the bits those of the
+    one-launch-per-operation kernels (which the automatic selection keeps above 16 rows: the two measure level)."""
     g, meta, arch, sd, px = golden_inputs("blip_base256")
     L = meta["max_length"]
-    eng = _engine(arch, "f32s", 256, L, "auto")
+    eng = _engine(arch, "f32s", 256, L, "tile")
     eng.load_state_dict(sd)
     out = eng.generate(px.cuda(), num_beams=1, max_length=L, output_logits=True)
     assert eng.last_decode_path == "tile"
     assert np.array_equal(out["sequences"].cpu().numpy(), g["greedy_sequences"])
-    eng.set_decode_path("batch")
+    eng.set_decode_path("auto")
     ref = eng.generate(px.cuda(), num_beams=1, max_length=L, output_logits=True)
     assert eng.last_decode_path == "batch"
     _same_bits(out, ref, arch, L)
@@ -104,10 +104,10 @@ def test_fused_cross_block_whole_headline_batch_and_the_automatic_selection():
     with pytest.raises(CaptionerHipError, match="fused batch decode path"):
         eng.generate(px[:32].cuda(), num_beams=3, max_length=L)
     eng.close()
-    # fp32 cross-attention rows at 197 keys (cross_cache="fp32"): chunks of 56 keys do not fit the fused kernel's registers - the
-    # selection keeps the batch kernels
+    # fp32 cross-attention rows at 197 keys (cross_cache="fp32"): chunks of 56 keys do not fit the fused kernel's registers
     eng = CaptionerEngine(arch, dtype="f32s", max_batch=32, max_beams=1, max_len=L, cross_cache="fp32")
     eng.load_state_dict(sd)
-    eng.generate(px[:32].cuda(), num_beams=1, max_length=L)
-    assert eng.last_decode_path == "batch"
+    eng.set_decode_path("tile")
+    with pytest.raises(CaptionerHipError, match="fused batch decode path"):
+        eng.generate(px[:32].cuda(), num_beams=1, max_length=L)
     eng.close()

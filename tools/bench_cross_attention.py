@@ -3,12 +3,14 @@
 blocks of 12 layers in turn (cold: 12 x 2 x 116 MB), fp32 cache (mode 0) against the split mode's KV16 cache (mode 1: int16 rows +
 one scale each, 132 bytes per row).  Round 3 with the 24-bit cache this one replaced: 53.8 us = 5.76 TB/s (fp32) against 43.3 us =
 5.36 TB/s (192-byte rows); a double-buffered variant (chunks of 40 keys x 2) ran at 76 us and non-temporal loads at 42.8 - neither
-kept.     python tools/bench_cross_attention.py"""
+kept.     python tools/bench_cross_attention.py [rows]
+(rows < 256: what the launch would cost with the captions that are still open compacted to the front - round 5)"""
 import ctypes as C, sys, os, torch
 sys.path.insert(0, os.getcwd())
 from embodied_captioning_amd import _native
 lib=_native.load_library(); s=C.c_void_p(torch.cuda.current_stream().cuda_stream)
-R,H,NK=256,12,197
+R=int(sys.argv[1]) if len(sys.argv)>1 else 256
+H,NK=12,197
 rows=R*H*NK
 q=torch.randn(R,H*64,device='cuda')
 nb=12   # distinct caches (12 layers) so data is cold: 12 x 2 x 116 MB
