@@ -139,7 +139,9 @@ class CaptionerEngine:
     def set_decode_path(self, path: str) -> None:
         """Kernels of the decode steps (BLIP, "f32s" / "bf16"): "auto" = the fused small-batch kernels for images x beams <= 16
         rows (6 launches per layer-step instead of 11; same bits), the batch kernels above; "batch" / "small" force one
-        (forcing "small" makes generate fail for calls those kernels do not take)."""
+        (forcing "small" makes generate fail for calls those kernels do not take); "tile" = the batch kernels with every layer's
+        cross block as one launch (csrc/decode_tile.hip: 9 launches per layer-step, same bits, measured level with "batch" -
+        greedy calls of more than 16 rows only)."""
         N.check(self.lib.cap_set_decode_path(self._h, self.DECODE_PATHS[path]), "cap_set_decode_path")
 
     @property

@@ -2,19 +2,19 @@
 # rocprofv3 passes of a bench command for profiles/: kernel-trace stats, then (PMC=1) hardware counters in SEPARATE passes
 # (never combined with other trace domains) of the same workload's timed steps only.  The program comes directly after `--`.
 # Run on the GPU box from the repo root:
-#   bash tools/profile_round.sh r04_bench                          # default bench command (f32s headline), stats + PMC
-#   PMC=0 bash tools/profile_round.sh r04_bench_beam3 --beams 3 --batch 64
-#   bash tools/profile_round.sh r04_bench_bf16 --dtype bf16
+#   bash tools/profile_round.sh r05_bench                          # default bench command (f32s headline), stats + PMC
+#   PMC=0 bash tools/profile_round.sh r05_bench_beam3 --beams 3 --batch 64
+#   bash tools/profile_round.sh r05_bench_bf16 --dtype bf16
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r04_bench}; shift || true
+TAG=${1:-r05_bench}; shift || true
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # one stream: with the default stream pool kernels of different batches co-run and share the GPU, so their durations in the
 # trace are not those of the kernel alone (vit_attention_split: 963 us pooled, 228 us alone) - the bench's roofline pass, which
 # these averages must agree with, also runs one engine on one stream
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $ROOT/bench.py --steps 3 --warmup 1 --streams 1 --no-extra-modes --no-cpu-baseline --no-latency "$@" > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $ROOT/bench.py --steps 3 --warmup 1 --streams 1 --no-extra-modes --no-cpu-baseline --no-latency --no-strong "$@" > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 echo "stats pass done"
 cd "$ROOT"
 python3 tools/summarize_prof.py stats "$OUT/stats" "$OUT/kernel_stats.md"
