@@ -7,17 +7,20 @@
 // tile would move five times its own operands.  What does carry over is the cross-attention block, whose cost is its K/V
 // stream anyway:
 //
-//   dec_tile_cross_kernel   workgroup = (16-row tile, head), 8 waves:
-//       LayerNorm of the tile's 16 rows (split-K consumer of the self-attention output projection: slabs + bias + residual; two
-//       rows per wave, every load of both rows in flight at once) -> G8 / bf16 row image in LDS, fp32 rows by the head-0 workgroup
-//       the head's 64 query columns of the 16 rows on the MFMA pipe: wave = (K slice, column half), chains j % 4 - the sums of
-//       the batch path's cq GEMM (gemm_rows_kernel: S slices x 4 chains, chains then slices then bias)
-//       16 (row, head) attention units, two per wave, decode_attn.h's online unit with the chunking of the batch kernel, the
-//       next chunk's loads in flight under the current one's arithmetic
+//   dec_tile_cross_kernel   workgroup = (16-row tile, head), 16 waves, each wave:
+//       LayerNorm of ONE of the tile's rows (split-K consumer of the self-attention output projection: slabs + bias + residual,
+//       every load in flight at once) -> G8 / bf16 row image in LDS, fp32 rows by the head-0 workgroup;
+//       one 16-column block of one K slice of the head's 64 query columns for all 16 rows on the MFMA pipe: chains j % 4 - the
+//       sums of the batch path's cq GEMM (gemm_rows_kernel: S slices x 4 chains, chains then slices then bias);
+//       ONE (row, head) attention unit - decode_attn.h's online unit with the chunking of the batch kernel: all 16 units of
+//       the tile stream at once, a wave per unit as in the batch path's attention kernel.
 //
 // replaces reduce_layernorm_row_kernel + gemm_rows_kernel (cq) + decode_attention_online_kernel: three launches -> one, and the
 // q partial sums, the G8 LayerNorm rows and their re-reads never leave the CU.  Same bits: every function that forms a sum is
 // the one the batch kernels call (decode_frag.h, decode_attn.h, ln.h), in the same order (tests/test_tile_decode_gpu.py).
+// MEASURED LEVEL with the three launches (40.1 us against 29.3 + 7.0 + 9.0 inside a 256-frame generate; docs/experiments.md,
+// round 5: the prologue streams 441 KB per workgroup through the CU's fill path) - selectable (cap_set_decode_path 3), not what
+// the automatic selection runs.  (First version: 8 waves, two units per wave, the next chunk in a second register buffer: 44.8 us.)
 #include "gemm_tile.h"
 #include "ln.h"
 #include "decode_attn.h"
