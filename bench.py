@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--beams", type=int, default=1, help="> 1: extra line for SURVEY config 3 (HF beam search; use --batch 64)")
     ap.add_argument("--streams", type=int, default=3, help="blip: engines (own arena + HIP stream each) the timed steps rotate "
                     "over, so that consecutive batches overlap; 1 = one engine, one stream (the profiling passes always use one)")
+    ap.add_argument("--coalesce-rows", type=int, default=1024, help="blip: dynamic batching of the engine pool - consecutive steps' batches "
+                    "are merged into passes of at most this many rows (EnginePool.generate_many(coalesce_rows=)); a frame has the same "
+                    "bits alone, in its batch and in a merged pass; 0 = every batch its own pass (the `pool_uncoalesced` key)")
     ap.add_argument("--early-exit", type=int, default=0, help="poll the device every N decode steps and leave the loop when "
                     "every caption is finished (HF's stopping rule; 0 = never, the default: no host sync in generate)")
     ap.add_argument("--eos-boost", type=float, default=9.0, help="blip: EOS logit offset of the procedural weights (9 = the "
@@ -154,7 +157,7 @@ class _NoPower:
         return None
 
 
-def timed_steps(eng, px, L, steps, warmup, world, gather, beams=1, dev="cuda"):
+def timed_steps(eng, px, L, steps, warmup, world, gather, beams=1, dev="cuda", coalesce=0):
     """`eng`: a CaptionerEngine, or an EnginePool - consecutive steps then run on the pool's engines / streams and overlap
     (each step is still one whole batch through encoder + decode + gather; all of them finish inside the timed region)."""
     pool = eng if hasattr(eng, "submit") else None
@@ -167,7 +170,7 @@ def timed_steps(eng, px, L, steps, warmup, world, gather, beams=1, dev="cuda"):
             return res
         # the batches overlap on the pool's streams; the caption all-gathers (one per step, as before) are issued in step
         # order on the caller's stream once the batches are joined - every rank issues its collectives in the same order
-        outs = pool.generate_many([px] * n, threads=True, num_beams=beams, max_length=L)   # a host thread per engine
+        outs = pool.generate_many([px] * n, threads=True, coalesce_rows=coalesce, num_beams=beams, max_length=L)   # a host thread per engine
         for out in outs:
             res = gather(out["sequences"], out["lengths"])
         return res
@@ -581,7 +584,7 @@ def main_blip2(a):
     print(json.dumps(line))
 
 
-def extra_mode(arch, sd, px, L, B, dev, dtype, streams, ref_ids, golden, cross_cache="auto"):
+def extra_mode(arch, sd, px, L, B, dev, dtype, streams, ref_ids, golden, cross_cache="auto", coalesce=0):
     """One of the non-headline arithmetic modes on the same workload: pooled timed steps, the encoder-GEMM roofline of one
     engine, token agreement with the headline run and with the HF golden.  cross_cache="fp32": the split mode with fp32
     cross-attention K/V rows instead of KV16 (the encoder is the headline's: no roofline pass)."""
@@ -589,13 +592,14 @@ def extra_mode(arch, sd, px, L, B, dev, dtype, streams, ref_ids, golden, cross_c
     kw = {"cross_cache": cross_cache} if cross_cache != "auto" else {}
     eng = CaptionerEngine(arch, dtype=dtype, max_batch=B, max_beams=1, max_len=L, device=dev, **kw)
     eng.load_state_dict(sd)
-    runner = EnginePool(arch, n=streams, device=dev, dtype=dtype, max_batch=B, max_beams=1, max_len=L, weights_of=eng, **kw) if streams > 1 else eng
-    steps = 6 if dtype != "f32" else 2
-    dt, (ids, _) = timed_steps(runner, px, L, steps, 2 if dtype != "f32" else 1, 1, lambda i, l: (i, l))
+    coalesce = coalesce if streams > 1 else 0
+    runner = EnginePool(arch, n=streams, device=dev, dtype=dtype, max_batch=max(B, coalesce), max_beams=1, max_len=L, weights_of=eng, **kw) if streams > 1 else eng
+    steps = 12 if dtype != "f32" else 2
+    dt, (ids, _) = timed_steps(runner, px, L, steps, 3 if dtype != "f32" else 1, 1, lambda i, l: (i, l), coalesce=coalesce)
     if streams > 1:
         runner.close()
     out = {"value": round(B * steps / dt, 2), "unit": "captions/s", "ms_per_step": round(1e3 * dt / steps, 3), "streams": streams,
-           "cross_cache": eng.cross_cache_kind}
+           "coalesce_rows": coalesce, "cross_cache": eng.cross_cache_kind}
     if cross_cache == "auto":
         out["roofline"] = roofline_pass(eng, px, L, dtype, arch, B)[0]
     out["rows_identical_to_headline"] = round(float((ids == ref_ids).all(dim=1).float().mean().item()), 4)
@@ -869,19 +873,27 @@ def main():
     eng.set_early_exit(a.early_exit)
     eng.set_decode_path(a.decode_path)
     runner = eng
+    # dynamic batching only where it is the plain greedy workload on a pool (beams / early exit / other sizes: extra lines as before)
+    coal = a.coalesce_rows if (a.streams > 1 and a.beams == 1 and not a.early_exit and a.coalesce_rows > B) else 0
     if a.streams > 1:
         from embodied_captioning_amd.engine import EnginePool
-        runner = EnginePool(arch, n=a.streams, device=dev, dtype=a.dtype, max_batch=B, max_beams=a.beams, max_len=L, weights_of=eng)
+        runner = EnginePool(arch, n=a.streams, device=dev, dtype=a.dtype, max_batch=max(B, coal), max_beams=a.beams, max_len=L, weights_of=eng)
         runner.set_early_exit(a.early_exit)
         runner.set_decode_path(a.decode_path)
     log(f"weights loaded once, {a.streams} engine(s) / stream(s) on them; timing ({a.dtype})")
-    dt, (ids, lens) = timed_steps(runner, px, L, a.steps, a.warmup, world, gather, a.beams)
+    dt, (ids, lens) = timed_steps(runner, px, L, a.steps, a.warmup, world, gather, a.beams, coalesce=coal)
+    uncoalesced = None
+    if coal and a.streams > 1 and not a.lite:
+        # the same steps with every batch as its own pass (rounds 1-4's headline), for the record
+        udt, _ = timed_steps(runner, px, L, a.steps, a.streams, world, gather, a.beams)
+        uncoalesced = {"value": round(world * B * a.steps / udt, 2), "unit": "captions/s", "ms_per_step": round(1e3 * udt / a.steps, 3),
+                       "steps": a.steps, "streams": a.streams}
     decode_steps = (runner.engines[0] if a.streams > 1 else eng).last_decode_steps
     log(f"timed region: {dt:.3f}s for {a.steps} steps (max over ranks)")
     strong = None
     if not (a.no_strong or a.lite or a.beams > 1 or arch.image_size != 224 or a.early_exit):
         log(f"strong-scaling job: {a.frames} frames in total over {world} rank(s)")
-        strong = strong_figure(a, arch, runner, dev, world, L, B)
+        strong = strong_figure(a, arch, runner, dev, world, L, max(B, coal))      # micro-batches of the merged passes' size
     if a.streams > 1:
         runner.close()
 
@@ -899,8 +911,14 @@ def main():
                 "config": {"workload": f"BLIP-base ViT-B/16 encoder + {'greedy' if a.beams == 1 else f'beam-{a.beams}'} decode, {B} frames/GPU {S}x{S}, "
                                        f"max_length={L}, caption all-gather", "global_batch": world * B,
                            "parallelism": f"dp{world}", "streams": a.streams, "compute_mode": a.dtype,
-                           "value_is": (f"consecutive batches overlapped on {a.streams} engines / HIP streams of one GPU (EnginePool); one batch at a "
-                                        f"time on one stream is the `single_stream` key") if a.streams > 1 else "one batch at a time on one stream"}}
+                           "value_is": (f"consecutive batches overlapped on {a.streams} engines / HIP streams of one GPU (EnginePool)"
+                                        + (f", the pool's dynamic batching merging consecutive steps' batches into passes of up to {coal} rows "
+                                           f"(a frame has the same bits alone, in its batch and in a merged pass); every batch as its own pass is the "
+                                           f"`pool_uncoalesced` key" if coal else "")
+                                        + "; one batch at a time on one stream is the `single_stream` key") if a.streams > 1 else "one batch at a time on one stream",
+                           "coalesce_rows": coal}}
+        if uncoalesced:
+            line["pool_uncoalesced"] = uncoalesced
         ln = lens[:B].float()
         line["caption_tokens"] = {"mean": round(float(ln.mean()), 2), "max": int(ln.max()), "of": L}
         if strong:
@@ -959,12 +977,12 @@ def main():
                 if a.dtype != "f32s" and other == "f32":
                     continue
                 log(f"extra mode: {other}")
-                line[key] = extra_mode(arch, sd, px, L, B, dev, other, a.streams if other != "f32" else 1, ids, golden)
+                line[key] = extra_mode(arch, sd, px, L, B, dev, other, a.streams if other != "f32" else 1, ids, golden, coalesce=coal)
             if a.dtype == "f32s":
                 # the headline's arithmetic with fp32 cross-attention K/V rows (CapConfig.cross_kv_fp32): what the split mode costs
                 # when the checkpoint's K/V heads are refused for KV16 - and the line's figure without the 15-bit cache
                 log("extra mode: f32s with fp32 cross-attention K/V rows")
-                line["f32s_fp32kv"] = extra_mode(arch, sd, px, L, B, dev, "f32s", a.streams, ids, golden, cross_cache="fp32")
+                line["f32s_fp32kv"] = extra_mode(arch, sd, px, L, B, dev, "f32s", a.streams, ids, golden, cross_cache="fp32", coalesce=coal)
         if world == 1 and not a.no_cpu_baseline:
             log(f"cpu baseline: {a.cpu_sample} captions on {host_cores()} host threads")
             cb, _ = cpu_baseline(sd, arch, L, a.cpu_sample)

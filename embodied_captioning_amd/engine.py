@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import json
-from typing import Dict, Optional
+from typing import Dict, List, Optional, Sequence
 
 import torch
 
@@ -370,11 +370,63 @@ class EnginePool:
         for s in self.streams:
             cur.wait_stream(s)
 
-    def generate_many(self, batches, threads: bool = False, **generate_kw):
+    @staticmethod
+    def coalesce_plan(rows: Sequence[int], n_engines: int, max_rows: int) -> List[List[int]]:
+        """Dynamic batching plan: consecutive batches (their row counts in `rows`) merged into passes of at most `max_rows` rows -
+        as few passes as the rows allow, but never fewer than engines (concurrency comes first) and rounded up to a multiple of
+        the engine count (every engine runs the same number of passes); the rows spread over the passes as evenly as the order
+        permits.  -> lists of batch indices, in order.  A batch larger than `max_rows` is a pass of its own."""
+        nb = len(rows)
+        if nb == 0:
+            return []
+        if max_rows <= 0:
+            return [[i] for i in range(nb)]
+        total = sum(rows)
+        passes = max(-(-total // max_rows), min(nb, n_engines))
+        if passes % n_engines:
+            passes = min(nb, (passes // n_engines + 1) * n_engines)
+        plan: List[List[int]] = []
+        cur: List[int] = []
+        cur_rows, left = 0, total
+        for i, r in enumerate(rows):
+            groups_left = max(1, passes - len(plan))
+            # close the open pass when the next batch would overflow it, or when it already holds its share of what is left
+            if cur and (cur_rows + r > max_rows or cur_rows >= (left + cur_rows) / groups_left):
+                plan.append(cur)
+                cur, cur_rows = [], 0
+            cur.append(i)
+            cur_rows += r
+            left -= r
+        plan.append(cur)
+        return plan
+
+    def generate_many(self, batches, threads: bool = False, coalesce_rows: int = 0, **generate_kw):
         """All batches, in order.  threads=True: one host thread per engine (batch j goes to engine j % n) - needed when
         the engines poll for early exit (cap_set_early_exit synchronises its stream: from a single host thread that would
-        stall the launches of the other streams; ctypes releases the GIL during cap_generate, so the threads do overlap)."""
+        stall the launches of the other streams; ctypes releases the GIL during cap_generate, so the threads do overlap).
+        coalesce_rows > 0: dynamic batching - consecutive batches of the same frame shape are concatenated into passes of at most
+        that many rows (`coalesce_plan`; the engines must have been built with max_batch >= coalesce_rows) and the outputs split
+        back per batch.  A frame decodes to the same bits alone, in its own batch and in a merged pass (batch invariance,
+        DESIGN.md section 2), so the results are those of the uncoalesced call; what changes is that the decode chain's fixed
+        costs are paid once per pass: 256-frame batches on 3 engines 5 840 captions/s, merged to 1024 rows 6 400 (round 5)."""
         batches = list(batches)
+        if coalesce_rows and len(batches) > 1 and not generate_kw.get("output_logits"):
+            same = all(b.shape[1:] == batches[0].shape[1:] and b.dtype == batches[0].dtype and b.device == batches[0].device for b in batches)
+            cap_rows = min(coalesce_rows, min(e.max_batch for e in self.engines))
+            plan = self.coalesce_plan([int(b.shape[0]) for b in batches], len(self.engines), cap_rows) if same else None
+            if plan is not None and any(len(g) > 1 for g in plan):
+                merged = [batches[g[0]] if len(g) == 1 else torch.cat([batches[j] for j in g], dim=0) for g in plan]
+                outs_m = self.generate_many(merged, threads=threads, **generate_kw)
+                outs: list = [None] * len(batches)
+                for g, mb, om in zip(plan, merged, outs_m):
+                    total, r0 = int(mb.shape[0]), 0
+                    for j in g:
+                        n_j = int(batches[j].shape[0])
+                        # per-row outputs (sequences, lengths, scores) are split; anything else is passed through
+                        outs[j] = {k: (v[r0:r0 + n_j] if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == total else v)
+                                   for k, v in om.items()}
+                        r0 += n_j
+                return outs
         if not threads or len(self.engines) == 1 or len(batches) <= 1:
             outs = [self.submit(b, **generate_kw) for b in batches]
             self.join()

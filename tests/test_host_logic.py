@@ -210,3 +210,20 @@ def test_kv16_guard_sees_outliers_through_the_post_layernorm_gamma():
     g = sd["vision_model.post_layernorm.weight"].clone(); g[3] *= 200
     assert cross_kv_head_spread({**sd, key: w}) < 3                                      # the rows alone: level
     assert cross_kv_head_spread({**sd, key: w, "vision_model.post_layernorm.weight": g}) > KV16_MAX_HEAD_SPREAD
+
+
+def test_engine_pool_coalesce_plan():
+    """EnginePool's dynamic batching plan: consecutive batches merged up to a row limit, never fewer passes than engines, the pass
+    count a multiple of the engine count where the batches allow it, batches spread evenly and kept in order."""
+    from embodied_captioning_amd.engine import EnginePool
+    P = EnginePool.coalesce_plan
+    assert [len(g) for g in P([256] * 20, 3, 1024)] == [4, 4, 3, 3, 3, 3]
+    assert [len(g) for g in P([256] * 12, 3, 1024)] == [4, 4, 4]
+    assert [len(g) for g in P([256] * 5, 3, 1024)] == [2, 2, 1]
+    assert P([256] * 2, 3, 1024) == [[0], [1]]                       # two engines in parallel beat one merged pass
+    assert P([256] * 4, 3, 256) == [[0], [1], [2], [3]] and P([300, 10], 2, 256) == [[0], [1]]
+    for rows, n, cap in (([64] * 40, 3, 1024), ([100, 256, 30, 7, 256], 2, 600), ([256] * 7, 3, 512)):
+        plan = P(rows, n, cap)
+        assert [j for g in plan for j in g] == list(range(len(rows)))
+        assert all(sum(rows[j] for j in g) <= max(cap, max(rows)) for g in plan)
+    assert P([], 3, 1024) == []

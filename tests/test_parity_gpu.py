@@ -457,3 +457,25 @@ def test_pool_engines_share_one_copy_of_the_weights():
         CaptionerEngine(dataclasses.replace(arch, t_layers=arch.t_layers + 1), dtype="f32s", max_batch=B, max_beams=1, max_len=L,
                         share_weights_with=pool.engines[1])
     pool.engines[1].close(); pool.engines[2].close(); own.close()
+
+
+def test_pool_dynamic_batching_returns_the_uncoalesced_bits():
+    """EnginePool.generate_many(coalesce_rows=): consecutive batches merged into larger passes and split back - every batch's
+    tokens and lengths equal the uncoalesced call's and the HF golden (a frame has the same bits alone, in its batch and in a
+    merged pass), also with ragged batch sizes."""
+    from embodied_captioning_amd.engine import EnginePool
+    g, meta, arch, sd, px = golden_inputs("blip_base64")
+    L = meta["max_length"]
+    pool = EnginePool(arch, n=3, dtype="f32s", max_batch=64, max_beams=1, max_len=L)
+    pool.load_state_dict(sd)
+    pxd = px.cuda()
+    for sizes in ([8] * 8, [16, 8, 24, 4, 12]):
+        cuts = np.cumsum([0] + sizes)
+        batches = [pxd[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+        plain = pool.generate_many(batches, threads=True, num_beams=1, max_length=L)
+        merged = pool.generate_many(batches, threads=True, coalesce_rows=32, num_beams=1, max_length=L)
+        assert any(len(gp) > 1 for gp in EnginePool.coalesce_plan(sizes, 3, 32))
+        for a, b, lo, hi in zip(plain, merged, cuts[:-1], cuts[1:]):
+            assert torch.equal(a["sequences"], b["sequences"]) and torch.equal(a["lengths"], b["lengths"])
+            assert np.array_equal(b["sequences"].cpu().numpy(), g["greedy_sequences"][lo:hi])
+    pool.close()
