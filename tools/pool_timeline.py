@@ -111,8 +111,11 @@ def report(path):
                 if cur:
                     out.append(cur)
                 cur = [typ, r[1], r[2], 1]
-        out.append(cur)
+        if cur:
+            out.append(cur)
         big = [s for s in out if s[3] > 30]
+        if not big:
+            continue
         enc = [s for s in big if s[0] == "E"]
         dec = [s for s in big if s[0] == "D"]
         print(f"queue {q}: " + "; ".join(f"encode {(s[1] - A) / 1e6:.1f}-{(s[2] - A) / 1e6:.1f} ms" for s in enc))
