@@ -874,7 +874,9 @@ def main():
     eng.set_decode_path(a.decode_path)
     runner = eng
     # dynamic batching only where it is the plain greedy workload on a pool (beams / early exit / other sizes: extra lines as before)
-    coal = a.coalesce_rows if (a.streams > 1 and a.beams == 1 and not a.early_exit and a.coalesce_rows > B) else 0
+    coal = a.coalesce_rows if (a.streams > 1 and not a.early_exit and a.coalesce_rows > B) else 0
+    if a.beams > 1:
+        coal = min(coal, 4 * B)                # (config 3's batch is 64 images: passes of up to 256 images x beams)
     if a.streams > 1:
         from embodied_captioning_amd.engine import EnginePool
         runner = EnginePool(arch, n=a.streams, device=dev, dtype=a.dtype, max_batch=max(B, coal), max_beams=a.beams, max_len=L, weights_of=eng)

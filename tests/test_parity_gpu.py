@@ -479,3 +479,13 @@ def test_pool_dynamic_batching_returns_the_uncoalesced_bits():
             assert torch.equal(a["sequences"], b["sequences"]) and torch.equal(a["lengths"], b["lengths"])
             assert np.array_equal(b["sequences"].cpu().numpy(), g["greedy_sequences"][lo:hi])
     pool.close()
+    # beam search (config 3: beam 3): every image's beams are its own - same sequences and scores in merged passes
+    pool = EnginePool(arch, n=3, dtype="f32s", max_batch=64, max_beams=3, max_len=L)
+    pool.load_state_dict(sd)
+    batches = [pxd[i:i + 8] for i in range(0, 64, 8)]
+    plain = pool.generate_many(batches, threads=True, num_beams=3, max_length=L)
+    merged = pool.generate_many(batches, threads=True, coalesce_rows=32, num_beams=3, max_length=L)
+    for a, b in zip(plain, merged):
+        assert torch.equal(a["sequences"], b["sequences"]) and torch.equal(a["lengths"], b["lengths"])
+        assert torch.equal(a["sequences_scores"], b["sequences_scores"])
+    pool.close()
