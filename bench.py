@@ -175,7 +175,9 @@ def timed_steps(eng, px, L, steps, warmup, world, gather, beams=1, dev="cuda", c
             res = gather(out["sequences"], out["lengths"])
         return res
     from embodied_captioning_amd.distributed import timed_region
-    run(max(warmup, len(pool)) if pool is not None else warmup)       # every engine of a pool runs once untimed
+    # every engine of a pool runs once untimed - with dynamic batching at the timed passes' size (their merged input buffers come
+    # out of the allocator's cache in the timed region)
+    run(max(warmup, len(pool) * max(1, coalesce // max(1, int(px.shape[0])))) if pool is not None else warmup)
     on_gpu = dev != "cpu"
     with (PowerSampler(torch.cuda.current_device()) if on_gpu else _NoPower()) as ps:
         # barrier + synchronise, the K steps, synchronise + barrier, MAX over ranks (distributed.timed_region)
@@ -918,7 +920,8 @@ def main():
                                            f"(a frame has the same bits alone, in its batch and in a merged pass); every batch as its own pass is the "
                                            f"`pool_uncoalesced` key" if coal else "")
                                         + "; one batch at a time on one stream is the `single_stream` key") if a.streams > 1 else "one batch at a time on one stream",
-                           "coalesce_rows": coal}}
+                           "coalesce_rows": coal,
+                           "untimed_steps_run": max(a.warmup, a.streams * max(1, coal // B)) if a.streams > 1 else a.warmup}}
         if uncoalesced:
             line["pool_uncoalesced"] = uncoalesced
         ln = lens[:B].float()
