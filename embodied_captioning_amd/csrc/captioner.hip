@@ -1101,7 +1101,10 @@ int gemm_splitk_reduce_ln(Captioner* m, hipStream_t s, const Dec& d, const char*
         TRY(launch_gemm(m->gdt, p, decode_tile(m), s));
     }
     ProfScope ps(m, s, "dec_reduce_ln", 0, (double)(S + 2) * d.R * N * 4 + (double)d.R * N * m->esz);
-    return launch_reduce_layernorm(m->gdt, d.dpart, S, bias, resid ? resid : d.dx, g, b, eps, out_t, out_f, y_out, d.R, N, s, true);
+    // one 256-thread block per row up to a few hundred rows (one memory round trip, latency-bound); at the pool's merged passes
+    // (~1 000 rows) the wave-per-row kernel: 5.6 us against 7.4 at 1 024 rows.  Same sums in the same order - the two kernels give
+    // the same bits (tests/test_kernels_gpu.py::test_reduce_layernorm_kernels_agree_bit_for_bit), so the row count may choose.
+    return launch_reduce_layernorm(m->gdt, d.dpart, S, bias, resid ? resid : d.dx, g, b, eps, out_t, out_f, y_out, d.R, N, s, d.R < 512 || N > 1024);
 }
 
 // x: the fp32 LayerNorm row buffer the consumer adds as its residual and replaces (d.dx, or d.dx2 on the fused paths)

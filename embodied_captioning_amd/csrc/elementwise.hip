@@ -502,9 +502,10 @@ int launch_reduce_layernorm(int dtype, const void* part, int S, const float* bia
                             int M, int D, hipStream_t s, bool per_row_block, bool part_in_t) {
     if (per_row_block && part_in_t) { cap_set_error("reduce_layernorm: the per-row-block kernel takes fp32 partial sums"); return -1; }
     if (D % 4 != 0 || D > 256 * LN_MAXV || S < 1 || (dtype == CAP_DT_G8 && D % 8 != 0)) { cap_set_error("reduce_layernorm: unsupported width %d / slices %d", D, S); return -1; }
-    // per_row_block: the decoder's choice (a few hundred rows, latency-bound).  The two kernels round differently in the
-    // last bit, so the choice is the CALLER's (by path), never the row count's: a frame's result must not depend on the
-    // batch it rides in.
+    // per_row_block: the decoder's choice up to a few hundred rows (latency-bound).  For rows up to 1024 wide the block-per-row
+    // kernel forms the wave-per-row kernel's sums in its order (slices, bias, residual; statistics: thread j + 64 i = lane j,
+    // vector i) and the two agree bit for bit (tests/test_kernels_gpu.py::test_reduce_layernorm_kernels_agree_bit_for_bit), so a
+    // caller may pick by row count there; the WIDE block kernel (rows beyond 1024) has its own order: by path only.
     if (per_row_block && D <= 1024) {
 #define CAP_RR(TT) hipLaunchKernelGGL(reduce_layernorm_row_kernel<TT>, dim3(M), dim3(256), 0, s, (const float*)part, S, bias, resid, gamma, beta, eps, (TT*)out_t, out_f, y_out, M, D)
         CAP_DISPATCH_T(dtype, CAP_RR);

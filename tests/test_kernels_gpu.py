@@ -430,3 +430,27 @@ def test_cross_kv_gemm_scatters_into_the_cache_layout(lib, dtype, geom):
     got = cache.cpu().double().view(layers, 2, n_img, heads, tokens, 64)
     tol = 2e-4 * math.sqrt(K / 64) if dtype == "f32" else 0.03
     assert torch.isfinite(got).all() and (got - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("S,with_resid", [(1, True), (2, True), (4, True), (4, False), (3, True)])
+@pytest.mark.parametrize("D", [768, 128, 1024])
+def test_reduce_layernorm_kernels_agree_bit_for_bit(lib, D, S, with_resid):
+    """The decoder's split-K consumer runs as one block per row up to a few hundred rows and as one wave per row at the engine
+    pool's merged passes (~1 000 rows): a frame's LayerNorm row must not depend on which - same fp32 row, same G8 / bf16 operand
+    row, bit for bit."""
+    M = 333
+    g = torch.Generator().manual_seed(D + S)
+    part = (torch.randn(S, M, D, generator=g) * 3).cuda()
+    bias, gamma, beta = torch.randn(D, generator=g).cuda(), torch.randn(D, generator=g).cuda(), torch.randn(D, generator=g).cuda()
+    resid = (torch.randn(M, D, generator=g) * 2).cuda() if with_resid else None
+    for tag, tdt in ((2, torch.float32), (1, torch.bfloat16)):          # split mode (G8 container: 4 bytes per element), bf16
+        outs = []
+        for row_block in (1, 0):
+            out_t = torch.zeros(M, D, dtype=tdt, device="cuda")
+            out_f = torch.zeros(M, D, device="cuda")
+            _check(lib, lib.cap_op_reduce_layernorm(tag, _p(part), S, _p(bias), _p(resid), _p(gamma), _p(beta), C.c_float(1e-12), _p(out_t),
+                                                    _p(out_f), _p(None), M, D, row_block, _stream()))
+            torch.cuda.synchronize()
+            outs.append((out_t, out_f))
+        assert torch.equal(outs[0][1], outs[1][1])
+        assert torch.equal(outs[0][0].view(torch.int32 if tdt == torch.float32 else torch.int16), outs[1][0].view(torch.int32 if tdt == torch.float32 else torch.int16))
