@@ -6,10 +6,20 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W            # the driver's form: WORLD_SIZE is set, nothing is spawned
 
-One step = one pass of the hot path (ViT encoder -> cross-K/V -> 19 greedy decode steps) over one batch of 256
-synthetic 224x224 frames per GPU that are already resident in HBM, followed by the RCCL all-gather of the caption
-records (ids int32 [256,20] + lengths) that feeds the consensus step.  Frames and weights are synthetic/procedural
-(no dataset or checkpoint exists offline).  Rank 0 prints ONE JSON line.
+One step = the hot path (ViT encoder -> cross-K/V -> 19 greedy decode steps) over one batch of 256 synthetic 224x224 frames
+per GPU that are already resident in HBM, followed by the RCCL all-gather of the caption records (ids int32 [256,20] + lengths)
+that feeds the consensus step.  Frames and weights are synthetic/procedural (no dataset or checkpoint exists offline).  Rank 0
+prints ONE JSON line.
+
+`value` is measured the way the product's batch entry points run (`BLIP.generate_batch` / `Captioner.caption_batch` /
+`pseudolabeler.BatchedBoxCaptioner` with `captioner.streams: 3`): the K timed steps' batches go to an EnginePool of --streams
+engines whose dynamic batching (--coalesce-rows, default 1024) merges CONSECUTIVE STEPS' batches into passes of up to 1024 rows -
+20 steps run as passes of 4, 4, 3, 3, 3, 3 batches - and splits the captions back per step.  A frame decodes to the same bits
+alone, in its 256-frame batch and in a merged pass (tests/test_merged_passes_gpu.py), so the captions are those of the unmerged
+steps; what a merged pass changes is the latency of a batch (its pass finishes as a whole) and the number of decode chains.
+`config.workload` / `config.pass_rows` name the pass size; the figure with every 256-frame batch as its own pass
+(--coalesce-rows 0; rounds 1-4's headline, BASELINE's "batch=256" read strictly) is on the same line as `pool_uncoalesced` and in
+`config.also`; one batch at a time on one stream is `single_stream`.
 
 The headline (`value`, `dtype`, `roofline`, `kernels`, `parity`) is the mode that holds the metric's parity clause: "f32s" =
 CAP_F32_SPLIT, fp32 values carried into every GEMM as two fp16 halves with three fp16 MFMAs per product (DESIGN.md section
@@ -82,7 +92,7 @@ def parse():
     ap.add_argument("--stub-engine", action="store_true", help="TEST ONLY (tests/test_distributed_cpu.py): the launch / rendezvous / "
                     "timed-region / gather / strong-scaling plumbing on CPU ranks over gloo with a fake captioner whose ids are a "
                     "function of the frame index; prints a line marked \"stub\": true and never touches a GPU")
-    ap.add_argument("--decode-path", default="auto", choices=["auto", "batch", "small", "tile"],
+    ap.add_argument("--decode-path", default="auto", choices=["auto", "batch", "small"],
                     help="blip: decode kernels of the timed steps (engine.set_decode_path; A/B of the batch path's kernel sets)")
     ap.add_argument("--lite", action="store_true", help="timed steps only (profiler counter passes): no roofline / "
                     "encoder-only / parity / fp32 / CPU legs")
@@ -624,7 +634,7 @@ def golden_parity(ids, g, arch, L, B, tau):
             "reference": "HF transformers 5.15 BlipForConditionalGeneration greedy, fp32 CPU (tests/golden/blip_base256.npz)"}
 
 
-LAYER_STEP_TAGS = ("dec_gemm_qkv", "dec_self_attn", "dec_gemm_so", "dec_reduce_ln", "dec_gemm_cq", "dec_cross_attn", "dec_gemm_co",
+LAYER_STEP_TAGS = ("dec_gemm_qkv", "dec_self_attn", "dec_gemm_so", "dec_reduce_ln", "dec_reduce_ln_wave", "dec_gemm_cq", "dec_cross_attn", "dec_gemm_co",
                    "dec_gemm_f1", "dec_gemm_f2", "dec_small_qkv", "dec_small_so", "dec_small_cross", "dec_small_co", "dec_small_f1",
                    "dec_small_f2")
 
@@ -814,6 +824,31 @@ def main_stub(a, dev, rank, world):
         torch.distributed.destroy_process_group()
 
 
+def finish_line(line):
+    """The figures that qualify the headline, in two places a truncating reader still sees: inside `config` (`also`) and as the
+    LAST key of the line (`summary`) - numbers only; the keys they come from carry the details."""
+    def pick(key, *path):
+        v = line.get(key)
+        for k in path:
+            v = v.get(k) if isinstance(v, dict) else None
+        return v
+    par = line.get("parity") or {}
+    also = {"value_batch256_passes": pick("pool_uncoalesced", "value"), "single_stream": pick("single_stream", "value"),
+            "strong_scaling_captions_per_s": pick("strong_scaling", "captions_per_s"),
+            "strong_scaling_at_micro_batch_256": pick("strong_scaling", "at_micro_batch_256", "captions_per_s"),
+            "golden_rows_identical": f"{par.get('token_identical_rows')}/{par.get('rows')}" if par else None,
+            "enc_gemm_frac": pick("roofline", "frac"), "enc_gemm_frac_executed": pick("roofline", "frac_executed"),
+            "decode_gemm_hbm_frac": pick("decode", "gemm", "frac"), "cross_attention_hbm_frac": pick("decode", "cross_attention", "frac"),
+            "decode_kernels_ms_per_pass": pick("decode", "ms_per_step_all_decode_kernels"),
+            "encoder_only_images_per_s": pick("encoder_only", "images_per_s"),
+            "f32s_fp32kv": pick("f32s_fp32kv", "value"), "f32_exact": pick("f32_exact", "value"), "bf16_not_parity": pick("bf16", "value"),
+            "cpu_baseline": pick("cpu_baseline", "value")}
+    also = {k: v for k, v in also.items() if v is not None}
+    line["config"]["also"] = also
+    line["summary"] = dict(also, value=line["value"], ms_per_step=line["ms_per_step"], pass_rows=line["config"].get("pass_rows"))
+    return line
+
+
 def main():
     a = parse()
     if a.dtype is None:
@@ -879,8 +914,8 @@ def main():
     coal = a.coalesce_rows if (a.streams > 1 and not a.early_exit and a.coalesce_rows > B) else 0
     if a.beams > 1:
         coal = min(coal, 4 * B)                # (config 3's batch is 64 images: passes of up to 256 images x beams)
+    from embodied_captioning_amd.engine import EnginePool
     if a.streams > 1:
-        from embodied_captioning_amd.engine import EnginePool
         runner = EnginePool(arch, n=a.streams, device=dev, dtype=a.dtype, max_batch=max(B, coal), max_beams=a.beams, max_len=L, weights_of=eng)
         runner.set_early_exit(a.early_exit)
         runner.set_decode_path(a.decode_path)
@@ -898,6 +933,10 @@ def main():
     if not (a.no_strong or a.lite or a.beams > 1 or arch.image_size != 224 or a.early_exit):
         log(f"strong-scaling job: {a.frames} frames in total over {world} rank(s)")
         strong = strong_figure(a, arch, runner, dev, world, L, max(B, coal))      # micro-batches of the merged passes' size
+        if coal > B:                             # and at SURVEY config 4's own micro-batch (256), every micro-batch its own pass
+            s256 = strong_figure(a, arch, runner, dev, world, L, B)
+            if strong is not None and s256 is not None:
+                strong["at_micro_batch_256"] = {k: s256[k] for k in ("captions_per_s", "job_s", "micro_batch", "objects")}
     if a.streams > 1:
         runner.close()
 
@@ -908,20 +947,25 @@ def main():
                         "cross-attention K/V cache = KV16 (int16 + one fp32 scale per 64-wide head row: 15 value bits); LayerNorm / softmax / "
                         "residual stream / self-attention cache fp32.  The exact-product fp32 MFMA mode of the same run is the `f32_exact` key",
                 "bf16": "bf16 operands and K/V caches, fp32 accumulate / LayerNorm / softmax / residual stream", "f32": "f32 (fp32 MFMA, exact products)"}[a.dtype]
+        short = {"f32s": "f32s (fp32 as split fp16: 3 fp16 MFMA per MAC, fp32 accumulate; KV16 cross cache)", "bf16": "bf16", "f32": "f32"}[a.dtype]
+        untimed = (max(a.warmup, a.streams * max(1, coal // B)) if a.streams > 1 else a.warmup)
+        passes = EnginePool.coalesce_plan([B] * a.steps, a.streams, coal) if (coal and a.streams > 1) else None
+        pass_rows = sorted({len(gp) * B for gp in passes}, reverse=True) if passes else [B]
         line = {"metric": f"captions/sec ({S}x{S}, beam={a.beams})", "value": round(value, 2), "unit": "captions/s",
-                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": mode,
+                "n_gpus": world, "steps": a.steps, "warmup": untimed, "ms_per_step": round(1e3 * dt / a.steps, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": short,
                 "data": "synthetic frames (PCG64, seed = frame index), procedural weights (no checkpoint offline)",
-                "config": {"workload": f"BLIP-base ViT-B/16 encoder + {'greedy' if a.beams == 1 else f'beam-{a.beams}'} decode, {B} frames/GPU {S}x{S}, "
-                                       f"max_length={L}, caption all-gather", "global_batch": world * B,
-                           "parallelism": f"dp{world}", "streams": a.streams, "compute_mode": a.dtype,
+                "config": {"workload": f"BLIP-base ViT-B/16 encoder + {'greedy' if a.beams == 1 else f'beam-{a.beams}'} decode, {B} frames/GPU per step {S}x{S}, "
+                                       f"max_length={L}, caption all-gather"
+                                       + (f"; {a.steps} steps merged by the engine pool into {len(passes)} passes of {'/'.join(str(r) for r in pass_rows)} rows" if passes else ""),
+                           "global_batch": world * B, "pass_rows": pass_rows,
+                           "parallelism": f"dp{world}", "streams": a.streams, "compute_mode": a.dtype, "compute_mode_note": mode,
                            "value_is": (f"consecutive batches overlapped on {a.streams} engines / HIP streams of one GPU (EnginePool)"
                                         + (f", the pool's dynamic batching merging consecutive steps' batches into passes of up to {coal} rows "
                                            f"(a frame has the same bits alone, in its batch and in a merged pass); every batch as its own pass is the "
                                            f"`pool_uncoalesced` key" if coal else "")
                                         + "; one batch at a time on one stream is the `single_stream` key") if a.streams > 1 else "one batch at a time on one stream",
-                           "coalesce_rows": coal,
-                           "untimed_steps_run": max(a.warmup, a.streams * max(1, coal // B)) if a.streams > 1 else a.warmup}}
+                           "coalesce_rows": coal, "warmup_requested": a.warmup, "untimed_steps_run": untimed}}
         if uncoalesced:
             line["pool_uncoalesced"] = uncoalesced
         ln = lens[:B].float()
@@ -993,7 +1037,7 @@ def main():
             cb, _ = cpu_baseline(sd, arch, L, a.cpu_sample)
             line["cpu_baseline"] = cb
             line["vs_cpu_baseline"] = round(value / cb["value"], 1)       # context only: the roofline fractions judge the kernels
-        print(json.dumps(line))
+        print(json.dumps(finish_line(line)))
     else:
         eng.close()
     if world > 1:

@@ -22,7 +22,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libcaptioner_hip.so")
-SOURCES = ["captioner.hip", "gemm.hip", "gemm_pp.hip", "gemm_skinny.hip", "elementwise.hip", "attention.hip", "decode_small.hip", "decode_tile.hip", "beam.hip", "preprocess.hip"]
+SOURCES = ["captioner.hip", "gemm.hip", "gemm_pp.hip", "gemm_skinny.hip", "elementwise.hip", "attention.hip", "decode_small.hip", "beam.hip", "preprocess.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 

@@ -80,12 +80,25 @@ class BLIP(CaptioningPredictor):
         # this engine's weight store)
         self.pool = None
         n_streams = int(getattr(cfg, "streams", 1) or 1)
+        # cfg.coalesce_rows (with streams > 1): dynamic batching - the pool merges consecutive micro-batches of one
+        # generate_batch call into passes of at most that many rows (EnginePool.generate_many(coalesce_rows=); a frame decodes
+        # to the same bits alone, in its micro-batch and in a merged pass, so the captions are those of the unmerged call and
+        # the decode chain's per-launch costs are paid once per pass).  None = on: four micro-batches, at most 1024 rows (the
+        # arenas of the pool's engines are sized for it); 0 = every micro-batch its own pass.
+        cr = getattr(cfg, "coalesce_rows", None)
+        self.coalesce_rows = 0
         if n_streams > 1:
+            self.coalesce_rows = min(4 * self.batch_size, 1024) if cr is None else max(0, int(cr))
+            if self.coalesce_rows <= self.batch_size:
+                self.coalesce_rows = 0
             from ....engine import EnginePool
-            self.pool = EnginePool(self.arch, n=n_streams, device=self._device, dtype=dtype, max_batch=self.batch_size,
+            self.pool = EnginePool(self.arch, n=n_streams, device=self._device, dtype=dtype,
+                                   max_batch=max(self.batch_size, self.coalesce_rows),
                                    max_beams=getattr(self, "num_beams", 1), max_len=self.engine.max_len, weights_of=self.engine,
                                    cross_cache=self.engine.cross_cache)
             self.pool.set_early_exit(poll)
+        elif cr:
+            logger.warning("captioner.coalesce_rows is the engine pool's dynamic batching: it needs captioner.streams > 1 - ignored")
 
     # nn.Module surface the callers use; weights live in the engine, so .to() only re-targets host-side tensors
     @property
@@ -140,7 +153,8 @@ class BLIP(CaptioningPredictor):
         seqs, lens, scores, logits = [], [], [], []
         chunks = [px[i:i + self.batch_size].to(self._device) for i in range(0, px.shape[0], self.batch_size)]
         if getattr(self, "pool", None) is not None and len(chunks) > 1 and not output_logits:
-            outs = self.pool.generate_many(chunks, threads=True, num_beams=self.num_beams, max_length=self.max_length)
+            outs = self.pool.generate_many(chunks, threads=True, coalesce_rows=self.coalesce_rows, num_beams=self.num_beams,
+                                           max_length=self.max_length)
         else:
             outs = [self.engine.generate(c, num_beams=self.num_beams, max_length=self.max_length, output_logits=output_logits)
                     for c in chunks]

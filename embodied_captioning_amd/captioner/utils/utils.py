@@ -2,6 +2,8 @@
 plus optional keys (defaults keep existing yamls working): num_beams, max_length, dtype, batch_size, device,
 image_size (CoCa: open_clip's force_image_size), streams (BLIP: engines / HIP streams the micro-batches of one call rotate
 over, engine.EnginePool; 1 = one engine; the BLIP-2 / CoCa wrappers run one engine and warn when asked for more),
+coalesce_rows (BLIP with streams > 1: the pool merges consecutive micro-batches into passes of at most that many rows - same
+captions, fewer decode chains; None = 4 x batch_size up to 1024, 0 = off),
 early_exit_poll (look for "every caption finished" every n decode steps; None = 4), max_new_tokens (BLIP-2: tokens to
 generate, HF's name; None = 20 as HF's generate default - `max_length` is BLIP's / CoCa's total length and is not read by
 BLIP-2).  dtype: "f32s" (default for BLIP: fp32-grade split-fp16 GEMMs, token-identical to the fp32 reference), "bf16",
@@ -23,7 +25,8 @@ class CaptionerField:
                  num_beams=1, max_length=20, dtype=None, batch_size=8, device="cuda:0", image_size=None, streams=1,
                  early_exit_poll=None, max_new_tokens=None, num_beam_groups=None, tokenizer_dir=None,
                  generation_type=None, top_k=None, top_p=None, temperature=None, repetition_penalty=None,
-                 load_in_8bit=None, load_in_4bit=None, torch_dtype=None, cross_cache=None, strict_range=False):
+                 load_in_8bit=None, load_in_4bit=None, torch_dtype=None, cross_cache=None, strict_range=False,
+                 coalesce_rows=None):
         self.arch_name = arch_name
         self.model_name = model_name
         self.checkpoint_name = checkpoint_name
@@ -56,3 +59,6 @@ class CaptionerField:
         # strict_range: a value that leaves the mode's range (clamped and counted by the library) raises instead of being logged
         self.cross_cache = cross_cache
         self.strict_range = strict_range
+        # BLIP with streams > 1: the pool's dynamic batching merges the micro-batches of one generate_batch / caption_batch call
+        # into passes of at most this many rows (same captions; None = 4 x batch_size up to 1024, 0 = off)
+        self.coalesce_rows = coalesce_rows

@@ -18,7 +18,6 @@
 #include "gemm.h"
 #include "ops.h"
 #include "decode_small.h"
-#include "decode_tile.h"
 
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local char g_err[2048] = "";
@@ -1100,11 +1099,12 @@ int gemm_splitk_reduce_ln(Captioner* m, hipStream_t s, const Dec& d, const char*
         ProfScope ps(m, s, tag, 2.0 * d.R * N * K, ((double)d.R * K + (double)N * K) * m->esz + (double)S * d.R * N * 4);
         TRY(launch_gemm(m->gdt, p, decode_tile(m), s));
     }
-    ProfScope ps(m, s, "dec_reduce_ln", 0, (double)(S + 2) * d.R * N * 4 + (double)d.R * N * m->esz);
+    const bool per_row_block = d.R < 512 || N > 1024;
+    ProfScope ps(m, s, per_row_block ? "dec_reduce_ln" : "dec_reduce_ln_wave", 0, (double)(S + 2) * d.R * N * 4 + (double)d.R * N * m->esz);
     // one 256-thread block per row up to a few hundred rows (one memory round trip, latency-bound); at the pool's merged passes
     // (~1 000 rows) the wave-per-row kernel: 5.6 us against 7.4 at 1 024 rows.  Same sums in the same order - the two kernels give
     // the same bits (tests/test_kernels_gpu.py::test_reduce_layernorm_kernels_agree_bit_for_bit), so the row count may choose.
-    return launch_reduce_layernorm(m->gdt, d.dpart, S, bias, resid ? resid : d.dx, g, b, eps, out_t, out_f, y_out, d.R, N, s, d.R < 512 || N > 1024);
+    return launch_reduce_layernorm(m->gdt, d.dpart, S, bias, resid ? resid : d.dx, g, b, eps, out_t, out_f, y_out, d.R, N, s, per_row_block);
 }
 
 // x: the fp32 LayerNorm row buffer the consumer adds as its residual and replaces (d.dx, or d.dx2 on the fused paths)
@@ -1113,46 +1113,11 @@ int gemm_splitk_ln(Captioner* m, hipStream_t s, const Dec& d, const char* tag, c
     return gemm_splitk_reduce_ln(m, s, d, tag, A, W, bias, g, b, m->c.t_eps, N, K, d.dx_t, x ? x : d.dx, nullptr, x);
 }
 
-// cross block of layer i as the fused kernel's parameter block (decode_tile.hip): consumer of the self-attention output
-// projection's slabs (S_so slices in d.dpart) + LayerNorm, query projection, attention; LayerNorm rows: resid -> x_out
-SmallCross tile_cross_params(const Captioner* m, const Dec& d, const TLayer& L, int i, int K, int S_so, const float* resid, float* x_out,
-                             const int* skip) {
-    const CapConfig& c = m->c;
-    const int T = c.t_hidden, H = c.t_heads, NT = m->NT;
-    SmallCross x;
-    memset(&x, 0, sizeof(x));
-    x.W = L.w_cq; x.bias = L.b_cq; x.R = d.R; x.D = T; x.H = H; x.S = decode_splitk(m, T, T, 4);
-    x.ln.part = d.dpart; x.ln.S = S_so; x.ln.bias = L.b_so; x.ln.gamma = L.so_g; x.ln.beta = L.so_b; x.ln.eps = c.t_eps;
-    x.ln.resid = resid; x.ln.x_out = x_out;
-    const size_t blk = m->cross_block((size_t)d.Btot * H * NT);
-    x.kbase = (char*)m->cross + ((size_t)i * 2 + 0) * blk;
-    x.vbase = (char*)m->cross + ((size_t)i * 2 + 1) * blk;
-    x.kv_row0 = (size_t)d.b0 * H * NT;
-    x.rows_per_kv = K; x.kv_ld = NT; x.n_keys = NT;
-    x.kv_kind = m->kv16 ? SMALL_KV_KV16 : (m->dt == CAP_DT_BF16 ? SMALL_KV_BF16 : SMALL_KV_F32);
-    x.skip = skip; x.out = d.dctx;
-    return x;
-}
-
-// The batch path's fused kernels take the call: BLIP, split or bf16 mode, greedy (one row per image), more rows than the
-// small-batch kernels take
-bool tile_path_takes(const Captioner* m, const Dec& d, int K) {
-    const CapConfig& c = m->c;
-    if (m->gdt == CAP_DT_F32 || c.arch != CAP_ARCH_BLIP || K != 1 || d.R <= SMALL_MAX_ROWS) return false;
-    TLayer none;
-    memset((void*)&none, 0, sizeof(none));
-    return tile_cross_takes(m->gdt, tile_cross_params(m, d, none, 0, K, decode_splitk(m, c.t_hidden, c.t_hidden, 4), nullptr, nullptr, nullptr));
-}
-
-// fused: the cross block of every layer as ONE launch (decode_tile.hip) instead of reduce_layernorm + cq GEMM + attention:
-// 9 launches per layer-step instead of 11, the same bits (tests/test_tile_decode_gpu.py)
 int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, int t, int K, const int* anc, int Lm,
-                     hipStream_t s, bool fused = false) {
+                     hipStream_t s) {
     const CapConfig& c = m->c;
     const int T = c.t_hidden, F = c.t_ffn, H = c.t_heads, R = d.R, NT = m->NT;
     const size_t e = m->esz;
-    float* xcur = d.dx;                            // fp32 LayerNorm rows: the residual of the next consumer (fused: ping-pong with
-    float* xalt = d.dx2;                           // d.dx2 - the head-0 workgroup of a tile writes the rows the others still read)
     // greedy: the attention kernels leave the rows of ended captions alone (d.finished is set by greedy_select one step
     // before); the GEMMs still cover every row - they are bound by the weight stream, not by the row count
     const int* skip = K == 1 ? d.finished : nullptr;
@@ -1175,17 +1140,6 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
             ProfScope ps(m, s, "dec_self_attn", 4.0 * R * H * (t + 1) * 64, 2.0 * R * H * (t + 1) * 64 * e);
             TRY(launch_decode_attention(m->dt, d.dq, kc, vc, anc, Lm, 1, Lm, t + 1, d.dctx, R, H, 0, s, nullptr, 0, nullptr, 0, 0, 0, m->gdt, skip));
         }
-        if (fused) {
-            int S = 1;
-            TRY(gemm_partial(m, s, "dec_gemm_so", d.dctx, L.w_so, d.dpart, R, T, T, 4, &S));
-            const SmallCross x = tile_cross_params(m, d, L, i, K, S, xcur, xalt, skip);
-            {
-                ProfScope ps(m, s, "dec_tile_cross", 2.0 * R * T * T + 4.0 * R * H * NT * 64,
-                             (double)T * T * e + (double)(S + 2) * R * T * 4 + 2.0 * d.B * H * NT * m->kvrow);
-                TRY(launch_tile_cross(m->gdt, x, s));
-            }
-            float* tmp = xcur; xcur = xalt; xalt = tmp;
-        } else {
         TRY(gemm_splitk_ln(m, s, d, "dec_gemm_so", d.dctx, L.w_so, L.b_so, L.so_g, L.so_b, T, T));
         {
             int S = 1;
@@ -1199,10 +1153,9 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
             TRY(launch_decode_attention(m->dt, nullptr, ck, cv, nullptr, 0, K, NT, NT, d.dctx, R, H, 0, s, d.dpart, S, L.b_cq,
                                         T, 0, 0, m->gdt, skip, m->kv16 ? 1 : 0, m->kv16 ? row0 : 0));
         }
-        }
-        TRY(gemm_splitk_ln(m, s, d, "dec_gemm_co", d.dctx, L.w_co, L.b_co, L.co_g, L.co_b, T, T, xcur));
+        TRY(gemm_splitk_ln(m, s, d, "dec_gemm_co", d.dctx, L.w_co, L.b_co, L.co_g, L.co_b, T, T));
         TRY(gemm_rows(m, s, "dec_gemm_f1", d.dx_t, L.w_f1, d.dh, L.b_f1, R, F, T, 1));
-        TRY(gemm_splitk_ln(m, s, d, "dec_gemm_f2", d.dh, L.w_f2, L.b_f2, L.f_g, L.f_b, T, F, xcur));
+        TRY(gemm_splitk_ln(m, s, d, "dec_gemm_f2", d.dh, L.w_f2, L.b_f2, L.f_g, L.f_b, T, F));
     }
     TRY(gemm(m, s, "dec_gemm_tr", d.dx_t, T, m->w_tr, T, d.dy, T, m->b_tr, nullptr, R, T, T, 1, 1));
     {
@@ -1557,20 +1510,13 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
                 return -1;
             }
             const bool small = can && (m->decode_path == 0 || m->decode_path == 2);
-            const bool can_tile = !coca && tile_path_takes(m, d, K);
-            if (m->decode_path == 3 && !can_tile) {
-                cap_set_error("cap_generate: the fused batch decode path was forced (cap_set_decode_path 3) but does not take this call "
-                              "(%d rows, %d beam(s), compute type %d): more than %d rows, greedy, split or bf16 mode, BLIP", R, K, m->gdt, SMALL_MAX_ROWS);
-                return -1;
-            }
-            const bool tile = !small && can_tile && m->decode_path == 3;      // (measured level with the batch kernels: not the automatic choice)
-            m->last_path = small ? 2 : (tile ? 3 : 1);
+            m->last_path = small ? 2 : 1;
             if (coca) {
                 if (small) TRY(run_coca_step_small(m, d, tokens, Lm, t, K, anc, Lm, s));
                 else TRY(run_coca_step(m, d, tokens, Lm, t, K, anc, Lm, s));
             } else {
                 if (small) TRY(run_decoder_step_small(m, d, tokens, Lm, t, K, anc, Lm, s));
-                else TRY(run_decoder_step(m, d, tokens, Lm, t, K, anc, Lm, s, tile));
+                else TRY(run_decoder_step(m, d, tokens, Lm, t, K, anc, Lm, s));
             }
         }
         if (out_step_logits) {
@@ -1756,7 +1702,7 @@ int cap_last_decode_steps(CapHandle h) { return h ? ((Captioner*)h)->last_steps 
 int cap_set_decode_path(CapHandle h, int path) {
     Captioner* m = (Captioner*)h;
     if (!m) { cap_set_error("cap_set_decode_path: null handle"); return -1; }
-    if (path < 0 || path > 3) { cap_set_error("cap_set_decode_path: path must be 0 (by row count), 1 (batch kernels, one launch per operation), 2 (small-batch kernels) or 3 (batch kernels with the fused cross block), got %d", path); return -1; }
+    if (path < 0 || path > 2) { cap_set_error("cap_set_decode_path: path must be 0 (by row count), 1 (batch kernels, one launch per operation) or 2 (small-batch kernels), got %d", path); return -1; }
     m->decode_path = path;
     return 0;
 }
@@ -1916,8 +1862,7 @@ long long cap_g8_saturations(int reset) {
     if (hipDeviceSynchronize() != hipSuccess) { cap_set_error("cap_g8_saturations: device synchronisation failed"); return -1; }
     unsigned long long total = 0;
     if (cap_g8_clamped_gemm(&total, reset) != 0 || cap_g8_clamped_gemm_pp(&total, reset) != 0 || cap_g8_clamped_elementwise(&total, reset) != 0 ||
-        cap_g8_clamped_attention(&total, reset) != 0 || cap_g8_clamped_decode_small(&total, reset) != 0 ||
-        cap_g8_clamped_decode_tile(&total, reset) != 0)
+        cap_g8_clamped_attention(&total, reset) != 0 || cap_g8_clamped_decode_small(&total, reset) != 0)
         return -1;
     return (long long)total;
 }

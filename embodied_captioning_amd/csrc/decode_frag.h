@@ -1,4 +1,4 @@
-// Building blocks shared by the fused decode kernels (decode_small.hip: up to 16 rows; decode_tile.hip: 16-row tiles of a batch):
+// Building blocks shared by the fused decode kernels (decode_small.hip: up to 16 rows):
 // MFMA operand fragments read straight from global memory / an LDS row image, the product sequence of one K slab, and the
 // split-K consumer + LayerNorm of a row in registers.  Everything is in an anonymous namespace: include from a translation unit
 // that defines such kernels, after gemm_tile.h, ln.h, decode_attn.h and decode_small.h.

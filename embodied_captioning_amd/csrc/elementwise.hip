@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void reduce_layernorm_kernel(const P* __restri
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float eps, T* out_t,
                                                                 float* out_f, float* y_out, int M, int D) {
+#pragma clang fp contract(off)      // sums and LayerNorm as written: the three consumers of a row count range agree bit for bit
     // one wave per row.  Decode (a few hundred rows) launches one wave per block so every row gets its own CU slot and
     // all of its S*nv + 2*nv 16-byte loads are issued before the first add; the encoder launches 4 rows per block.
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(256) void reduce_layernorm_row_kernel(const float* 
                                                                     const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, float eps, T* out_t,
                                                                     float* out_f, float* y_out, int M, int D) {
+#pragma clang fp contract(off)
     __shared__ float sp[2][256];
     const int row = blockIdx.x, tid = threadIdx.x, c = tid * 4;
     const bool act = c < D;
@@ -207,6 +209,7 @@ __global__ __launch_bounds__(256) void reduce_layernorm_wide_kernel(const float*
                                                                      const float* __restrict__ gamma,
                                                                      const float* __restrict__ beta, float eps, T* out_t,
                                                                      float* out_f, float* y_out, int M, int D) {
+#pragma clang fp contract(off)
     __shared__ float sp[2][4];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -11,6 +11,7 @@ constexpr int LN_MAXV = 12;   // rows up to 3072 wide (OPT-2.7b: 2560)
 template <typename T, int MAXV = LN_MAXV>
 __device__ __forceinline__ void ln_row(const float4 (&v)[MAXV], int nv, int lane, int D, const float* gamma,
                                        const float* beta, float eps, T* out_t, float* out_f) {
+#pragma clang fp contract(off)      // as written, wherever it is inlined: the block-per-row consumer must give the same bits
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
@@ -44,6 +45,7 @@ __device__ __forceinline__ void ln_row(const float4 (&v)[MAXV], int nv, int lane
 template <typename T, int MAXV>
 __device__ __forceinline__ void ln_row_regs(const float4 (&v)[MAXV], int nv, int lane, int D, const float4 (&g)[MAXV],
                                             const float4 (&be)[MAXV], float eps, T* out_t, float* out_f) {
+#pragma clang fp contract(off)
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)

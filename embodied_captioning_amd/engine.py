@@ -7,12 +7,15 @@ from __future__ import annotations
 
 import ctypes as C
 import json
+import logging
 from typing import Dict, List, Optional, Sequence
 
 import torch
 
 from . import _native as N
 from .config import Blip2Arch, BlipArch, CocaArch, MiniLMArch
+
+logger = logging.getLogger(__name__)
 
 OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -134,19 +137,17 @@ class CaptionerEngine:
         """Layout of this handle's cross-attention K/V cache: "fp32", "bf16" or "kv16"."""
         return {0: "fp32", 1: "bf16", 2: "kv16"}[int(self.lib.cap_cross_cache_kind(self._h))]
 
-    DECODE_PATHS = {"auto": 0, "batch": 1, "small": 2, "tile": 3}
+    DECODE_PATHS = {"auto": 0, "batch": 1, "small": 2}
 
     def set_decode_path(self, path: str) -> None:
         """Kernels of the decode steps (BLIP, "f32s" / "bf16"): "auto" = the fused small-batch kernels for images x beams <= 16
         rows (6 launches per layer-step instead of 11; same bits), the batch kernels above; "batch" / "small" force one
-        (forcing "small" makes generate fail for calls those kernels do not take); "tile" = the batch kernels with every layer's
-        cross block as one launch (csrc/decode_tile.hip: 9 launches per layer-step, same bits, measured level with "batch" -
-        greedy calls of more than 16 rows only)."""
+        (forcing "small" makes generate fail for calls those kernels do not take)."""
         N.check(self.lib.cap_set_decode_path(self._h, self.DECODE_PATHS[path]), "cap_set_decode_path")
 
     @property
     def last_decode_path(self) -> str:
-        return {0: "none", 1: "batch", 2: "small", 3: "tile"}[int(self.lib.cap_last_decode_path(self._h))]
+        return {0: "none", 1: "batch", 2: "small"}[int(self.lib.cap_last_decode_path(self._h))]
 
     # ------------------------------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> Dict[str, object]:
@@ -319,6 +320,7 @@ class EnginePool:
         with torch.cuda.device(self.device):
             self.streams = [torch.cuda.Stream(self.device) for _ in range(n)]
         self.arch, self._next = arch, 0
+        self.last_coalesce = None
 
     def __len__(self) -> int:
         return len(self.engines)
@@ -370,6 +372,9 @@ class EnginePool:
         for s in self.streams:
             cur.wait_stream(s)
 
+    # outputs of `generate` whose leading dimension is the batch's rows (what a merged pass is split back by)
+    _PER_ROW_OUTPUTS = ("sequences", "lengths", "sequences_scores")
+
     @staticmethod
     def coalesce_plan(rows: Sequence[int], n_engines: int, max_rows: int) -> List[List[int]]:
         """Dynamic batching plan: consecutive batches (their row counts in `rows`) merged into passes of at most `max_rows` rows -
@@ -410,23 +415,35 @@ class EnginePool:
         DESIGN.md section 2), so the results are those of the uncoalesced call; what changes is that the decode chain's fixed
         costs are paid once per pass: 256-frame batches on 3 engines 5 840 captions/s, merged to 1024 rows 6 400 (round 5)."""
         batches = list(batches)
-        if coalesce_rows and len(batches) > 1 and not generate_kw.get("output_logits"):
+        self.last_coalesce = None            # what the last call did with coalesce_rows: the plan, or why it was not applied
+        if coalesce_rows and len(batches) > 1:
             same = all(b.shape[1:] == batches[0].shape[1:] and b.dtype == batches[0].dtype and b.device == batches[0].device for b in batches)
             cap_rows = min(coalesce_rows, min(e.max_batch for e in self.engines))
-            plan = self.coalesce_plan([int(b.shape[0]) for b in batches], len(self.engines), cap_rows) if same else None
-            if plan is not None and any(len(g) > 1 for g in plan):
-                merged = [batches[g[0]] if len(g) == 1 else torch.cat([batches[j] for j in g], dim=0) for g in plan]
-                outs_m = self.generate_many(merged, threads=threads, **generate_kw)
-                outs: list = [None] * len(batches)
-                for g, mb, om in zip(plan, merged, outs_m):
-                    total, r0 = int(mb.shape[0]), 0
-                    for j in g:
-                        n_j = int(batches[j].shape[0])
-                        # per-row outputs (sequences, lengths, scores) are split; anything else is passed through
-                        outs[j] = {k: (v[r0:r0 + n_j] if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == total else v)
-                                   for k, v in om.items()}
-                        r0 += n_j
-                return outs
+            if generate_kw.get("output_logits"):
+                self.last_coalesce = "not applied: per-step logits are recorded per pass"
+            elif not same:
+                self.last_coalesce = "not applied: the batches differ in frame shape, dtype or device"
+            else:
+                plan = self.coalesce_plan([int(b.shape[0]) for b in batches], len(self.engines), cap_rows)
+                if any(len(g) > 1 for g in plan):
+                    self.last_coalesce = plan
+                    merged = [batches[g[0]] if len(g) == 1 else torch.cat([batches[j] for j in g], dim=0) for g in plan]
+                    outs_m = self.generate_many(merged, threads=threads, **generate_kw)
+                    self.last_coalesce = plan
+                    outs: list = [None] * len(batches)
+                    for g, om in zip(plan, outs_m):
+                        unknown = sorted(set(om) - set(self._PER_ROW_OUTPUTS))
+                        if unknown:              # a new output key must say here whether it is per row - never guessed from its shape
+                            raise N.CaptionerHipError(f"generate_many(coalesce_rows=): output(s) {unknown} are not in the list of per-row "
+                                                      f"outputs {self._PER_ROW_OUTPUTS}; cannot split a merged pass")
+                        r0 = 0
+                        for j in g:
+                            n_j = int(batches[j].shape[0])
+                            outs[j] = {k: v[r0:r0 + n_j] for k, v in om.items()}
+                            r0 += n_j
+                    return outs
+                self.last_coalesce = f"not applied: {len(batches)} batches on {len(self.engines)} engines leave nothing to merge within {cap_rows} rows"
+            logger.debug("generate_many(coalesce_rows=%d) %s", coalesce_rows, self.last_coalesce)
         if not threads or len(self.engines) == 1 or len(batches) <= 1:
             outs = [self.submit(b, **generate_kw) for b in batches]
             self.join()

@@ -34,7 +34,8 @@ class Captioner(_Base):
     def get_captioner(self, cfg):
         """Get the captioner model based on the configuration settings (reference :190-202)."""
         extra = {k: getattr(cfg, k) for k in ("num_beams", "max_length", "max_new_tokens", "dtype", "batch_size", "device",
-                                              "streams", "early_exit_poll", "image_size", "num_beam_groups", "tokenizer_dir")
+                                              "streams", "early_exit_poll", "image_size", "num_beam_groups", "tokenizer_dir",
+                                              "coalesce_rows", "cross_cache", "strict_range")
                  if hasattr(cfg, k)}
         captioner_cfg = Configuration(arch_name=cfg.arch_name, model_name=cfg.model_name,
                                       checkpoint_name=getattr(cfg, "checkpoint_name", None), height=cfg.height,

@@ -132,14 +132,9 @@ int cap_last_decode_steps(CapHandle h);
  * (csrc/decode_small.hip) instead of the batch path's 11.  Both paths form the same sums in the same order: tokens, logits and
  * scores have the same bits (tests/test_small_decode_gpu.py).
  *   path 0 (default): by row count;  1: always the batch kernels;  2: always the small-batch kernels - cap_generate then fails for
- *   calls they do not take (more than 16 rows, more than 32 positions [checked at entry], CAP_F32, other architectures);
- *   3: the batch kernels with the cross block of every layer - split-K consumer + LayerNorm, query projection, cross-attention - as
- *   ONE launch per 16-row tile and head (csrc/decode_tile.hip: 9 launches per layer-step, the same bits; greedy BLIP calls of more
- *   than 16 rows in the split / bf16 modes with a KV16 / bf16 cross cache, else cap_generate fails by name).  It measures level
- *   with path 1 (docs/experiments.md, round 5), so path 0 does not select it. */
+ *   calls they do not take (more than 16 rows, more than 32 positions [checked at entry], CAP_F32, other architectures). */
 int cap_set_decode_path(CapHandle h, int path);
-/* 1 = batch kernels, 2 = small-batch kernels, 3 = batch kernels with the fused cross block: what the last decode step of the last
- * cap_generate ran on (0 before any). */
+/* 1 = batch kernels, 2 = small-batch kernels: what the last decode step of the last cap_generate ran on (0 before any). */
 int cap_last_decode_path(CapHandle h);
 /* Layout of the handle's cross-attention K/V cache: 0 = fp32 rows, 1 = bf16 rows, 2 = KV16 (int16 + one fp32 scale per 64-wide
  * head row; CAP_F32_SPLIT unless CapConfig.cross_kv_fp32).  -1 for a null handle. */

@@ -191,7 +191,7 @@ def test_bench_multi_rank_paths_world2():
     procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

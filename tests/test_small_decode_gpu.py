@@ -149,7 +149,7 @@ def test_six_launches_per_layer_step_and_early_exit():
     eng.profile(False)
     per = sum(r["launches"] for t, r in rep.items() if t.startswith("dec_small_") and t not in ("dec_small_tr", "dec_small_vocab"))
     assert per == 6 * arch.t_layers * (L - 1), rep
-    assert not any(t.startswith("dec_gemm_") or t in ("dec_reduce_ln", "dec_self_attn", "dec_cross_attn") for t in rep), rep
+    assert not any(t.startswith("dec_gemm_") or t in ("dec_reduce_ln", "dec_reduce_ln_wave", "dec_self_attn", "dec_cross_attn") for t in rep), rep
     eng.set_early_exit(2)
     early = eng.generate(px.cuda(), num_beams=1, max_length=L)
     assert torch.equal(early["sequences"], full["sequences"])
