@@ -94,6 +94,8 @@ def parse():
                     "function of the frame index; prints a line marked \"stub\": true and never touches a GPU")
     ap.add_argument("--decode-path", default="auto", choices=["auto", "batch", "small"],
                     help="blip: decode kernels of the timed steps (engine.set_decode_path; A/B of the batch path's kernel sets)")
+    ap.add_argument("--row-compaction", default="on", choices=["on", "off"],
+                    help="blip: the greedy decode loop on the open captions' rows only (engine.set_row_compaction; same tokens; off = A/B)")
     ap.add_argument("--lite", action="store_true", help="timed steps only (profiler counter passes): no roofline / "
                     "encoder-only / parity / fp32 / CPU legs")
     ap.add_argument("--no-latency", action="store_true", help="skip the small-batch `latency` block (profiler passes: its B = 1 / 8 / 64 "
@@ -909,6 +911,7 @@ def main():
     eng.load_state_dict(sd)
     eng.set_early_exit(a.early_exit)
     eng.set_decode_path(a.decode_path)
+    eng.set_row_compaction(a.row_compaction == "on")
     runner = eng
     # dynamic batching only where it is the plain greedy workload on a pool (beams / early exit / other sizes: extra lines as before)
     coal = a.coalesce_rows if (a.streams > 1 and not a.early_exit and a.coalesce_rows > B) else 0
@@ -919,6 +922,7 @@ def main():
         runner = EnginePool(arch, n=a.streams, device=dev, dtype=a.dtype, max_batch=max(B, coal), max_beams=a.beams, max_len=L, weights_of=eng)
         runner.set_early_exit(a.early_exit)
         runner.set_decode_path(a.decode_path)
+        runner.set_row_compaction(a.row_compaction == "on")
     log(f"weights loaded once, {a.streams} engine(s) / stream(s) on them; timing ({a.dtype})")
     dt, (ids, lens) = timed_steps(runner, px, L, a.steps, a.warmup, world, gather, a.beams, coalesce=coal)
     uncoalesced = None
@@ -965,7 +969,8 @@ def main():
                                            f"(a frame has the same bits alone, in its batch and in a merged pass); every batch as its own pass is the "
                                            f"`pool_uncoalesced` key" if coal else "")
                                         + "; one batch at a time on one stream is the `single_stream` key") if a.streams > 1 else "one batch at a time on one stream",
-                           "coalesce_rows": coal, "warmup_requested": a.warmup, "untimed_steps_run": untimed}}
+                           "coalesce_rows": coal, "row_compaction": a.row_compaction,
+                           "warmup_requested": a.warmup, "untimed_steps_run": untimed}}
         if uncoalesced:
             line["pool_uncoalesced"] = uncoalesced
         ln = lens[:B].float()

@@ -56,6 +56,8 @@ _SIGNATURES = {
     "cap_last_decode_steps": (C.c_int, [C.c_void_p]),
     "cap_set_decode_path": (C.c_int, [C.c_void_p, C.c_int]),
     "cap_last_decode_path": (C.c_int, [C.c_void_p]),
+    "cap_set_row_compaction": (C.c_int, [C.c_void_p, C.c_int]),
+    "cap_last_row_compaction": (C.c_int, [C.c_void_p]),
     "cap_cross_cache_kind": (C.c_int, [C.c_void_p]),
     "cap_device_bytes": (C.c_size_t, [C.c_void_p]),
     "cap_g8_saturations": (C.c_longlong, [C.c_int]),

@@ -953,13 +953,15 @@ __global__ __launch_bounds__(256, 3) void decode_attention_wave_kernel(const T* 
                                                                     const int* __restrict__ anc, int anc_ld,
                                                                     int rows_per_kv, int kv_ld, int n_keys,
                                                                     TO* __restrict__ out, int R, int H, QSource qs,
-                                                                    const int* __restrict__ skip) {
+                                                                    const int* __restrict__ skip, RowMap map) {
     const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (unit >= R * H) return;
-    const int row = unit / H, h = unit - row * H;
+    const int crow = unit / H, h = unit - crow * H;      // row of q / the partial sums / out; the caches belong to `row`
+    if (map.n && crow >= *map.n) return;
+    const int row = map.live ? map.live[crow] : crow;
     if (skip && skip[row]) return;          // caption already ended: its logits are never looked at again
-    decode_attention_wave_unit<T, NI, TO>(q, kbase, vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, out + (size_t)row * H * 64, R, H,
-                                          qs, row, h, threadIdx.x & 63, true);
+    decode_attention_wave_unit<T, NI, TO>(q, kbase, vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, out + (size_t)crow * H * 64, R, H,
+                                          qs, row, h, threadIdx.x & 63, true, nullptr, crow);
 }
 
 
@@ -972,19 +974,21 @@ __global__ __launch_bounds__(256, 3) void decode_attention_online_kernel(const T
                                                                       const int* __restrict__ anc, int anc_ld,
                                                                       int rows_per_kv, int kv_ld, int n_keys,
                                                                       TO* __restrict__ out, int R, int H, QSource qs,
-                                                                      const int* __restrict__ skip, size_t ri0 = 0) {
+                                                                      const int* __restrict__ skip, size_t ri0 = 0, RowMap map = RowMap()) {
     // ri0: row index of the first K/V row the launch may touch, for caches addressed by row index (KV16: kbase / vbase are the
     // bases of the layer's whole k / v block).
     // G = key groups (of 8 keys) per chunk, chosen by the launcher so the chunks are balanced (197 keys -> 4 x 56).
     const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (unit >= R * H) return;
-    const int row = unit / H, h = unit - row * H;
+    const int crow = unit / H, h = unit - crow * H;      // row of q / the partial sums / out; the K/V block belongs to `row`
+    if (map.n && crow >= *map.n) return;
+    const int row = map.live ? map.live[crow] : crow;
     // a caption that has ended keeps its row, but nothing reads the row's logits any more (the selection kernels emit pad):
     // its 100-200 KB of K/V per layer are not streamed.  On the bench workload the mean caption is ~11 of 19 steps long.
     if (skip && skip[row]) return;
-    decode_attention_online_unit<T, G, DB, NT, TO, TKV>(q, kbase, vbase, anc, anc_ld, kv_ld, n_keys, out + (size_t)row * H * 64, R, H, qs,
+    decode_attention_online_unit<T, G, DB, NT, TO, TKV>(q, kbase, vbase, anc, anc_ld, kv_ld, n_keys, out + (size_t)crow * H * 64, R, H, qs,
                                                         row, h, threadIdx.x & 63, ri0,
-                                                        ri0 + ((size_t)(row / rows_per_kv) * H + h) * kv_ld, nullptr);
+                                                        ri0 + ((size_t)(row / rows_per_kv) * H + h) * kv_ld, nullptr, nullptr, crow);
 }
 
 
@@ -1547,7 +1551,7 @@ int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
 int launch_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             hipStream_t s, const float* q_part, int q_S, const float* q_bias, int q_ld, int q_col0,
-                            int append_kv, int out_dtype, const int* skip_rows, int kv16, size_t kv_row0) {
+                            int append_kv, int out_dtype, const int* skip_rows, int kv16, size_t kv_row0, RowMap map) {
     // kv16: kbase / vbase are the bases of KV16 blocks (common.h), the launch's first row has index kv_row0 in them
     if (out_dtype < 0) out_dtype = dtype;
     if (kv16 && !(dtype == CAP_DT_F32 && impl == 0 && !anc && !append_kv && n_keys > 32)) {
@@ -1565,9 +1569,13 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
         return -1;
     }
     if (n_keys <= 0 || n_keys > 8192) { cap_set_error("decode_attention: bad key count %d", n_keys); return -1; }
+    if ((map.live || map.n) && (impl != 0 || rows_per_kv != 1 || anc)) {
+        cap_set_error("decode_attention: a row map is taken by the greedy kernels only (impl 0, one row per K/V block, no ancestry)");
+        return -1;
+    }
 #define CAP_DA_WAVE_O(TT, NI, TOO)                                                                                     \
     hipLaunchKernelGGL((decode_attention_wave_kernel<TT, NI, TOO>), dim3((R * H + 3) / 4), dim3(256), 0, s, (const TT*)q,  \
-                       (TT*)kbase, (TT*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, (TOO*)out, R, H, qs, skip_rows)
+                       (TT*)kbase, (TT*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys, (TOO*)out, R, H, qs, skip_rows, map)
 #define CAP_DA_WAVE(TT, NI) CAP_DA_WAVE_O(TT, NI, TT)
     // bf16: chunks of 40 keys, double-buffered (168 VGPRs -> 3 waves/SIMD, all of a 256-row launch resident at once;
     // 197 image tokens = 5 chunks).  fp32: chunks of 56 keys, single buffer (same register budget).
@@ -1577,7 +1585,7 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
 #define CAP_DA_ONLINE_NT(TT, DBB, NTT)                                                                                 \
     hipLaunchKernelGGL((decode_attention_online_kernel<TT, (DBB ? 5 : 7), DBB, NTT>), dim3((R * H + 3) / 4), dim3(256), 0, \
                        s, (const TT*)q, (const TT*)kbase, (const TT*)vbase, anc, anc_ld, rows_per_kv, kv_ld, n_keys,      \
-                       (TT*)out, R, H, qs, skip_rows)
+                       (TT*)out, R, H, qs, skip_rows, (size_t)0, map)
 #define CAP_DA_ONLINE(TT, DBB)                                                                                         \
     do {                                                                                                               \
         if (DBB && rows_per_kv == 1 && !anc) CAP_DA_ONLINE_NT(TT, DBB, DBB); else CAP_DA_ONLINE_NT(TT, DBB, false);    \
@@ -1623,18 +1631,18 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
                 // ~4 us of launch, 160 MB in the rest is the HBM rate
                 hipLaunchKernelGGL((decode_attention_online_kernel<float, 5, false, false, g8_t, kv16_t>), dim3((R * H + 3) / 4), dim3(256), 0,
                                    s, (const float*)q, (const float*)kbase, (const float*)vbase, anc, anc_ld, rows_per_kv, kv_ld,
-                                   n_keys, (g8_t*)out, R, H, qs, skip_rows, kv_row0);
+                                   n_keys, (g8_t*)out, R, H, qs, skip_rows, kv_row0, map);
             else
                 hipLaunchKernelGGL((decode_attention_online_kernel<float, 7, false, false, g8_t>), dim3((R * H + 3) / 4), dim3(256), 0,
                                    s, (const float*)q, (const float*)kbase, (const float*)vbase, anc, anc_ld, rows_per_kv, kv_ld,
-                                   n_keys, (g8_t*)out, R, H, qs, skip_rows);
+                                   n_keys, (g8_t*)out, R, H, qs, skip_rows, (size_t)0, map);
         } else {
             if (ng8 <= 1) CAP_DA_WAVE(float, 1); else if (ng8 <= 2) CAP_DA_WAVE(float, 2);
             else if (ng8 <= 4) CAP_DA_WAVE(float, 4);
             else if (kv16)
                 hipLaunchKernelGGL((decode_attention_online_kernel<float, 5, false, false, float, kv16_t>), dim3((R * H + 3) / 4), dim3(256), 0,
                                    s, (const float*)q, (const float*)kbase, (const float*)vbase, anc, anc_ld, rows_per_kv, kv_ld,
-                                   n_keys, (float*)out, R, H, qs, skip_rows, kv_row0);
+                                   n_keys, (float*)out, R, H, qs, skip_rows, kv_row0, map);
             else CAP_DA_ONLINE(float, false);
         }
         CAP_HIP_CHECK(hipGetLastError());

@@ -136,6 +136,9 @@ struct Captioner {
     int decode_path = 0;         // cap_set_decode_path: 0 = by row count (<= SMALL_MAX_ROWS rows: the fused small-batch kernels),
                                  // 1 = always the batch kernels, 2 = always the small-batch kernels (an error beyond their row limit)
     int last_path = 0;           // what the last cap_generate's decode steps ran on (cap_last_decode_path): 1 batch, 2 small-batch
+    int compaction = 1;          // cap_set_row_compaction: 1 = the greedy batch path works on the open captions' rows only (RowMap)
+    int last_compacted = 0;      // did the last cap_generate's decode loop run compacted (cap_last_row_compaction)
+    int *live = nullptr, *n_live = nullptr;       // RowMap storage: int32 [max rows] + the count
     // vision weights
     float *cls, *vpos, *b_patch, *post_g, *post_b;
     void* w_patch;
@@ -475,6 +478,8 @@ int build_arena(Captioner* m) {
     TRY(dev_alloc(m, (void**)&m->seq, R * Lm * 4));
     TRY(dev_alloc(m, (void**)&m->finished, R * 4));
     TRY(dev_alloc(m, (void**)&m->lens, R * 4));
+    TRY(dev_alloc(m, (void**)&m->live, R * 4));
+    TRY(dev_alloc(m, (void**)&m->n_live, 256));
     TRY(dev_alloc(m, (void**)&m->anc, 2 * R * Lm * 4));
     TRY(dev_alloc(m, (void**)&m->dx, R * T * 4));
     TRY(dev_alloc(m, (void**)&m->dy, R * T * 4));
@@ -549,7 +554,7 @@ int poll_all_finished(Captioner* m, int step, int steps, const int* finished, in
 // ---------------------------------------------------------------------------------------------- BLIP-2 OPT
 int run_encoder(Captioner* m, const void* pixels, int fmt, int B, float* out_embeds, hipStream_t s);
 int gemm_partial(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, float* part, int R, int N,
-                 int K, int max_S, int* S_out);
+                 int K, int max_S, int* S_out, const int* m_live = nullptr);
 __global__ void init_seq_kernel(int* seq, int* fin, int* len, int R, int L, int bos, int pad);
 __global__ void copy_logits_kernel(const float* src, int ld, float* dst, int R, int V);
 __global__ void copy_new_tokens_kernel(const int* seq, int seq_ld, int P, const int* lens, int* out_ids, int* out_len, int B, int n) {
@@ -1019,6 +1024,7 @@ struct Dec {
     int *seq, *finished, *lens, *anc;
     void* beam;
     size_t cache_off;     // byte offset of this slice's [k|v][R][H][Lm][64] block inside every layer's self cache
+    RowMap map;           // compacted greedy loop: the open rows (live / count on the device); null pointers = every row
 };
 
 Dec make_slice(Captioner* m, int b0, int B, int Btot, int K, int Lm) {
@@ -1060,12 +1066,12 @@ int decode_splitk(const Captioner* m, int N, int K, int max_S) {
 inline int decode_tile(const Captioner* m) { return m->gdt == CAP_DT_F32 ? 2 : 6; }
 
 int gemm_partial(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, float* part, int R, int N,
-                 int K, int max_S, int* S_out) {
+                 int K, int max_S, int* S_out, const int* m_live) {
     const int S = decode_splitk(m, N, K, max_S);
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = part; p.ldc = N; p.M = R; p.N = N; p.K = K;
-    p.out_f32 = 1; p.epi = EPI_PARTIAL; p.splitk = S;
+    p.out_f32 = 1; p.epi = EPI_PARTIAL; p.splitk = S; p.m_live = m_live;
     *S_out = S;
     ProfScope ps(m, s, tag, 2.0 * R * N * K, ((double)R * K + (double)N * K) * m->esz + (double)S * R * N * 4);
     return launch_gemm(m->gdt, p, decode_tile(m), s);
@@ -1074,11 +1080,11 @@ int gemm_partial(Captioner* m, hipStream_t s, const char* tag, const void* A, co
 // A finished decode projection (bias + activation -> operand type): fc1 of the text layers.  Same kernel family as the
 // split-K ones at every row count.
 int gemm_rows(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, void* C, const float* bias, int R, int N,
-              int K, int act) {
+              int K, int act, const int* m_live = nullptr) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = C; p.ldc = N; p.bias = bias; p.ldr = N; p.M = R; p.N = N; p.K = K;
-    p.gelu = act; p.out_f32 = 0; p.epi = EPI_STORE; p.splitk = 1;
+    p.gelu = act; p.out_f32 = 0; p.epi = EPI_STORE; p.splitk = 1; p.m_live = m_live;
     ProfScope ps(m, s, tag, 2.0 * R * N * K, ((double)R * K + (double)N * K + (double)R * N) * m->esz);
     return launch_gemm(m->gdt, p, m->gdt == CAP_DT_F32 ? 0 : 6, s);
 }
@@ -1094,7 +1100,7 @@ int gemm_splitk_reduce_ln(Captioner* m, hipStream_t s, const Dec& d, const char*
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = K; p.W = W; p.ldw = K; p.C = d.dpart; p.ldc = N; p.M = d.R; p.N = N; p.K = K;
-    p.out_f32 = 1; p.epi = EPI_PARTIAL; p.splitk = S;
+    p.out_f32 = 1; p.epi = EPI_PARTIAL; p.splitk = S; p.m_live = d.map.n;
     {
         ProfScope ps(m, s, tag, 2.0 * d.R * N * K, ((double)d.R * K + (double)N * K) * m->esz + (double)S * d.R * N * 4);
         TRY(launch_gemm(m->gdt, p, decode_tile(m), s));
@@ -1104,7 +1110,7 @@ int gemm_splitk_reduce_ln(Captioner* m, hipStream_t s, const Dec& d, const char*
     // one 256-thread block per row up to a few hundred rows (one memory round trip, latency-bound); at the pool's merged passes
     // (~1 000 rows) the wave-per-row kernel: 5.6 us against 7.4 at 1 024 rows.  Same sums in the same order - the two kernels give
     // the same bits (tests/test_kernels_gpu.py::test_reduce_layernorm_kernels_agree_bit_for_bit), so the row count may choose.
-    return launch_reduce_layernorm(m->gdt, d.dpart, S, bias, resid ? resid : d.dx, g, b, eps, out_t, out_f, y_out, d.R, N, s, per_row_block);
+    return launch_reduce_layernorm(m->gdt, d.dpart, S, bias, resid ? resid : d.dx, g, b, eps, out_t, out_f, y_out, d.R, N, s, per_row_block, false, d.map.n);
 }
 
 // x: the fp32 LayerNorm row buffer the consumer adds as its residual and replaces (d.dx, or d.dx2 on the fused paths)
@@ -1118,10 +1124,15 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
     const CapConfig& c = m->c;
     const int T = c.t_hidden, F = c.t_ffn, H = c.t_heads, R = d.R, NT = m->NT;
     const size_t e = m->esz;
-    // greedy: the attention kernels leave the rows of ended captions alone (d.finished is set by greedy_select one step
-    // before); the GEMMs still cover every row - they are bound by the weight stream, not by the row count
-    const int* skip = K == 1 ? d.finished : nullptr;
-    TRY(launch_embed(m->gdt, tokens, tok_ld, t, m->word_f32, m->tpos, m->emb_g, m->emb_b, c.t_eps, d.dx_t, d.dx, R, T, s));
+    // greedy: a caption that has ended (d.finished, set by greedy_select one step before) is not computed any more.  Compacted
+    // (d.map, the merged passes of ~1 000 rows: at that size the projections are no longer a weight stream - 47 % of the decode
+    // kernels' time): every kernel of the step works on the open captions' rows, packed to the front - activations, split-K
+    // slabs and logits are indexed by the compact row, tokens / self-attention cache rows / the image's cross K/V through
+    // map.live[c]; row tiles, rows and (row, head) units from *map.n on return at once.  Without a map (beams, per-step logits
+    // wanted, forced off): the attention kernels skip ended rows in place and the GEMMs cover every row.
+    const bool cm = d.map.n != nullptr;
+    const int* skip = (K == 1 && !cm) ? d.finished : nullptr;
+    TRY(launch_embed(m->gdt, tokens, tok_ld, t, m->word_f32, m->tpos, m->emb_g, m->emb_b, c.t_eps, d.dx_t, d.dx, R, T, s, nullptr, d.map));
     for (int i = 0; i < c.t_layers; ++i) {
         const TLayer& L = m->tl[i];
         char* kc = (char*)L.self_cache + d.cache_off;
@@ -1130,11 +1141,12 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
             // q/k/v projection as split-K partial sums; the attention kernel finishes the reduction, appends k/v to the
             // cache and attends (one memory round trip per kernel instead of two in the GEMM)
             int S = 1;
-            TRY(gemm_partial(m, s, "dec_gemm_qkv", d.dx_t, L.w_qkv, d.dpart, R, 3 * T, T, 4, &S));
+            TRY(gemm_partial(m, s, "dec_gemm_qkv", d.dx_t, L.w_qkv, d.dpart, R, 3 * T, T, 4, &S, d.map.n));
             ProfScope ps(m, s, "dec_self_attn", 4.0 * R * H * (t + 1) * 64, 2.0 * R * H * (t + 1) * 64 * e + (double)S * R * 3 * T * 4);
             TRY(launch_decode_attention(m->dt, nullptr, kc, vc, anc, Lm, 1, Lm, t + 1, d.dctx, R, H, 0, s, d.dpart, S,
-                                        L.b_qkv, 3 * T, 0, 1, m->gdt, skip));
+                                        L.b_qkv, 3 * T, 0, 1, m->gdt, skip, 0, 0, d.map));
         } else {
+            if (cm) { cap_set_error("run_decoder_step: the compacted loop takes up to 32 positions"); return -1; }   // (run_generate never asks)
             TRY(gemm(m, s, "dec_gemm_qkv", d.dx_t, T, L.w_qkv, T, d.dq, T, L.b_qkv, nullptr, R, 3 * T, T, 0, 0, EPI_QKVCACHE,
                      R, H, Lm, t, nullptr, kc));
             ProfScope ps(m, s, "dec_self_attn", 4.0 * R * H * (t + 1) * 64, 2.0 * R * H * (t + 1) * 64 * e);
@@ -1143,7 +1155,7 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
         TRY(gemm_splitk_ln(m, s, d, "dec_gemm_so", d.dctx, L.w_so, L.b_so, L.so_g, L.so_b, T, T));
         {
             int S = 1;
-            TRY(gemm_partial(m, s, "dec_gemm_cq", d.dx_t, L.w_cq, d.dpart, R, T, T, 4, &S));
+            TRY(gemm_partial(m, s, "dec_gemm_cq", d.dx_t, L.w_cq, d.dpart, R, T, T, 4, &S, d.map.n));
             // beam-shared cross K/V of layer i: [k|v][image (whole batch)][head][token][64]; this slice starts at image b0.  A KV16
             // cache is addressed by row index inside the layer's k / v block: the kernel gets the block bases and the first row
             const size_t blk = m->cross_block((size_t)d.Btot * H * NT), row0 = (size_t)d.b0 * H * NT;
@@ -1151,10 +1163,10 @@ int run_decoder_step(Captioner* m, const Dec& d, const int* tokens, int tok_ld, 
             const char* cv = (char*)m->cross + ((size_t)i * 2 + 1) * blk + (m->kv16 ? 0 : row0 * m->kvrow);
             ProfScope ps(m, s, "dec_cross_attn", 4.0 * R * H * NT * 64, 2.0 * d.B * H * NT * m->kvrow);
             TRY(launch_decode_attention(m->dt, nullptr, ck, cv, nullptr, 0, K, NT, NT, d.dctx, R, H, 0, s, d.dpart, S, L.b_cq,
-                                        T, 0, 0, m->gdt, skip, m->kv16 ? 1 : 0, m->kv16 ? row0 : 0));
+                                        T, 0, 0, m->gdt, skip, m->kv16 ? 1 : 0, m->kv16 ? row0 : 0, d.map));
         }
         TRY(gemm_splitk_ln(m, s, d, "dec_gemm_co", d.dctx, L.w_co, L.b_co, L.co_g, L.co_b, T, T));
-        TRY(gemm_rows(m, s, "dec_gemm_f1", d.dx_t, L.w_f1, d.dh, L.b_f1, R, F, T, 1));
+        TRY(gemm_rows(m, s, "dec_gemm_f1", d.dx_t, L.w_f1, d.dh, L.b_f1, R, F, T, 1, d.map.n));
         TRY(gemm_splitk_ln(m, s, d, "dec_gemm_f2", d.dh, L.w_f2, L.b_f2, L.f_g, L.f_b, T, F));
     }
     TRY(gemm(m, s, "dec_gemm_tr", d.dx_t, T, m->w_tr, T, d.dy, T, m->b_tr, nullptr, R, T, T, 1, 1));
@@ -1484,9 +1496,18 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
     const bool coca = c.arch == CAP_ARCH_COCA;
     const bool greedy = K == 1 && !force_beam;
     TRY(run_image_side(m, pixels, fmt, B, s));
-    const Dec d = make_slice(m, 0, B, B, K, Lm);
+    Dec d = make_slice(m, 0, B, B, K, Lm);
+    // Row compaction (ops.h, RowMap): the greedy BLIP loop on the batch kernels, when nobody asked for per-step logits (their rows
+    // are the batch's rows) and every position takes the fused self-attention (<= 32: the k / v append goes through map.live)
+    const bool compact = greedy && c.arch == CAP_ARCH_BLIP && m->compaction && m->live && !out_step_logits && Lm - 1 <= 32 &&
+                         R > SMALL_MAX_ROWS && m->decode_path != 2;
+    m->last_compacted = compact ? 1 : 0;
     if (greedy) {
         hipLaunchKernelGGL(init_seq_kernel, dim3(64), dim3(256), 0, s, d.seq, d.finished, d.lens, R, Lm, c.bos, c.pad);
+        if (compact) {
+            d.map.live = m->live; d.map.n = m->n_live;
+            TRY(launch_compact_rows(d.finished, R, m->live, m->n_live, s));
+        }
     } else {
         TRY(launch_beam_init(d.beam, B, K, Lm, c.bos, c.pad, c.eos, s, coca ? BEAM_LEGACY_RAW : BEAM_HF_V5));
         hipLaunchKernelGGL(iota_rows_kernel, dim3(64), dim3(256), 0, s, d.anc, R, Lm);
@@ -1526,8 +1547,11 @@ int run_generate(Captioner* m, const void* pixels, int fmt, int B, int K, int Lm
         }
         ProfScope ps(m, s, greedy ? "greedy_select" : "beam_step", 0, (double)R * c.vocab * 4);
         if (greedy)
+        {
             TRY(launch_greedy_select(d.logits, m->ldl, c.vocab, d.seq, Lm, t, Lm, c.eos, c.pad, d.finished, d.lens, R, s,
-                                     coca ? c.min_len : 0, coca ? 1 : 0));
+                                     coca ? c.min_len : 0, coca ? 1 : 0, d.map));
+            if (compact) TRY(launch_compact_rows(d.finished, R, m->live, m->n_live, s));
+        }
         else
             TRY(launch_beam_step(d.beam, d.logits, m->ldl, c.vocab, B, K, Lm, cur_len, c.eos, lp, d.anc, Lm, s,
                                  coca ? BEAM_LEGACY_RAW : BEAM_HF_V5, coca ? c.min_len : 0));
@@ -1707,6 +1731,14 @@ int cap_set_decode_path(CapHandle h, int path) {
     return 0;
 }
 int cap_last_decode_path(CapHandle h) { return h ? ((Captioner*)h)->last_path : -1; }
+
+int cap_set_row_compaction(CapHandle h, int on) {
+    Captioner* m = (Captioner*)h;
+    if (!m || (on != 0 && on != 1)) { cap_set_error("cap_set_row_compaction: null handle, or a value other than 0 / 1"); return -1; }
+    m->compaction = on;
+    return 0;
+}
+int cap_last_row_compaction(CapHandle h) { return h ? ((Captioner*)h)->last_compacted : -1; }
 int cap_cross_cache_kind(CapHandle h) {
     const Captioner* m = (const Captioner*)h;
     if (!m) return -1;

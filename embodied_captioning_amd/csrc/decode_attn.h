@@ -123,8 +123,11 @@ template <typename T, int NI, typename TO>
 __device__ __forceinline__ void decode_attention_wave_unit(const T* __restrict__ q, T* __restrict__ kbase, T* __restrict__ vbase,
                                                            const int* __restrict__ anc, int anc_ld, int rows_per_kv, int kv_ld,
                                                            int n_keys, TO* out_row, int R, int H, const QSource& qs, int row, int h,
-                                                           int lane, bool write_kv, const float* q_ready = nullptr) {
+                                                           int lane, bool write_kv, const float* q_ready = nullptr, int prow = -1) {
 #pragma clang fp contract(off)      // as written, wherever it is inlined (batch kernel / small-batch prologue): same bits
+    // prow >= 0 (compacted decode loop, ops.h RowMap): the row of the split-K partial sums / the `q` tensor, when it is not `row` -
+    // `row` stays the row that owns the caches and the ancestry
+    const int pr = prow >= 0 ? prow : row;
     const int Dh = H * 64;
     const int ksub = lane >> 3, dch = lane & 7;
     const bool fused_kv = qs.part != nullptr && qs.append_kv;
@@ -137,10 +140,10 @@ __device__ __forceinline__ void decode_attention_wave_unit(const T* __restrict__
         srcs[i] = (anc && key < n_keys) ? anc[(size_t)row * anc_ld + key] : row / rows_per_kv;
     }
     Part8 pq, pk, pv;
-    if (qs.part) pq.issue(qs, R, row, qs.col0 + h * 64 + dch * 8);
+    if (qs.part) pq.issue(qs, R, pr, qs.col0 + h * 64 + dch * 8);
     if (fused_kv) {
-        pk.issue(qs, R, row, qs.col0 + Dh + h * 64 + dch * 8);
-        pv.issue(qs, R, row, qs.col0 + 2 * Dh + h * 64 + dch * 8);
+        pk.issue(qs, R, pr, qs.col0 + Dh + h * 64 + dch * 8);
+        pv.issue(qs, R, pr, qs.col0 + 2 * Dh + h * 64 + dch * 8);
     }
     Raw8<T> kk[NI], vv[NI];
 #pragma unroll
@@ -161,7 +164,7 @@ __device__ __forceinline__ void decode_attention_wave_unit(const T* __restrict__
     } else if (qs.part) {
         pq.finish<T>(qs, qv);
     } else {
-        load8<T>(q + (size_t)row * Dh + h * 64 + dch * 8, qv);
+        load8<T>(q + (size_t)pr * Dh + h * 64 + dch * 8, qv);
     }
     if (fused_kv) {
         // every lane finishes the newest position's k/v for its 8 columns (same addresses across the 8 key sub-lanes);
@@ -271,8 +274,9 @@ __device__ __forceinline__ void decode_attention_online_unit(const T* __restrict
                                                              const int* __restrict__ anc, int anc_ld, int kv_ld, int n_keys,
                                                              TO* out_row, int R, int H, const QSource& qs, int row, int h, int lane,
                                                              size_t ri0, size_t ri_base, const float* q_ready,
-                                                             const float* sc_ready = nullptr) {
+                                                             const float* sc_ready = nullptr, int prow = -1) {
 #pragma clang fp contract(off)      // as written, wherever it is inlined: same bits on every path
+    const int pr = prow >= 0 ? prow : row;              // row of the partial sums / `q` (see decode_attention_wave_unit)
     // SCR (compile time): the scores come from sc_ready
     constexpr int CH = 8 * G;
     const int Dh = H * 64;
@@ -328,14 +332,14 @@ __device__ __forceinline__ void decode_attention_online_unit(const T* __restrict
         } else if (qs.part) {
             pq.finish<T>(qs, qv);
         } else {
-            load8<T>(q + (size_t)row * Dh + h * 64 + dch * 8, qv);
+            load8<T>(q + (size_t)pr * Dh + h * 64 + dch * 8, qv);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) qv[e] *= 0.125f;
     };
 
     Part8 pq;
-    if (!q_ready && qs.part) pq.issue(qs, R, row, qs.col0 + h * 64 + dch * 8);
+    if (!q_ready && qs.part) pq.issue(qs, R, pr, qs.col0 + h * 64 + dch * 8);
     Raw8<TKV> ka[G], va[G];
     issue(ka, va, 0);
     if constexpr (DB) {

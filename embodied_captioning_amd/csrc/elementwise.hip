@@ -106,12 +106,13 @@ __global__ __launch_bounds__(256) void reduce_layernorm_kernel(const P* __restri
                                                                 const float* __restrict__ resid,
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float eps, T* out_t,
-                                                                float* out_f, float* y_out, int M, int D) {
+                                                                float* out_f, float* y_out, int M, int D,
+                                                                const int* __restrict__ n_rows) {
 #pragma clang fp contract(off)      // sums and LayerNorm as written: the three consumers of a row count range agree bit for bit
     // one wave per row.  Decode (a few hundred rows) launches one wave per block so every row gets its own CU slot and
     // all of its S*nv + 2*nv 16-byte loads are issued before the first add; the encoder launches 4 rows per block.
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= M) return;
+    if (row >= M || (n_rows && row >= *n_rows)) return;
     const int nv = (D + 255) / 256;
     float4 v[MAXV];
 #pragma unroll
@@ -154,10 +155,12 @@ __global__ __launch_bounds__(256) void reduce_layernorm_row_kernel(const float* 
                                                                     const float* __restrict__ resid,
                                                                     const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, float eps, T* out_t,
-                                                                    float* out_f, float* y_out, int M, int D) {
+                                                                    float* out_f, float* y_out, int M, int D,
+                                                                    const int* __restrict__ n_rows) {
 #pragma clang fp contract(off)
     __shared__ float sp[2][256];
     const int row = blockIdx.x, tid = threadIdx.x, c = tid * 4;
+    if (n_rows && row >= *n_rows) return;                // (uniform over the block: before any barrier)
     const bool act = c < D;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 pz[8], bb = z4, rr = z4, g = z4, be = z4;
@@ -270,10 +273,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void embed_kernel(const int* __restrict__ seq, int seq_ld, int t,
                                                     const float* __restrict__ word, const float* __restrict__ pos,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    float eps, T* out_t, float* out_f, float* y_out, int R, int D) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= R) return;
-    const int tok = seq[(size_t)row * seq_ld + t];
+                                                    float eps, T* out_t, float* out_f, float* y_out, int R, int D, RowMap map) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // (compact) output row
+    if (row >= R || (map.n && row >= *map.n)) return;
+    const int tok = seq[(size_t)(map.live ? map.live[row] : row) * seq_ld + t];
     const int nv = (D + 255) / 256;
     float4 v[LN_MAXV];
     const float* w = word + (size_t)tok * D;
@@ -348,13 +351,15 @@ __global__ __launch_bounds__(256) void mean_pool_normalize_kernel(const float* _
 __global__ __launch_bounds__(256) void greedy_select_kernel(const float* __restrict__ logits, int ld, int V,
                                                             int* __restrict__ seq, int seq_ld, int t, int max_len,
                                                             int eos, int pad, int* __restrict__ finished,
-                                                            int* __restrict__ out_len, int min_len, int force_eos) {
+                                                            int* __restrict__ out_len, int min_len, int force_eos, RowMap map) {
     // min_len > 0: EOS cannot win while the row has fewer than min_len tokens (HF MinLengthLogitsProcessor, used by the
     // reference's CoCa loop coca_model.py:235-240); force_eos (= "this is the CoCa loop"): the last position is EOS
     // (coca_model.py:317-318) and a sampled pad id ends the row (:305)
-    const int row = blockIdx.x, tid = threadIdx.x;
+    const int crow = blockIdx.x, tid = threadIdx.x;      // logits row; the caption it belongs to is row map.live[crow]
+    if (map.n && crow >= *map.n) return;                 // (uniform over the block: before any barrier)
+    const int row = map.live ? map.live[crow] : crow;
     const bool mask_eos = min_len > 0 && t + 1 < min_len;
-    const float* x = logits + (size_t)row * ld;
+    const float* x = logits + (size_t)crow * ld;
     float best = -INFINITY;
     int bi = 0x7fffffff;
     // 16-byte loads, 4 independent chunks in flight per thread; ascending index order inside a thread keeps "first
@@ -502,7 +507,8 @@ int launch_layernorm(int dtype, const float* in, int ld_in, const float* gamma, 
 
 int launch_reduce_layernorm(int dtype, const void* part, int S, const float* bias, const float* resid,
                             const float* gamma, const float* beta, float eps, void* out_t, float* out_f, float* y_out,
-                            int M, int D, hipStream_t s, bool per_row_block, bool part_in_t) {
+                            int M, int D, hipStream_t s, bool per_row_block, bool part_in_t, const int* n_rows) {
+    if (n_rows && per_row_block && D > 1024) { cap_set_error("reduce_layernorm: the wide block kernel takes no row count from the device"); return -1; }
     if (per_row_block && part_in_t) { cap_set_error("reduce_layernorm: the per-row-block kernel takes fp32 partial sums"); return -1; }
     if (D % 4 != 0 || D > 256 * LN_MAXV || S < 1 || (dtype == CAP_DT_G8 && D % 8 != 0)) { cap_set_error("reduce_layernorm: unsupported width %d / slices %d", D, S); return -1; }
     // per_row_block: the decoder's choice up to a few hundred rows (latency-bound).  For rows up to 1024 wide the block-per-row
@@ -510,7 +516,7 @@ int launch_reduce_layernorm(int dtype, const void* part, int S, const float* bia
     // vector i) and the two agree bit for bit (tests/test_kernels_gpu.py::test_reduce_layernorm_kernels_agree_bit_for_bit), so a
     // caller may pick by row count there; the WIDE block kernel (rows beyond 1024) has its own order: by path only.
     if (per_row_block && D <= 1024) {
-#define CAP_RR(TT) hipLaunchKernelGGL(reduce_layernorm_row_kernel<TT>, dim3(M), dim3(256), 0, s, (const float*)part, S, bias, resid, gamma, beta, eps, (TT*)out_t, out_f, y_out, M, D)
+#define CAP_RR(TT) hipLaunchKernelGGL(reduce_layernorm_row_kernel<TT>, dim3(M), dim3(256), 0, s, (const float*)part, S, bias, resid, gamma, beta, eps, (TT*)out_t, out_f, y_out, M, D, n_rows)
         CAP_DISPATCH_T(dtype, CAP_RR);
 #undef CAP_RR
         CAP_HIP_CHECK(hipGetLastError());
@@ -527,7 +533,7 @@ int launch_reduce_layernorm(int dtype, const void* part, int S, const float* bia
     const dim3 grid((M + wpb - 1) / wpb), block(64 * wpb);
 #define CAP_RLN(TT, PP, MV)                                                                                             \
     hipLaunchKernelGGL((reduce_layernorm_kernel<TT, PP, MV>), grid, block, 0, s, (const PP*)part, S, bias, resid, gamma,  \
-                       beta, eps, (TT*)out_t, out_f, y_out, M, D)
+                       beta, eps, (TT*)out_t, out_f, y_out, M, D, n_rows)
 #define CAP_RLN_T(TT, PP) do { if (D <= 1024) CAP_RLN(TT, PP, 4); else if (D <= 2048) CAP_RLN(TT, PP, 8); else CAP_RLN(TT, PP, LN_MAXV); } while (0)
     if (dtype == CAP_DT_BF16 && part_in_t) CAP_RLN_T(bf16_t, bf16_t);
     else if (dtype == CAP_DT_BF16) CAP_RLN_T(bf16_t, float);
@@ -589,9 +595,9 @@ int launch_mean_pool_normalize(const float* x, const int* lens, int B, int L, in
 
 int launch_embed(int dtype, const int* seq, int seq_ld, int t, const float* word, const float* pos,
                  const float* gamma, const float* beta, float eps, void* out_t, float* out_f, int R, int D,
-                 hipStream_t s, float* y_out) {
+                 hipStream_t s, float* y_out, RowMap map) {
     if (D % 4 != 0 || D > 256 * LN_MAXV) { cap_set_error("embed: unsupported width %d", D); return -1; }
-#define CAP_EM(TT) hipLaunchKernelGGL(embed_kernel<TT>, dim3((R + 3) / 4), dim3(256), 0, s, seq, seq_ld, t, word, pos, gamma, beta, eps, (TT*)out_t, out_f, y_out, R, D)
+#define CAP_EM(TT) hipLaunchKernelGGL(embed_kernel<TT>, dim3((R + 3) / 4), dim3(256), 0, s, seq, seq_ld, t, word, pos, gamma, beta, eps, (TT*)out_t, out_f, y_out, R, D, map)
     CAP_DISPATCH_T(dtype, CAP_EM);
 #undef CAP_EM
     CAP_HIP_CHECK(hipGetLastError());
@@ -599,9 +605,42 @@ int launch_embed(int dtype, const int* seq, int seq_ld, int t, const float* word
 }
 
 int launch_greedy_select(const float* logits, int ld, int V, int* seq, int seq_ld, int t, int max_len, int eos,
-                         int pad, int* finished, int* out_len, int R, hipStream_t s, int min_len, int force_eos) {
+                         int pad, int* finished, int* out_len, int R, hipStream_t s, int min_len, int force_eos, RowMap map) {
     hipLaunchKernelGGL(greedy_select_kernel, dim3(R), dim3(256), 0, s, logits, ld, V, seq, seq_ld, t, max_len, eos, pad,
-                       finished, out_len, min_len, force_eos);
+                       finished, out_len, min_len, force_eos, map);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// The open rows in ascending order (stable: a caption's compact position only ever moves towards the front) and their count.
+__global__ __launch_bounds__(1024) void compact_rows_kernel(const int* __restrict__ finished, int R, int* __restrict__ live,
+                                                            int* __restrict__ n_live) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < R; r0 += 1024) {
+        const int r = r0 + tid;
+        const bool on = r < R && finished[r] == 0;
+        const unsigned long long b = __ballot(on);
+        if (lane == 0) wsum[w] = __popcll(b);
+        __syncthreads();
+        int off = base;
+        for (int i = 0; i < w; ++i) off += wsum[i];
+        if (on) live[off + __popcll(b & ((1ull << lane) - 1ull))] = r;
+        __syncthreads();
+        if (tid == 0) {
+            int sum = 0;
+            for (int i = 0; i < 16; ++i) sum += wsum[i];
+            base += sum;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *n_live = base;
+}
+int launch_compact_rows(const int* finished, int R, int* live, int* n_live, hipStream_t s) {
+    hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), 0, s, finished, R, live, n_live);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -31,6 +31,9 @@ struct GemmParams {
     int kv16;                      // EPI_CROSSKV with an fp32 output: 1 = write the K/V rows as KV16 blocks (common.h: int16 + one
                                    // scale per head row; gemm_pp.hip is the only producer) instead of fp32; C = base of block (layer 0, k)
     int tile0, tile1;              // set by launch_big2 only: the range of 256 x 256 tiles one launch covers (0, 0 = all)
+    const int* m_live;             // device int32 or null (tile 6, the decode "rows" kernel): row tiles that start at or beyond
+                                   // *m_live return at once - the compacted greedy decode loop (ops.h, RowMap); M keeps
+                                   // the slab stride / capacity meaning
 };
 
 // dtype: CAP_DT_F32 / CAP_DT_BF16.  tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 256x256 persistent LDS-DMA kernel

@@ -837,6 +837,7 @@ __global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmParams p) {
     const int tn = bid % ntn, kz = bid / ntn;
     if constexpr (EPI == EPI_PARTIAL) p.p3 = kz;
     const int m0 = tm * 64, n0 = tn * 64;
+    if (p.m_live && m0 >= *p.m_live) return;               // compacted decode loop: no open caption in this row tile
     const int nkb = p.K / S / SLAB;                        // slabs of this block
 
     const int tid = threadIdx.x, lane = tid & 63;

@@ -3,6 +3,17 @@
 #pragma once
 #include "common.h"
 
+// Row compaction of the greedy decode loop (captioner.hip, run_decoder_step): the rows of captions that are still open, in
+// row order, and their count - both on the device, rebuilt after every token selection.  A kernel given a RowMap works on
+// COMPACT rows c < *n (activations, split-K slabs, logits) and reaches what a caption owns across steps - its tokens, its
+// self-attention cache rows, its image's cross K/V - through live[c]; compact rows from *n on return at once.  Null pointers =
+// no map (every row, c = row).  A caption's arithmetic does not depend on the row it sits in (batch invariance), so the
+// compacted loop produces the bits of the uncompacted one.
+struct RowMap {
+    const int* live = nullptr;     // int32 [R]: live[c] = row of the batch
+    const int* n = nullptr;        // int32: open rows
+};
+
 // ---- elementwise.hip -------------------------------------------------------------------------
 // fp32 -> T copy (weight upload / activation cast); dst rows may be padded: dst[r*dst_ld + c] = src[r*cols + c]
 int launch_convert(int dtype, const float* src, void* dst, size_t n, hipStream_t s);
@@ -22,7 +33,8 @@ int launch_layernorm(int dtype, const float* in, int ld_in, const float* gamma, 
 // receives y, then LayerNorm(y) goes to out_t / out_f as above (out_f may alias resid when y_out is null)
 int launch_reduce_layernorm(int dtype, const void* part, int S, const float* bias, const float* resid,
                             const float* gamma, const float* beta, float eps, void* out_t, float* out_f, float* y_out,
-                            int M, int D, hipStream_t s, bool per_row_block = false, bool part_in_t = false);
+                            int M, int D, hipStream_t s, bool per_row_block = false, bool part_in_t = false,
+                            const int* n_rows = nullptr);   // device int32: rows from *n_rows on are left alone (RowMap::n)
 // decoder embeddings: x = LN(word[tok] + pos[t]); tok = seq[row*seq_ld + t]
 int launch_reduce_bias_act(int dtype, const float* part, int S, const float* bias, void* out, int M, int N, int act, hipStream_t s);
 int launch_embed_tokens(int dtype, const int* ids, int L, const float* word, const float* pos, const float* type0,
@@ -33,10 +45,14 @@ int launch_text_attention(int dtype, const void* qkv, const int* lens, void* ctx
                           hipStream_t s);
 int launch_embed(int dtype, const int* seq, int seq_ld, int t, const float* word, const float* pos,
                  const float* gamma, const float* beta, float eps, void* out_t, float* out_f, int R, int D,
-                 hipStream_t s, float* y_out = nullptr);   // y_out: the un-normalised sum (pre-LN residual stream)
+                 hipStream_t s, float* y_out = nullptr,    // y_out: the un-normalised sum (pre-LN residual stream)
+                 RowMap map = RowMap());                    // compact output row c reads the token of row map.live[c]
 // greedy selection: argmax (lowest index wins ties), pad after EOS, append at seq[row][t+1], track finished/len
 int launch_greedy_select(const float* logits, int ld, int V, int* seq, int seq_ld, int t, int max_len, int eos,
-                         int pad, int* finished, int* out_len, int R, hipStream_t s, int min_len = 0, int force_eos = 0);
+                         int pad, int* finished, int* out_len, int R, hipStream_t s, int min_len = 0, int force_eos = 0,
+                         RowMap map = RowMap());            // logits row c belongs to row map.live[c] (seq / finished / out_len)
+// live[] = the rows with finished[r] == 0 in ascending order, *n_live = their count (one workgroup; stable)
+int launch_compact_rows(const int* finished, int R, int* live, int* n_live, hipStream_t s);
 int launch_fill_i32(int* p, int v, size_t n, hipStream_t s);
 int launch_fill_f32(float* p, float v, size_t n, hipStream_t s);
 int launch_copy_f32(const float* src, float* dst, size_t n, hipStream_t s);
@@ -83,7 +99,9 @@ int launch_decode_attention(int dtype, const void* q, const void* kbase, const v
                             int q_ld = 0, int q_col0 = 0, int append_kv = 0, int out_dtype = -1,   // out_dtype: see launch_vit_attention
                             const int* skip_rows = nullptr,    // int32 [R] or null: rows with a non-zero flag are left untouched
                             int kv16 = 0,                      // 1: kbase / vbase are the bases of KV16 blocks (common.h; fp32 q, no
-                            size_t kv_row0 = 0);               // ancestry, > 32 keys); kv_row0 = index of the launch's first row in them
+                            size_t kv_row0 = 0,                // ancestry, > 32 keys); kv_row0 = index of the launch's first row in them
+                            RowMap map = RowMap());            // q_part / out rows are compact, caches and ancestry belong to map.live[c]
+                                                               // (wave / online kernels, impl 0)
 // fp32 rows [n_rows, 64] -> one KV16 block of kv16_block_bytes(n_rows) bytes: what the cross-K/V GEMM's epilogue writes, as a
 // kernel of its own (tests)
 int launch_pack_kv16(const float* src, void* dst, size_t n_rows, hipStream_t s);

@@ -145,6 +145,15 @@ class CaptionerEngine:
         (forcing "small" makes generate fail for calls those kernels do not take)."""
         N.check(self.lib.cap_set_decode_path(self._h, self.DECODE_PATHS[path]), "cap_set_decode_path")
 
+    def set_row_compaction(self, on: bool) -> None:
+        """Greedy BLIP decode on the batch kernels: work on the rows of the captions still open only (default on; same tokens
+        and lengths either way - off is for A/B runs and the equality tests)."""
+        N.check(self.lib.cap_set_row_compaction(self._h, int(bool(on))), "cap_set_row_compaction")
+
+    @property
+    def last_row_compaction(self) -> bool:
+        return int(self.lib.cap_last_row_compaction(self._h)) == 1
+
     @property
     def last_decode_path(self) -> str:
         return {0: "none", 1: "batch", 2: "small"}[int(self.lib.cap_last_decode_path(self._h))]
@@ -335,6 +344,10 @@ class EnginePool:
     def set_decode_path(self, path: str) -> None:
         for e in self.engines:
             e.set_decode_path(path)
+
+    def set_row_compaction(self, on: bool) -> None:
+        for e in self.engines:
+            e.set_row_compaction(on)
 
     def close(self) -> None:
         for e in self.engines:

@@ -136,6 +136,14 @@ int cap_last_decode_steps(CapHandle h);
 int cap_set_decode_path(CapHandle h, int path);
 /* 1 = batch kernels, 2 = small-batch kernels: what the last decode step of the last cap_generate ran on (0 before any). */
 int cap_last_decode_path(CapHandle h);
+/* Row compaction of the greedy decode loop (CAP_ARCH_BLIP, batch kernels, more than 16 rows, max_len <= 33, no per-step logits):
+ * after every token selection the rows of the captions still open are packed to the front and every kernel of the next step
+ * works on those rows only (HF's greedy loop, generation/utils.py:2894-2937, keeps feeding pad tokens to a finished row; its
+ * outputs are never read).  A caption's arithmetic does not depend on the row it sits in, so tokens and lengths are the bits of the
+ * uncompacted loop (tests/test_merged_passes_gpu.py).  on = 1 (default) / 0. */
+int cap_set_row_compaction(CapHandle h, int on);
+/* 1 if the decode loop of the last cap_generate ran compacted, 0 if not (-1: null handle). */
+int cap_last_row_compaction(CapHandle h);
 /* Layout of the handle's cross-attention K/V cache: 0 = fp32 rows, 1 = bf16 rows, 2 = KV16 (int16 + one fp32 scale per 64-wide
  * head row; CAP_F32_SPLIT unless CapConfig.cross_kv_fp32).  -1 for a null handle. */
 int cap_cross_cache_kind(CapHandle h);
