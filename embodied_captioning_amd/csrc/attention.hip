@@ -871,6 +871,180 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split(const g8_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// The single-pass case of vit_attention_split (ONE && EXACT: 193..224 tokens = KC full key blocks, ViT-B/16 at 224: 197) as a
+// PERSISTENT kernel: one workgroup per CU walks the (image, head) units u = blockIdx.x, + gridDim.x, ... and the loads of the next
+// unit run under the arithmetic of the current one.  K is needed by the score products only and V by the context products only,
+// so the two 56 KiB buffers are refilled at different times:
+//   barrier A (K_u, q_u have landed; every wave is done with V_{u-1}):  issue the DMA of V_u          -> S^T = K.Q^T
+//   barrier B (V_u has landed; every wave is done with K_u):            issue the DMA of K_{u+1}, load q_{u+1} -> softmax, O^T = V^T.P^T, store
+// In vit_attention_split every workgroup starts with its 112 KiB of DMA and a barrier in front of the first MFMA (~3 us of an
+// ~18 us unit at one workgroup per CU).  The per-unit arithmetic is that kernel's, statement for statement: the context has the
+// same bits (tests/test_split_gpu.py::test_vit_attention_persistent_matches_per_unit_kernel).  Measured, interleaved in one process
+// (tools/bench_vit_attention.py, 256 x 12 units): 182 us per launch against 215 for the per-unit kernel; 1024 x 12: 702 / 797.
+// Tried on this structure and not kept: the probabilities of key half-block t + 1 (exp, denominator, hi / lo split) formed in the
+// scheduling region of half-block t's context products, the running maximum inside the score chains - the same bits, but the
+// lane's ~170 fragment addresses are loop invariant here and get hoisted out of the unit loop; with the pipeline's second
+// probability buffer the kernel spills 30-110 registers per unit (laundering the lane coordinates per unit: 128 bytes of
+// scratch left): 260 us per launch.
+template <int KC>
+__global__ __launch_bounds__(512, 1) void vit_attention_split_pw(const g8_t* __restrict__ qkv, g8_t* __restrict__ ctx, int N, int H, int n_units) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NP = KC * 32;
+    char* Ks = smem;                                   // [NP] rows of 256 B
+    char* Vs = smem + NP * 256;
+    const int D = H * 64, ld = 3 * D;
+    const int tid = threadIdx.x, lane = tid & 63, r32 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t rowb = (size_t)ld * 4;
+    auto koff = [](int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); };
+    auto voff = [](int row, int chunk) { return row * 256 + ((chunk ^ ((row & 1) | ((row & 2) << 2))) << 4); };
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
+    const float c1 = 0.125f * LOG2E;
+    const bool live = wave < KC;                       // query tile `wave` of the unit (nqt == KC); the eighth wave only moves data
+    const int q = wave * 32 + r32, qc = min(q, N - 1);
+
+    auto unit_base = [&](int u) { return (const char*)(qkv + (size_t)(u / H) * N * ld + (u % H) * 64); };
+    auto issue_k = [&](const char* base) {
+        for (int p = wave; p < NP / 4; p += 8) {
+            const int row = p * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (row & 15);
+            const char* src = base + (size_t)min(row, N - 1) * rowb;
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(src + (size_t)D * 4 + c * 16), CAP_LPTR(Ks + p * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_v = [&](const char* base) {
+        for (int p = wave; p < NP / 4; p += 8) {
+            const int row = p * 4 + (lane >> 4);
+            const int cv = (lane & 15) ^ ((row & 1) | ((row & 2) << 2));
+            const char* src = base + (size_t)min(row, N - 1) * rowb;
+            __builtin_amdgcn_global_load_lds(CAP_GPTR(src + (size_t)2 * D * 4 + cv * 16), CAP_LPTR(Vs + p * 1024), 16, 0, 0);
+        }
+    };
+    f16x8 qh[4], ql[4];
+    auto load_q = [&](const char* base) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const char* qp = base + (size_t)qc * rowb + (2 * ks + hh) * 32;
+            qh[ks] = *(const f16x8*)qp;
+            ql[ks] = *(const f16x8*)(qp + 16);
+        }
+    };
+
+    int u = blockIdx.x;
+    if (u >= n_units) return;
+    const char* base = unit_base(u);
+    issue_k(base);
+    load_q(base);
+    for (;;) {
+        __syncthreads();                               // A
+        issue_v(base);
+        f32x16 s[KC];
+        float cm = -INFINITY;
+        if (live) {
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[kc][e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const f16x8 kh = *(const f16x8*)(Ks + koff(kc * 32 + r32, 2 * (2 * ks + hh)));
+                    const f16x8 kl = *(const f16x8*)(Ks + koff(kc * 32 + r32, 2 * (2 * ks + hh) + 1));
+                    s[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s[kc], 0, 0, 0);
+                    s[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s[kc], 0, 0, 0);
+                    s[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s[kc], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                               // B
+        const int un = u + (int)gridDim.x;
+        const char* nbase = base;
+        if (un < n_units) {
+            nbase = unit_base(un);
+            issue_k(nbase);
+            load_q(nbase);
+        }
+        if (live) {
+            // scores for query column r32: key(kc, e) = kc*32 + (e&3) + 8*(e>>2) + 4*hh
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (kc == KC - 1) {
+                        const int key = kc * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        if (key >= N) s[kc][e] = -INFINITY;     // padding keys of the last block
+                    }
+                    cm = fmaxf(cm, s[kc][e]);
+                }
+            cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+            const float mn = cm;
+            float l = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float pe = __builtin_amdgcn_exp2f((s[kc][e] - mn) * c1);
+                    s[kc][e] = pe;
+                    l += pe;
+                }
+            f32x16 o[2];
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    // B operand: element j of lane half hh is P^T[key = kc*32 + 16*s2 + 8*(j>>2) + 4*hh + (j&3)][q]
+                    f16x8 ph, pl;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float pv = s[kc][8 * s2 + j];
+                        const f16_t hv = (f16_t)pv;
+                        ph[j] = hv;
+                        pl[j] = (f16_t)(pv - (float)hv);
+                    }
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        // A operand (see vit_attention_mfma): this lane ADDRESSES row key0 (+8), dims dcol..dcol+3 and RECEIVES
+                        // column (lane & 15) of the 4 rows of its 16-lane group; once from the hi chunk, once from the lo chunk
+                        const int dcol = db * 32 + (tg & 1) * 16 + tp * 4;
+                        const int key0 = kc * 32 + 16 * s2 + 4 * (tg >> 1) + tq;
+                        const int ch = 2 * (dcol >> 3), sub = (dcol & 7) * 2;
+                        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + voff(key0, ch) + sub));
+                        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + voff(key0 + 8, ch) + sub));
+                        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + voff(key0, ch + 1) + sub));
+                        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + voff(key0 + 8, ch + 1) + sub));
+                        const f16x8 vh = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                        const f16x8 vl = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[db], 0, 0, 0);
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[db], 0, 0, 0);
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[db], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            l += __shfl_xor(l, 32, 64);
+            if (q < N) {
+                const float inv = 1.0f / l;
+                g8_t* op = ctx + ((size_t)(u / H) * N + q) * D;
+                const int h = u % H;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        store4(op, h * 64 + db * 32 + 8 * g + 4 * hh,
+                               make_float4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
+            }
+        }
+        if (un >= n_units) break;
+        u = un;
+        base = nbase;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 
 template <typename T>
 __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restrict__ q, const T* __restrict__ kbase,
@@ -1454,6 +1628,18 @@ int launch_split_kc(const void* qkv, void* ctx, int B, int N, int H, hipStream_t
     return 0;
 }
 
+template <int KC>
+int launch_split_pw(const void* qkv, void* ctx, int B, int N, int H, hipStream_t s) {
+    const int lds = 2 * KC * 32 * 256;
+    auto kern = vit_attention_split_pw<KC>;
+    int n_cu = 0;
+    if (cap_kernel_setup((const void*)kern, lds, &n_cu) != 0) return -1;
+    const int units = B * H;
+    hipLaunchKernelGGL(kern, dim3(units < n_cu ? units : n_cu), dim3(512), lds, s, (const g8_t*)qkv, (g8_t*)ctx, N, H, units);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 template <int KB, typename TO>
 int launch_f32_mfma_kb(const void* qkv, void* ctx, int B, int N, int H, hipStream_t s) {
     const int lds = 2 * KB * 32 * 68 * 4;
@@ -1494,7 +1680,10 @@ int launch_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, in
             return -1;
         }
         if (N <= 64) return launch_split_kc<2, true>(qkv, ctx, B, N, H, s);       // fixture-sized inputs
-        if (N > 192 && N <= 224) return launch_split_kc<7, true, true>(qkv, ctx, B, N, H, s);     // 197 tokens: one pass, 7 key blocks
+        // 197 tokens: one pass, 7 key blocks.  More units than CUs: the persistent form (loads of the next unit under the current
+        // one's arithmetic); impl 5 = the per-unit kernel (tests, A/B)
+        if (N > 192 && N <= 224 && impl != 5 && B * H > 256) return launch_split_pw<7>(qkv, ctx, B, N, H, s);
+        if (N > 192 && N <= 224) return launch_split_kc<7, true, true>(qkv, ctx, B, N, H, s);
         if (N <= 224) return launch_split_kc<7, true>(qkv, ctx, B, N, H, s);
         return launch_split_kc<4, false>(qkv, ctx, B, N, H, s);                  // chunks of 128 keys, online softmax
     }

@@ -1965,8 +1965,8 @@ int cap_op_layernorm(int dtype, const float* in, const float* gamma, const float
 int cap_op_vit_attention(int dtype, const void* qkv, void* ctx, int B, int N, int H, int impl, void* stream) {
     // dtype CAP_F32_SPLIT: impl 3 = G8 q|k|v in (what the split mode's qkv GEMM writes; the split-fp16 MFMA kernel), any other
     // impl = fp32 q|k|v in; the context is G8 either way
-    if (dtype == CAP_F32_SPLIT && impl == 3)
-        return launch_vit_attention(CAP_DT_G8, qkv, ctx, B, N, H, 0, (hipStream_t)stream, 64, 0, CAP_DT_G8);
+    if (dtype == CAP_F32_SPLIT && (impl == 3 || impl == 5))      // 5: the one-workgroup-per-unit kernel where 3 would pick the persistent one
+        return launch_vit_attention(CAP_DT_G8, qkv, ctx, B, N, H, impl == 5 ? 5 : 0, (hipStream_t)stream, 64, 0, CAP_DT_G8);
     return launch_vit_attention(in_dt_of(dtype), qkv, ctx, B, N, H, impl, (hipStream_t)stream, 64, 0, dt_of(dtype));
 }
 int cap_op_vit_attention_hd(int dtype, const void* qkv, void* ctx, int B, int N, int H, int head_dim, int impl, void* stream) {

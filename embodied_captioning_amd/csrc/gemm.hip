@@ -826,8 +826,15 @@ __global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int S = EPI == EPI_PARTIAL ? p.splitk : 1;
-    const int ntm = (p.M + 63) / 64, ntn = (p.N + 63) / 64, nwg = ntm * ntn * S;
+    // compacted decode loop (GemmParams::m_live): the open captions are the first *m_live rows.  The grid is the host's (every
+    // row tile of M); the workgroups are numbered over the LIVE row tiles only, so the ones without work are the highest block
+    // ids - dispatched last, behind every workgroup that has a tile - and return at once.  (Numbered over all row tiles with
+    // the dead ones returning in place, row tile fastest, a dead workgroup sat between every few live ones in the dispatch
+    // order and held a CU - 128 KiB of LDS - for its launch and one scalar load each.)
+    const int m_rows = p.m_live ? min(p.M, *p.m_live) : p.M;
+    const int ntm = (m_rows + 63) / 64, ntn = (p.N + 63) / 64, nwg = ntm * ntn * S;
     int bid = blockIdx.x;
+    if (bid >= nwg) return;
     {
         int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -837,7 +844,6 @@ __global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmParams p) {
     const int tn = bid % ntn, kz = bid / ntn;
     if constexpr (EPI == EPI_PARTIAL) p.p3 = kz;
     const int m0 = tm * 64, n0 = tn * 64;
-    if (p.m_live && m0 >= *p.m_live) return;               // compacted decode loop: no open caption in this row tile
     const int nkb = p.K / S / SLAB;                        // slabs of this block
 
     const int tid = threadIdx.x, lane = tid & 63;

@@ -40,6 +40,10 @@
 // instead of two interleaved (level); the W rows of a column group staged half by each of the two waves that read them (9 + 8 DMA
 // instructions per wave and stage instead of 13 + 4, group 1's half two stages ahead, right after its own W fragments landed):
 // correct, 3 940-3 980 cycles per stage against 3 710-3 750 - the second issue burst sits in front of MFMAs that were ready.
+// Round 6: group 0's epilogue deferred past the next barrier (its strips in the W rows of the stage buffer it had just finished), so
+// that the two groups' epilogues run side by side instead of one after the other: bit-identical, and LEVEL (tools/ab_gemm_libs.py,
+// same process: qkv 420.3 / 419.5, fc1 620-634 / 616-626, proj 152-156 / 152-161 us) - the epilogue is bound by what the two waves
+// of a SIMD share (VALU issue, the CU's store path), so two at once take twice as long each.  Not kept.
 #include <stdlib.h>
 
 #include <algorithm>
@@ -513,33 +517,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
             mma_block(i);
         });
     };
-    // Tile boundary.  Until round 5 each group ran its epilogue right after its last half-stage: group 0 at the end of step 2L+1 (group 1,
-    // done with half0(L), waiting at the barrier), group 1 at the end of step 2L+2 (group 0, done with the next tile's first
-    // half-stage, waiting) - the two epilogues one after the other, 2 E cycles per tile in which one wave of every SIMD sits at a
-    // barrier (E = 4 600 fp32 out / 7 200 G8 out / ~13 000 G8 + GELU cycles against 24 x ~4 000 per K = 768 tile).  Now group 0 DEFERS its
-    // epilogue past the next barrier: in step 2L+2 group 0 runs E0 and then half0 of the next tile while group 1 runs half1(L) and
-    // then E1 - the epilogues side by side, each group's MFMAs issued while the other is in its epilogue.  Group 0's strips for that
-    // are the W rows of the stage buffer it has just finished (8 KiB per wave: its own DMA target, next written by its own
-    // issue() after the epilogue; group 1 took its W fragments of that stage before the barrier), group 1 keeps the dedicated strips.
-    auto tile_epilogue = [&](char* strip2) __attribute__((always_inline)) {
-        const int item = first + c_x * nl;
-        const int t = tile0 + item / SUB, sub = item % SUB;
-        int tm, tn;
-        tile_coords(t, tm, tn);
-        pp_epilogue<T, OUT_F32, EPI, MI, NI, RESID>(p, acc, has_bias ? bias_rows + (c_x & 1) * 1024 + wq * 256 : nullptr, strip2,
-                                                    tm * 256 + sub * BM + wm0, tn * BN + wn0, lane);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = 0.f;
-        ++c_x;
-    };
-    // (the bf16 kernel with the residual operand sits at 256 registers and went 20 bytes per lane into scratch with the deferred
-    // form: it keeps the old order)
-    constexpr bool DEFER_G0 = G8 || !RESID;
-    bool pend = false;                                   // group 0: a finished tile whose epilogue is still to run
-    auto half1 = [&](int S, auto defer_tag) __attribute__((always_inline)) {
-        constexpr bool DEFER = decltype(defer_tag)::value;
+    auto half1 = [&](int S) __attribute__((always_inline)) {
         const unsigned sa = lds0 + (S & 1) * STAGE;
         const unsigned aH = sa + wm0 * 128 + f_hi, aL = sa + wm0 * 128 + f_lo;
         static_for<MH, MI>([&](auto ic) {
@@ -553,19 +531,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
             mma_block(i);
         });
         if (++c_kt == nk) {
+            // tile finished (for this group): bias / activation / convert / whole-line stores through this wave's strip; no
+            // barrier inside.  The other group is one half-stage away from the same point.
+            const long long e0 = PROF ? clock64() : 0;
+            wait_vm<0>();                                // this wave's pieces of the next stage: before the stores enter the counter
+            confirmed = true;
+            if constexpr (PROF) prof_ew += clock64() - e0;
+            const int item = first + c_x * nl;
+            const int t = tile0 + item / SUB, sub = item % SUB;
+            int tm, tn;
+        tile_coords(t, tm, tn);
+            pp_epilogue<T, OUT_F32, EPI, MI, NI, RESID>(p, acc, has_bias ? bias_rows + (c_x & 1) * 1024 + wq * 256 : nullptr, strips + wq * (2 * 16 * 144),
+                                              tm * 256 + sub * BM + wm0, tn * BN + wn0, lane);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = 0.f;
             c_kt = 0;
-            if constexpr (DEFER) {
-                pend = true;
-            } else {
-                // tile finished (for this group): bias / activation / convert / whole-line stores through this wave's strips; no
-                // barrier inside
-                const long long e0 = PROF ? clock64() : 0;
-                wait_vm<0>();                            // this wave's pieces of the next stage: before the stores enter the counter
-                confirmed = true;
-                if constexpr (PROF) prof_ew += clock64() - e0;
-                tile_epilogue(strips + wq * (2 * 16 * 144));
-                if constexpr (PROF) prof_epi += clock64() - e0;
-            }
+            ++c_x;
+            if constexpr (PROF) prof_epi += clock64() - e0;
         }
     };
 
@@ -574,26 +558,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     // Both groups pass the same 2 NS + 1 barriers; each group's loop holds one whole stage of ITS work, so the fragment
     // registers are not live around the back edge (one loop over half-steps for both groups spilled them).
     if (g == 0) {
-        for (int S = 0; S <= NS; ++S) {
-            sync(S < NS);
-            if (pend) {                                  // the tile that ended with stage S - 1, beside group 1's half1(S - 1) + epilogue
-                const long long e0 = PROF ? clock64() : 0;
-                tile_epilogue(smem + ((S - 1) & 1) * STAGE + BM * 128 + wq * 8192);
-                pend = false;
-                if constexpr (PROF) prof_epi += clock64() - e0;
-            }
-            if (S == NS) break;
+        for (int S = 0; S < NS; ++S) {
+            sync(true);
             half0(S);
             sync(false);
-            half1(S, std::integral_constant<bool, DEFER_G0>{});
+            half1(S);
         }
+        sync(false);
     } else {
         sync(false);
         for (int S = 0; S < NS; ++S) {
             sync(true);
             half0(S);
             sync(false);
-            half1(S, std::false_type{});
+            half1(S);
         }
     }
     if constexpr (PROF) {

@@ -375,7 +375,7 @@ def cross_kv_head_spread(sd: Dict[str, torch.Tensor]) -> float:
             if k.endswith(".weight") and (".crossattention.self.key." in k or ".crossattention.self.value." in k):
                 b = sd.get(k[:-6] + "bias")
                 w = w.float()
-                b = b.float() if b is not None else torch.zeros(w.shape[0])
+                b = b.float() if b is not None else w.new_zeros(w.shape[0])
                 if pg is not None and pg.numel() == w.shape[1]:
                     if pb is not None:
                         b = b + w @ pb.float()

@@ -318,6 +318,28 @@ def test_vit_attention_split_mfma_on_g8_qkv(lib, N):
 
 
 @gpu
+@pytest.mark.parametrize("N,B,H", [(197, 30, 12), (197, 23, 12), (224, 25, 12), (193, 300, 1)])
+def test_vit_attention_persistent_matches_per_unit_kernel(lib, N, B, H):
+    """193..224 tokens with more (image, head) units than CUs: the persistent kernel (one workgroup per CU walks the units, the
+    next unit's K / V / q loads under the current unit's arithmetic) against the one-workgroup-per-unit kernel (impl 5): the same
+    bits - unit counts that are and are not multiples of the CU count."""
+    g = torch.Generator().manual_seed(N + B)
+    qkv = torch.randn(B * N, 3 * H * 64, generator=g) * 1.5
+    qd = _g8(qkv)
+    outs = []
+    for impl in (5, 3):
+        ctx = torch.full((B * N, H * 64), float("nan"), dtype=torch.float32, device="cuda")
+        _check(lib, lib.cap_op_vit_attention(SPLIT, _p(qd), _p(ctx), B, N, H, impl, _stream()))
+        torch.cuda.synchronize()
+        outs.append(ctx)
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    got = g8_decode(outs[1].cpu().numpy())
+    assert np.isfinite(got).all()
+    err = np.abs(got.astype(np.float64) - _attn_ref(qkv, B, N, H).numpy()).max()
+    assert err < 1e-5, err
+
+
+@gpu
 def test_split_mode_refuses_out_of_range_weights_instead_of_clipping_them():
     """Weights travel as fp16 halves of 4096 w: |w| > 15.87 does not fit.  cap_load_weight names the tensor and fails; nothing
     is clipped silently (the mode was the plugin default before it could say so)."""
