@@ -337,7 +337,7 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-PMC_FILES = {"f32s": "r05_bench_pmc.json", "bf16": "r05_bench_bf16_pmc.json"}
+PMC_FILES = {"f32s": "r06_bench_pmc.json", "bf16": "r06_bench_bf16_pmc.json"}
 
 
 def _kernel_in_build(name: str, lib_bytes: bytes) -> bool:

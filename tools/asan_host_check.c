@@ -85,6 +85,10 @@ int main(void) {
     EXPECT(cap_set_decode_path(NULL, 0) != 0);
     EXPECT(cap_last_decode_path(NULL) == -1);
     EXPECT(cap_cross_cache_kind(NULL) == -1);
+    /* round 6: row compaction switch (the decode path numbers stop at 2 since the fused-tile path left the tree) */
+    EXPECT(cap_set_row_compaction(NULL, 1) != 0 && strlen(cap_last_error()) > 0);
+    EXPECT(cap_last_row_compaction(NULL) == -1);
+    EXPECT(cap_op_vit_attention(CAP_F32_SPLIT, w, w, 1, 197, 12, 5, NULL) != 0 || 1);       /* no GPU: a clean error from the launch */
     {
         long long sat = cap_g8_saturations(0);                                                /* no GPU: a clean error, or a count */
         EXPECT(sat >= -1);

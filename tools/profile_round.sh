@@ -2,12 +2,13 @@
 # rocprofv3 passes of a bench command for profiles/: kernel-trace stats, then (PMC=1) hardware counters in SEPARATE passes
 # (never combined with other trace domains) of the same workload's timed steps only.  The program comes directly after `--`.
 # Run on the GPU box from the repo root:
-#   bash tools/profile_round.sh r05_bench                          # default bench command (f32s headline), stats + PMC
-#   PMC=0 bash tools/profile_round.sh r05_bench_beam3 --beams 3 --batch 64
-#   bash tools/profile_round.sh r05_bench_bf16 --dtype bf16
+#   bash tools/profile_round.sh r06_bench                          # default bench command (f32s headline), stats + PMC
+#   PMC=0 bash tools/profile_round.sh r06_bench_beam3 --beams 3 --batch 64
+#   bash tools/profile_round.sh r06_bench_bf16 --dtype bf16
+#   POOLED=1 PMC=0 bash tools/profile_round.sh r06_bench               # + the pooled trace (3 streams, merged passes): stats and timeline
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r05_bench}; shift || true
+TAG=${1:-r06_bench}; shift || true
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
@@ -29,4 +30,15 @@ if [ "${PMC:-1}" = "1" ]; then
   cd "$ROOT"
   python3 tools/summarize_prof.py pmc "$OUT/pmc" "$OUT/pmc.json"
 fi
-rm -rf "$OUT/stats" "$OUT/pmc"      # keep only the summaries (the raw csv files are large)
+if [ "${POOLED:-0}" = "1" ]; then
+  # the headline's own execution shape: 3 engines / streams, the pool merging steps into 768-1024-row passes.  Durations in this
+  # trace include the wait for CUs held by kernels of the other streams (a kernel's start stamp is its dispatch)
+  cd /tmp
+  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pooled" -- python3 $ROOT/bench.py --steps 12 --warmup 3 --lite "$@" > "$OUT/pooled_bench.json" 2> "$OUT/pooled.err"
+  echo "pooled pass done"
+  cd "$ROOT"
+  python3 tools/summarize_prof.py stats "$OUT/pooled" "$OUT/pooled_kernel_stats.md"
+  python3 tools/pool_timeline.py pack "$OUT/pooled" "$OUT/pooled_trace.pkl.gz"
+  python3 tools/pool_timeline.py report "$OUT/pooled_trace.pkl.gz" > "$OUT/pool_timeline.txt"
+fi
+rm -rf "$OUT/stats" "$OUT/pmc" "$OUT/pooled"      # keep only the summaries (the raw csv files are large)
