@@ -880,12 +880,15 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split(const g8_t* __rest
 // In vit_attention_split every workgroup starts with its 112 KiB of DMA and a barrier in front of the first MFMA (~3 us of an
 // ~18 us unit at one workgroup per CU).  The per-unit arithmetic is that kernel's, statement for statement: the context has the
 // same bits (tests/test_split_gpu.py::test_vit_attention_persistent_matches_per_unit_kernel).  Measured, interleaved in one process
-// (tools/bench_vit_attention.py, 256 x 12 units): 182 us per launch against 215 for the per-unit kernel; 1024 x 12: 702 / 797.
+// (tools/bench_vit_attention.py, 256 x 12 units): 180 us per launch against 214 for the per-unit kernel; 1024 x 12: 711 / 799.
 // Tried on this structure and not kept: the probabilities of key half-block t + 1 (exp, denominator, hi / lo split) formed in the
-// scheduling region of half-block t's context products, the running maximum inside the score chains - the same bits, but the
-// lane's ~170 fragment addresses are loop invariant here and get hoisted out of the unit loop; with the pipeline's second
-// probability buffer the kernel spills 30-110 registers per unit (laundering the lane coordinates per unit: 128 bytes of
-// scratch left): 260 us per launch.
+// scheduling region of half-block t's context products, i.e. one wave's softmax VALU work under its own MFMAs - the same bits; first
+// with the compiler's addresses (every one of the lane's ~170 LDS fragment addresses its own register, hoisted out of the unit loop:
+// 276-444 bytes of scratch per lane, 260 us per launch), then with the explicit lane bases below (239 registers, no scratch): 184 us
+// against 180 for this form - level.  And, to run the two waves of a SIMD out of phase: a workgroup per (image, head, HALF of the query
+// tiles) - four waves, one 56 KiB buffer that holds K and then V (the V DMA under the softmax), two workgroups per CU (162
+// registers) - same bits, 190 us.  The three forms land within 15 % of each other because the launch moves 620 MB (q | k | v in,
+// context out) - 3.4 TB/s at 180 us: it is more than half way to the HBM rate, not an MFMA- or VALU-bound kernel any more.
 template <int KC>
 __global__ __launch_bounds__(512, 1) void vit_attention_split_pw(const g8_t* __restrict__ qkv, g8_t* __restrict__ ctx, int N, int H, int n_units) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -896,8 +899,6 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split_pw(const g8_t* __r
     const int tid = threadIdx.x, lane = tid & 63, r32 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t rowb = (size_t)ld * 4;
-    auto koff = [](int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); };
-    auto voff = [](int row, int chunk) { return row * 256 + ((chunk ^ ((row & 1) | ((row & 2) << 2))) << 4); };
     const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
     const float c1 = 0.125f * LOG2E;
     const bool live = wave < KC;                       // query tile `wave` of the unit (nqt == KC); the eighth wave only moves data
@@ -930,6 +931,27 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split_pw(const g8_t* __r
         }
     };
 
+    // LDS fragment addresses as a lane base + a compile-time offset.  K: block kc, k-step ks, half hl is row kc * 32 + r32, chunk
+    // 2 (2 ks + hh) + hl, swizzled by the row's low four bits = r32's: 8 bases, + kc * 8192.  V (ds_read_b64_tr_b16): row key0 = kc * 32 +
+    // 16 s2 + 4 (tg >> 1) + tq (+ 8), chunk ch = 2 (dcol >> 3) + hl swizzled by the row's low two bits = tq's: 4 bases, + (kc * 32 + 16 s2
+    // [+ 8]) * 256.  Written out because the compiler does not see through the XOR: left to it, every one of the ~170 addresses is its
+    // own register, hoisted out of the unit loop.
+    unsigned kb[4][2], vb[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) kb[ks][hl] = (unsigned)(r32 * 256 + (((2 * (2 * ks + hh) + hl) ^ (r32 & 15)) << 4));
+    {
+        const int keyv = (tq & 1) | ((tq & 2) << 2);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) {
+                const int dcol = db * 32 + (tg & 1) * 16 + tp * 4;
+                vb[db][hl] = (unsigned)((4 * (tg >> 1) + tq) * 256 + (((2 * (dcol >> 3) + hl) ^ keyv) << 4) + (dcol & 7) * 2);
+            }
+    }
+
     int u = blockIdx.x;
     if (u >= n_units) return;
     const char* base = unit_base(u);
@@ -947,8 +969,8 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split_pw(const g8_t* __r
                 for (int e = 0; e < 16; ++e) s[kc][e] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const f16x8 kh = *(const f16x8*)(Ks + koff(kc * 32 + r32, 2 * (2 * ks + hh)));
-                    const f16x8 kl = *(const f16x8*)(Ks + koff(kc * 32 + r32, 2 * (2 * ks + hh) + 1));
+                    const f16x8 kh = *(const f16x8*)(Ks + kb[ks][0] + kc * 8192);
+                    const f16x8 kl = *(const f16x8*)(Ks + kb[ks][1] + kc * 8192);
                     s[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s[kc], 0, 0, 0);
                     s[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s[kc], 0, 0, 0);
                     s[kc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s[kc], 0, 0, 0);
@@ -979,6 +1001,11 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split_pw(const g8_t* __r
             cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
             const float mn = cm;
             float l = 0.f;
+            f32x16 o[2];
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
@@ -987,11 +1014,6 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split_pw(const g8_t* __r
                     s[kc][e] = pe;
                     l += pe;
                 }
-            f32x16 o[2];
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[db][e] = 0.f;
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
@@ -1009,13 +1031,11 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split_pw(const g8_t* __r
                     for (int db = 0; db < 2; ++db) {
                         // A operand (see vit_attention_mfma): this lane ADDRESSES row key0 (+8), dims dcol..dcol+3 and RECEIVES
                         // column (lane & 15) of the 4 rows of its 16-lane group; once from the hi chunk, once from the lo chunk
-                        const int dcol = db * 32 + (tg & 1) * 16 + tp * 4;
-                        const int key0 = kc * 32 + 16 * s2 + 4 * (tg >> 1) + tq;
-                        const int ch = 2 * (dcol >> 3), sub = (dcol & 7) * 2;
-                        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + voff(key0, ch) + sub));
-                        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + voff(key0 + 8, ch) + sub));
-                        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + voff(key0, ch + 1) + sub));
-                        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + voff(key0 + 8, ch + 1) + sub));
+                        const int ro = (kc * 32 + 16 * s2) * 256;                    // compile-time after unrolling
+                        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + vb[db][0] + ro));
+                        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + vb[db][0] + ro + 2048));
+                        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + vb[db][1] + ro));
+                        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + vb[db][1] + ro + 2048));
                         const f16x8 vh = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
                         const f16x8 vl = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
                         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[db], 0, 0, 0);
@@ -1025,6 +1045,7 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split_pw(const g8_t* __r
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+        
             l += __shfl_xor(l, 32, 64);
             if (q < N) {
                 const float inv = 1.0f / l;

@@ -327,7 +327,7 @@ def test_vit_attention_persistent_matches_per_unit_kernel(lib, N, B, H):
     qkv = torch.randn(B * N, 3 * H * 64, generator=g) * 1.5
     qd = _g8(qkv)
     outs = []
-    for impl in (5, 3):
+    for impl in (5, 3):                          # per unit; persistent
         ctx = torch.full((B * N, H * 64), float("nan"), dtype=torch.float32, device="cuda")
         _check(lib, lib.cap_op_vit_attention(SPLIT, _p(qd), _p(ctx), B, N, H, impl, _stream()))
         torch.cuda.synchronize()
