@@ -43,7 +43,9 @@
 // Round 6: group 0's epilogue deferred past the next barrier (its strips in the W rows of the stage buffer it had just finished), so
 // that the two groups' epilogues run side by side instead of one after the other: bit-identical, and LEVEL (tools/ab_gemm_libs.py,
 // same process: qkv 420.3 / 419.5, fc1 620-634 / 616-626, proj 152-156 / 152-161 us) - the epilogue is bound by what the two waves
-// of a SIMD share (VALU issue, the CU's store path), so two at once take twice as long each.  Not kept.
+// of a SIMD share (VALU issue, the CU's store path), so two at once take twice as long each.  Not kept.  `s_setprio 1` around every
+// 12-MFMA block (0 after it), same-process A/B on six shapes: qkv 423.1 / 423.6, fc1 623.5 / 626.4, proj 151.9 / 152.9, fc2 532.9 /
+// 534.8, qkv and fc1 at 1 024 frames 1 688 / 1 687 and 2 442 / 2 448 us: level.  Not kept.
 #include <stdlib.h>
 
 #include <algorithm>

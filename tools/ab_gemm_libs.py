@@ -30,7 +30,8 @@ def operand(x, w=False):
 for lib in (old, new):
     lib.cap_op_gemm.restype = C.c_int
     lib.cap_op_gemm.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p]
-for name, M, N, K, gelu, f32out in (("qkv", 50432, 2304, 768, 0, 0), ("fc1", 50432, 3072, 768, 1, 0), ("proj", 50432, 768, 768, 0, 1)):
+for name, M, N, K, gelu, f32out in (("qkv", 50432, 2304, 768, 0, 0), ("fc1", 50432, 3072, 768, 1, 0), ("proj", 50432, 768, 768, 0, 1), ("fc2", 50432, 768, 3072, 0, 1),
+                                   ("qkv1024", 201728, 2304, 768, 0, 0), ("fc1_1024", 201728, 3072, 768, 1, 0)):
     A = operand(torch.randn(M, K, device="cuda"))
     W = operand(torch.randn(N, K, device="cuda") / K ** 0.5, True)
     bias = torch.randn(N, device="cuda")
