@@ -842,6 +842,8 @@ def finish_line(line):
             "enc_gemm_frac": pick("roofline", "frac"), "enc_gemm_frac_executed": pick("roofline", "frac_executed"),
             "decode_gemm_hbm_frac": pick("decode", "gemm", "frac"), "cross_attention_hbm_frac": pick("decode", "cross_attention", "frac"),
             "decode_kernels_ms_per_pass": pick("decode", "ms_per_step_all_decode_kernels"),
+            "decode_ms_per_256_frames_at_pass_rows": pick("pass_rows_profile", "decode_ms_per_256_frames"),
+            "image_side_ms_per_256_frames_at_pass_rows": pick("pass_rows_profile", "image_side_ms_per_256_frames"),
             "encoder_only_images_per_s": pick("encoder_only", "images_per_s"),
             "f32s_fp32kv": pick("f32s_fp32kv", "value"), "f32_exact": pick("f32_exact", "value"), "bf16_not_parity": pick("bf16", "value"),
             "cpu_baseline": pick("cpu_baseline", "value")}
@@ -1012,6 +1014,26 @@ def main():
         line["kernels"] = {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                            for k, v in kernels.items()}
         line["kernel_ms_per_step"] = round(kernel_ms, 3)           # sum of ONE stream's kernel durations (see single_stream)
+        if coal > B and a.streams > 1:
+            # the same per-kernel pass at the size of the merged passes the timed steps ran (one engine, one stream): where a
+            # 1024-row pass goes.  The projections are no longer a weight stream at this size: their bytes per
+            # second are reported for continuity, the bound is the CUs' L2 -> LDS fill rate
+            k = coal // B
+            big = CaptionerEngine(arch, dtype=a.dtype, max_batch=k * B, max_beams=1, max_len=L, device=dev, share_weights_with=eng)
+            big.set_row_compaction(a.row_compaction == "on")
+            pxk = torch.cat([px] * k)
+            for _ in range(2):                       # a fresh 1024-row arena: its first passes touch new memory
+                big.generate(pxk, num_beams=1, max_length=L)
+            torch.cuda.synchronize()
+            _, kern_k, total_k, dec_k = roofline_pass(big, pxk, L, a.dtype, arch, k * B)
+            big.close()
+            enc_ms = sum(v["ms_per_step"] for t, v in kern_k.items() if not (t.startswith("dec_") or t in ("greedy_select", "beam_step")))
+            line["pass_rows_profile"] = {
+                "rows": k * B, "kernel_ms_per_pass": round(total_k, 3), "image_side_ms_per_256_frames": round(enc_ms / k, 3),
+                "decode_ms_per_256_frames": round(dec_k["ms_per_step_all_decode_kernels"] / k, 3),
+                "decode_gemm": {x: dec_k["gemm"][x] for x in ("achieved", "frac", "avg_launch_us", "ms_per_step")},
+                "cross_attention": {x: dec_k["cross_attention"][x] for x in ("achieved", "frac", "avg_launch_us", "ms_per_step")},
+                "top_kernels_ms": {t: round(v["ms_per_step"], 3) for t, v in sorted(kern_k.items(), key=lambda kv: -kv[1]["ms_per_step"])[:12]}}
         line["encoder_only"] = encoder_only(eng, px, arch)
         eng.close()
         if not a.no_latency:
