@@ -34,7 +34,7 @@ if [ "${POOLED:-0}" = "1" ]; then
   # the headline's own execution shape: 3 engines / streams, the pool merging steps into 768-1024-row passes.  Durations in this
   # trace include the wait for CUs held by kernels of the other streams (a kernel's start stamp is its dispatch)
   cd /tmp
-  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pooled" -- python3 $ROOT/bench.py --steps 12 --warmup 3 --lite "$@" > "$OUT/pooled_bench.json" 2> "$OUT/pooled.err"
+  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pooled" -- python3 $ROOT/bench.py --steps 20 --warmup 3 --lite "$@" > "$OUT/pooled_bench.json" 2> "$OUT/pooled.err"
   echo "pooled pass done"
   cd "$ROOT"
   python3 tools/summarize_prof.py stats "$OUT/pooled" "$OUT/pooled_kernel_stats.md"
