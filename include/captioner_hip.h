@@ -20,6 +20,10 @@
  *                       detector/pseudolabeler.py:568,677 `SentenceTransformer("all-MiniLM-L6-v2").encode(caption)`  (CAP_ARCH_MINILM handle)
  *   one crop per call   coca.py:27-33, blip2.py:24-29, goal_exploration.py:95-105,     cap_generate (rows <= 16: fused
  *                       pseudolabeler.py:673-676 (the callers hand over ONE image)      launches), cap_set_decode_path
+ *   greedy stopping     HF generation/utils.py:2894-2937 (a finished row keeps its slot and   cap_set_row_compaction (the open
+ *                       is fed pad tokens; `unfinished_sequences.max() == 0` ends the loop)  rows only), cap_set_early_exit
+ *   batches of crops    detector/pseudolabeler.py:664-711, scripts/run_pseudolabeler.py:77-107  cap_create_shared (n engines on one
+ *                       (one generate per crop; here: micro-batches merged into passes)          weight store: engine.EnginePool)
  *   load options        blip2.py:19-22 `load_in_8bit=True, torch_dtype=float16`;       CapConfig.compute_dtype,
  *                       evaluate_finetuned_model.py:147-148 `PeftModel.from_pretrained`  CapConfig.cross_kv_fp32 (host side:
  *                                                                                      weights.merge_peft_lora)
