@@ -426,7 +426,7 @@ class EnginePool:
         that many rows (`coalesce_plan`; the engines must have been built with max_batch >= coalesce_rows) and the outputs split
         back per batch.  A frame decodes to the same bits alone, in its own batch and in a merged pass (batch invariance,
         DESIGN.md section 2), so the results are those of the uncoalesced call; what changes is that the decode chain's fixed
-        costs are paid once per pass: 256-frame batches on 3 engines 5 840 captions/s, merged to 1024 rows 6 400 (round 5)."""
+        costs are paid once per pass: 256-frame batches on 3 engines 6 010 captions/s, merged to 1024 rows 6 600 (round 6)."""
         batches = list(batches)
         self.last_coalesce = None            # what the last call did with coalesce_rows: the plan, or why it was not applied
         if coalesce_rows and len(batches) > 1:
@@ -439,10 +439,9 @@ class EnginePool:
             else:
                 plan = self.coalesce_plan([int(b.shape[0]) for b in batches], len(self.engines), cap_rows)
                 if any(len(g) > 1 for g in plan):
-                    self.last_coalesce = plan
                     merged = [batches[g[0]] if len(g) == 1 else torch.cat([batches[j] for j in g], dim=0) for g in plan]
                     outs_m = self.generate_many(merged, threads=threads, **generate_kw)
-                    self.last_coalesce = plan
+                    self.last_coalesce = plan            # (the inner call cleared it)
                     outs: list = [None] * len(batches)
                     for g, om in zip(plan, outs_m):
                         unknown = sorted(set(om) - set(self._PER_ROW_OUTPUTS))
