@@ -13,6 +13,8 @@
 //                      8 lanes x 16 B cover one 128-byte key row, 8 keys per wave-instruction.
 #include <algorithm>
 
+#include <type_traits>
+
 #include "ops.h"
 #include "decode_attn.h"
 
@@ -889,6 +891,18 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split(const g8_t* __rest
 // tiles) - four waves, one 56 KiB buffer that holds K and then V (the V DMA under the softmax), two workgroups per CU (162
 // registers) - same bits, 190 us.  The three forms land within 15 % of each other because the launch moves 620 MB (q | k | v in,
 // context out) - 3.4 TB/s at 180 us: it is more than half way to the HBM rate, not an MFMA- or VALU-bound kernel any more.
+template <int I, int N, typename F> __device__ __forceinline__ void att_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        att_static_for<I + 1, N>(f);
+    }
+}
+template <int OFF> __device__ __forceinline__ s16x4 ds_read_tr16(unsigned addr) {
+    s16x4 d;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+    return d;
+}
+
 template <int KC>
 __global__ __launch_bounds__(512, 1) void vit_attention_split_pw(const g8_t* __restrict__ qkv, g8_t* __restrict__ ctx, int N, int H, int n_units) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1014,38 +1028,44 @@ __global__ __launch_bounds__(512, 1) void vit_attention_split_pw(const g8_t* __r
                     s[kc][e] = pe;
                     l += pe;
                 }
+            // The V fragment reads are asm statements: the compiler cannot tell an LDS read from Vs from the LDS-DMA into Ks that is
+            // in flight (the next unit's K, issued at barrier B) and waits vmcnt(0) in front of the first ds_read_b64_tr_b16 - which
+            // puts the whole prefetch, q rows included, in front of the context products instead of under them.  V itself was
+            // confirmed (vmcnt(0)) before barrier B.
+            const unsigned vaddr[2][2] = {{(unsigned)(size_t)CAP_LPTR(Vs) + vb[0][0], (unsigned)(size_t)CAP_LPTR(Vs) + vb[0][1]},
+                                          {(unsigned)(size_t)CAP_LPTR(Vs) + vb[1][0], (unsigned)(size_t)CAP_LPTR(Vs) + vb[1][1]}};
+            att_static_for<0, 2 * KC>([&](auto tc) {
+                constexpr int t = decltype(tc)::value, kc = t >> 1, s2 = t & 1, ro = (kc * 32 + 16 * s2) * 256;
+                // B operand: element j of lane half hh is P^T[key = kc*32 + 16*s2 + 8*(j>>2) + 4*hh + (j&3)][q]
+                f16x8 ph, pl;
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc) {
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    // B operand: element j of lane half hh is P^T[key = kc*32 + 16*s2 + 8*(j>>2) + 4*hh + (j&3)][q]
-                    f16x8 ph, pl;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float pv = s[kc][8 * s2 + j];
-                        const f16_t hv = (f16_t)pv;
-                        ph[j] = hv;
-                        pl[j] = (f16_t)(pv - (float)hv);
-                    }
-#pragma unroll
-                    for (int db = 0; db < 2; ++db) {
-                        // A operand (see vit_attention_mfma): this lane ADDRESSES row key0 (+8), dims dcol..dcol+3 and RECEIVES
-                        // column (lane & 15) of the 4 rows of its 16-lane group; once from the hi chunk, once from the lo chunk
-                        const int ro = (kc * 32 + 16 * s2) * 256;                    // compile-time after unrolling
-                        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + vb[db][0] + ro));
-                        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + vb[db][0] + ro + 2048));
-                        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + vb[db][1] + ro));
-                        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + vb[db][1] + ro + 2048));
-                        const f16x8 vh = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-                        const f16x8 vl = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
-                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[db], 0, 0, 0);
-                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[db], 0, 0, 0);
-                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[db], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < 8; ++j) {
+                    const float pv = s[kc][8 * s2 + j];
+                    const f16_t hv = (f16_t)pv;
+                    ph[j] = hv;
+                    pl[j] = (f16_t)(pv - (float)hv);
                 }
-            }
-        
+                // A operand (see vit_attention_mfma): this lane ADDRESSES row key0 (+8), dims dcol..dcol+3 and RECEIVES column
+                // (lane & 15) of the 4 rows of its 16-lane group; once from the hi chunk, once from the lo chunk
+                s16x4 h0[2], h1[2], l0[2], l1[2];
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    h0[db] = ds_read_tr16<ro>(vaddr[db][0]);
+                    h1[db] = ds_read_tr16<ro + 2048>(vaddr[db][0]);
+                    l0[db] = ds_read_tr16<ro>(vaddr[db][1]);
+                    l1[db] = ds_read_tr16<ro + 2048>(vaddr[db][1]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0[0]), "+v"(h1[0]), "+v"(l0[0]), "+v"(l1[0]), "+v"(h0[1]), "+v"(h1[1]), "+v"(l0[1]), "+v"(l1[1]));
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const f16x8 vh = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0[db], h1[db], 0, 1, 2, 3, 4, 5, 6, 7));
+                    const f16x8 vl = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0[db], l1[db], 0, 1, 2, 3, 4, 5, 6, 7));
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[db], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
             l += __shfl_xor(l, 32, 64);
             if (q < N) {
                 const float inv = 1.0f / l;
