@@ -454,3 +454,18 @@ def test_reduce_layernorm_kernels_agree_bit_for_bit(lib, D, S, with_resid):
             outs.append((out_t, out_f))
         assert torch.equal(outs[0][1], outs[1][1])
         assert torch.equal(outs[0][0].view(torch.int32 if tdt == torch.float32 else torch.int16), outs[1][0].view(torch.int32 if tdt == torch.float32 else torch.int16))
+        if with_resid:
+            # the pre-LN form the CoCa decoder calls: the sum goes back into the residual stream IN PLACE (y_out aliases resid),
+            # no fp32 LayerNorm row - same sum and same operand row from both kernels
+            ys = []
+            for row_block in (1, 0):
+                x = resid.clone()
+                out_t = torch.zeros(M, D, dtype=tdt, device="cuda")
+                _check(lib, lib.cap_op_reduce_layernorm(tag, _p(part), S, _p(bias), _p(x), _p(gamma), _p(beta), C.c_float(1e-5), _p(out_t),
+                                                        _p(None), _p(x), M, D, row_block, _stream()))
+                torch.cuda.synchronize()
+                ys.append((x, out_t))
+            assert torch.equal(ys[0][0], ys[1][0])
+            assert torch.equal(ys[0][1].view(torch.int32 if tdt == torch.float32 else torch.int16), ys[1][1].view(torch.int32 if tdt == torch.float32 else torch.int16))
+            want = part.sum(0) + bias + resid
+            assert (ys[0][0] - want).abs().max().item() < 1e-4
