@@ -333,7 +333,10 @@ __device__ __forceinline__ void pp_epilogue(const GemmParams& p, const f32x4 (&a
     }
 }
 
-template <typename T, bool OUT_F32, int EPI, bool PROF, int BM = 256, bool RESID = false>
+// ABL (-DCAP_EXPERIMENTS builds, CAP_EXP_ABLATE): what a launch costs WITHOUT parts of the kernel - bit 0 = no DMA after the second
+// stage, bit 1 = no fragment reads after the first stage, bit 2 = no epilogue (careful: the compiler then deletes the MFMAs too), bit 3 = the
+// DMA of every stage re-reads the first stage's addresses (issue and LDS-write cost stay, the traffic beyond L2 goes); results are garbage
+template <typename T, bool OUT_F32, int EPI, bool PROF, int BM = 256, bool RESID = false, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     // T = g8_t: 32 k values per 128-byte stage row, chunks [H0 L0 H1 L1 ..]: fragment 0 / 1 = the hi / lo chunk of k-group kg,
     // three MFMAs per product.  T = bf16_t: 64 k values per row, fragment 0 / 1 = k-step 0 / 1 (chunks kg / 4 + kg), one MFMA each.
@@ -424,12 +427,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     int i_kt = 0, i_x = 0;
     auto issue = [&](int s) __attribute__((always_inline)) {                            // this group's slot of stage s; then on to the next stage
         char* st = smem + (s & 1) * STAGE;
-        const char* ab = (const char*)p.A + (size_t)i_kt * 128;
+        const char* ab = (const char*)p.A + (size_t)((ABL & 8) ? 0 : i_kt) * 128;        // (ABL bit 3: every stage re-reads k = 0 of the first tile: L2 hits)
 #pragma unroll
         for (int j = 0; j < PQ; ++j)
             __builtin_amdgcn_global_load_lds(CAP_GPTR(ab + oa[j]), CAP_LPTR(st + (wm0 + (wq * PQ + j) * 8) * 128), 16, 0, 0);
         if (g == 0) {
-            const char* wb = (const char*)p.W + (size_t)i_kt * 128;
+            const char* wb = (const char*)p.W + (size_t)((ABL & 8) ? 0 : i_kt) * 128;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 __builtin_amdgcn_global_load_lds(CAP_GPTR(wb + ow[j]), CAP_LPTR(st + BM * 128 + (wq * 8 + j) * 1024), 16, 0, 0);
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         }
         if (++i_kt == nk) {
             i_kt = 0;
-            if (++i_x < ntl) set_ptrs(i_x);
+            if (++i_x < ntl && !(ABL & 8)) set_ptrs(i_x);
         }
     };
 
@@ -495,16 +498,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         const unsigned sa = lds0 + (S & 1) * STAGE;
         const unsigned aH = sa + wm0 * 128 + f_hi, aL = sa + wm0 * 128 + f_lo;
         const unsigned bH = sa + (BM + wn0) * 128 + f_hi, bL = sa + (BM + wn0) * 128 + f_lo;
+        const bool rd = !((ABL & 2) && S >= 1);
         // 12 reads; the first product needs the first four of them
-        ds_read16<0>(bl[0], bL); ds_read16<0>(ah[0], aH); ds_read16<0>(bh[0], bH); ds_read16<0>(al[0], aL);
-        ds_read16<2048>(bl[1], bL); ds_read16<2048>(bh[1], bH);
-        ds_read16<4096>(bl[2], bL); ds_read16<4096>(bh[2], bH);
-        ds_read16<6144>(bl[3], bL); ds_read16<6144>(bh[3], bH);
-        ds_read16<2048>(ah[1], aH); ds_read16<2048>(al[1], aL);
+        if (rd) {
+            ds_read16<0>(bl[0], bL); ds_read16<0>(ah[0], aH); ds_read16<0>(bh[0], bH); ds_read16<0>(al[0], aL);
+            ds_read16<2048>(bl[1], bL); ds_read16<2048>(bh[1], bH);
+            ds_read16<4096>(bl[2], bL); ds_read16<4096>(bh[2], bH);
+            ds_read16<6144>(bl[3], bL); ds_read16<6144>(bh[3], bH);
+            ds_read16<2048>(ah[1], aH); ds_read16<2048>(al[1], aL);
+        }
         __builtin_amdgcn_sched_barrier(0);
         {
             const long long t2 = PROF ? clock64() : 0;
-            if (S + 1 < NS) issue(S + 1);
+            if (S + 1 < NS && !((ABL & 1) && S >= 1)) issue(S + 1);
             if constexpr (PROF) prof_iss += clock64() - t2;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
         mma_pair(acc[0][2], acc[0][3], 2, 0);
         static_for<1, MH>([&](auto ic) {
             constexpr int i = decltype(ic)::value;       // i + 1 <= MH < MI: the first block of the second half included
-            ds_read16<(i + 1) * 2048>(ah[(i + 1) & 1], aH); ds_read16<(i + 1) * 2048>(al[(i + 1) & 1], aL);
+            if (rd) { ds_read16<(i + 1) * 2048>(ah[(i + 1) & 1], aH); ds_read16<(i + 1) * 2048>(al[(i + 1) & 1], aL); }
             wait_lgkm<2>(ah[i & 1], al[i & 1]);
             mma_block(i);
         });
@@ -522,10 +528,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
     auto half1 = [&](int S) __attribute__((always_inline)) {
         const unsigned sa = lds0 + (S & 1) * STAGE;
         const unsigned aH = sa + wm0 * 128 + f_hi, aL = sa + wm0 * 128 + f_lo;
+        const bool rd = !((ABL & 2) && S >= 1);
         static_for<MH, MI>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             if constexpr (i + 1 < MI) {
-                ds_read16<(i + 1) * 2048>(ah[(i + 1) & 1], aH); ds_read16<(i + 1) * 2048>(al[(i + 1) & 1], aL);
+                if (rd) { ds_read16<(i + 1) * 2048>(ah[(i + 1) & 1], aH); ds_read16<(i + 1) * 2048>(al[(i + 1) & 1], aL); }
                 wait_lgkm<2>(ah[i & 1], al[i & 1]);
             } else {
                 wait_lgkm<0>(ah[i & 1], al[i & 1]);
@@ -543,8 +550,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmParams p) {
             const int t = tile0 + item / SUB, sub = item % SUB;
             int tm, tn;
         tile_coords(t, tm, tn);
-            pp_epilogue<T, OUT_F32, EPI, MI, NI, RESID>(p, acc, has_bias ? bias_rows + (c_x & 1) * 1024 + wq * 256 : nullptr, strips + wq * (2 * 16 * 144),
-                                              tm * 256 + sub * BM + wm0, tn * BN + wn0, lane);
+            if constexpr (!(ABL & 4))
+                pp_epilogue<T, OUT_F32, EPI, MI, NI, RESID>(p, acc, has_bias ? bias_rows + (c_x & 1) * 1024 + wq * 256 : nullptr, strips + wq * (2 * 16 * 144),
+                                                            tm * 256 + sub * BM + wm0, tn * BN + wn0, lane);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -594,6 +602,21 @@ int launch_pp_t(const GemmParams& p, hipStream_t stream) {
     if (cap_kernel_setup((const void*)kern, LDS, &n_cu) != 0) return -1;
 #ifdef CAP_EXPERIMENTS
     if (const char* e = getenv("CAP_EXP_CUS")) n_cu = std::min(n_cu, std::max(8, atoi(e)));
+    if (!PROF && !RESID) {
+        if (const char* e = getenv("CAP_EXP_ABLATE")) {   // ablated forms of the product kernel (timing only: see gemm_pp_kernel)
+            const int nt = ((p.M + 255) / 256) * ((p.N + 255) / 256), gr = nt < n_cu ? nt : n_cu, abl = atoi(e);
+#define CAP_ABL(A)                                                                                                     \
+    do {                                                                                                               \
+        auto ka = gemm_pp_kernel<T, OUT_F32, EPI, false, 256, false, A>;                                               \
+        if (cap_kernel_setup((const void*)ka, LDS, nullptr) != 0) return -1;                                            \
+        hipLaunchKernelGGL(ka, dim3(gr), dim3(512), LDS, stream, p);                                                   \
+    } while (0)
+            if (abl == 1) CAP_ABL(1); else if (abl == 3) CAP_ABL(3); else if (abl == 8) CAP_ABL(8); else if (abl == 10) CAP_ABL(10); else CAP_ABL(0);
+#undef CAP_ABL
+            CAP_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
     if (getenv("CAP_EXP_NONPERSIST")) {                  // one tile per workgroup: workgroups retire all the time (tools/stagger_experiment.py)
         hipLaunchKernelGGL(kern, dim3(((p.M + 255) / 256) * ((p.N + 255) / 256)), dim3(512), LDS, stream, p);
         CAP_HIP_CHECK(hipGetLastError());
