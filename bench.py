@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--model", default="blip", choices=["blip", "coca", "minilm", "blip2"],
                     help="blip = BASELINE.json metric workload (default); coca = extra line for config 5's model "
                          "(CoCa ViT-L/14, reference top-k(1) loop, seq_len 30)")
+    ap.add_argument("--load-in-8bit", action="store_true", help="blip2: the reference's load mode (blip2.py:19-22) - int8 Linear weights as "
+                    "bitsandbytes stores them, bf16 activations (forces --dtype bf16, one engine)")
     ap.add_argument("--beams", type=int, default=1, help="> 1: extra line for SURVEY config 3 (HF beam search; use --batch 64)")
     ap.add_argument("--streams", type=int, default=3, help="blip: engines (own arena + HIP stream each) the timed steps rotate "
                     "over, so that consecutive batches overlap; 1 = one engine, one stream (the profiling passes always use one)")
@@ -560,10 +562,13 @@ def main_blip2(a):
     sd = procedural_blip2_state_dict(arch, 0, eos_boost=0.0)
     log(f"... {time.perf_counter() - t0:.0f}s; loading")
     px = synthetic_pixels(B, arch.image_size, seed=0).cuda()
-    eng = CaptionerEngine(arch, dtype=a.dtype, max_batch=B, max_beams=1, max_len=arch.max_new_tokens)
+    q8 = bool(getattr(a, "load_in_8bit", False))
+    if q8:
+        a.dtype, a.streams = "bf16", 1
+    eng = CaptionerEngine(arch, dtype=a.dtype, max_batch=B, max_beams=1, max_len=arch.max_new_tokens, weight_int8=q8)
     eng.load_state_dict(sd)
     log(f"weights loaded ({eng.device_bytes / 2**30:.1f} GiB on device); timing")
-    pool = pooled(a, arch, sd, max_batch=B, max_beams=1, max_len=arch.max_new_tokens)
+    pool = None if q8 else pooled(a, arch, sd, max_batch=B, max_beams=1, max_len=arch.max_new_tokens)
     dt, (ids, lens) = timed_steps(pool or eng, px, arch.max_new_tokens, a.steps, a.warmup, 1, lambda i, l: (i, l))
     if pool is not None:
         pool.close()
@@ -575,8 +580,9 @@ def main_blip2(a):
     fl = sum(rep[t]["flops"] for t in tags); ms = sum(rep[t]["ms"] for t in tags)
     line = {"metric": "captions/sec (BLIP-2 OPT-2.7b geometry, 224x224, greedy, 20 new tokens)", "value": round(B * a.steps / dt, 2),
             "unit": "captions/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-            "higher_is_better": True, "dtype": a.dtype, "data": "synthetic frames, procedural weights",
-            "config": {"workload": f"ViT-g/14 + Q-Former + OPT-2.7b prefill (33 positions) + 19 cached decode steps, {B} frames", "streams": a.streams},
+            "higher_is_better": True, "dtype": a.dtype + ("+int8w" if q8 else ""), "data": "synthetic frames, procedural weights",
+            "config": {"workload": f"ViT-g/14 + Q-Former + OPT-2.7b prefill (33 positions) + 19 cached decode steps, {B} frames", "streams": a.streams,
+                       "load_in_8bit": q8, "device_GiB": round(eng.device_bytes / 2**30, 2)},
             "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel (ViT-g qkv/proj/fc1/fc2)",
                          "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
                          "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_TFLOPS[a.dtype], 4), "traffic": None},
@@ -586,7 +592,7 @@ def main_blip2(a):
         torch.set_num_threads(host_cores())
         n = 2
         t0 = time.perf_counter()
-        ref = R.greedy_generate(sd, arch, px[:n].cpu())
+        ref = R.greedy_generate(R.int8_state_dict(sd) if q8 else sd, arch, px[:n].cpu())
         cdt = time.perf_counter() - t0
         new = ref["sequences"][:, arch.num_query_tokens + 1:]
         ours = ids[:n, : new.shape[1]].cpu()

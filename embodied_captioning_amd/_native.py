@@ -30,7 +30,7 @@ class CapConfig(C.Structure):
         ("min_len", C.c_int32),
         ("q_hidden", C.c_int32), ("q_layers", C.c_int32), ("q_heads", C.c_int32), ("q_ffn", C.c_int32),
         ("q_cross_freq", C.c_int32), ("num_query_tokens", C.c_int32), ("q_eps", C.c_float),
-        ("cross_kv_fp32", C.c_int32),
+        ("cross_kv_fp32", C.c_int32), ("weight_int8", C.c_int32),
     ]
 
 
@@ -76,6 +76,10 @@ _SIGNATURES = {
     "cap_op_gemm_skinny": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p]),
     "cap_op_gemm_skinny_slices": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "cap_op_quant_i8_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "cap_op_gemm_skinny_i8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_int, C.c_int, C.c_void_p]),
+    "cap_op_gemm_skinny_i8_slices": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "cap_op_vit_attention_hd": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p]),
     "cap_op_decode_attention": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

@@ -6,7 +6,7 @@ Arithmetic: libcaptioner_hip.so (`CaptionerEngine` with a `Blip2Arch`: ViT-g/14,
 ``model_name``:
   * a local HF directory / cached hub id (``Salesforce/blip2-opt-2.7b``): config.json, model.safetensors or the sharded
     ``model-0000x-of-0000y.safetensors`` + index, tokenizer files;
-  * ``procedural-blip2[-tiny][:seed[:eos_boost]]`` - seeded weights of the published / the fixture geometry (no vocabulary:
+  * ``procedural-blip2[-tiny|-small][:seed[:eos_boost]]`` - seeded weights of the published / the fixture geometry (no vocabulary:
     captions come back as space-separated token ids);
   * a BLIP(-base) captioning checkpoint selected with ``arch_name: blip2`` still runs through the BLIP path (compatibility
     with configs written before this class existed).
@@ -15,8 +15,12 @@ here: the checkpoint's tensors are taken at the prec
 checkpoint enters fp32 / the split format exactly (every fp16 value is a hi half with a zero lo half) - and the arithmetic is
 ``dtype``: "f32s" by default (fp32-grade split-fp16 GEMMs, token-identical to HF's fp32 CPU model on the committed golden,
 tests/test_blip2_gpu.py - the parity clause's mode), "bf16" (halves the decoder's weight stream, about 2x the captions/s,
-near-tie token flips), "f32" (exact).  bitsandbytes' LLM.int8 quantisation is NOT implemented: ``load_in_8bit`` is rejected by
-name rather than silently replaced by another arithmetic.
+near-tie token flips), "f32" (exact).  ``load_in_8bit: true`` (the reference's own mode) selects bf16 activations with the
+weight half of bitsandbytes' LLM.int8: every Linear HF would convert is row-quantised to int8 exactly as bitsandbytes stores it
+(q = rint(w * 127 / absmax(row)), scale = absmax / 127), the OPT decoder layers' weights stay bytes in HBM and the decode GEMMs
+stream them (half the bytes of a bf16 step); the activation half (int8 rows with fp16 outlier columns) is not restated -
+activations stay bf16, which is closer to the fp16 model than LLM.int8 itself.  Parity of this mode is UNPINNED (bitsandbytes is
+absent here): tests establish HIP = the restatement with the quantised weights.  ``load_in_4bit`` is rejected by name.
 ``checkpoint_name`` (optional): a PEFT LoRA adapter directory (``adapter_config.json`` + ``adapter_model.safetensors``) - what
 the reference's fine-tuned BLIP-2 is (``scripts/evaluate_finetuned_model.py:147-148``: ``PeftModel.from_pretrained``) - merged
 into the base weights at load (weights.merge_peft_lora), or a state-dict file that overrides tensors of the base checkpoint.
@@ -98,23 +102,27 @@ class BLIP2(BLIP):
             super().__init__(cfg)                       # a BLIP captioning checkpoint under arch_name blip2
             return
         CaptioningPredictor.__init__(self, cfg)
-        if getattr(cfg, "load_in_8bit", None) or getattr(cfg, "load_in_4bit", None):
-            raise ValueError("BLIP2(cfg): load_in_8bit / load_in_4bit (bitsandbytes quantisation, reference blip2.py:19-22) is not "
-                             "implemented by the MI355X captioner library - drop the key: the checkpoint's tensors are used at their "
-                             "stored precision and the arithmetic is cfg.dtype ('f32s' default | 'bf16' | 'f32')")
+        if getattr(cfg, "load_in_4bit", None):
+            raise ValueError("BLIP2(cfg): load_in_4bit (bitsandbytes NF4) is not implemented by the MI355X captioner library - "
+                             "use load_in_8bit (the reference's own mode, blip2.py:19-22) or drop the key")
+        # the reference's load mode (blip2.py:19-22: load_in_8bit=True, torch_dtype=float16): int8 Linear weights as bitsandbytes
+        # stores them, half-precision activations - here bf16; any other cfg.dtype with it is a contradiction
+        self.load_in_8bit = bool(getattr(cfg, "load_in_8bit", None))
+        if self.load_in_8bit and (getattr(cfg, "dtype", None) or "bf16") != "bf16":
+            raise ValueError(f"BLIP2(cfg): load_in_8bit runs with half-precision activations (dtype 'bf16'); got dtype={cfg.dtype!r}")
         td = getattr(cfg, "torch_dtype", None)
         if td is not None and str(td).replace("torch.", "") not in ("float16", "half", "bfloat16", "float32", "float"):
             raise ValueError(f"BLIP2(cfg): torch_dtype={td!r} is not a floating type a checkpoint is stored in")
         self.num_beams = 1
         self.batch_size = int(getattr(cfg, "batch_size", 8) or 8)
-        dtype = getattr(cfg, "dtype", None) or "f32s"      # parity-grade default: tokens identical to HF fp32 on the golden
+        dtype = "bf16" if self.load_in_8bit else getattr(cfg, "dtype", None) or "f32s"   # parity-grade default: tokens identical to HF fp32 on the golden
         if int(getattr(cfg, "streams", 1) or 1) > 1:
             logger.warning("captioner.streams > 1 is implemented for arch_name 'blip' only: running one engine")
         self._device = torch.device(getattr(cfg, "device", "cuda:0") or "cuda:0")
         self.tokenizer = None
         if model_dir is None:
             parts = name.split(":")
-            self.arch = Blip2Arch.tiny() if parts[0] == "procedural-blip2-tiny" else Blip2Arch()
+            self.arch = {"procedural-blip2-tiny": Blip2Arch.tiny, "procedural-blip2-small": Blip2Arch.small}.get(parts[0], Blip2Arch)()
             sd = procedural_blip2_state_dict(self.arch, int(parts[1]) if len(parts) > 1 else 0,
                                              eos_boost=float(parts[2]) if len(parts) > 2 else 0.0)
         else:
@@ -137,7 +145,8 @@ class BLIP2(BLIP):
         # name) overrides that.  The plugin's `max_length` key is BLIP's / CoCa's TOTAL length and is not read here.
         self.max_length = int(getattr(cfg, "max_new_tokens", 0) or self.arch.max_new_tokens)
         self.engine = CaptionerEngine(self.arch, dtype=dtype, max_batch=self.batch_size, max_beams=1, max_len=self.max_length,
-                                      device=self._device, cross_cache=getattr(cfg, "cross_cache", None) or "auto")
+                                      device=self._device, cross_cache=getattr(cfg, "cross_cache", None) or "auto",
+                                      weight_int8=self.load_in_8bit)
         # HF generate stops once every caption has its EOS; look every few steps (cfg early_exit_poll, 0 = never)
         poll = getattr(cfg, "early_exit_poll", None)
         self.engine.set_early_exit(4 if poll is None else int(poll))

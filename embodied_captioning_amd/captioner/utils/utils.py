@@ -50,8 +50,9 @@ class CaptionerField:
         self.top_p = top_p
         self.temperature = temperature
         self.repetition_penalty = repetition_penalty
-        # the reference's BLIP-2 load options (blip2.py:19-22): load_in_8bit is rejected by name (no int8 arithmetic here),
-        # torch_dtype only names the precision the checkpoint is stored in
+        # the reference's BLIP-2 load options (blip2.py:19-22): load_in_8bit = int8 Linear weights as bitsandbytes stores them + bf16
+        # activations (models/blip2/blip2.py), load_in_4bit is rejected by name, torch_dtype only names the precision the
+        # checkpoint is stored in
         self.load_in_8bit = load_in_8bit
         self.load_in_4bit = load_in_4bit
         self.torch_dtype = torch_dtype

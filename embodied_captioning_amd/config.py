@@ -227,3 +227,10 @@ class Blip2Arch:
         return Blip2Arch(image_size=28, patch_size=14, v_hidden=192, v_layers=2, v_heads=8, v_mlp=256, q_hidden=128, q_layers=2,
                          q_heads=2, q_ffn=256, num_query_tokens=8, t_hidden=64, t_layers=2, t_heads=4, t_ffn=128, vocab=512,
                          max_pos=64, eos=3, image_token=511)
+
+    @staticmethod
+    def small() -> "Blip2Arch":
+        # the fixture geometry with OPT widths the int8 weight stream takes (`load_in_8bit`: multiples of 256)
+        return Blip2Arch(image_size=28, patch_size=14, v_hidden=192, v_layers=2, v_heads=8, v_mlp=256, q_hidden=128, q_layers=2,
+                         q_heads=2, q_ffn=256, num_query_tokens=8, t_hidden=256, t_layers=2, t_heads=4, t_ffn=512, vocab=512,
+                         max_pos=64, eos=3, image_token=511)

@@ -59,6 +59,7 @@ struct Slot {            // where one checkpoint tensor (or a row range of a fus
     int dtype = CAP_DT_F32;   // storage type at dst: compute dtype or fp32
     int64_t rows = 0, cols = 0;
     int dst_ld = 0;
+    void* aux = nullptr;      // CAP_DT_I8W: the rows' fp32 scales
     bool loaded = false;
 };
 
@@ -88,6 +89,7 @@ struct QLayer {            // BLIP-2 Q-Former layer (queries only): self-attenti
 };
 struct OLayer {            // OPT decoder layer (pre-LN): fused q|k|v, out_proj, fc1 (ReLU), fc2; K/V caches [B][Lmax][T]
     void *w_qkv, *w_o, *w_f1, *w_f2, *kc, *vc;
+    float *s_qkv = nullptr, *s_o = nullptr, *s_f1 = nullptr, *s_f2 = nullptr;   // CapConfig.weight_int8: row scales of the int8 weights
     float *b_qkv, *b_o, *b_f1, *b_f2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
 };
 struct TLayer {
@@ -173,6 +175,7 @@ struct Captioner {
     // ---- BLIP-2 (CAP_ARCH_BLIP2)
     std::vector<QLayer> ql;
     std::vector<OLayer> ol;
+    bool wq8 = false;            // CapConfig.weight_int8: the OPT decoder's Linear weights are row-quantised int8 (gemm_skinny.hip)
     float *q_x0 = nullptr, *b_lproj = nullptr, *o_tok = nullptr, *o_pos = nullptr, *o_lnf_g = nullptr, *o_lnf_b = nullptr;
     void *w_lproj = nullptr, *o_tok_t = nullptr;
     float *qx = nullptr, *qy = nullptr, *lm_proj = nullptr, *ox = nullptr;      // activations
@@ -220,9 +223,9 @@ int walloc(Captioner* m, void** p, size_t bytes) {
     return 0;
 }
 
-int add_slot(Captioner* m, const std::string& name, void* dst, int dtype, int64_t rows, int64_t cols, int dst_ld = 0) {
+int add_slot(Captioner* m, const std::string& name, void* dst, int dtype, int64_t rows, int64_t cols, int dst_ld = 0, void* aux = nullptr) {
     if (m->replay) return 0;
-    Slot s; s.dst = dst; s.dtype = dtype; s.rows = rows; s.cols = cols; s.dst_ld = dst_ld ? dst_ld : (int)cols;
+    Slot s; s.dst = dst; s.dtype = dtype; s.rows = rows; s.cols = cols; s.dst_ld = dst_ld ? dst_ld : (int)cols; s.aux = aux;
     m->ws->slots.insert({name, s});
     return 0;
 }
@@ -238,6 +241,13 @@ int reg_mat(Captioner* m, const std::string& name, void** p, int64_t rows, int64
     TRY(walloc(m, p, (size_t)rows * ld * m->esz));
     if (ld != cols && !m->replay) CAP_HIP_CHECK(hipMemset(*p, 0, (size_t)rows * ld * m->esz));
     return add_slot(m, name, *p, m->gdt, rows, cols, ld);
+}
+
+// allocate an int8 weight [rows, cols] in fragment order + its row scales and register it (CapConfig.weight_int8)
+int reg_mat_i8(Captioner* m, const std::string& name, void** p, float** scale, int64_t rows, int64_t cols) {
+    TRY(walloc(m, p, (size_t)rows * cols));
+    TRY(walloc(m, (void**)scale, (size_t)rows * 4));
+    return add_slot(m, name, *p, CAP_DT_I8W, rows, cols, 0, *scale);
 }
 
 int build_blip(Captioner* m) {
@@ -646,19 +656,28 @@ int build_blip2(Captioner* m) {
     for (int i = 0; i < c.t_layers; ++i) {
         OLayer& L = m->ol[i];
         const std::string p = lm + "layers." + std::to_string(i) + ".";
-        TRY(walloc(m, &L.w_qkv, (size_t)3 * T * T * m->esz));
+        TRY(walloc(m, &L.w_qkv, (size_t)3 * T * T * (m->wq8 ? 1 : m->esz)));
+        if (m->wq8) TRY(walloc(m, (void**)&L.s_qkv, (size_t)3 * T * 4));
         TRY(walloc(m, (void**)&L.b_qkv, (size_t)3 * T * 4));
         for (int j = 0; j < 3; ++j) {
-            add_slot(m, p + "self_attn." + pn[j] + ".weight", (char*)L.w_qkv + (size_t)j * T * T * m->esz, m->gdt, T, T);
+            // (int8: a 16-row tile's blocks are contiguous, so rows j T .. of the fused matrix start at byte j T T)
+            if (m->wq8) add_slot(m, p + "self_attn." + pn[j] + ".weight", (char*)L.w_qkv + (size_t)j * T * T, CAP_DT_I8W, T, T, 0, L.s_qkv + (size_t)j * T);
+            else add_slot(m, p + "self_attn." + pn[j] + ".weight", (char*)L.w_qkv + (size_t)j * T * T * m->esz, m->gdt, T, T);
             add_slot(m, p + "self_attn." + pn[j] + ".bias", L.b_qkv + (size_t)j * T, CAP_DT_F32, 1, T);
         }
-        TRY(reg_mat(m, p + "self_attn.out_proj.weight", &L.w_o, T, T));
+        if (m->wq8) {
+            TRY(reg_mat_i8(m, p + "self_attn.out_proj.weight", &L.w_o, &L.s_o, T, T));
+            TRY(reg_mat_i8(m, p + "fc1.weight", &L.w_f1, &L.s_f1, G, T));
+            TRY(reg_mat_i8(m, p + "fc2.weight", &L.w_f2, &L.s_f2, T, G));
+        } else {
+            TRY(reg_mat(m, p + "self_attn.out_proj.weight", &L.w_o, T, T));
+            TRY(reg_mat(m, p + "fc1.weight", &L.w_f1, G, T));
+            TRY(reg_mat(m, p + "fc2.weight", &L.w_f2, T, G));
+        }
         TRY(reg_f32(m, p + "self_attn.out_proj.bias", &L.b_o, T));
         TRY(reg_f32(m, p + "self_attn_layer_norm.weight", &L.ln1_g, T));
         TRY(reg_f32(m, p + "self_attn_layer_norm.bias", &L.ln1_b, T));
-        TRY(reg_mat(m, p + "fc1.weight", &L.w_f1, G, T));
         TRY(reg_f32(m, p + "fc1.bias", &L.b_f1, G));
-        TRY(reg_mat(m, p + "fc2.weight", &L.w_f2, T, G));
         TRY(reg_f32(m, p + "fc2.bias", &L.b_f2, T));
         TRY(reg_f32(m, p + "final_layer_norm.weight", &L.ln2_g, T));
         TRY(reg_f32(m, p + "final_layer_norm.bias", &L.ln2_b, T));
@@ -693,7 +712,14 @@ int build_blip2(Captioner* m) {
     TRY(dev_alloc(m, &m->oqkv, Bm * P * 3 * T * e));
     TRY(dev_alloc(m, &m->octx, Bm * P * T * e));
     TRY(dev_alloc(m, &m->off, Bm * P * G * e));
-    TRY(dev_alloc(m, (void**)&m->dpart, (size_t)8 * Bm * std::max(3 * T, G) * 4));     // split-K slabs of the decode-step GEMMs
+    {
+        size_t dpart_bytes = (size_t)8 * Bm * std::max(3 * T, G) * 4;                     // split-K slabs of the decode-step GEMMs
+        if (m->wq8) {                                   // int8 weights: the prompt pass runs the same chain over Bm * P rows
+            const size_t Sm = (size_t)std::max(skinny_i8_plan(T, T, false), skinny_i8_plan(T, G, false));
+            dpart_bytes = std::max(dpart_bytes, Sm * Bm * P * T * 4);
+        }
+        TRY(dev_alloc(m, (void**)&m->dpart, dpart_bytes));
+    }
     TRY(dev_alloc(m, (void**)&m->seq, Bm * Lmax * 4));
     TRY(dev_alloc(m, (void**)&m->finished, Bm * 4));
     TRY(dev_alloc(m, (void**)&m->lens, Bm * 4));
@@ -741,12 +767,43 @@ int run_qformer(Captioner* m, int B, hipStream_t s) {
 
 // OPT decoder over L new positions per row (x = ox [B * L, T] fp32 with positions already added), cached prefix of `past`
 // positions; leaves the logits of each row's last new position in m->logits.
+int opt_step_gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, const float* bias, int act, void* out_t, int B,
+                  int N, int K, bool ln, int* S_out, int out_dt, const float* wscale);
+
 int run_opt(Captioner* m, int B, int L, int past, hipStream_t s) {
     const CapConfig& c = m->c;
     const int T = c.t_hidden, G = c.t_ffn, H = c.t_heads, hd = T / H, R = B * L;
     const int Lmax = c.num_query_tokens + 1 + c.max_len;
     const size_t e = m->esz;
     const int af = m->gdt == CAP_DT_G8 ? 1 : 0;     // split mode: q | k | v for the attention kernels and the caches are fp32
+    if (m->wq8) {
+        // int8 weights: the prompt's rows go through the decode step's chain (the weight-streaming GEMMs take any row count: further
+        // row groups re-read a unit's bytes from the XCD's L2; out_proj / fc2 as slice sums finished by the reduce + LayerNorm
+        // consumer) with the prompt's causal attention in place of the cached one.  A one-crop prompt is 33 rows: a weight stream too.
+        int S = 1;
+        TRY(launch_layernorm(m->gdt, m->ox, T, m->ol[0].ln1_g, m->ol[0].ln1_b, c.t_eps, m->oh_t, nullptr, R, T, s));
+        for (int i = 0; i < c.t_layers; ++i) {
+            const OLayer& Ly = m->ol[i];
+            TRY(opt_step_gemm(m, s, "opt_gemm_qkv", m->oh_t, Ly.w_qkv, Ly.b_qkv, 0, m->oqkv, R, 3 * T, T, false, &S, m->dt, Ly.s_qkv));
+            TRY(launch_kv_append(m->dt, m->oqkv, Ly.kc, Ly.vc, B, L, T, Lmax, past, s));
+            {
+                ProfScope ps(m, s, "opt_attn", 4.0 * B * H * (double)L * (past + L) * hd, 2.0 * B * (past + L) * T * e);
+                if (past == 0) TRY(launch_vit_attention(m->dt, m->oqkv, m->octx, B, L, H, 0, s, hd, 1, m->gdt));
+                else TRY(launch_generic_attention(m->dt, m->oqkv, 3 * T, (long)L * 3 * T, Ly.kc, T, (long)Lmax * T, Ly.vc, T, (long)Lmax * T, m->octx, T,
+                                                  (long)L * T, B, L, past + L, H, hd, past, s, m->gdt));
+            }
+            TRY(opt_step_gemm(m, s, "opt_gemm_o", m->octx, Ly.w_o, nullptr, 0, nullptr, R, T, T, true, &S, m->gdt, Ly.s_o));
+            TRY(launch_reduce_layernorm(m->gdt, m->dpart, S, Ly.b_o, m->ox, Ly.ln2_g, Ly.ln2_b, c.t_eps, m->oh_t, nullptr, m->ox, R, T, s, true));
+            TRY(opt_step_gemm(m, s, "opt_gemm_f1", m->oh_t, Ly.w_f1, Ly.b_f1, 2, m->off, R, G, T, false, &S, m->gdt, Ly.s_f1));
+            const bool last = i + 1 == c.t_layers;
+            TRY(opt_step_gemm(m, s, "opt_gemm_f2", m->off, Ly.w_f2, nullptr, 0, nullptr, R, T, G, true, &S, m->gdt, Ly.s_f2));
+            TRY(launch_reduce_layernorm(m->gdt, m->dpart, S, Ly.b_f2, m->ox, last ? m->o_lnf_g : m->ol[i + 1].ln1_g,
+                                        last ? m->o_lnf_b : m->ol[i + 1].ln1_b, c.t_eps, m->oh_t, nullptr, m->ox, R, T, s, true));
+        }
+        // oh_t = final LayerNorm of every row: the tied LM head (bf16, no bias) reads each image's last position
+        return gemm(m, s, "opt_gemm_vocab", (const char*)m->oh_t + (size_t)(L - 1) * T * e, L * T, m->o_tok_t, T, m->logits, m->ldl, nullptr, nullptr, B,
+                    c.vocab, T, 0, 1);
+    }
     for (int i = 0; i < c.t_layers; ++i) {
         const OLayer& Ly = m->ol[i];
         TRY(launch_layernorm(m->gdt, m->ox, T, Ly.ln1_g, Ly.ln1_b, c.t_eps, m->oh_t, nullptr, R, T, s));
@@ -778,8 +835,14 @@ int run_opt(Captioner* m, int B, int L, int past, hipStream_t s) {
 // (ln == false: bias + act -> out_t) or as slice sums for the reduce+LayerNorm consumer.  Otherwise the tiled split-K GEMM
 // with a reduce kernel.  The choice depends on dtype and (N, K) only - never on the row count.
 int opt_step_gemm(Captioner* m, hipStream_t s, const char* tag, const void* A, const void* W, const float* bias, int act,
-                  void* out_t, int B, int N, int K, bool ln, int* S_out, int out_dt) {       // out_dt: type of out_t (split mode:
-                                                                                           // fp32 for q|k|v, G8 for a GEMM operand)
+                  void* out_t, int B, int N, int K, bool ln, int* S_out, int out_dt,        // out_dt: type of out_t (split mode:
+                  const float* wscale = nullptr) {                                         // fp32 for q|k|v, G8 for a GEMM operand)
+    if (m->wq8) {                                       // int8 weights (load_in_8bit): W = fragment-ordered bytes, wscale = row scales
+        const int S8 = skinny_i8_plan(N, K, !ln);
+        ProfScope ps(m, s, tag, 2.0 * B * N * K, (double)B * K * 2 + (double)N * K + (ln ? (double)S8 * B * N * 4 : (double)B * N * 2));
+        *S_out = S8;
+        return launch_gemm_skinny_i8(A, K, W, wscale, bias, act, out_t, N, ln ? m->dpart : nullptr, B, N, K, s) == S8 ? 0 : -1;
+    }
     const int S = m->dt == CAP_DT_BF16 ? skinny_plan(N, K, !ln) : 0;
     if (S >= 1) {
         ProfScope ps(m, s, tag, 2.0 * B * N * K, ((double)B * K + (double)N * K) * 2 + (ln ? (double)S * B * N * 4 : (double)B * N * 2));
@@ -799,7 +862,7 @@ int run_opt_step(Captioner* m, int B, int past, hipStream_t s) {
     int S = 1;
     for (int i = 0; i < c.t_layers; ++i) {
         const OLayer& Ly = m->ol[i];
-        TRY(opt_step_gemm(m, s, "opt_gemm_qkv", m->oh_t, Ly.w_qkv, Ly.b_qkv, 0, m->oqkv, B, 3 * T, T, false, &S, m->dt));
+        TRY(opt_step_gemm(m, s, "opt_gemm_qkv", m->oh_t, Ly.w_qkv, Ly.b_qkv, 0, m->oqkv, B, 3 * T, T, false, &S, m->dt, Ly.s_qkv));
         {
             ProfScope ps(m, s, "opt_attn", 4.0 * B * H * (double)(past + 1) * hd, 2.0 * B * (past + 1) * T * e);
             if (hd % 8 == 0 && hd <= 128)
@@ -810,11 +873,11 @@ int run_opt_step(Captioner* m, int B, int past, hipStream_t s) {
                                              past + 1, H, hd, past, s, m->gdt));
             }
         }
-        TRY(opt_step_gemm(m, s, "opt_gemm_o", m->octx, Ly.w_o, nullptr, 0, nullptr, B, T, T, true, &S, m->gdt));
+        TRY(opt_step_gemm(m, s, "opt_gemm_o", m->octx, Ly.w_o, nullptr, 0, nullptr, B, T, T, true, &S, m->gdt, Ly.s_o));
         TRY(launch_reduce_layernorm(m->gdt, m->dpart, S, Ly.b_o, m->ox, Ly.ln2_g, Ly.ln2_b, c.t_eps, m->oh_t, nullptr, m->ox, B, T, s, true));
-        TRY(opt_step_gemm(m, s, "opt_gemm_f1", m->oh_t, Ly.w_f1, Ly.b_f1, 2, m->off, B, G, T, false, &S, m->gdt));
+        TRY(opt_step_gemm(m, s, "opt_gemm_f1", m->oh_t, Ly.w_f1, Ly.b_f1, 2, m->off, B, G, T, false, &S, m->gdt, Ly.s_f1));
         const bool last = i + 1 == c.t_layers;
-        TRY(opt_step_gemm(m, s, "opt_gemm_f2", m->off, Ly.w_f2, nullptr, 0, nullptr, B, T, G, true, &S, m->gdt));
+        TRY(opt_step_gemm(m, s, "opt_gemm_f2", m->off, Ly.w_f2, nullptr, 0, nullptr, B, T, G, true, &S, m->gdt, Ly.s_f2));
         TRY(launch_reduce_layernorm(m->gdt, m->dpart, S, Ly.b_f2, m->ox, last ? m->o_lnf_g : m->ol[i + 1].ln1_g,
                                     last ? m->o_lnf_b : m->ol[i + 1].ln1_b, c.t_eps, m->oh_t, nullptr, m->ox, B, T, s, true));
     }
@@ -1662,8 +1725,21 @@ static int create_impl(const CapConfig* cfg, Captioner* share, CapHandle* out) {
             return -1;
         }
     }
+    if (cfg->weight_int8) {
+        const int T = cfg->t_hidden, G = cfg->t_ffn;
+        if (cfg->weight_int8 != 1 || cfg->arch != CAP_ARCH_BLIP2 || cfg->compute_dtype != CAP_BF16) {
+            cap_set_error("cap_create: weight_int8 (load_in_8bit) is built for CAP_ARCH_BLIP2 with CAP_BF16 activations");
+            return -1;
+        }
+        if (skinny_i8_plan(3 * T, T, true) < 1 || skinny_i8_plan(G, T, true) < 1 || skinny_i8_plan(T, T, false) < 1 || skinny_i8_plan(T, G, false) < 1) {
+            cap_set_error("cap_create: weight_int8 needs OPT widths the int8 weight stream takes (hidden %d, ffn %d: multiples of 256 that "
+                          "split into waves of at most 320 k)", T, G);
+            return -1;
+        }
+    }
     Captioner* m = new Captioner();
     m->c = *cfg;
+    m->wq8 = cfg->weight_int8 != 0;
     if (share) { m->ws = share->ws; m->ws->refs.fetch_add(1); m->replay = true; }
     else { m->ws = new WeightStore(); m->ws->device = dev; }
     m->dt = cfg->compute_dtype == CAP_BF16 ? CAP_DT_BF16 : CAP_DT_F32;
@@ -1793,7 +1869,8 @@ int cap_load_weight(CapHandle h, const char* name, const float* data, int on_dev
                           (long long)sl.rows, (long long)sl.cols);
             return -1;
         }
-        TRY(launch_convert2d(sl.dtype, src, sl.dst, (int)sl.rows, (int)sl.cols, sl.dst_ld, s, sl.dtype == CAP_DT_G8 ? G8_WSCALE : 1.0f));
+        if (sl.dtype == CAP_DT_I8W) TRY(launch_quant_i8_pack(src, sl.dst, (float*)sl.aux, (int)sl.rows, (int)sl.cols, s));
+        else TRY(launch_convert2d(sl.dtype, src, sl.dst, (int)sl.rows, (int)sl.cols, sl.dst_ld, s, sl.dtype == CAP_DT_G8 ? G8_WSCALE : 1.0f));
         sl.loaded = true;
     }
     CAP_HIP_CHECK(hipStreamSynchronize(s));
@@ -1993,6 +2070,14 @@ int cap_op_gemm_skinny(const void* A, const void* W, const float* bias, int act,
     return launch_gemm_skinny(A, K, W, K, bias, act, out, N, part, M, N, K, (hipStream_t)stream);
 }
 int cap_op_gemm_skinny_slices(int N, int K, int finished) { return skinny_plan(N, K, finished != 0); }
+int cap_op_quant_i8_pack(const float* W, void* packed, float* scale, int rows, int cols, void* stream) {
+    return launch_quant_i8_pack(W, packed, scale, rows, cols, (hipStream_t)stream);
+}
+int cap_op_gemm_skinny_i8(const void* A, const void* packed, const float* scale, const float* bias, int act, void* out, float* part, int M,
+                          int N, int K, void* stream) {
+    return launch_gemm_skinny_i8(A, K, packed, scale, bias, act, out, N, part, M, N, K, (hipStream_t)stream);
+}
+int cap_op_gemm_skinny_i8_slices(int N, int K, int finished) { return skinny_i8_plan(N, K, finished != 0); }
 int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int32_t* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             void* stream) {

@@ -18,7 +18,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 // compute dtype tags (match include/captioner_hip.h)
-enum { CAP_DT_F32 = 0, CAP_DT_BF16 = 1, CAP_DT_G8 = 2 };
+enum { CAP_DT_F32 = 0, CAP_DT_BF16 = 1, CAP_DT_G8 = 2,
+       CAP_DT_I8W = 3 };   // storage only: row-quantised int8 weights in MFMA fragment order (gemm_skinny.hip), never a compute type
 
 // ---- G8: the GEMM-operand layout of the split-fp16 mode (CAP_F32_SPLIT) -------------------------------------------
 // An fp32 value x travels as two fp16 halves, hi = rn16(x) and lo = rn16(x - hi) (x - hi is exact in fp32), so

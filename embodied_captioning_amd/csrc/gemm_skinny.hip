@@ -215,3 +215,206 @@ int launch_gemm_skinny(const void* A, int lda, const void* W, int ldw, const flo
     else rc = small ? skinny_launch<4, 2, 32>(p, grid, s) : skinny_launch<4, 4, 32>(p, grid, s);
     return rc == 0 ? S : rc;
 }
+
+// ================================================================================================================
+// int8 weights (BLIP-2 `load_in_8bit`, reference captioner/models/blip2/blip2.py:19-22): the same weight-streaming GEMM with W
+// stored as bitsandbytes stores a Linear8bitLt weight - one signed byte per element, q = rint(w * 127 / absmax(row)), and the
+// row's absmax / 127 as an fp32 scale - so a decode step streams half the bytes of the bf16 form.  The activations stay bf16
+// (bitsandbytes also quantises them to int8 per token, with columns beyond its threshold kept in fp16: not restated - this is
+// the weight half of LLM.int8, "W8A16").  C = (A . q^T) * scale[n] (+ bias, act): the integers are exact in bf16, the sums fp32.
+//
+// Layout (written once by launch_quant_i8_pack): the bytes sit in MFMA FRAGMENT ORDER, so that a wave's global_load_dwordx4
+// IS the operand fetch - no LDS staging, no swizzle, every instruction one contiguous KiB:
+//   block (t, s) = weight rows 16 t .. 16 t + 15, k = 64 s .. 64 s + 63: 1 KiB at ((t * K / 64) + s) * 1024;
+//   inside it lane l = r + 16 g (row r, k-group g) owns bytes 16 l .. 16 l + 15 = k-step 0 [8 bytes: k = 64 s + 8 g ..] then
+//   k-step 1 [8 bytes: k = 64 s + 32 + 8 g ..].
+// A row tile's blocks are consecutive in s: a wave walks contiguous memory.  The slice plan (S, waves, k per wave) is the bf16
+// kernel's skinny_plan with 32-row workgroups, so sums depend on (N, K) and the output form only, never on the row count.
+namespace {
+
+typedef unsigned int sk_u32x4 __attribute__((ext_vector_type(4)));
+
+struct SkinnyI8Params {
+    const bf16_t* A; int lda;
+    const unsigned char* Wp; const float* wscale; int nslab;      // nslab = K / 64
+    const float* bias;
+    bf16_t* out; int ldc;
+    float* part;
+    int M, N, S, nks, act;
+    int G, units;
+};
+
+__device__ __forceinline__ bf16x8 i8x8_to_bf16(unsigned lo, unsigned hi) {
+    bf16x8 w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        w[e] = (bf16_t)(float)(int)(signed char)((lo >> (8 * e)) & 0xFFu);
+        w[4 + e] = (bf16_t)(float)(int)(signed char)((hi >> (8 * e)) & 0xFFu);
+    }
+    return w;
+}
+
+// XT = 16-row tiles of activations per workgroup (1: up to 16 rows per group - the one-crop decode step; 2: 32)
+template <int NW, int XT>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_i8_kernel(SkinnyI8Params p) {
+    constexpr int TR = 32, WT = 2, PITCH = WT * 16 + 4, MR = XT * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int per = 8 * p.G, rr = blockIdx.x % per;              // (unit, row group): as in gemm_skinny_kernel
+    const int unit = (blockIdx.x / per) * 8 + (rr & 7);
+    if (unit >= p.units) return;
+    const int nt = unit / p.S, z = unit % p.S;
+    const int n0 = nt * TR, m0 = (rr >> 3) * MR;
+    const int kw = (z * NW + wave) * p.nks * 32;
+    const int nsl = p.nks >> 1;
+
+    // the weight stream first: every block of this wave's K range in flight at once (one memory round trip)
+    sk_u32x4 wq[WT][SK_MAXKS / 2];
+#pragma unroll
+    for (int t = 0; t < WT; ++t) {
+        const sk_u32x4* wp = (const sk_u32x4*)(p.Wp + ((size_t)(nt * WT + t) * p.nslab + (kw >> 6)) * 1024) + lane;
+#pragma unroll
+        for (int sl = 0; sl < SK_MAXKS / 2; ++sl)
+            if (sl < nsl) wq[t][sl] = __builtin_nontemporal_load(wp + sl * 64);
+    }
+    // activations (L2 hits): straight into the MFMA operand layout
+    bf16x8 af[XT][SK_MAXKS];
+#pragma unroll
+    for (int t = 0; t < XT; ++t) {
+        const bf16_t* ap = p.A + (size_t)min(m0 + t * 16 + r16, p.M - 1) * p.lda + kw + kg * 8;
+#pragma unroll
+        for (int j = 0; j < SK_MAXKS; ++j)
+            if (j < p.nks) af[t][j] = *(const bf16x8*)(ap + j * 32);
+    }
+    f32x4 acc[WT][XT];
+#pragma unroll
+    for (int a = 0; a < WT; ++a)
+#pragma unroll
+        for (int b = 0; b < XT; ++b) acc[a][b] = f32x4(0.f);
+#pragma unroll
+    for (int sl = 0; sl < SK_MAXKS / 2; ++sl)
+        if (sl < nsl) {
+#pragma unroll
+            for (int wt = 0; wt < WT; ++wt) {
+                const bf16x8 w0 = i8x8_to_bf16(wq[wt][sl].x, wq[wt][sl].y), w1 = i8x8_to_bf16(wq[wt][sl].z, wq[wt][sl].w);
+#pragma unroll
+                for (int xt = 0; xt < XT; ++xt) {
+                    acc[wt][xt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, af[xt][2 * sl], acc[wt][xt], 0, 0, 0);
+                    acc[wt][xt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, af[xt][2 * sl + 1], acc[wt][xt], 0, 0, 0);
+                }
+            }
+        }
+    // the waves' tiles summed through LDS in wave order, then scale (+ bias, act) or the slice sum
+    float* red = (float*)smem;
+#pragma unroll
+    for (int wt = 0; wt < WT; ++wt)
+#pragma unroll
+        for (int xt = 0; xt < XT; ++xt)
+            *(f32x4*)(red + (wave * MR + xt * 16 + r16) * PITCH + wt * 16 + 4 * kg) = acc[wt][xt];
+    __syncthreads();
+    for (int o = tid; o < MR * (TR / 2); o += NW * 64) {
+        const int m = o / (TR / 2), n = (o % (TR / 2)) * 2;
+        f32x2 v = *(const f32x2*)(red + m * PITCH + n);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += *(const f32x2*)(red + (w * MR + m) * PITCH + n);
+        if (m0 + m >= p.M) continue;
+        v *= *(const f32x2*)(p.wscale + n0 + n);
+        if (p.part) {
+            *(f32x2*)(p.part + ((size_t)z * p.M + m0 + m) * p.N + n0 + n) = v;
+            continue;
+        }
+        if (p.bias) v += *(const f32x2*)(p.bias + n0 + n);
+        if (p.act == 2) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }
+        else if (p.act == 1) { v[0] = gelu_erf_fast(v[0]); v[1] = gelu_erf_fast(v[1]); }
+        bf16x2 ob;
+        ob[0] = (bf16_t)v[0]; ob[1] = (bf16_t)v[1];
+        *(bf16x2*)(p.out + (size_t)(m0 + m) * p.ldc + n0 + n) = ob;
+    }
+}
+
+// fp32 [rows, cols] -> row scales + the fragment-ordered bytes.  One workgroup per 16-row tile: row maxima first (16 threads per
+// row), then every thread writes whole 16-byte lane pieces.  q = rint(w * (127 / absmax)) in fp32 (IEEE divide, round-half-even):
+// the arithmetic of oracle/blip2_ref.py::quantize_int8_rowwise, bit for bit.
+__global__ __launch_bounds__(256) void quant_i8_pack_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, float* __restrict__ scale,
+                                                            int cols) {
+    __shared__ float rmax[16][17];
+    __shared__ float rinv[16];
+    const int t = blockIdx.x, tid = threadIdx.x, r = tid >> 4, c16 = tid & 15;
+    const float* row = src + (size_t)(t * 16 + r) * cols;
+    float am = 0.f;
+    for (int c = c16; c < cols; c += 16) am = fmaxf(am, fabsf(row[c]));
+    rmax[r][c16] = am;
+    __syncthreads();
+    if (tid < 16) {
+        float a = 0.f;
+        for (int j = 0; j < 16; ++j) a = fmaxf(a, rmax[tid][j]);
+        scale[t * 16 + tid] = a / 127.0f;
+        rinv[tid] = a > 0.f ? 127.0f / a : 0.f;
+    }
+    __syncthreads();
+    const int nslab = cols >> 6;
+    unsigned char* blk = dst + (size_t)t * nslab * 1024;
+    for (int o = tid; o < nslab * 64; o += 256) {
+        const int sl = o >> 6, l = o & 63, rr = l & 15, g = l >> 4;
+        const float* sp = src + (size_t)(t * 16 + rr) * cols + sl * 64 + g * 8;
+        const float inv = rinv[rr];
+        unsigned w[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {                     // words 0, 1: k-step 0; words 2, 3: k-step 1
+            const float* q = sp + (h >> 1) * 32 + (h & 1) * 4;
+            unsigned u = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u |= ((unsigned)(int)__builtin_rintf(q[e] * inv) & 0xFFu) << (8 * e);
+            w[h] = u;
+        }
+        *(sk_u32x4*)(blk + (size_t)o * 16) = sk_u32x4{w[0], w[1], w[2], w[3]};
+    }
+}
+
+template <int NW, int XT>
+int skinny_i8_launch(const SkinnyI8Params& p, dim3 grid, hipStream_t s) {
+    constexpr int lds = NW * XT * 16 * (2 * 16 + 4) * 4;
+    hipLaunchKernelGGL((gemm_skinny_i8_kernel<NW, XT>), grid, dim3(NW * 64), lds, s, p);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// the int8 form's plan: skinny_plan with 32-row workgroups only (N % 32 == 0)
+int skinny_i8_plan(int N, int K, bool finished, int* nw_out) {
+    if (N % 32 != 0) return 0;
+    int nw = 0, tr = 0;
+    const int S = skinny_plan(N, K, finished, &nw, &tr, 1 << 30);      // (a row count that never asks for 40-row workgroups)
+    if (S < 1 || tr != 32) return 0;
+    if (nw_out) *nw_out = nw;
+    return S;
+}
+
+int launch_quant_i8_pack(const float* src, void* dst, float* scale, int rows, int cols, hipStream_t s) {
+    if (rows % 16 != 0 || cols % 64 != 0) { cap_set_error("quant_i8_pack: rows %% 16 / cols %% 64 (%d x %d)", rows, cols); return -1; }
+    hipLaunchKernelGGL(quant_i8_pack_kernel, dim3(rows / 16), dim3(256), 0, s, src, (unsigned char*)dst, scale, cols);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_skinny_i8(const void* A, int lda, const void* Wp, const float* wscale, const float* bias, int act, void* out, int ldc,
+                          float* part, int M, int N, int K, hipStream_t s) {
+    int nw = 0;
+    const int S = skinny_i8_plan(N, K, part == nullptr, &nw);
+    if (S < 1 || M < 1 || (lda & 7) || (!part && (!out || (ldc & 1)))) {
+        cap_set_error("gemm_skinny_i8: unsupported shape M=%d N=%d K=%d", M, N, K);
+        return -1;
+    }
+    SkinnyI8Params p;
+    p.A = (const bf16_t*)A; p.lda = lda; p.Wp = (const unsigned char*)Wp; p.wscale = wscale; p.nslab = K / 64; p.bias = bias;
+    p.out = (bf16_t*)out; p.ldc = ldc; p.part = part; p.M = M; p.N = N; p.S = S; p.nks = K / (nw * 32 * S); p.act = act;
+    const bool one = M <= 16;                             // one 16-row tile of activations per workgroup
+    p.G = one ? 1 : (M + 31) / 32; p.units = (N / 32) * S;
+    const dim3 grid(((p.units + 7) / 8) * 8 * p.G);
+    int rc;
+    if (nw == 8) rc = one ? skinny_i8_launch<8, 1>(p, grid, s) : skinny_i8_launch<8, 2>(p, grid, s);
+    else rc = one ? skinny_i8_launch<4, 1>(p, grid, s) : skinny_i8_launch<4, 2>(p, grid, s);
+    return rc == 0 ? S : rc;
+}

@@ -120,6 +120,14 @@ int skinny_plan(int N, int K, bool finished, int* nw_out = nullptr, int* tr_out 
 int launch_gemm_skinny(const void* A, int lda, const void* W, int ldw, const float* bias, int act, void* out, int ldc,
                        float* part, int M, int N, int K, hipStream_t s);
 
+// int8 weights (BLIP-2 load_in_8bit): W as row-quantised signed bytes in MFMA fragment order + fp32 row scales (layout and
+// arithmetic: gemm_skinny.hip).  launch_quant_i8_pack: fp32 [rows, cols] (rows % 16 == 0, cols % 64 == 0) -> dst (rows * cols
+// bytes) and scale [rows].  skinny_i8_plan / launch_gemm_skinny_i8: as the bf16 pair, N % 32 == 0.
+int skinny_i8_plan(int N, int K, bool finished, int* nw_out = nullptr);
+int launch_quant_i8_pack(const float* src, void* dst, float* scale, int rows, int cols, hipStream_t s);
+int launch_gemm_skinny_i8(const void* A, int lda, const void* Wp, const float* wscale, const float* bias, int act, void* out, int ldc,
+                          float* part, int M, int N, int K, hipStream_t s);
+
 // ---- preprocess.hip ----------------------------------------------------------------------------
 // n boxes of one uint8 HWC frame -> out uint8 [n, S, S, 3] RGB, bit-exact with Pillow's crop + BICUBIC resize.
 // rects int32 [n, 4] (x1, y1, x2, y2, inside the frame); hb/vb int32 [n, S, 2] (first tap, tap count) and hk/vk int32

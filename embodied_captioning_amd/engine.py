@@ -35,8 +35,11 @@ class CaptionerEngine:
 
     def __init__(self, arch: BlipArch, dtype: str = "bf16", max_batch: int = 8, max_beams: int = 1,
                  max_len: int = 20, device: str | torch.device = "cuda:0", share_weights_with: "CaptionerEngine | None" = None,
-                 cross_cache: str = "auto"):
-        """cross_cache: "auto" = the mode's own cross-attention K/V cache ("f32s": KV16 - int16 + one scale per 64-wide head row,
+                 cross_cache: str = "auto", weight_int8: bool = False):
+        """weight_int8 (BLIP-2, dtype "bf16" only): the reference's `load_in_8bit=True` (blip2.py:19-22) - the OPT decoder layers' Linear
+        weights are kept as row-quantised int8 + fp32 row scales (bitsandbytes' storage) and streamed as bytes by the decode GEMMs,
+        the vision tower's Linears and language_projection pass through the same quantiser at load; activations stay bf16.
+        cross_cache: "auto" = the mode's own cross-attention K/V cache ("f32s": KV16 - int16 + one scale per 64-wide head row,
         the decode side's HBM stream at half the bytes; "bf16": bf16 rows; "f32": fp32 rows); "fp32" = fp32 rows in "f32s" too
         (`cross_cache_kind` tells what the handle uses).
         share_weights_with: an engine of the same model / dtype / GPU whose (read-only) weights this one uses instead of
@@ -85,6 +88,10 @@ class CaptionerEngine:
             raise ValueError(f"cross_cache must be 'auto' or 'fp32', got {cross_cache!r}")
         cfg.cross_kv_fp32 = int(cross_cache == "fp32")
         self.cross_cache = cross_cache
+        self.weight_int8 = bool(weight_int8)
+        if self.weight_int8 and not (self.is_blip2 and dtype == "bf16"):
+            raise ValueError("weight_int8 (load_in_8bit) is built for BLIP-2 with dtype 'bf16'")
+        cfg.weight_int8 = int(self.weight_int8)
         for i in range(3):
             cfg.pix_mean[i] = OPENAI_CLIP_MEAN[i]
             cfg.pix_std[i] = OPENAI_CLIP_STD[i]
@@ -174,6 +181,11 @@ class CaptionerEngine:
                 q = sd["query_tokens"].float()[0]
                 sd["derived.qformer_x0"] = torch.nn.functional.layer_norm(
                     q, (q.shape[-1],), sd["qformer.layernorm.weight"].float(), sd["qformer.layernorm.bias"].float(), self.arch.q_eps)
+            if getattr(self, "weight_int8", False):
+                from .weights import blip2_int8_host_names, int8_roundtrip
+                sd = dict(sd)
+                for k in blip2_int8_host_names(sd):
+                    sd[k] = int8_roundtrip(sd[k])
         except KeyError as e:
             raise N.CaptionerHipError(f"state dict lacks {e}: this architecture derives tensors from the checkpoint at load "
                                       f"and needs the complete dict (keys with a 'model.' / 'module.' prefix? see "

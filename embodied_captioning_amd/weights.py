@@ -257,6 +257,32 @@ def blip2_param_specs(a: Blip2Arch) -> List[Tuple[str, Tuple[int, ...], str, flo
     return s
 
 
+def quantize_int8_rowwise(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """bitsandbytes' vector-wise int8 quantisation of a Linear weight [out, in] (what `load_in_8bit=True` stores in a
+    `Linear8bitLt`: `CB` int8 and the rows' absmax `SCB`): q = rint(w * (127 / absmax(row))) in fp32 (round-half-even), scale =
+    absmax / 127; w ~ q * scale.  The library does this on the device for the tensors it keeps as bytes (csrc/gemm_skinny.hip,
+    bit for bit this arithmetic); this host form is for the tensors that are stored dequantised."""
+    w = w.detach().float()
+    amax = w.abs().amax(dim=1, keepdim=True)
+    inv = torch.where(amax > 0, 127.0 / amax, torch.zeros_like(amax))
+    q = torch.round(w * inv).to(torch.int8)
+    return q, (amax / 127.0).squeeze(1)
+
+
+def int8_roundtrip(w: torch.Tensor) -> torch.Tensor:
+    q, s = quantize_int8_rowwise(w)
+    return q.float() * s[:, None]
+
+
+def blip2_int8_host_names(sd: Dict[str, torch.Tensor]) -> List[str]:
+    """`load_in_8bit` on BLIP-2 (transformers `replace_with_bnb_linear`): every nn.Linear outside `_keep_in_fp32_modules`
+    (= the Q-Former and the query tokens) and outside lm_head becomes int8.  The OPT decoder layers' Linears are kept as bytes by
+    the library (CapConfig.weight_int8); the names returned here - the vision tower's Linears and language_projection - are
+    the rest: stored at the compute dtype, so they pass through the quantiser on the host (weights only, same values)."""
+    return [k for k in sd if k.endswith(".weight") and sd[k].dim() == 2 and
+            ((k.startswith("vision_model.encoder.layers.") and (".self_attn." in k or ".mlp." in k)) or k == "language_projection.weight")]
+
+
 def procedural_blip2_state_dict(arch: Blip2Arch, seed: int = 0, eos_boost: float = 0.0) -> Dict[str, torch.Tensor]:
     """Seeded fp32 state dict; `language_model.lm_head.weight` is tied to the token table (shares storage).  The LM head has
     no bias: `eos_boost` adds boost * beta / |beta|^2 (beta = bias of the final LayerNorm) to the EOS row of the tied table,

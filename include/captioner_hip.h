@@ -92,6 +92,14 @@ typedef struct CapConfig {
     /* CAP_F32_SPLIT only: 1 = the cross-attention K/V cache keeps fp32 rows (as CAP_F32 does) instead of KV16.  0 (default): KV16
      * for images of more than 32 tokens.  Ignored by the other modes (bf16 rows / fp32 rows). */
     int32_t cross_kv_fp32;
+    /* CAP_ARCH_BLIP2 + CAP_BF16 only: 1 = the reference's own load mode for BLIP-2 (captioner/models/blip2/blip2.py:19-22,
+     * `load_in_8bit=True`): the OPT decoder layers' Linear weights (q / k / v / out_proj / fc1 / fc2 - where the bytes of a decode
+     * step are) are kept as bitsandbytes keeps a Linear8bitLt weight - one signed byte per element, q = rint(w * 127 /
+     * absmax(row)), and the row's absmax / 127 in fp32 - quantised on the device by cap_load_weight from the fp32 tensor it is
+     * given; the GEMMs stream the bytes and multiply the row sums by the scales.  Activations stay bf16 (bitsandbytes' int8
+     * activation path with fp16 outlier columns is not restated: weights-only, "W8A16").  lm_head stays bf16 (HF does not
+     * convert it either).  Needs OPT widths the int8 weight stream takes (opt-2.7b's 2560 / 10240 are). */
+    int32_t weight_int8;
 } CapConfig;
 
 const char* cap_last_error(void);
@@ -252,6 +260,14 @@ int cap_op_reduce_layernorm(int dtype, const float* part, int S, const float* bi
 int cap_op_gemm_skinny(const void* A, const void* W, const float* bias, int act, void* out, float* part, int M, int N,
                        int K, void* stream);
 int cap_op_gemm_skinny_slices(int N, int K, int finished);
+/* The int8 form (CapConfig.weight_int8).  cap_op_quant_i8_pack: fp32 W [rows, cols] (rows % 16 == 0, cols % 64 == 0) ->
+ * packed (rows * cols bytes, MFMA fragment order: block (t, s) = rows 16 t.., k = 64 s.. is the KiB at (t * cols / 64 + s) * 1024,
+ * lane r + 16 g owns bytes 16 l..: k = 64 s + 8 g.. + 7, then k = 64 s + 32 + 8 g.. + 7) and scale [rows] = absmax(row) / 127.
+ * cap_op_gemm_skinny_i8: as cap_op_gemm_skinny with (packed, scale) for W; N % 32 == 0; cap_op_gemm_skinny_i8_slices = its plan. */
+int cap_op_quant_i8_pack(const float* W, void* packed, float* scale, int rows, int cols, void* stream);
+int cap_op_gemm_skinny_i8(const void* A, const void* packed, const float* scale, const float* bias, int act, void* out, float* part,
+                          int M, int N, int K, void* stream);
+int cap_op_gemm_skinny_i8_slices(int N, int K, int finished);
 int cap_op_decode_attention(int dtype, const void* q, const void* kbase, const void* vbase, const int32_t* anc,
                             int anc_ld, int rows_per_kv, int kv_ld, int n_keys, void* out, int R, int H, int impl,
                             void* stream);        /* impl | 16: kbase / vbase are KV16 blocks (no ancestry, > 32 keys) */

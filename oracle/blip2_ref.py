@@ -13,6 +13,13 @@ The arithmetic lives in transformers (not in /root/reference; installed here: 5.
                                         offset 2, final_layer_norm, tied lm_head without bias.
   HF:generation/utils.py                greedy `_sample`; with no length argument HF uses max_length = prompt + 20.
 Pinned by tests/golden/blip2_tiny.npz (tools/make_goldens_blip2.py runs the real HF model on seeded weights).
+
+`load_in_8bit` (reference blip2.py:19-22; bitsandbytes 0.4x `Linear8bitLt`, NOT in /root/reference and not installed here:
+PARITY UNPINNED for this part): `quantize_int8_rowwise` restates the published vector-wise quantisation of a weight
+(`int8_vectorwise_quant`: CB = round(W * 127 / absmax(row)), SCB = absmax(row); dequantised W' = CB * SCB / 127) and
+`int8_state_dict` applies it to the modules transformers converts (`replace_with_bnb_linear`: every nn.Linear outside
+`_keep_in_fp32_modules = ["query_tokens", "qformer"]` and lm_head).  LLM.int8's activation half (per-token int8 rows, columns
+with a value beyond 6.0 in fp16) is not restated: activations stay floating point, as in the product.
 """
 from __future__ import annotations
 
@@ -23,6 +30,38 @@ import torch
 import torch.nn.functional as F
 
 from . import blip_ref
+
+
+def quantize_int8_rowwise(w: torch.Tensor):
+    """-> (q int8 [out, in], scale fp32 [out]) with w ~ q * scale; fp32 arithmetic, round-half-even."""
+    w = w.detach().float()
+    amax = w.abs().amax(dim=1, keepdim=True)
+    inv = torch.where(amax > 0, 127.0 / amax, torch.zeros_like(amax))
+    return torch.round(w * inv).to(torch.int8), (amax / 127.0).squeeze(1)
+
+
+def int8_linear_names(sd) -> List[str]:
+    lm = "language_model.model.decoder.layers."
+    out = []
+    for k, v in sd.items():
+        if not k.endswith(".weight") or v.dim() != 2:
+            continue
+        if k.startswith(lm) and any(t in k for t in ("q_proj", "k_proj", "v_proj", "out_proj", "fc1", "fc2")):
+            out.append(k)
+        elif k.startswith("vision_model.encoder.layers.") and (".self_attn." in k or ".mlp." in k):
+            out.append(k)
+        elif k == "language_projection.weight":
+            out.append(k)
+    return out
+
+
+def int8_state_dict(sd) -> Dict[str, torch.Tensor]:
+    """The state dict a `load_in_8bit` model computes with: converted Linears replaced by their dequantised int8 weights."""
+    sd = dict(sd)
+    for k in int8_linear_names(sd):
+        q, sc = quantize_int8_rowwise(sd[k])
+        sd[k] = q.float() * sc[:, None]
+    return sd
 
 
 def _lin(sd, name, x):

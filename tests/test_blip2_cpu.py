@@ -60,3 +60,21 @@ def test_restatement_matches_hf_golden_at_production_width():
     got = torch.gather(lg, 2, torch.from_numpy(g["top8_ids"]).long()).numpy()
     assert np.abs(got - g["top8_values"]).max() < 1e-4
     assert np.array_equal(torch.topk(lg, 8, dim=-1).indices.numpy(), g["top8_ids"])
+
+
+def test_int8_quantiser_host_form_is_the_restatement_and_names_match():
+    """`load_in_8bit`: the product's host quantiser (weights.py: tensors stored dequantised) and name policy against the restatement's
+    (oracle/blip2_ref.py; PARITY UNPINNED against bitsandbytes, absent here)."""
+    from embodied_captioning_amd.weights import blip2_int8_host_names, int8_roundtrip, quantize_int8_rowwise
+    g, meta, a, sd, px = load_blip2()
+    w = sd["vision_model.encoder.layers.0.mlp.fc1.weight"].clone()
+    w[2] = 0.0
+    q, s = quantize_int8_rowwise(w)
+    q2, s2 = R.quantize_int8_rowwise(w)
+    assert torch.equal(q, q2) and torch.equal(s, s2) and int(q.abs().max()) == 127 and (q[2] == 0).all() and s[2] == 0
+    assert (int8_roundtrip(w) - w).abs().max() <= s.max() * 0.5 * (1 + 1e-6)
+    host = set(blip2_int8_host_names(sd))
+    lm = "language_model.model.decoder.layers."
+    assert host | {k for k in R.int8_linear_names(sd) if k.startswith(lm)} == set(R.int8_linear_names(sd))
+    assert not any(k.startswith(("qformer.", "language_model.lm_head", lm)) for k in host)
+    assert len(host) == 4 * a.v_layers + 1

@@ -134,12 +134,15 @@ def test_generation_options_are_rejected_by_name():
             CoCa(cfg)
 
 
-def test_blip2_rejects_8bit_loading_by_name():
-    """blip2.py:19-22 asks for bitsandbytes int8 weights: not implemented, so the key raises instead of changing the arithmetic
-    silently."""
+def test_blip2_rejects_4bit_loading_and_contradicting_dtype_by_name():
+    """blip2.py:19-22 asks for bitsandbytes int8 weights: `load_in_8bit` is the int8-weight mode with bf16 activations (tests/
+    test_blip2_int8_gpu.py); NF4 and a dtype that contradicts it raise instead of changing the arithmetic silently."""
     from embodied_captioning_amd.captioner.models.blip2.blip2 import BLIP2
     from embodied_captioning_amd.captioner.utils.utils import Configuration
-    cfg = Configuration(arch_name="blip2", model_name="procedural-blip2-tiny:1", height=224, width=224, load_in_8bit=True).captioner
+    cfg = Configuration(arch_name="blip2", model_name="procedural-blip2-tiny:1", height=224, width=224, load_in_4bit=True).captioner
+    with pytest.raises(ValueError, match="load_in_4bit"):
+        BLIP2(cfg)
+    cfg = Configuration(arch_name="blip2", model_name="procedural-blip2-tiny:1", height=224, width=224, load_in_8bit=True, dtype="f32s").captioner
     with pytest.raises(ValueError, match="load_in_8bit"):
         BLIP2(cfg)
     cfg = Configuration(arch_name="blip2", model_name="procedural-blip2-tiny:1", height=224, width=224, torch_dtype="int8").captioner
