@@ -264,7 +264,7 @@ def quantize_int8_rowwise(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     bit for bit this arithmetic); this host form is for the tensors that are stored dequantised."""
     w = w.detach().float()
     amax = w.abs().amax(dim=1, keepdim=True)
-    inv = torch.where(amax > 0, 127.0 / amax, torch.zeros_like(amax))
+    inv = torch.where(amax > 0, torch.full_like(amax, 127.0) / amax, torch.zeros_like(amax))   # (a true division: `127.0 / t` is t.reciprocal() * 127 in torch)
     q = torch.round(w * inv).to(torch.int8)
     return q, (amax / 127.0).squeeze(1)
 

@@ -36,7 +36,7 @@ def quantize_int8_rowwise(w: torch.Tensor):
     """-> (q int8 [out, in], scale fp32 [out]) with w ~ q * scale; fp32 arithmetic, round-half-even."""
     w = w.detach().float()
     amax = w.abs().amax(dim=1, keepdim=True)
-    inv = torch.where(amax > 0, 127.0 / amax, torch.zeros_like(amax))
+    inv = torch.where(amax > 0, torch.full_like(amax, 127.0) / amax, torch.zeros_like(amax))   # (a true division: `127.0 / t` is t.reciprocal() * 127 in torch)
     return torch.round(w * inv).to(torch.int8), (amax / 127.0).squeeze(1)
 
 
