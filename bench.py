@@ -94,6 +94,9 @@ def parse():
     ap.add_argument("--stub-engine", action="store_true", help="TEST ONLY (tests/test_distributed_cpu.py): the launch / rendezvous / "
                     "timed-region / gather / strong-scaling plumbing on CPU ranks over gloo with a fake captioner whose ids are a "
                     "function of the frame index; prints a line marked \"stub\": true and never touches a GPU")
+    ap.add_argument("--share-gpu", action="store_true", help="REHEARSAL ONLY (a one-GPU box): every rank of --gpus N on cuda:0, process "
+                    "group over gloo - the N > 1 code path (shards, per-step gather, timed region, strong-scaling job) with the real "
+                    "engines, everything but RCCL; the line says so and its value is not a scaling figure")
     ap.add_argument("--decode-path", default="auto", choices=["auto", "batch", "small"],
                     help="blip: decode kernels of the timed steps (engine.set_decode_path; A/B of the batch path's kernel sets)")
     ap.add_argument("--row-compaction", default="on", choices=["on", "off"],
@@ -880,6 +883,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does)")
+    if a.share_gpu:
+        local = 0
     if a.stub_engine:
         dev = torch.device("cpu")
     else:
@@ -887,7 +892,7 @@ def main():
         dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.stub_engine:
+        if a.stub_engine or a.share_gpu:
             torch.distributed.init_process_group("gloo")
         else:
             torch.distributed.init_process_group("nccl", device_id=dev)
@@ -971,7 +976,7 @@ def main():
                                        f"max_length={L}, caption all-gather"
                                        + (f"; {a.steps} steps merged by the engine pool into {len(passes)} passes of {'/'.join(str(r) for r in pass_rows)} rows" if passes else ""),
                            "global_batch": world * B, "pass_rows": pass_rows,
-                           "parallelism": f"dp{world}", "streams": a.streams, "compute_mode": a.dtype, "compute_mode_note": mode,
+                           "parallelism": f"dp{world}" + (" REHEARSAL: all ranks share cuda:0 over gloo (--share-gpu) - not a scaling figure" if a.share_gpu else ""), "streams": a.streams, "compute_mode": a.dtype, "compute_mode_note": mode,
                            "value_is": (f"consecutive batches overlapped on {a.streams} engines / HIP streams of one GPU (EnginePool)"
                                         + (f", the pool's dynamic batching merging consecutive steps' batches into passes of up to {coal} rows "
                                            f"(a frame has the same bits alone, in its batch and in a merged pass); every batch as its own pass is the "
