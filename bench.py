@@ -1007,6 +1007,9 @@ def main():
         if a.lite or a.beams > 1 or S != 224:
             print(json.dumps(line))
             eng.close()
+            if world > 1:                    # the other ranks are waiting at the closing barrier below
+                torch.distributed.barrier()
+                torch.distributed.destroy_process_group()
             return
         if a.streams > 1:                    # the timed steps ran on the pool's engines: this one has not touched its arena yet
             eng.generate(px, num_beams=1, max_length=L)
