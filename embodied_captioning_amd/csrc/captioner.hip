@@ -1168,11 +1168,15 @@ int gemm_splitk_reduce_ln(Captioner* m, hipStream_t s, const Dec& d, const char*
         ProfScope ps(m, s, tag, 2.0 * d.R * N * K, ((double)d.R * K + (double)N * K) * m->esz + (double)S * d.R * N * 4);
         TRY(launch_gemm(m->gdt, p, decode_tile(m), s));
     }
-    const bool per_row_block = d.R < 512 || N > 1024;
+    const bool per_row_block = d.R < 832 || N > 1024;
     ProfScope ps(m, s, per_row_block ? "dec_reduce_ln" : "dec_reduce_ln_wave", 0, (double)(S + 2) * d.R * N * 4 + (double)d.R * N * m->esz);
-    // one 256-thread block per row up to a few hundred rows (one memory round trip, latency-bound); at the pool's merged passes
-    // (~1 000 rows) the wave-per-row kernel: 5.6 us against 7.4 at 1 024 rows.  Same sums in the same order - the two kernels give
-    // the same bits (tests/test_kernels_gpu.py::test_reduce_layernorm_kernels_agree_bit_for_bit), so the row count may choose.
+    // one 256-thread block per row up to several hundred rows (one memory round trip, latency-bound); at the pool's 1 024-row
+    // passes the wave-per-row kernel.  Launches replayed from a captured graph (tools/bench_reduce_ln.py, us per launch, block / wave,
+    // split mode | bf16 in place, the CoCa form): 512 rows 5.6 / 6.3 | 5.3 / 6.2, 640 (config 5: 128 images x 5 beams) 6.5 / 6.5 | 6.3 /
+    // 6.6, 768 6.6 / 6.7 | 6.4 / 6.8, 896 7.6 / 7.0 | 7.3 / 7.0, 1 024 7.8 / 7.4 | 7.4 / 7.2: the crossing is between 768 and 896 (round 5
+    // had put it at 512 from the 1 024-row figure alone, which cost config 5 ~4 % - dec_reduce_ln 17.6 -> 22.3 ms per step).  Same sums in
+    // the same order - the two kernels give the same bits (tests/test_kernels_gpu.py::test_reduce_layernorm_kernels_agree_bit_for_bit),
+    // so the row count may choose.
     return launch_reduce_layernorm(m->gdt, d.dpart, S, bias, resid ? resid : d.dx, g, b, eps, out_t, out_f, y_out, d.R, N, s, per_row_block, false, d.map.n);
 }
 
