@@ -242,6 +242,32 @@ FP32_MFMA_PEAK = 157.3                                                 # the pip
 POWER_LIMITED_MFMA = {"f32s": 1960.0}     # v_mfma_f32_16x16x32_f16, tools/mfma_power_probe.sh (measured, one box)
 
 
+def vendor_gemm_context(batch, n_tokens, D, Mv, seconds=1.0):
+    """CONTEXT ONLY - nothing in the product calls a vendor GEMM: what torch.mm (hipBLASLt / rocBLAS, AMD's tuned kernels) sustains
+    on this board on the same four ViT Linear shapes with plain fp16 operands (ONE MFMA product per MAC, no bias / GELU / split
+    epilogue), random normal data, the four in rotation for ~1 s.  The split kernel's `executed_tflops` is the figure beside it."""
+    try:
+        M = batch * n_tokens
+        shapes = [(3 * D, D), (D, D), (Mv, D), (D, Mv)]
+        ops = [(torch.randn(M, K, device="cuda", dtype=torch.float16), (torch.randn(N, K, device="cuda") * 0.03).half()) for N, K in shapes]
+        fl = sum(2.0 * M * N * K for N, K in shapes)
+        for a, w in ops:
+            torch.mm(a, w.t())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); n = 0
+        while time.perf_counter() - t0 < seconds:
+            for a, w in ops:
+                torch.mm(a, w.t())
+            n += 1
+            if n % 20 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return round(fl * n / (time.perf_counter() - t0) / 1e12, 1)
+    except Exception as e:  # noqa: BLE001 - context only
+        log(f"vendor GEMM context skipped: {e!r}")
+        return None
+
+
 def roofline_pass(eng, px, L, dtype, arch, batch):
     """Per-kernel HIP-event timing (events recorded on the launch stream inside the library).
 
@@ -285,6 +311,9 @@ def roofline_pass(eng, px, L, dtype, arch, batch):
             # power limit (~1.3 kW) holds the clock at 2.0 GHz (profiles/r03_mfma_power.txt; 2 390 TFLOP/s with one constant pair)
             "power_limited_mfma_tflops": POWER_LIMITED_MFMA.get(dtype), "frac_executed_vs_power_limited":
             round(k * alg / POWER_LIMITED_MFMA[dtype], 4) if POWER_LIMITED_MFMA.get(dtype) else None,
+            # context, measured in this run: AMD's own tuned GEMM (torch.mm -> hipBLASLt) on the same four shapes with plain fp16
+            # operands, one product per MAC and no epilogue work - what the vendor's kernel makes of this board on these shapes
+            "vendor_fp16_gemm_tflops_same_shapes": vendor_gemm_context(batch, arch.n_tokens, arch.v_hidden, arch.v_mlp) if dtype == "f32s" else None,
             "traffic_source": pm["source"], "pmc_stale": pm["pmc_stale"], "pmc_stale_why": pm["pmc_stale_why"],
             "note": "achieved = 2MNK of the ViT Linear layers per launch / HIP-event launch time (the proj / fc2 launches also add their "
                     "output into the fp32 residual stream in place: +155 MB read each, counted in algorithmic_bytes_per_launch); frac = achieved / dense peak of "
@@ -849,6 +878,7 @@ def finish_line(line):
             "strong_scaling_at_micro_batch_256": pick("strong_scaling", "at_micro_batch_256", "captions_per_s"),
             "golden_rows_identical": f"{par.get('token_identical_rows')}/{par.get('rows')}" if par else None,
             "enc_gemm_frac": pick("roofline", "frac"), "enc_gemm_frac_executed": pick("roofline", "frac_executed"),
+            "enc_gemm_executed_tflops": pick("roofline", "executed_tflops"), "vendor_fp16_gemm_tflops_same_shapes": pick("roofline", "vendor_fp16_gemm_tflops_same_shapes"),
             "decode_gemm_hbm_frac": pick("decode", "gemm", "frac"), "cross_attention_hbm_frac": pick("decode", "cross_attention", "frac"),
             "decode_kernels_ms_per_pass": pick("decode", "ms_per_step_all_decode_kernels"),
             "decode_ms_per_256_frames_at_pass_rows": pick("pass_rows_profile", "decode_ms_per_256_frames"),
