@@ -1717,18 +1717,6 @@ static int create_impl(const CapConfig* cfg, Captioner* share, CapHandle* out) {
         }
         if (cfg->v_hidden % 64 || cfg->v_mlp % 64 || cfg->t_ffn % 64) { cap_set_error("cap_create: widths must be multiples of 64"); return -1; }
     }
-    int dev = 0;
-    CAP_HIP_CHECK(hipGetDevice(&dev));
-    if (share) {
-        // same model, same arithmetic, same GPU; only the capacity of the arena may differ
-        CapConfig a = *cfg, b = share->c;
-        a.max_batch = b.max_batch = 0; a.max_beams = b.max_beams = 0; a.max_len = b.max_len = 0;
-        if (memcmp(&a, &b, sizeof(a)) != 0 || share->ws->device != dev) {
-            cap_set_error("cap_create_shared: the new handle must describe the same model, compute dtype and GPU as the handle "
-                          "whose weights it shares");
-            return -1;
-        }
-    }
     if (cfg->weight_int8) {
         const int T = cfg->t_hidden, G = cfg->t_ffn;
         if (cfg->weight_int8 != 1 || cfg->arch != CAP_ARCH_BLIP2 || cfg->compute_dtype != CAP_BF16) {
@@ -1738,6 +1726,18 @@ static int create_impl(const CapConfig* cfg, Captioner* share, CapHandle* out) {
         if (skinny_i8_plan(3 * T, T, true) < 1 || skinny_i8_plan(G, T, true) < 1 || skinny_i8_plan(T, T, false) < 1 || skinny_i8_plan(T, G, false) < 1) {
             cap_set_error("cap_create: weight_int8 needs OPT widths the int8 weight stream takes (hidden %d, ffn %d: multiples of 256 that "
                           "split into waves of at most 320 k)", T, G);
+            return -1;
+        }
+    }
+    int dev = 0;
+    CAP_HIP_CHECK(hipGetDevice(&dev));
+    if (share) {
+        // same model, same arithmetic, same GPU; only the capacity of the arena may differ
+        CapConfig a = *cfg, b = share->c;
+        a.max_batch = b.max_batch = 0; a.max_beams = b.max_beams = 0; a.max_len = b.max_len = 0;
+        if (memcmp(&a, &b, sizeof(a)) != 0 || share->ws->device != dev) {
+            cap_set_error("cap_create_shared: the new handle must describe the same model, compute dtype and GPU as the handle "
+                          "whose weights it shares");
             return -1;
         }
     }

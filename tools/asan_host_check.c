@@ -95,6 +95,23 @@ int main(void) {
         int rcp = cap_op_pack_kv16(w, w, 0, NULL);                                            /* zero rows: nothing to launch */
         EXPECT(rcp == 0 || strlen(cap_last_error()) > 0);
     }
+    /* round 6, second session: int8 weights (CapConfig.weight_int8) - the configuration checks and the host planner / argument
+     * checks of the int8 weight stream run before any HIP call */
+    c = blip_cfg(); c.weight_int8 = 1;                                                        /* not BLIP-2 */
+    EXPECT(cap_create(&c, &h) != 0 && strstr(cap_last_error(), "weight_int8"));
+    c = blip_cfg(); c.arch = CAP_ARCH_BLIP2; c.compute_dtype = CAP_F32_SPLIT; c.weight_int8 = 1;   /* not bf16 */
+    EXPECT(cap_create(&c, &h) != 0);
+    c = blip_cfg(); c.arch = CAP_ARCH_BLIP2; c.compute_dtype = CAP_BF16; c.weight_int8 = 7;    /* not a flag value */
+    EXPECT(cap_create(&c, &h) != 0);
+    for (int n = 32; n <= 12288; n += 160)
+        for (int k = 64; k <= 10240; k += 448) { (void)cap_op_gemm_skinny_i8_slices(n, k, 0); (void)cap_op_gemm_skinny_i8_slices(n, k, 1); }
+    EXPECT(cap_op_gemm_skinny_i8_slices(2560, 2560, 1) == 1 && cap_op_gemm_skinny_i8_slices(2560, 10240, 0) >= 1);
+    EXPECT(cap_op_gemm_skinny_i8_slices(40, 2560, 1) == 0);                                   /* N % 32 */
+    EXPECT(cap_op_quant_i8_pack(w, w, w, 20, 64, NULL) != 0 && strstr(cap_last_error(), "quant_i8_pack"));   /* rows % 16 */
+    EXPECT(cap_op_quant_i8_pack(w, w, w, 32, 100, NULL) != 0);                                /* cols % 64 */
+    EXPECT(cap_op_gemm_skinny_i8(w, w, w, NULL, 0, w, NULL, 4, 40, 256, NULL) != 0 && strstr(cap_last_error(), "gemm_skinny_i8"));
+    EXPECT(cap_op_gemm_skinny_i8(w, w, w, NULL, 0, w, NULL, 0, 256, 256, NULL) != 0);          /* no rows */
+    EXPECT(cap_op_gemm_skinny_i8(w, w, w, NULL, 0, NULL, NULL, 4, 256, 256, NULL) != 0);       /* neither output */
     printf(failures ? "asan host check: %d FAILED\n" : "asan host check: all calls returned cleanly (%d failures)\n", failures);
     return failures ? 1 : 0;
 }
