@@ -242,10 +242,15 @@ FP32_MFMA_PEAK = 157.3                                                 # the pip
 POWER_LIMITED_MFMA = {"f32s": 1960.0}     # v_mfma_f32_16x16x32_f16, tools/mfma_power_probe.sh (measured, one box)
 
 
+VENDOR_CONTEXT = True        # main() clears it for --no-extra-modes / --lite runs (profiler passes: only the product's kernels in the trace)
+
+
 def vendor_gemm_context(batch, n_tokens, D, Mv, seconds=1.0):
     """CONTEXT ONLY - nothing in the product calls a vendor GEMM: what torch.mm (hipBLASLt / rocBLAS, AMD's tuned kernels) sustains
     on this board on the same four ViT Linear shapes with plain fp16 operands (ONE MFMA product per MAC, no bias / GELU / split
     epilogue), random normal data, the four in rotation for ~1 s.  The split kernel's `executed_tflops` is the figure beside it."""
+    if not VENDOR_CONTEXT:
+        return None
     try:
         M = batch * n_tokens
         shapes = [(3 * D, D), (D, D), (Mv, D), (D, Mv)]
@@ -931,6 +936,8 @@ def main():
     if a.stub_engine:
         return main_stub(a, dev, rank, world)
 
+    global VENDOR_CONTEXT
+    VENDOR_CONTEXT = not (a.no_extra_modes or a.no_strict or a.lite)
     arch = BlipArch()
     arch.image_size = a.image_size
     L, B = a.max_length, a.batch
