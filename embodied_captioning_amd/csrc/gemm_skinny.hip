@@ -333,6 +333,102 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_i8_kernel(SkinnyI8Params 
     }
 }
 
+// More than 32 activation rows (the prompt pass of a batch: B x 33 rows): one workgroup per unit walks ALL row groups with its
+// weight fragments converted once and kept in registers (separate workgroups per row group, the bf16 kernel's way, repeat the
+// byte -> bf16 conversion of the unit's weights for every group).  Per row the MFMA sequence and the wave-order sum are
+// gemm_skinny_i8_kernel's: the same bits whichever kernel the row count picks.
+// Measured (tools/bench_skinny_i8.py: graph replay over rotating weight copies, us per launch, int8 / bf16 kernel):
+//   rows      1            16           32           64           1056
+//   qkv     6.5 / 10.3   8.0 / 11.2   11.2 / 13.3  18.6 / 20.1  184 / 215
+//   out     4.3 /  5.6   5.4 /  6.2    7.2 /  7.1  13.4 /  9.6  111 /  64
+//   fc1     8.9 / 12.9  11.5 / 13.9   17.6 / 16.1  34.3 / 27.9  365 / 286
+//   fc2     8.5 / 13.0  11.4 / 13.7   17.5 / 15.5  33.8 / 26.9  357 / 280
+// The mode is built for the reference's call pattern (one crop per call, a few at most): up to 16 rows the byte stream is 20-35 %
+// shorter per launch; from ~32 rows on a launch is paced by the ACTIVATION fragments every workgroup pulls from L2 (32 rows x K
+// x 2 bytes per 32 weight rows: twice the weight bytes at 32 rows), which the bytes saved on W do not touch, and a batch's prompt
+// pass (1 056 rows at 32 crops) is a GEMM proper that the bf16 mode gives to the tiled kernel (gemm_pp) and this mode does not:
+// at 32 crops a generate takes 113 ms against 85.5 in bf16.  Not built: dequantising into a bf16 scratch for the tiled kernel
+// with the row scales applied to its fp32 output.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_i8_rows_kernel(SkinnyI8Params p) {
+    constexpr int TR = 32, WT = 2, XT = 2, PITCH = WT * 16 + 4, MR = XT * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int unit = blockIdx.x;
+    if (unit >= p.units) return;
+    const int nt = unit / p.S, z = unit % p.S;
+    const int n0 = nt * TR;
+    const int kw = (z * NW + wave) * p.nks * 32;
+    const int nsl = p.nks >> 1;
+    bf16x8 wf[WT][SK_MAXKS / 2][2];
+#pragma unroll
+    for (int t = 0; t < WT; ++t) {
+        const sk_u32x4* wp = (const sk_u32x4*)(p.Wp + ((size_t)(nt * WT + t) * p.nslab + (kw >> 6)) * 1024) + lane;
+#pragma unroll
+        for (int sl = 0; sl < SK_MAXKS / 2; ++sl)
+            if (sl < nsl) {
+                const sk_u32x4 q = __builtin_nontemporal_load(wp + sl * 64);
+                wf[t][sl][0] = i8x8_to_bf16(q.x, q.y);
+                wf[t][sl][1] = i8x8_to_bf16(q.z, q.w);
+            }
+    }
+    float* red = (float*)smem;
+    const f32x2 sc = *(const f32x2*)(p.wscale + n0 + (tid % (TR / 2)) * 2);
+    for (int g = 0; g < p.G; ++g) {
+        const int m0 = g * MR;
+        bf16x8 af[XT][SK_MAXKS];
+#pragma unroll
+        for (int t = 0; t < XT; ++t) {
+            const bf16_t* ap = p.A + (size_t)min(m0 + t * 16 + r16, p.M - 1) * p.lda + kw + kg * 8;
+#pragma unroll
+            for (int j = 0; j < SK_MAXKS; ++j)
+                if (j < p.nks) af[t][j] = *(const bf16x8*)(ap + j * 32);
+        }
+        f32x4 acc[WT][XT];
+#pragma unroll
+        for (int a = 0; a < WT; ++a)
+#pragma unroll
+            for (int b = 0; b < XT; ++b) acc[a][b] = f32x4(0.f);
+#pragma unroll
+        for (int sl = 0; sl < SK_MAXKS / 2; ++sl)
+            if (sl < nsl) {
+#pragma unroll
+                for (int wt = 0; wt < WT; ++wt)
+#pragma unroll
+                    for (int xt = 0; xt < XT; ++xt) {
+                        acc[wt][xt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[wt][sl][0], af[xt][2 * sl], acc[wt][xt], 0, 0, 0);
+                        acc[wt][xt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[wt][sl][1], af[xt][2 * sl + 1], acc[wt][xt], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+        for (int wt = 0; wt < WT; ++wt)
+#pragma unroll
+            for (int xt = 0; xt < XT; ++xt)
+                *(f32x4*)(red + (wave * MR + xt * 16 + r16) * PITCH + wt * 16 + 4 * kg) = acc[wt][xt];
+        __syncthreads();
+        for (int o = tid; o < MR * (TR / 2); o += NW * 64) {                 // (NW * 64 is a multiple of TR / 2: a thread's columns are fixed)
+            const int m = o / (TR / 2), n = (o % (TR / 2)) * 2;
+            f32x2 v = *(const f32x2*)(red + m * PITCH + n);
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += *(const f32x2*)(red + (w * MR + m) * PITCH + n);
+            if (m0 + m >= p.M) continue;
+            v *= sc;
+            if (p.part) {
+                *(f32x2*)(p.part + ((size_t)z * p.M + m0 + m) * p.N + n0 + n) = v;
+                continue;
+            }
+            if (p.bias) v += *(const f32x2*)(p.bias + n0 + n);
+            if (p.act == 2) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }
+            else if (p.act == 1) { v[0] = gelu_erf_fast(v[0]); v[1] = gelu_erf_fast(v[1]); }
+            bf16x2 ob;
+            ob[0] = (bf16_t)v[0]; ob[1] = (bf16_t)v[1];
+            *(bf16x2*)(p.out + (size_t)(m0 + m) * p.ldc + n0 + n) = ob;
+        }
+        __syncthreads();                                                     // the next group's tiles reuse the buffer
+    }
+}
+
 // fp32 [rows, cols] -> row scales + the fragment-ordered bytes.  One workgroup per 16-row tile: row maxima first (16 threads per
 // row), then every thread writes whole 16-byte lane pieces.  q = rint(w * (127 / absmax)) in fp32 (IEEE divide, round-half-even):
 // the arithmetic of oracle/blip2_ref.py::quantize_int8_rowwise, bit for bit.
@@ -412,8 +508,15 @@ int launch_gemm_skinny_i8(const void* A, int lda, const void* Wp, const float* w
     p.out = (bf16_t*)out; p.ldc = ldc; p.part = part; p.M = M; p.N = N; p.S = S; p.nks = K / (nw * 32 * S); p.act = act;
     const bool one = M <= 16;                             // one 16-row tile of activations per workgroup
     p.G = one ? 1 : (M + 31) / 32; p.units = (N / 32) * S;
+    int rc = 0;
+    if (p.G > 1) {                                        // several row groups: one workgroup per unit walks them all
+        constexpr int lds8 = 8 * 32 * 36 * 4, lds4 = 4 * 32 * 36 * 4;
+        if (nw == 8) hipLaunchKernelGGL(gemm_skinny_i8_rows_kernel<8>, dim3(p.units), dim3(512), lds8, s, p);
+        else hipLaunchKernelGGL(gemm_skinny_i8_rows_kernel<4>, dim3(p.units), dim3(256), lds4, s, p);
+        CAP_HIP_CHECK(hipGetLastError());
+        return S;
+    }
     const dim3 grid(((p.units + 7) / 8) * 8 * p.G);
-    int rc;
     if (nw == 8) rc = one ? skinny_i8_launch<8, 1>(p, grid, s) : skinny_i8_launch<8, 2>(p, grid, s);
     else rc = one ? skinny_i8_launch<4, 1>(p, grid, s) : skinny_i8_launch<4, 2>(p, grid, s);
     return rc == 0 ? S : rc;

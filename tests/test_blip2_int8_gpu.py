@@ -56,7 +56,7 @@ SHAPES = [(7680, 2560), (2560, 2560), (10240, 2560), (2560, 10240), (768, 256), 
 
 
 @pytest.mark.parametrize("N_,K", SHAPES)
-@pytest.mark.parametrize("M", [1, 5, 16, 17, 33, 70])
+@pytest.mark.parametrize("M", [1, 5, 16, 17, 33, 70, 1056])      # 33 .. : the kernel that walks the row groups (a prompt pass)
 def test_int8_weight_stream_gemm_against_integer_arithmetic(N_, K, M):
     Nn, lib = _lib()
     g = torch.Generator().manual_seed(N_ * 7 + K + M)
