@@ -1454,6 +1454,80 @@ __global__ __launch_bounds__(64) void generic_attention_kernel(const T* __restri
     }
 }
 
+// The same attention for ONE block of up to 64 queries without a mask (the Q-Former: 32 queries against themselves and against the
+// 257 image tokens), keys split over the four waves of a 256-thread workgroup: generic_attention_kernel walks all keys with one
+// wave per query block - 260 us per launch at 257 keys whatever the batch (a launch has B x heads such workgroups and each is one
+// wave's serial loop; BLIP-2, one crop: 1.6 ms of Q-Former cross-attention per caption).  Each wave runs the online softmax over its
+// quarter of the keys (staged wave-privately), then the four states (m, l, o) are merged: o = sum_w o_w e^(m_w - M) / sum_w l_w e^(m_w - M).
+template <typename T, int HDP, typename TO = T>
+__global__ __launch_bounds__(256) void generic_attention_kp_kernel(const T* __restrict__ q, long ldq, long qbs, const T* __restrict__ k, long ldk,
+                                                                   long kbs, const T* __restrict__ v, long ldv, long vbs, TO* __restrict__ out,
+                                                                   long ldo, long obs, int Lq, int Lk, int H, int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float kp_sm[];
+    const int bh = blockIdx.x, h = bh % H, b = bh / H;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, qi = lane;
+    const bool live = qi < Lq;
+    float* Ks = kp_sm + wave * (2 * 32 * HDP);
+    float* Vs = Ks + 32 * HDP;
+    float qv[HDP], o[HDP];
+#pragma unroll
+    for (int d = 0; d < HDP; ++d) {
+        qv[d] = (live && d < hd) ? to_f32(q[(size_t)b * qbs + (size_t)qi * ldq + h * hd + d]) * scale : 0.f;
+        o[d] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    const int per = (Lk + 3) / 4, j0 = wave * per, j1 = min(Lk, j0 + per);
+    for (int c = 0; c < per; c += 32) {                  // the same trip count in every wave: the barriers are workgroup barriers
+        const int k0 = j0 + c;
+        __syncthreads();
+        for (int i = lane; i < 32 * HDP; i += 64) {
+            const int j = i / HDP, d = i - j * HDP;
+            const bool ok = k0 + j < j1 && d < hd;
+            Ks[i] = ok ? to_f32(k[(size_t)b * kbs + (size_t)(k0 + j) * ldk + h * hd + d]) : 0.f;
+            Vs[i] = ok ? to_f32(v[(size_t)b * vbs + (size_t)(k0 + j) * ldv + h * hd + d]) : 0.f;
+        }
+        __syncthreads();
+        const int jn = min(32, j1 - k0);
+        for (int j = 0; j < jn; ++j) {
+            float sc = 0.f;
+#pragma unroll
+            for (int d = 0; d < HDP; ++d) sc = fmaf(qv[d], Ks[j * HDP + d], sc);
+            const float mn = fmaxf(m, sc);
+            const float cc = expf(m - mn), pj = expf(sc - mn);
+            l = l * cc + pj;
+#pragma unroll
+            for (int d = 0; d < HDP; ++d) o[d] = fmaf(pj, Vs[j * HDP + d], o[d] * cc);
+            m = mn;
+        }
+    }
+    __syncthreads();                                      // staging is done: the space holds the four states now
+    float* st = kp_sm + wave * ((HDP + 2) * 64);          // [HDP + 2][64 lanes]
+    st[lane] = m;
+    st[64 + lane] = l;
+#pragma unroll
+    for (int d = 0; d < HDP; ++d) st[(2 + d) * 64 + lane] = o[d];
+    __syncthreads();
+    if (!live) return;
+    float mw[4], M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { mw[w] = kp_sm[w * ((HDP + 2) * 64) + lane]; M = fmaxf(M, mw[w]); }
+    float f[4], L = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        f[w] = mw[w] == -INFINITY ? 0.f : expf(mw[w] - M);               // a wave without keys contributes nothing
+        L += kp_sm[w * ((HDP + 2) * 64) + 64 + lane] * f[w];
+    }
+    const float inv = 1.0f / L;
+    TO* orow = out + (size_t)b * obs + (size_t)qi * ldo;
+    for (int d = wave * (HDP / 4); d < (wave + 1) * (HDP / 4); ++d) {    // each wave finishes a quarter of the head's dimensions
+        if (d >= hd) break;
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc += kp_sm[w * ((HDP + 2) * 64) + (2 + d) * 64 + lane] * f[w];
+        store1(orow, h * hd + d, acc * inv);
+    }
+}
+
 // One query per (batch, head) against a short history (OPT decode step): lanes = keys for the scores, lanes = head
 // dimensions for the weighted sum; q and the probabilities pass through LDS.
 template <typename T, typename TO = T>
@@ -1947,6 +2021,22 @@ int launch_generic_attention(int dtype, const void* q, long ldq, long qbs, const
         return 0;
     }
     const int hdp = hd <= 32 ? 32 : hd <= 64 ? 64 : hd <= 96 ? 96 : 128;
+    if (causal_off < 0 && Lq <= 64 && Lk >= 16 && hdp <= 64) {        // one unmasked query block: keys over four waves (the Q-Former)
+#define CAP_GK(TT, HDP, TO)                                                                                            \
+    do {                                                                                                               \
+        constexpr int lds = ((4 * 2 * 32 * HDP) > (4 * (HDP + 2) * 64) ? (4 * 2 * 32 * HDP) : (4 * (HDP + 2) * 64)) * 4;   \
+        auto kk = generic_attention_kp_kernel<TT, HDP, TO>;                                                             \
+        if (cap_kernel_setup((const void*)kk, lds, nullptr) != 0) return -1;                                            \
+        hipLaunchKernelGGL(kk, dim3(B * H), dim3(256), lds, s, (const TT*)q, ldq, qbs, (const TT*)k, ldk, kbs, (const TT*)v, ldv, vbs, \
+                           (TO*)out, ldo, obs, Lq, Lk, H, hd, scale);                                                   \
+    } while (0)
+#define CAP_GK_T(TT, TO) do { if (hdp == 32) CAP_GK(TT, 32, TO); else CAP_GK(TT, 64, TO); } while (0)
+        if (dtype == CAP_DT_BF16) CAP_GK_T(bf16_t, bf16_t); else if (g8o) CAP_GK_T(float, g8_t); else CAP_GK_T(float, float);
+#undef CAP_GK_T
+#undef CAP_GK
+        CAP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const dim3 grid(B * H * ((Lq + 63) / 64));
 #define CAP_GA(TT, HDP, TO)                                                                                            \
     hipLaunchKernelGGL((generic_attention_kernel<TT, HDP, TO>), grid, dim3(64), 0, s, (const TT*)q, ldq, qbs, (const TT*)k, ldk, \
