@@ -627,7 +627,7 @@ def main_blip2(a):
     if not a.no_cpu_baseline:
         from oracle import blip2_ref as R
         torch.set_num_threads(host_cores())
-        n = 2
+        n = min(2, B)
         t0 = time.perf_counter()
         ref = R.greedy_generate(R.int8_state_dict(sd) if q8 else sd, arch, px[:n].cpu())
         cdt = time.perf_counter() - t0
