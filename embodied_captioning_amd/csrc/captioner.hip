@@ -87,6 +87,12 @@ struct QLayer {            // BLIP-2 Q-Former layer (queries only): self-attenti
     float *b_qkv = nullptr, *b_so = nullptr, *so_g = nullptr, *so_b = nullptr, *b_cq = nullptr, *b_ckv = nullptr, *b_co = nullptr,
           *co_g = nullptr, *co_b = nullptr, *b_f1 = nullptr, *b_f2 = nullptr, *f_g = nullptr, *f_b = nullptr;
 };
+// int8 weights: up to this many crops per call the prompt pass (crops x 33 rows) runs on the weight-streaming kernels like a decode
+// step; beyond, it is a GEMM proper and goes to the tiled kernels (run_opt).  Within each range a crop's bits do not depend on the
+// batch it is in; across the two the prompt's sums are formed in a different order (fp32-rounding-level differences before the bf16
+// roundings).
+constexpr int kI8SkinnyPromptCrops = 4;
+
 struct OLayer {            // OPT decoder layer (pre-LN): fused q|k|v, out_proj, fc1 (ReLU), fc2; K/V caches [B][Lmax][T]
     void *w_qkv, *w_o, *w_f1, *w_f2, *kc, *vc;
     float *s_qkv = nullptr, *s_o = nullptr, *s_f1 = nullptr, *s_f2 = nullptr;   // CapConfig.weight_int8: row scales of the int8 weights
@@ -176,6 +182,7 @@ struct Captioner {
     std::vector<QLayer> ql;
     std::vector<OLayer> ol;
     bool wq8 = false;            // CapConfig.weight_int8: the OPT decoder's Linear weights are row-quantised int8 (gemm_skinny.hip)
+    void* w8_scratch = nullptr;  // one weight matrix as row-major bf16 integers: the prompt pass of more than kI8SkinnyPromptCrops crops
     float *q_x0 = nullptr, *b_lproj = nullptr, *o_tok = nullptr, *o_pos = nullptr, *o_lnf_g = nullptr, *o_lnf_b = nullptr;
     void *w_lproj = nullptr, *o_tok_t = nullptr;
     float *qx = nullptr, *qy = nullptr, *lm_proj = nullptr, *ox = nullptr;      // activations
@@ -716,7 +723,11 @@ int build_blip2(Captioner* m) {
         size_t dpart_bytes = (size_t)8 * Bm * std::max(3 * T, G) * 4;                     // split-K slabs of the decode-step GEMMs
         if (m->wq8) {                                   // int8 weights: the prompt pass runs the same chain over Bm * P rows
             const size_t Sm = (size_t)std::max(skinny_i8_plan(T, T, false), skinny_i8_plan(T, G, false));
-            dpart_bytes = std::max(dpart_bytes, Sm * Bm * P * T * 4);
+            dpart_bytes = std::max(dpart_bytes, Sm * std::min<size_t>(Bm, kI8SkinnyPromptCrops) * P * T * 4);
+            if (Bm > (size_t)kI8SkinnyPromptCrops) {    // larger batches: the tiled GEMM's fp32 output [Bm * P, N] + the bf16 scratch
+                dpart_bytes = std::max(dpart_bytes, Bm * P * (size_t)std::max(3 * T, G) * 4);
+                TRY(dev_alloc(m, &m->w8_scratch, (size_t)std::max(3 * T, G) * T * 2));
+            }
         }
         TRY(dev_alloc(m, (void**)&m->dpart, dpart_bytes));
     }
@@ -776,6 +787,40 @@ int run_opt(Captioner* m, int B, int L, int past, hipStream_t s) {
     const int Lmax = c.num_query_tokens + 1 + c.max_len;
     const size_t e = m->esz;
     const int af = m->gdt == CAP_DT_G8 ? 1 : 0;     // split mode: q | k | v for the attention kernels and the caches are fp32
+    if (m->wq8 && B > kI8SkinnyPromptCrops) {
+        // int8 weights, a batch's prompt pass: B x 33 rows is a GEMM proper.  Each weight matrix is unpacked into a row-major bf16
+        // scratch of its INTEGERS (exact), multiplied by the tiled kernel into fp32, the row scales applied to that output, and the
+        // decode step's consumers (S = 1) finish it: (A . q^T) * scale + bias as in the weight-streaming kernels, the sums in the
+        // tiled kernel's order.  Measured at 32 crops (us per fc1 GEMM): 365 on the rows-walking weight-stream kernel, ~135 here.
+        auto tiled = [&](const char* tag, const void* A, const void* Wp, const float* wscale, int N, int K) -> int {
+            TRY(launch_dequant_i8_rowmajor(Wp, m->w8_scratch, N, K, s));
+            TRY(gemm(m, s, tag, A, K, m->w8_scratch, K, m->dpart, N, nullptr, nullptr, R, N, K, 0, 1));
+            return launch_scale_cols(m->dpart, wscale, R, N, s);
+        };
+        TRY(launch_layernorm(m->gdt, m->ox, T, m->ol[0].ln1_g, m->ol[0].ln1_b, c.t_eps, m->oh_t, nullptr, R, T, s));
+        for (int i = 0; i < c.t_layers; ++i) {
+            const OLayer& Ly = m->ol[i];
+            TRY(tiled("opt_gemm_qkv", m->oh_t, Ly.w_qkv, Ly.s_qkv, 3 * T, T));
+            TRY(launch_reduce_bias_act(m->dt, m->dpart, 1, Ly.b_qkv, m->oqkv, R, 3 * T, 0, s));
+            TRY(launch_kv_append(m->dt, m->oqkv, Ly.kc, Ly.vc, B, L, T, Lmax, past, s));
+            {
+                ProfScope ps(m, s, "opt_attn", 4.0 * B * H * (double)L * (past + L) * hd, 2.0 * B * (past + L) * T * e);
+                if (past == 0) TRY(launch_vit_attention(m->dt, m->oqkv, m->octx, B, L, H, 0, s, hd, 1, m->gdt));
+                else TRY(launch_generic_attention(m->dt, m->oqkv, 3 * T, (long)L * 3 * T, Ly.kc, T, (long)Lmax * T, Ly.vc, T, (long)Lmax * T, m->octx, T,
+                                                  (long)L * T, B, L, past + L, H, hd, past, s, m->gdt));
+            }
+            TRY(tiled("opt_gemm_o", m->octx, Ly.w_o, Ly.s_o, T, T));
+            TRY(launch_reduce_layernorm(m->gdt, m->dpart, 1, Ly.b_o, m->ox, Ly.ln2_g, Ly.ln2_b, c.t_eps, m->oh_t, nullptr, m->ox, R, T, s, true));
+            TRY(tiled("opt_gemm_f1", m->oh_t, Ly.w_f1, Ly.s_f1, G, T));
+            TRY(launch_reduce_bias_act(m->gdt, m->dpart, 1, Ly.b_f1, m->off, R, G, 2, s));
+            const bool last = i + 1 == c.t_layers;
+            TRY(tiled("opt_gemm_f2", m->off, Ly.w_f2, Ly.s_f2, T, G));
+            TRY(launch_reduce_layernorm(m->gdt, m->dpart, 1, Ly.b_f2, m->ox, last ? m->o_lnf_g : m->ol[i + 1].ln1_g,
+                                        last ? m->o_lnf_b : m->ol[i + 1].ln1_b, c.t_eps, m->oh_t, nullptr, m->ox, R, T, s, true));
+        }
+        return gemm(m, s, "opt_gemm_vocab", (const char*)m->oh_t + (size_t)(L - 1) * T * e, L * T, m->o_tok_t, T, m->logits, m->ldl, nullptr, nullptr, B,
+                    c.vocab, T, 0, 1);
+    }
     if (m->wq8) {
         // int8 weights: the prompt's rows go through the decode step's chain (the weight-streaming GEMMs take any row count: further
         // row groups re-read a unit's bytes from the XCD's L2; out_proj / fc2 as slice sums finished by the reduce + LayerNorm

@@ -14,6 +14,8 @@
 #include "ops.h"
 #include <stdlib.h>
 
+#include <algorithm>
+
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -345,10 +347,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_i8_kernel(SkinnyI8Params 
 //   fc2     8.5 / 13.0  11.4 / 13.7   17.5 / 15.5  33.8 / 26.9  357 / 280
 // The mode is built for the reference's call pattern (one crop per call, a few at most): up to 16 rows the byte stream is 20-35 %
 // shorter per launch; from ~32 rows on a launch is paced by the ACTIVATION fragments every workgroup pulls from L2 (32 rows x K
-// x 2 bytes per 32 weight rows: twice the weight bytes at 32 rows), which the bytes saved on W do not touch, and a batch's prompt
-// pass (1 056 rows at 32 crops) is a GEMM proper that the bf16 mode gives to the tiled kernel (gemm_pp) and this mode does not:
-// at 32 crops a generate takes 113 ms against 85.5 in bf16.  Not built: dequantising into a bf16 scratch for the tiled kernel
-// with the row scales applied to its fp32 output.
+// x 2 bytes per 32 weight rows: twice the weight bytes at 32 rows), which the bytes saved on W do not touch.  A batch's prompt
+// pass (1 056 rows at 32 crops) is a GEMM proper: beyond 4 crops per call run_opt unpacks each matrix into a bf16 scratch of the
+// exact integers (dequant_i8_rowmajor_kernel) for the tiled kernel and applies the row scales to its fp32 output
+// (scale_cols_kernel): ms per generate, int8 / bf16, by crops per call: 1: 44.0 / 52.7, 4: 49.9 / 55.4, 8: 55.4 / 59.6 (58.3 with this
+// kernel for the prompt), 32: 91.3 / 85.5 (113).
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_i8_rows_kernel(SkinnyI8Params p) {
     constexpr int TR = 32, WT = 2, XT = 2, PITCH = WT * 16 + 4, MR = XT * 16;
@@ -468,6 +471,30 @@ __global__ __launch_bounds__(256) void quant_i8_pack_kernel(const float* __restr
     }
 }
 
+// The fragment-ordered bytes back as a row-major bf16 matrix of the INTEGERS (exact in bf16), for the tiled GEMM: a batch's prompt
+// pass is a GEMM proper (B x 33 rows), and every workgroup of the weight-streaming kernels pulls all of A through its own L2 port.
+__global__ __launch_bounds__(256) void dequant_i8_rowmajor_kernel(const unsigned char* __restrict__ src, bf16_t* __restrict__ dst, int cols, size_t nblk) {
+    const int nslab = cols >> 6, lane = threadIdx.x & 63;
+    for (size_t blk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nblk; blk += (size_t)gridDim.x * 4) {
+        const size_t t = blk / nslab;
+        const int sl = (int)(blk - t * nslab), r = lane & 15, g = lane >> 4;
+        const sk_u32x4 q = *((const sk_u32x4*)(src + blk * 1024) + lane);
+        bf16_t* o = dst + (t * 16 + r) * (size_t)cols + sl * 64 + g * 8;
+        *(bf16x8*)o = i8x8_to_bf16(q.x, q.y);
+        *(bf16x8*)(o + 32) = i8x8_to_bf16(q.z, q.w);
+    }
+}
+
+// part[m][n] *= scale[n]: the row scales of the int8 weights on the tiled GEMM's fp32 output (its epilogue has no such operand)
+__global__ __launch_bounds__(256) void scale_cols_kernel(float* __restrict__ part, const float* __restrict__ scale, size_t n4, int N) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % N);
+        f32x4 v = *((f32x4*)part + i);
+        v *= *(const f32x4*)(scale + c);
+        *((f32x4*)part + i) = v;
+    }
+}
+
 template <int NW, int XT>
 int skinny_i8_launch(const SkinnyI8Params& p, dim3 grid, hipStream_t s) {
     constexpr int lds = NW * XT * 16 * (2 * 16 + 4) * 4;
@@ -491,6 +518,23 @@ int skinny_i8_plan(int N, int K, bool finished, int* nw_out) {
 int launch_quant_i8_pack(const float* src, void* dst, float* scale, int rows, int cols, hipStream_t s) {
     if (rows % 16 != 0 || cols % 64 != 0) { cap_set_error("quant_i8_pack: rows %% 16 / cols %% 64 (%d x %d)", rows, cols); return -1; }
     hipLaunchKernelGGL(quant_i8_pack_kernel, dim3(rows / 16), dim3(256), 0, s, src, (unsigned char*)dst, scale, cols);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_dequant_i8_rowmajor(const void* packed, void* dst_bf16, int rows, int cols, hipStream_t s) {
+    if (rows % 16 != 0 || cols % 64 != 0) { cap_set_error("dequant_i8: rows %% 16 / cols %% 64 (%d x %d)", rows, cols); return -1; }
+    const size_t nblk = (size_t)(rows / 16) * (cols / 64);
+    hipLaunchKernelGGL(dequant_i8_rowmajor_kernel, dim3((unsigned)std::min<size_t>((nblk + 3) / 4, 4096)), dim3(256), 0, s, (const unsigned char*)packed,
+                       (bf16_t*)dst_bf16, cols, nblk);
+    CAP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_scale_cols(float* part, const float* scale, int M, int N, hipStream_t s) {
+    if (N % 4 != 0) { cap_set_error("scale_cols: N %% 4"); return -1; }
+    const size_t n4 = (size_t)M * N / 4;
+    hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, s, part, scale, n4, N);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }

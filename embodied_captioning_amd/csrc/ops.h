@@ -127,6 +127,9 @@ int skinny_i8_plan(int N, int K, bool finished, int* nw_out = nullptr);
 int launch_quant_i8_pack(const float* src, void* dst, float* scale, int rows, int cols, hipStream_t s);
 int launch_gemm_skinny_i8(const void* A, int lda, const void* Wp, const float* wscale, const float* bias, int act, void* out, int ldc,
                           float* part, int M, int N, int K, hipStream_t s);
+// the bytes as a row-major bf16 matrix of the integers (for the tiled GEMM) and part[m][n] *= scale[n] on its fp32 output
+int launch_dequant_i8_rowmajor(const void* packed, void* dst_bf16, int rows, int cols, hipStream_t s);
+int launch_scale_cols(float* part, const float* scale, int M, int N, hipStream_t s);
 
 // ---- preprocess.hip ----------------------------------------------------------------------------
 // n boxes of one uint8 HWC frame -> out uint8 [n, S, S, 3] RGB, bit-exact with Pillow's crop + BICUBIC resize.
