@@ -256,10 +256,13 @@ __device__ __forceinline__ bf16x8 i8x8_to_bf16(unsigned lo, unsigned hi) {
     return w;
 }
 
-// XT = 16-row tiles of activations per workgroup (1: up to 16 rows per group - the one-crop decode step; 2: 32)
-template <int NW, int XT>
+// XT = 16-row tiles of activations per workgroup (1: up to 16 rows per group - the one-crop decode step; 2: 32); WT = 16-row tiles
+// of WEIGHT rows per workgroup: 2, or 4 for 17-32 activation rows - every workgroup pulls the whole activation block (rows x K x 2
+// bytes) through its L2 port, at 32 rows twice its 32 weight rows' bytes: 64 weight rows per workgroup halve that traffic (fc1 at
+// 32 rows: 17.6 -> 12.9 us; the launcher says where).  An output element's MFMA sequence and wave-order sum are the same in every variant: same bits.
+template <int NW, int XT, int WT>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_i8_kernel(SkinnyI8Params p) {
-    constexpr int TR = 32, WT = 2, PITCH = WT * 16 + 4, MR = XT * 16;
+    constexpr int TR = 16 * WT, PITCH = WT * 16 + 4, MR = XT * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -343,15 +346,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_i8_kernel(SkinnyI8Params 
 //   rows      1            16           32           64           1056
 //   qkv     6.5 / 10.3   8.0 / 11.2   11.2 / 13.3  18.6 / 20.1  184 / 215
 //   out     4.3 /  5.6   5.4 /  6.2    7.2 /  7.1  13.4 /  9.6  111 /  64
-//   fc1     8.9 / 12.9  11.5 / 13.9   17.6 / 16.1  34.3 / 27.9  365 / 286
-//   fc2     8.5 / 13.0  11.4 / 13.7   17.5 / 15.5  33.8 / 26.9  357 / 280
+//   fc1     8.9 / 12.9  11.5 / 13.9   12.9 / 16.1  34.3 / 27.9  365 / 286      (32 rows: 17.6 / 17.5 with 32 weight rows per workgroup)
+//   fc2     8.5 / 13.0  11.4 / 13.7   12.7 / 15.5  33.8 / 26.9  357 / 280
 // The mode is built for the reference's call pattern (one crop per call, a few at most): up to 16 rows the byte stream is 20-35 %
 // shorter per launch; from ~32 rows on a launch is paced by the ACTIVATION fragments every workgroup pulls from L2 (32 rows x K
 // x 2 bytes per 32 weight rows: twice the weight bytes at 32 rows), which the bytes saved on W do not touch.  A batch's prompt
 // pass (1 056 rows at 32 crops) is a GEMM proper: beyond 4 crops per call run_opt unpacks each matrix into a bf16 scratch of the
 // exact integers (dequant_i8_rowmajor_kernel) for the tiled kernel and applies the row scales to its fp32 output
 // (scale_cols_kernel): ms per generate, int8 / bf16, by crops per call: 1: 44.0 / 52.7, 4: 49.9 / 55.4, 8: 55.4 / 59.6 (58.3 with this
-// kernel for the prompt), 32: 91.3 / 85.5 (113).
+// kernel for the prompt), 16: 66.9 / 67.8, 32: 83.9 / 85.5 (113; 91.3 before the 64-weight-row form of the 17-32 row steps).
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_i8_rows_kernel(SkinnyI8Params p) {
     constexpr int TR = 32, WT = 2, XT = 2, PITCH = WT * 16 + 4, MR = XT * 16;
@@ -495,10 +498,10 @@ __global__ __launch_bounds__(256) void scale_cols_kernel(float* __restrict__ par
     }
 }
 
-template <int NW, int XT>
+template <int NW, int XT, int WT = 2>
 int skinny_i8_launch(const SkinnyI8Params& p, dim3 grid, hipStream_t s) {
-    constexpr int lds = NW * XT * 16 * (2 * 16 + 4) * 4;
-    hipLaunchKernelGGL((gemm_skinny_i8_kernel<NW, XT>), grid, dim3(NW * 64), lds, s, p);
+    constexpr int lds = NW * XT * 16 * (WT * 16 + 4) * 4;
+    hipLaunchKernelGGL((gemm_skinny_i8_kernel<NW, XT, WT>), grid, dim3(NW * 64), lds, s, p);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -559,6 +562,15 @@ int launch_gemm_skinny_i8(const void* A, int lda, const void* Wp, const float* w
         else hipLaunchKernelGGL(gemm_skinny_i8_rows_kernel<4>, dim3(p.units), dim3(256), lds4, s, p);
         CAP_HIP_CHECK(hipGetLastError());
         return S;
+    }
+    // 17-32 rows: 64 weight rows per workgroup (half the activation traffic) where that still leaves a workgroup for most CUs
+    // (tools/bench_skinny_i8.py, 32 rows, us per launch, 32 / 64 weight rows: fc1 17.6 / 12.9, fc2 17.5 / 12.7 - 160 workgroups;
+    // qkv 11.2 / 12.4 - 120, out_proj 7.2 / 8.5 - 80: those keep 32)
+    if (!one && N % 64 == 0 && (N / 64) * S >= 160) {
+        p.units = (N / 64) * S;
+        const dim3 grid4(((p.units + 7) / 8) * 8);
+        rc = nw == 8 ? skinny_i8_launch<8, 2, 4>(p, grid4, s) : skinny_i8_launch<4, 2, 4>(p, grid4, s);
+        return rc == 0 ? S : rc;
     }
     const dim3 grid(((p.units + 7) / 8) * 8 * p.G);
     if (nw == 8) rc = one ? skinny_i8_launch<8, 1>(p, grid, s) : skinny_i8_launch<8, 2>(p, grid, s);
