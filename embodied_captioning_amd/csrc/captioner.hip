@@ -1213,7 +1213,7 @@ int gemm_splitk_reduce_ln(Captioner* m, hipStream_t s, const Dec& d, const char*
         ProfScope ps(m, s, tag, 2.0 * d.R * N * K, ((double)d.R * K + (double)N * K) * m->esz + (double)S * d.R * N * 4);
         TRY(launch_gemm(m->gdt, p, decode_tile(m), s));
     }
-    const bool per_row_block = d.R < 832 || N > 1024;
+    const bool per_row_block = d.R < (d.map.n ? 512 : 832) || N > 1024;
     ProfScope ps(m, s, per_row_block ? "dec_reduce_ln" : "dec_reduce_ln_wave", 0, (double)(S + 2) * d.R * N * 4 + (double)d.R * N * m->esz);
     // one 256-thread block per row up to several hundred rows (one memory round trip, latency-bound); at the pool's 1 024-row
     // passes the wave-per-row kernel.  Launches replayed from a captured graph (tools/bench_reduce_ln.py, us per launch, block / wave,
@@ -1221,7 +1221,10 @@ int gemm_splitk_reduce_ln(Captioner* m, hipStream_t s, const Dec& d, const char*
     // 6.6, 768 6.6 / 6.7 | 6.4 / 6.8, 896 7.6 / 7.0 | 7.3 / 7.0, 1 024 7.8 / 7.4 | 7.4 / 7.2: the crossing is between 768 and 896 (round 5
     // had put it at 512 from the 1 024-row figure alone, which cost config 5 ~4 % - dec_reduce_ln 17.6 -> 22.3 ms per step).  Same sums in
     // the same order - the two kernels give the same bits (tests/test_kernels_gpu.py::test_reduce_layernorm_kernels_agree_bit_for_bit),
-    // so the row count may choose.
+    // so the row count may choose.  In the COMPACTED greedy loop (d.map: rows beyond the live count return at once) the wave kernel
+    // keeps its round-5 threshold of 512 rows: a dead row costs it one wave's dispatch instead of four, and most steps of a 768-row
+    // pass have far fewer live rows than that - same box, `bench.py --lite`, three interleaved pairs, 512 / 832: 6 476 / 6 460, 6 511 /
+    // 6 476, 6 525 / 6 491 captions/s (+0.4 %).
     return launch_reduce_layernorm(m->gdt, d.dpart, S, bias, resid ? resid : d.dx, g, b, eps, out_t, out_f, y_out, d.R, N, s, per_row_block, false, d.map.n);
 }
 

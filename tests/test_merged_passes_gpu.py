@@ -27,7 +27,7 @@ def _tags_of_one_generate(eng, px, L):
 def test_merged_1024_row_passes_are_the_golden_and_the_unmerged_bits():
     """One EnginePool(max_batch=1024): 4 x the 256 golden frames merged into passes of up to 1024 rows, and a ragged 256 + 512 +
     256 - every batch token-identical to the HF golden AND equal (sequences, lengths) to the call with every batch its own pass;
-    the large-pass split-K consumer (wave per row, from 832 rows on) is the kernel a 1024-row pass runs."""
+    the large-pass split-K consumer (wave per row: from 512 rows on in the compacted loop, 832 otherwise) is the kernel a 1024-row pass runs."""
     from embodied_captioning_amd.engine import EnginePool
     g, meta, arch, sd, px = golden_inputs("blip_base256")
     B, L = meta["batch"], meta["max_length"]
@@ -108,7 +108,8 @@ def test_one_1024_row_generate_matches_the_golden(cross_cache):
 
 def test_tiny_arch_rows_alone_and_inside_an_860_row_pass_same_tokens_and_logits():
     """Across the consumer kernels' row-count threshold on the fixture-sized architecture: the same 24 frames generated alone (block
-    per row) and inside a pass of 860 rows (wave per row: from 832 rows on) - tokens AND per-step logits `torch.equal`."""
+    per row) and inside a pass of 860 rows (wave per row: per-step logits switch the compaction off, so from 832 rows on) - tokens AND
+    per-step logits `torch.equal`."""
     from embodied_captioning_amd.engine import CaptionerEngine
     from embodied_captioning_amd.weights import synthetic_pixels
     g, meta, arch, sd, px = golden_inputs("blip_tiny")
