@@ -24,8 +24,10 @@
  *                       is fed pad tokens; `unfinished_sequences.max() == 0` ends the loop)  rows only), cap_set_early_exit
  *   batches of crops    detector/pseudolabeler.py:664-711, scripts/run_pseudolabeler.py:77-107  cap_create_shared (n engines on one
  *                       (one generate per crop; here: micro-batches merged into passes)          weight store: engine.EnginePool)
- *   load options        blip2.py:19-22 `load_in_8bit=True, torch_dtype=float16`;       CapConfig.compute_dtype,
- *                       evaluate_finetuned_model.py:147-148 `PeftModel.from_pretrained`  CapConfig.cross_kv_fp32 (host side:
+ *   load options        blip2.py:19-22 `load_in_8bit=True, torch_dtype=float16`;       CapConfig.weight_int8 (int8 Linear weights as
+ *                       evaluate_finetuned_model.py:147-148 `PeftModel.from_pretrained`  bitsandbytes stores them, quantised by
+ *                                                                                      cap_load_weight), CapConfig.compute_dtype,
+ *                                                                                      CapConfig.cross_kv_fp32 (host side:
  *                                                                                      weights.merge_peft_lora)
  *   device move/free    predictor_utils.py:187 `.to(...)`; object lifetime            cap_destroy
  *   errors              Python exceptions (utils_captioner.py:6, factory.py:231,309)  int return codes + cap_last_error
