@@ -78,3 +78,28 @@ def test_int8_quantiser_host_form_is_the_restatement_and_names_match():
     assert host | {k for k in R.int8_linear_names(sd) if k.startswith(lm)} == set(R.int8_linear_names(sd))
     assert not any(k.startswith(("qformer.", "language_model.lm_head", lm)) for k in host)
     assert len(host) == 4 * a.v_layers + 1
+
+
+def test_int8_quantiser_properties():
+    """Size-independent properties of the row-wise int8 quantiser (product's host form = the restatement): |q| <= 127 with the row's
+    largest element at +-127, |w - q s| <= s / 2, zero rows -> zeros, and quantising the dequantised weights gives the same bytes back."""
+    from hypothesis import given, settings, strategies as st
+    from embodied_captioning_amd.weights import quantize_int8_rowwise
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(1, 24), st.integers(1, 96), st.integers(0, 2 ** 31 - 1), st.sampled_from([1e-6, 1e-3, 0.03, 1.0, 40.0]))
+    def prop(rows, cols, seed, scale):
+        g = torch.Generator().manual_seed(seed)
+        w = torch.randn(rows, cols, generator=g) * scale
+        if rows > 2:
+            w[1] = 0.0
+        q, s = quantize_int8_rowwise(w)
+        q2, s2 = R.quantize_int8_rowwise(w)
+        assert torch.equal(q, q2) and torch.equal(s, s2)
+        assert int(q.abs().max()) <= 127
+        nz = w.abs().amax(1) > 0
+        assert (q[nz].abs().amax(1) == 127).all() and (q[~nz] == 0).all() and (s[~nz] == 0).all()
+        assert ((w - q.float() * s[:, None]).abs() <= s[:, None] * 0.5 * (1 + 1e-5) + 1e-30).all()
+        q3, _ = quantize_int8_rowwise(q.float() * s[:, None])
+        assert torch.equal(q3, q)
+    prop()
