@@ -82,9 +82,10 @@ def parse():
     ap.add_argument("--beams", type=int, default=1, help="> 1: extra line for SURVEY config 3 (HF beam search; use --batch 64)")
     ap.add_argument("--streams", type=int, default=3, help="blip: engines (own arena + HIP stream each) the timed steps rotate "
                     "over, so that consecutive batches overlap; 1 = one engine, one stream (the profiling passes always use one)")
-    ap.add_argument("--coalesce-rows", type=int, default=1024, help="blip: dynamic batching of the engine pool - consecutive steps' batches "
-                    "are merged into passes of at most this many rows (EnginePool.generate_many(coalesce_rows=)); a frame has the same "
-                    "bits alone, in its batch and in a merged pass; 0 = every batch its own pass (the `pool_uncoalesced` key)")
+    ap.add_argument("--coalesce-rows", type=int, default=None, help="blip / coca: dynamic batching of the engine pool - consecutive steps' batches "
+                    "are merged into passes of at most this many rows (images, for coca) (EnginePool.generate_many(coalesce_rows=)); a frame "
+                    "has the same bits alone, in its batch and in a merged pass; 0 = every batch its own pass (the `pool_uncoalesced` key).  "
+                    "Default: 1024 (blip), 4 batches up to 512 images (coca: the wrapper's default)")
     ap.add_argument("--early-exit", type=int, default=0, help="poll the device every N decode steps and leave the loop when "
                     "every caption is finished (HF's stopping rule; 0 = never, the default: no host sync in generate)")
     ap.add_argument("--eos-boost", type=float, default=9.0, help="blip: EOS logit offset of the procedural weights (9 = the "
@@ -529,10 +530,13 @@ def main_coca(a):
     eng = CaptionerEngine(arch, dtype=a.dtype, max_batch=B, max_beams=K, max_len=arch.seq_len)
     eng.load_state_dict(sd)
     pool = None
+    # dynamic batching of the pool (as for BLIP): --coalesce-rows counts IMAGES per merged pass here (each image is K beam rows)
+    cr = min(4 * B, 512) if a.coalesce_rows is None else a.coalesce_rows
+    coal = cr if (a.streams > 1 and cr > B) else 0
     if a.streams > 1:
         from embodied_captioning_amd.engine import EnginePool
-        pool = EnginePool(arch, n=a.streams, dtype=a.dtype, max_batch=B, max_beams=K, max_len=arch.seq_len, weights_of=eng)
-    dt, _ = timed_steps(pool or eng, px, arch.seq_len, a.steps, a.warmup, 1, lambda i, l: (i, l), K)
+        pool = EnginePool(arch, n=a.streams, dtype=a.dtype, max_batch=max(B, coal), max_beams=K, max_len=arch.seq_len, weights_of=eng)
+    dt, _ = timed_steps(pool or eng, px, arch.seq_len, a.steps, a.warmup, 1, lambda i, l: (i, l), K, coalesce=coal)
     if pool is not None:
         pool.close()
     eng.profile(True)
@@ -548,7 +552,7 @@ def main_coca(a):
             "higher_is_better": True, "dtype": a.dtype, "data": "synthetic frames, procedural weights",
             "config": {"workload": f"CoCa ViT-L/14 encoder + attentional pooler + 29 KV-cached decode steps x {K} beam(s), {B} frames "
                                    "(SURVEY config 5's model and decode on ONE GPU; parity of this path is unpinned - DESIGN.md section 2)",
-                       "streams": a.streams, "beams": K},
+                       "streams": a.streams, "beams": K, "coalesce_images": coal},
             "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel (ViT-L qkv/proj/fc1/fc2)",
                          "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
                          "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_TFLOPS[a.dtype], 4), "traffic": None},
@@ -928,6 +932,8 @@ def main():
     a = parse()
     if a.dtype is None:
         a.dtype = {"blip": "f32s", "blip2": "f32s", "coca": "bf16", "minilm": "bf16"}[a.model]
+    if a.coalesce_rows is None and a.model != "coca":
+        a.coalesce_rows = 1024
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -296,3 +296,48 @@ def test_coca_wrapper_beam_groups_and_bpe_text(tmp_path):
         body = [t for t in row[:n] if t not in (a.sot, a.eos)]
         assert text == model.bpe.decode(body)            # cut at <end_of_text>, <start_of_text> dropped (coca.py:30)
         assert "<start_of_text>" not in text and "<end_of_text>" not in text and len(text) >= len(body)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32s"])
+def test_coca_pool_dynamic_batching_returns_the_unmerged_bits(dtype):
+    """The engine pool's dynamic batching on CoCa (config 5's mode in bench.py --model coca --coalesce-rows N): consecutive image batches
+    merged into larger passes and split back - every image's beams are its own and every kernel's sums are batch-independent, so
+    sequences, lengths and beam scores are those of the unmerged call bit for bit; greedy (top-k 1) too."""
+    from embodied_captioning_amd.config import CocaArch
+    from embodied_captioning_amd.engine import EnginePool
+    from embodied_captioning_amd.weights import procedural_coca_state_dict, synthetic_pixels
+    a = CocaArch.tiny()
+    sd = procedural_coca_state_dict(a, 7, eos_boost=2.0)
+    px = synthetic_pixels(48, a.image_size, seed=7).cuda()
+    for K in (5, 1):
+        pool = EnginePool(a, n=3, dtype=dtype, max_batch=24, max_beams=K, max_len=a.seq_len)
+        pool.load_state_dict(sd)
+        for sizes in ([8] * 6, [4, 12, 8, 2, 6, 16]):
+            cuts = np.cumsum([0] + sizes)
+            batches = [px[i:j] for i, j in zip(cuts[:-1], cuts[1:])]
+            plain = pool.generate_many(batches, threads=True, num_beams=K, max_length=a.seq_len)
+            merged = pool.generate_many(batches, threads=True, coalesce_rows=24, num_beams=K, max_length=a.seq_len)
+            assert isinstance(pool.last_coalesce, list) and any(len(gp) > 1 for gp in pool.last_coalesce), pool.last_coalesce
+            for x, y in zip(plain, merged):
+                assert torch.equal(x["sequences"], y["sequences"]) and torch.equal(x["lengths"], y["lengths"])
+                if K > 1:
+                    assert torch.equal(x["sequences_scores"], y["sequences_scores"])
+        pool.close()
+
+
+def test_coca_wrapper_streams_and_dynamic_batching_same_captions():
+    """`captioner.streams: 3` (+ the default `coalesce_rows`) on the CoCa wrapper: generate_batch over an engine pool with merged
+    passes returns what the one-engine wrapper returns - sequences, lengths, beam scores, texts."""
+    from PIL import Image
+    from embodied_captioning_amd.captioner.utils.utils import Configuration
+    from embodied_captioning_amd.captioner.utils.utils_captioner import select_captioner
+    rng = np.random.default_rng(5)
+    ims = [Image.fromarray(rng.integers(0, 256, size=(40 + i, 52, 3), dtype=np.uint8), "RGB") for i in range(14)]
+    kw = dict(arch_name="coca", model_name="procedural-coca-tiny:2:3.0", height=224, width=224, dtype="f32s", num_beams=3, batch_size=4)
+    one = select_captioner(Configuration(**kw).captioner).eval()
+    many = select_captioner(Configuration(streams=3, **kw).captioner).eval()
+    assert many.pool is not None and many.coalesce_rows == 16
+    a, b = one.generate_batch(ims), many.generate_batch(ims)
+    assert isinstance(many.pool.last_coalesce, list) and any(len(g) > 1 for g in many.pool.last_coalesce)
+    assert torch.equal(a["sequences"], b["sequences"]) and torch.equal(a["lengths"], b["lengths"]) and a["texts"] == b["texts"]
+    assert torch.equal(a["scores"], b["scores"])
