@@ -78,7 +78,7 @@ def parse():
                     help="blip = BASELINE.json metric workload (default); coca = extra line for config 5's model "
                          "(CoCa ViT-L/14, reference top-k(1) loop, seq_len 30)")
     ap.add_argument("--load-in-8bit", action="store_true", help="blip2: the reference's load mode (blip2.py:19-22) - int8 Linear weights as "
-                    "bitsandbytes stores them, bf16 activations (forces --dtype bf16, one engine)")
+                    "bitsandbytes stores them, bf16 activations (forces --dtype bf16)")
     ap.add_argument("--beams", type=int, default=1, help="> 1: extra line for SURVEY config 3 (HF beam search; use --batch 64)")
     ap.add_argument("--streams", type=int, default=3, help="blip: engines (own arena + HIP stream each) the timed steps rotate "
                     "over, so that consecutive batches overlap; 1 = one engine, one stream (the profiling passes always use one)")
@@ -631,11 +631,14 @@ def main_blip2(a):
     px = synthetic_pixels(B, arch.image_size, seed=0).cuda()
     q8 = bool(getattr(a, "load_in_8bit", False))
     if q8:
-        a.dtype, a.streams = "bf16", 1
+        a.dtype = "bf16"
     eng = CaptionerEngine(arch, dtype=a.dtype, max_batch=B, max_beams=1, max_len=arch.max_new_tokens, weight_int8=q8)
     eng.load_state_dict(sd)
     log(f"weights loaded ({eng.device_bytes / 2**30:.1f} GiB on device); timing")
-    pool = None if q8 else pooled(a, arch, sd, max_batch=B, max_beams=1, max_len=arch.max_new_tokens)
+    pool = None
+    if a.streams > 1:                       # engines on their own streams over THIS engine's weights
+        from embodied_captioning_amd.engine import EnginePool
+        pool = EnginePool(arch, n=a.streams, dtype=a.dtype, max_batch=B, max_beams=1, max_len=arch.max_new_tokens, weights_of=eng, weight_int8=q8)
     dt, (ids, lens) = timed_steps(pool or eng, px, arch.max_new_tokens, a.steps, a.warmup, 1, lambda i, l: (i, l))
     if pool is not None:
         pool.close()

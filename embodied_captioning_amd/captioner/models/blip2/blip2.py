@@ -116,8 +116,6 @@ class BLIP2(BLIP):
         self.num_beams = 1
         self.batch_size = int(getattr(cfg, "batch_size", 8) or 8)
         dtype = "bf16" if self.load_in_8bit else getattr(cfg, "dtype", None) or "f32s"   # parity-grade default: tokens identical to HF fp32 on the golden
-        if int(getattr(cfg, "streams", 1) or 1) > 1:
-            logger.warning("captioner.streams > 1 is implemented for arch_name 'blip' only: running one engine")
         self._device = torch.device(getattr(cfg, "device", "cuda:0") or "cuda:0")
         self.tokenizer = None
         if model_dir is None:
@@ -152,6 +150,26 @@ class BLIP2(BLIP):
         self.engine.set_early_exit(4 if poll is None else int(poll))
         self.engine.load_state_dict(sd)
         self.strict_range = bool(getattr(cfg, "strict_range", False))
+        # cfg.streams > 1 (as for BLIP / CoCa): the micro-batches of one generate_batch call rotate over that many engines / HIP
+        # streams on ONE copy of the weights (engine.EnginePool) - the decoder's weight-streaming launches of independent batches fill
+        # each other's gaps (OPT-2.7b geometry, 32 frames per micro-batch, bf16: 374 captions/s on one stream, 516 on three).  The pool's
+        # dynamic batching (cfg.coalesce_rows) stays OFF unless asked for: merged passes change the batch the prompt pass sees, which
+        # in the int8 mode picks its kernel (captioner.hip::kI8SkinnyPromptCrops) - same captions to bf16 rounding noise, not the same bits.
+        self.pool = None
+        n_streams = int(getattr(cfg, "streams", 1) or 1)
+        cr = getattr(cfg, "coalesce_rows", None)
+        self.coalesce_rows = 0
+        if n_streams > 1:
+            self.coalesce_rows = max(0, int(cr)) if cr else 0
+            if self.coalesce_rows <= self.batch_size:
+                self.coalesce_rows = 0
+            from ....engine import EnginePool
+            self.pool = EnginePool(self.arch, n=n_streams, device=self._device, dtype=dtype, max_batch=max(self.batch_size, self.coalesce_rows),
+                                   max_beams=1, max_len=self.max_length, weights_of=self.engine, cross_cache=self.engine.cross_cache,
+                                   weight_int8=self.load_in_8bit)
+            self.pool.set_early_exit(4 if poll is None else int(poll))
+        elif cr:
+            logger.warning("captioner.coalesce_rows is the engine pool's dynamic batching: it needs captioner.streams > 1 - ignored")
 
     def decode(self, ids: Sequence[int]) -> str:
         if not hasattr(self.arch, "num_query_tokens"):

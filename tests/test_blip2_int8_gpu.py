@@ -222,3 +222,21 @@ def test_wrapper_load_in_8bit_through_the_factory():
     cfg = Configuration(arch_name="blip2", model_name="procedural-blip2-tiny:11:0.5", height=224, width=224, load_in_8bit=True).captioner
     with pytest.raises(Exception, match="weight_int8"):
         select_captioner(cfg)
+
+
+@pytest.mark.parametrize("q8", [False, True])
+def test_blip2_wrapper_streams_same_captions(q8):
+    """`captioner.streams: 3` on the BLIP-2 wrapper (plain and `load_in_8bit`): generate_batch over the engine pool returns the one-engine
+    wrapper's sequences, lengths and texts (every micro-batch is computed by exactly the kernels of a single engine)."""
+    from PIL import Image
+    from embodied_captioning_amd.captioner.utils.utils import Configuration
+    from embodied_captioning_amd.captioner.utils.utils_captioner import select_captioner
+    rng = np.random.default_rng(9)
+    ims = [Image.fromarray(rng.integers(0, 256, size=(44 + i, 60, 3), dtype=np.uint8), "RGB") for i in range(11)]
+    kw = dict(arch_name="blip2", model_name="procedural-blip2-small:4:0.4", height=224, width=224, batch_size=3)
+    kw.update(dict(load_in_8bit=True) if q8 else dict(dtype="f32s"))
+    one = select_captioner(Configuration(**kw).captioner).eval()
+    many = select_captioner(Configuration(streams=3, **kw).captioner).eval()
+    assert many.pool is not None and len(many.pool) == 3 and many.coalesce_rows == 0 and many.pool.engines[0].weight_int8 == q8
+    a, b = one.generate_batch(ims), many.generate_batch(ims)
+    assert torch.equal(a["sequences"], b["sequences"]) and torch.equal(a["lengths"], b["lengths"]) and a["texts"] == b["texts"]
