@@ -639,7 +639,13 @@ def main_blip2(a):
     if a.streams > 1:                       # engines on their own streams over THIS engine's weights
         from embodied_captioning_amd.engine import EnginePool
         pool = EnginePool(arch, n=a.streams, dtype=a.dtype, max_batch=B, max_beams=1, max_len=arch.max_new_tokens, weights_of=eng, weight_int8=q8)
-    dt, (ids, lens) = timed_steps(pool or eng, px, arch.max_new_tokens, a.steps, a.warmup, 1, lambda i, l: (i, l))
+    # the wrapper's dynamic batching default: 4 micro-batches per pass, at most 64 crops (off for int8 micro-batches of <= 4 crops)
+    cr = (0 if (q8 and B <= 4) else min(4 * B, 64)) if a.coalesce_rows in (None, 1024) else a.coalesce_rows
+    coal = cr if (pool is not None and cr > B) else 0
+    if coal:
+        pool.close()
+        pool = EnginePool(arch, n=a.streams, dtype=a.dtype, max_batch=coal, max_beams=1, max_len=arch.max_new_tokens, weights_of=eng, weight_int8=q8)
+    dt, (ids, lens) = timed_steps(pool or eng, px, arch.max_new_tokens, a.steps, a.warmup, 1, lambda i, l: (i, l), coalesce=coal)
     if pool is not None:
         pool.close()
     eng.profile(True)
@@ -651,7 +657,7 @@ def main_blip2(a):
     line = {"metric": "captions/sec (BLIP-2 OPT-2.7b geometry, 224x224, greedy, 20 new tokens)", "value": round(B * a.steps / dt, 2),
             "unit": "captions/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
             "higher_is_better": True, "dtype": a.dtype + ("+int8w" if q8 else ""), "data": "synthetic frames, procedural weights",
-            "config": {"workload": f"ViT-g/14 + Q-Former + OPT-2.7b prefill (33 positions) + 19 cached decode steps, {B} frames", "streams": a.streams,
+            "config": {"workload": f"ViT-g/14 + Q-Former + OPT-2.7b prefill (33 positions) + 19 cached decode steps, {B} frames", "streams": a.streams, "coalesce_crops": coal,
                        "load_in_8bit": q8, "device_GiB": round(eng.device_bytes / 2**30, 2)},
             "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel (ViT-g qkv/proj/fc1/fc2)",
                          "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",

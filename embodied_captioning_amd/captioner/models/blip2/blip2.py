@@ -153,14 +153,20 @@ class BLIP2(BLIP):
         # cfg.streams > 1 (as for BLIP / CoCa): the micro-batches of one generate_batch call rotate over that many engines / HIP
         # streams on ONE copy of the weights (engine.EnginePool) - the decoder's weight-streaming launches of independent batches fill
         # each other's gaps (OPT-2.7b geometry, 32 frames per micro-batch, bf16: 374 captions/s on one stream, 516 on three).  The pool's
-        # dynamic batching (cfg.coalesce_rows) stays OFF unless asked for: merged passes change the batch the prompt pass sees, which
-        # in the int8 mode picks its kernel (captioner.hip::kI8SkinnyPromptCrops) - same captions to bf16 rounding noise, not the same bits.
+        # dynamic batching (cfg.coalesce_rows: crops per merged pass; None = 4 micro-batches, at most 64 crops) pays doubly here: a
+        # decode step streams the weights once per PASS whatever its rows.  A crop's bits do not depend on the batch it is in - except
+        # in the int8 mode across 4 crops per pass, where the prompt pass changes kernels (captioner.hip::kI8SkinnyPromptCrops: same
+        # captions to bf16 rounding noise, not the same bits): with load_in_8bit and micro-batches of up to 4 crops the default is
+        # therefore OFF (set coalesce_rows to opt in).
         self.pool = None
         n_streams = int(getattr(cfg, "streams", 1) or 1)
         cr = getattr(cfg, "coalesce_rows", None)
         self.coalesce_rows = 0
         if n_streams > 1:
-            self.coalesce_rows = max(0, int(cr)) if cr else 0
+            if cr is None:
+                self.coalesce_rows = 0 if (self.load_in_8bit and self.batch_size <= 4) else min(4 * self.batch_size, 64)
+            else:
+                self.coalesce_rows = max(0, int(cr))
             if self.coalesce_rows <= self.batch_size:
                 self.coalesce_rows = 0
             from ....engine import EnginePool

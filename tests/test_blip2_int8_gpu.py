@@ -224,8 +224,8 @@ def test_wrapper_load_in_8bit_through_the_factory():
         select_captioner(cfg)
 
 
-@pytest.mark.parametrize("q8", [False, True])
-def test_blip2_wrapper_streams_same_captions(q8):
+@pytest.mark.parametrize("mode", ["f32s", "bf16", "int8"])
+def test_blip2_wrapper_streams_same_captions(mode):
     """`captioner.streams: 3` on the BLIP-2 wrapper (plain and `load_in_8bit`): generate_batch over the engine pool returns the one-engine
     wrapper's sequences, lengths and texts (every micro-batch is computed by exactly the kernels of a single engine)."""
     from PIL import Image
@@ -234,9 +234,22 @@ def test_blip2_wrapper_streams_same_captions(q8):
     rng = np.random.default_rng(9)
     ims = [Image.fromarray(rng.integers(0, 256, size=(44 + i, 60, 3), dtype=np.uint8), "RGB") for i in range(11)]
     kw = dict(arch_name="blip2", model_name="procedural-blip2-small:4:0.4", height=224, width=224, batch_size=3)
-    kw.update(dict(load_in_8bit=True) if q8 else dict(dtype="f32s"))
+    q8 = mode == "int8"
+    kw.update(dict(load_in_8bit=True) if q8 else dict(dtype=mode))
     one = select_captioner(Configuration(**kw).captioner).eval()
     many = select_captioner(Configuration(streams=3, **kw).captioner).eval()
-    assert many.pool is not None and len(many.pool) == 3 and many.coalesce_rows == 0 and many.pool.engines[0].weight_int8 == q8
+    # dynamic batching: on by default (4 micro-batches per pass) - except load_in_8bit with micro-batches of up to 4 crops, where a
+    # merged pass would move the prompt pass to the other kernel range
+    assert many.pool is not None and len(many.pool) == 3 and many.coalesce_rows == (0 if q8 else 12) and many.pool.engines[0].weight_int8 == q8
     a, b = one.generate_batch(ims), many.generate_batch(ims)
+    if not q8:
+        assert isinstance(many.pool.last_coalesce, list) and any(len(g) > 1 for g in many.pool.last_coalesce)
     assert torch.equal(a["sequences"], b["sequences"]) and torch.equal(a["lengths"], b["lengths"]) and a["texts"] == b["texts"]
+    if q8:                                   # micro-batches of 5: merged or not, every prompt pass is in the tiled-GEMM range - same bits
+        kw5 = dict(kw, batch_size=5)
+        one5 = select_captioner(Configuration(**kw5).captioner).eval()
+        many5 = select_captioner(Configuration(streams=3, **kw5).captioner).eval()
+        assert many5.coalesce_rows == 20
+        a5, b5 = one5.generate_batch(ims + ims), many5.generate_batch(ims + ims)
+        assert isinstance(many5.pool.last_coalesce, list) and any(len(g) > 1 for g in many5.pool.last_coalesce)
+        assert torch.equal(a5["sequences"], b5["sequences"]) and torch.equal(a5["lengths"], b5["lengths"])
