@@ -942,7 +942,7 @@ def main():
     if a.dtype is None:
         a.dtype = {"blip": "f32s", "blip2": "f32s", "coca": "bf16", "minilm": "bf16"}[a.model]
     if a.coalesce_rows is None and a.model != "coca":
-        a.coalesce_rows = 1024
+        a.coalesce_rows, a.coalesce_defaulted = 1024, True
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1007,8 +1007,9 @@ def main():
     runner = eng
     # dynamic batching only where it is the plain greedy workload on a pool (beams / early exit / other sizes: extra lines as before)
     coal = a.coalesce_rows if (a.streams > 1 and not a.early_exit and a.coalesce_rows > B) else 0
-    if a.beams > 1:
-        coal = min(coal, 4 * B)                # (config 3's batch is 64 images: passes of up to 256 images x beams)
+    if a.beams > 1 and getattr(a, "coalesce_defaulted", False):
+        coal = min(coal, 8 * B)                # (config 3's batch is 64 images: passes of up to 512 images x beams - 24 steps: 4 080 captions/s
+                                               # against 3 930 with 256-image passes; --coalesce-rows overrides)
     from embodied_captioning_amd.engine import EnginePool
     if a.streams > 1:
         runner = EnginePool(arch, n=a.streams, device=dev, dtype=a.dtype, max_batch=max(B, coal), max_beams=a.beams, max_len=L, weights_of=eng)
