@@ -781,7 +781,7 @@ def latency_block(arch, sd, dev, dtype, L, batches=(1, 8, 64), reps=7):
             torch.cuda.synchronize()
             ts.append(1e3 * (time.perf_counter() - t0))
         out["forward_pil_ms"] = round(statistics.median(ts), 3)
-        out["forward_pil_note"] = ("BLIP.forward(PIL 640x480): host bicubic resize + upload + cap_generate with per-step logits "
+        out["forward_pil_note"] = ("BLIP.forward(PIL 640x480): upload + Pillow-exact bicubic resize on the device + cap_generate with per-step logits "
                                    "(early-exit poll 4, the plugin default) + detokenise")
         model.engine.close()
     except Exception as e:  # noqa: BLE001

@@ -150,6 +150,7 @@ class BLIP2(BLIP):
         self.engine.set_early_exit(4 if poll is None else int(poll))
         self.engine.load_state_dict(sd)
         self.strict_range = bool(getattr(cfg, "strict_range", False))
+        self.device_resize = getattr(cfg, "device_resize", None) is not False
         # cfg.streams > 1 (as for BLIP / CoCa): the micro-batches of one generate_batch call rotate over that many engines / HIP
         # streams on ONE copy of the weights (engine.EnginePool) - the decoder's weight-streaming launches of independent batches fill
         # each other's gaps (OPT-2.7b geometry, 32 frames per micro-batch, bf16: 374 captions/s on one stream, 516 on three).  The pool's

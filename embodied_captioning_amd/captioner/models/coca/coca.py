@@ -90,6 +90,7 @@ class CoCa(CaptioningPredictor):
         self.engine.set_early_exit(4 if poll is None else int(poll))
         self.engine.load_state_dict(sd)
         self.strict_range = bool(getattr(cfg, "strict_range", False))
+        self.device_resize = getattr(cfg, "device_resize", None) is not False
         # cfg.streams > 1 (as for BLIP): the micro-batches of one generate_batch call rotate over that many engines / HIP streams on
         # ONE copy of the weights (engine.EnginePool), and cfg.coalesce_rows (IMAGES per pass; None = 4 micro-batches, at most 512
         # images) lets the pool merge consecutive micro-batches into larger passes and split the outputs back - every image's
@@ -133,6 +134,13 @@ class CoCa(CaptioningPredictor):
             return images if images.dim() == 4 else images[None]
         if isinstance(images, Image.Image):
             images = [images]
+        if getattr(self, "device_resize", True):      # shorter-side bicubic resize + centre crop on the device, bit-exact with Pillow
+            from ....preprocess import crop_resize_u8
+            outs = []
+            for im in images:
+                a = np.array(im.convert("RGB"))
+                outs.append(crop_resize_u8(a, [(0, 0, a.shape[1], a.shape[0])], S, device=self._device, center_crop=True))
+            return torch.cat(outs) if len(outs) > 1 else outs[0]
         frames = []
         from ....preprocess import shorter_side_geometry
         for im in images:

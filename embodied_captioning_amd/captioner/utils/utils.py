@@ -26,7 +26,7 @@ class CaptionerField:
                  early_exit_poll=None, max_new_tokens=None, num_beam_groups=None, tokenizer_dir=None,
                  generation_type=None, top_k=None, top_p=None, temperature=None, repetition_penalty=None,
                  load_in_8bit=None, load_in_4bit=None, torch_dtype=None, cross_cache=None, strict_range=False,
-                 coalesce_rows=None):
+                 coalesce_rows=None, device_resize=None):
         self.arch_name = arch_name
         self.model_name = model_name
         self.checkpoint_name = checkpoint_name
@@ -63,3 +63,5 @@ class CaptionerField:
         # BLIP with streams > 1: the pool's dynamic batching merges the micro-batches of one generate_batch / caption_batch call
         # into passes of at most this many rows (same captions; None = 4 x batch_size up to 1024, 0 = off)
         self.coalesce_rows = coalesce_rows
+        # PIL inputs: the processor's bicubic resize runs on the device, bit-exact with Pillow (None / True); False = host PIL
+        self.device_resize = device_resize
