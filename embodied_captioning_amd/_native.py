@@ -50,6 +50,8 @@ _SIGNATURES = {
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "cap_crop_resize_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "cap_crop_resize_u8_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "cap_generate_groups": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "cap_set_early_exit": (C.c_int, [C.c_void_p, C.c_int]),

@@ -138,12 +138,8 @@ class BLIP(CaptioningPredictor):
         if getattr(self, "device_resize", True):
             # Pillow's bicubic resize on the device, bit-exact (csrc/preprocess.hip; tests/test_preprocess_gpu.py): one small upload and
             # two launches per image - 256 crops of 40-400 px: 26 ms against 130 ms of host PIL on one core (tools/pil_list_bench.py)
-            from ....preprocess import crop_resize_u8
-            outs = []
-            for im in images:
-                a = np.array(im.convert("RGB"))
-                outs.append(crop_resize_u8(a, [(0, 0, a.shape[1], a.shape[0])], S, device=self._device))
-            return torch.cat(outs) if len(outs) > 1 else outs[0]
+            from ....preprocess import resize_u8_list
+            return resize_u8_list([np.asarray(im.convert("RGB")) for im in images], S, device=self._device)
         frames = [np.asarray(im.convert("RGB").resize((S, S), resample=Image.BICUBIC)) for im in images]
         return torch.from_numpy(np.stack(frames))
 

@@ -135,12 +135,8 @@ class CoCa(CaptioningPredictor):
         if isinstance(images, Image.Image):
             images = [images]
         if getattr(self, "device_resize", True):      # shorter-side bicubic resize + centre crop on the device, bit-exact with Pillow
-            from ....preprocess import crop_resize_u8
-            outs = []
-            for im in images:
-                a = np.array(im.convert("RGB"))
-                outs.append(crop_resize_u8(a, [(0, 0, a.shape[1], a.shape[0])], S, device=self._device, center_crop=True))
-            return torch.cat(outs) if len(outs) > 1 else outs[0]
+            from ....preprocess import resize_u8_list
+            return resize_u8_list([np.asarray(im.convert("RGB")) for im in images], S, device=self._device, center_crop=True)
         frames = []
         from ....preprocess import shorter_side_geometry
         for im in images:

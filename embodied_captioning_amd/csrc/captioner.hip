@@ -2111,6 +2111,11 @@ int cap_crop_resize_u8(const uint8_t* frame, int H, int W, int bgr, const int32_
                        int KH, const int32_t* vb, const int32_t* vk, int KV, int n, int S, uint8_t* out, void* stream) {
     return launch_crop_resize_u8(frame, H, W, bgr, rects, hb, hk, KH, vb, vk, KV, n, S, out, (hipStream_t)stream);
 }
+int cap_crop_resize_u8_frames(const uint8_t* packed, const int64_t* frames, int bgr, const int32_t* rects, const int32_t* hb, const int32_t* hk,
+                              int KH, const int32_t* vb, const int32_t* vk, int KV, int n, int S, uint8_t* out, void* stream) {
+    if (!frames) { cap_set_error("crop_resize_frames: null frame table"); return -1; }
+    return launch_crop_resize_u8(packed, 0, 0, bgr, rects, hb, hk, KH, vb, vk, KV, n, S, out, (hipStream_t)stream, (const long long*)frames);
+}
 int cap_op_reduce_layernorm(int dtype, const float* part, int S, const float* bias, const float* resid, const float* gamma,
                             const float* beta, float eps, void* out_t, float* out_f, float* y_out, int M, int D,
                             int per_row_block, void* stream) {

@@ -140,7 +140,8 @@ int launch_scale_cols(float* part, const float* scale, int M, int N, hipStream_t
 int launch_crop_resize_tables(const int* rects, const int* geom, int n, int S, int KH, int KV, int* hb, int* hk, int* vb, int* vk,
                               hipStream_t s);
 int launch_crop_resize_u8(const uint8_t* frame, int H, int W, int bgr, const int* rects, const int* hb, const int* hk, int KH,
-                          const int* vb, const int* vk, int KV, int n, int S, uint8_t* out, hipStream_t s);
+                          const int* vb, const int* vk, int KV, int n, int S, uint8_t* out, hipStream_t s,
+                          const long long* frames = nullptr);     // frames int64 [n, 3] = (byte offset in `frame`, H, W) of box b's own frame
 
 // ---- beam.hip --------------------------------------------------------------------------------
 size_t beam_state_bytes(int B, int K, int max_len);

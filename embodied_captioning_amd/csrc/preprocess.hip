@@ -21,12 +21,19 @@ constexpr int PR_BITS = 22;
 
 __device__ __forceinline__ int clip8(int v) { return min(max(v >> PR_BITS, 0), 255); }
 
+// frames != null: box b is cut from ITS OWN frame (a list of crops of different sizes in one packed buffer): frames[b] = (byte
+// offset of the frame in `frame`, its height, its width) - one upload and one launch for the whole list.
 __global__ __launch_bounds__(256) void crop_resize_u8_kernel(const uint8_t* __restrict__ frame, int H, int W, int bgr,
                                                              const int* __restrict__ rects, const int* __restrict__ hb,
                                                              const int* __restrict__ hk, int KH, const int* __restrict__ vb,
                                                              const int* __restrict__ vk, int KV, int S,
-                                                             uint8_t* __restrict__ out) {
+                                                             uint8_t* __restrict__ out, const long long* __restrict__ frames) {
     const int yy = blockIdx.x, b = blockIdx.y;
+    if (frames) {
+        frame += frames[b * 3];
+        H = (int)frames[b * 3 + 1];
+        W = (int)frames[b * 3 + 2];
+    }
     const int x1 = rects[b * 4 + 0], y1 = rects[b * 4 + 1];
     const int ymin = vb[((size_t)b * S + yy) * 2], ycnt = vb[((size_t)b * S + yy) * 2 + 1];
     const int* kv = vk + ((size_t)b * S + yy) * KV;
@@ -121,12 +128,12 @@ int launch_crop_resize_tables(const int* rects, const int* geom, int n, int S, i
 }
 
 int launch_crop_resize_u8(const uint8_t* frame, int H, int W, int bgr, const int* rects, const int* hb, const int* hk, int KH,
-                          const int* vb, const int* vk, int KV, int n, int S, uint8_t* out, hipStream_t s) {
-    if (!frame || !rects || !hb || !hk || !vb || !vk || !out || H < 1 || W < 1 || n < 1 || S < 1 || S > 4096 || KH < 1 || KV < 1) {
+                          const int* vb, const int* vk, int KV, int n, int S, uint8_t* out, hipStream_t s, const long long* frames) {
+    if (!frame || !rects || !hb || !hk || !vb || !vk || !out || (!frames && (H < 1 || W < 1)) || n < 1 || S < 1 || S > 4096 || KH < 1 || KV < 1) {
         cap_set_error("crop_resize: null pointer or bad shape (H=%d W=%d n=%d S=%d KH=%d KV=%d)", H, W, n, S, KH, KV);
         return -1;
     }
-    hipLaunchKernelGGL(crop_resize_u8_kernel, dim3(S, n), dim3(256), 0, s, frame, H, W, bgr, rects, hb, hk, KH, vb, vk, KV, S, out);
+    hipLaunchKernelGGL(crop_resize_u8_kernel, dim3(S, n), dim3(256), 0, s, frame, H, W, bgr, rects, hb, hk, KH, vb, vk, KV, S, out, frames);
     CAP_HIP_CHECK(hipGetLastError());
     return 0;
 }

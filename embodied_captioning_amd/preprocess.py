@@ -136,3 +136,55 @@ def crop_resize_u8(frame, rects: Sequence[Sequence[int]], size: int, bgr: bool =
         for t in (out, ws_t, frame_d):
             t.record_stream(cur)
     return out
+
+
+def resize_u8_list(images: Sequence[np.ndarray], size: int, device: str | torch.device = "cuda:0", center_crop: bool = False) -> torch.Tensor:
+    """A list of uint8 RGB images [H_i, W_i, 3] of different sizes (the PIL crops `generate_batch` / `caption_batch` receive) ->
+    uint8 [n, size, size, 3] on the device, every image equal to ``Image.fromarray(a).resize((size, size), BICUBIC)`` (or, with
+    `center_crop`, to the shorter-side resize + centre crop of `shorter_side_geometry`): the images' bytes go up in ONE packed buffer
+    and the whole list is two launches (filter tables, resize) - `cap_crop_resize_u8_frames`."""
+    if not torch.cuda.is_available():
+        raise N.CaptionerHipError("resize_u8_list needs a GPU; there is no CPU fallback in the product path")
+    lib = N.load_library()
+    dev = torch.device(device)
+    n = len(images)
+    if n == 0:
+        return torch.empty((0, size, size, 3), dtype=torch.uint8, device=dev)
+    hw = np.empty((n, 2), dtype=np.int64)
+    for i, a in enumerate(images):
+        if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3 or a.shape[0] < 1 or a.shape[1] < 1:
+            raise ValueError(f"image {i} must be uint8 [H, W, 3], got {a.dtype} {a.shape}")
+        hw[i] = a.shape[:2]
+    nbytes = hw[:, 0] * hw[:, 1] * 3
+    offs = np.concatenate([[0], np.cumsum(nbytes)])
+    packed = torch.empty(int(offs[-1]), dtype=torch.uint8, pin_memory=True)
+    pk = packed.numpy()
+    for i, a in enumerate(images):
+        pk[offs[i]:offs[i + 1]] = a.reshape(-1)
+    rects = np.zeros((n, 4), dtype=np.int64)
+    rects[:, 2], rects[:, 3] = hw[:, 1], hw[:, 0]
+    if center_crop:
+        geom = np.array([shorter_side_geometry(int(w), int(h), size) for h, w in hw.tolist()], dtype=np.int64)
+    else:
+        geom = np.tile(np.array([size, size, 0, 0], dtype=np.int64), (n, 1))
+    KH, KV = _ksize(hw[:, 1], geom[:, 0]), _ksize(hw[:, 0], geom[:, 1])
+    frames = np.stack([offs[:-1], hw[:, 0], hw[:, 1]], axis=1).astype(np.int64)
+    stream = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)   # noqa: E731
+    with torch.cuda.device(dev):
+        packed_d = packed.to(dev, non_blocking=True)
+        frames_d = torch.from_numpy(frames).to(dev, non_blocking=True)
+        out = torch.empty((n, size, size, 3), dtype=torch.uint8, device=dev)
+        sizes = (n * 4, n * 4, n * size * 2, n * size * KH, n * size * 2, n * size * KV)   # rects, geom, hb, hk, vb, vk
+        o = np.concatenate([[0], np.cumsum(sizes)])
+        head = torch.from_numpy(np.concatenate([rects.ravel(), geom.ravel()]).astype(np.int32))
+        ws_t = torch.empty(int(o[-1]), dtype=torch.int32, device=dev)
+        ws_t[: 8 * n].copy_(head, non_blocking=True)
+        p = [C.c_void_p(ws_t.data_ptr() + 4 * int(x)) for x in o[:-1]]
+        N.check(lib.cap_crop_resize_tables(p[0], p[1], n, size, KH, KV, p[2], p[3], p[4], p[5], stream()), "cap_crop_resize_tables")
+        N.check(lib.cap_crop_resize_u8_frames(C.c_void_p(packed_d.data_ptr()), C.c_void_p(frames_d.data_ptr()), 0, p[0], p[2], p[3], KH, p[4], p[5],
+                                              KV, n, size, C.c_void_p(out.data_ptr()), stream()), "cap_crop_resize_u8_frames")
+        cur = torch.cuda.current_stream(dev)
+        for t in (out, ws_t, packed_d, frames_d):
+            t.record_stream(cur)
+        cur.synchronize()                                 # the pinned staging buffer is released when this returns
+    return out

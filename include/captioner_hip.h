@@ -182,6 +182,12 @@ int cap_crop_resize_tables(const int32_t* rects, const int32_t* geom, int n, int
 int cap_crop_resize_u8(const uint8_t* frame, int H, int W, int bgr, const int32_t* rects, const int32_t* hb,
                        const int32_t* hk, int KH, const int32_t* vb, const int32_t* vk, int KV, int n, int S, uint8_t* out,
                        void* stream);
+/* The same for a LIST of images (what generate_batch / caption_batch receive: PIL crops of different sizes): `packed` holds the n
+ * images' bytes back to back, frames int64 [n, 3] = (byte offset, height, width) of image b, rects[b] its rectangle inside it
+ * ((0, 0, W, H) for the whole image) - one upload and one launch for the whole list. */
+int cap_crop_resize_u8_frames(const uint8_t* packed, const int64_t* frames, int bgr, const int32_t* rects, const int32_t* hb,
+                              const int32_t* hk, int KH, const int32_t* vb, const int32_t* vk, int KV, int n, int S, uint8_t* out,
+                              void* stream);
 
 /* Image tower.  pixels: B frames in `pixel_fmt`; out_embeds: fp32 [B, tokens, v_hidden] (device). */
 int cap_encode(CapHandle h, const void* pixels, int pixel_fmt, int B, float* out_embeds, void* stream);

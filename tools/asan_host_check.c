@@ -112,6 +112,14 @@ int main(void) {
     EXPECT(cap_op_gemm_skinny_i8(w, w, w, NULL, 0, w, NULL, 4, 40, 256, NULL) != 0 && strstr(cap_last_error(), "gemm_skinny_i8"));
     EXPECT(cap_op_gemm_skinny_i8(w, w, w, NULL, 0, w, NULL, 0, 256, 256, NULL) != 0);          /* no rows */
     EXPECT(cap_op_gemm_skinny_i8(w, w, w, NULL, 0, NULL, NULL, 4, 256, 256, NULL) != 0);       /* neither output */
+    {   /* the list form of the crop + resize: the frame table is mandatory, shapes are checked before any HIP call */
+        int32_t iw[8] = {0};
+        uint8_t ob[4] = {0};
+        EXPECT(cap_crop_resize_u8_frames((const uint8_t*)w, NULL, 0, iw, iw, iw, 1, iw, iw, 1, 1, 1, ob, NULL) != 0 && strstr(cap_last_error(), "frame table"));
+        int64_t fr[3] = {0, 1, 1};
+        EXPECT(cap_crop_resize_u8_frames((const uint8_t*)w, fr, 0, iw, iw, iw, 0, iw, iw, 1, 1, 1, ob, NULL) != 0);          /* KH < 1 */
+        EXPECT(cap_crop_resize_u8_frames(NULL, fr, 0, iw, iw, iw, 1, iw, iw, 1, 1, 1, ob, NULL) != 0);
+    }
     printf(failures ? "asan host check: %d FAILED\n" : "asan host check: all calls returned cleanly (%d failures)\n", failures);
     return failures ? 1 : 0;
 }
