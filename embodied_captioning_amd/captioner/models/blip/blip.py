@@ -154,16 +154,35 @@ class BLIP(CaptioningPredictor):
     @torch.no_grad()
     def generate_batch(self, images, output_logits: bool = False) -> dict:
         """Batched extension: any number of frames -> {"texts": [str], "sequences": int32 [N, L], "lengths", "scores"}."""
-        px = self.preprocess(images)
         texts: List[str] = []
         seqs, lens, scores, logits = [], [], [], []
-        chunks = [px[i:i + self.batch_size].to(self._device) for i in range(0, px.shape[0], self.batch_size)]
-        if getattr(self, "pool", None) is not None and len(chunks) > 1 and not output_logits:
-            outs = self.pool.generate_many(chunks, threads=True, coalesce_rows=self.coalesce_rows, num_beams=self.num_beams,
-                                           max_length=self.max_length)
+        pool = getattr(self, "pool", None)
+        # a long list of PIL crops on a pool: in rounds of one pass per engine, the next round's crops are preprocessed (host
+        # `Image.convert` + pack, upload, device resize) by a helper thread while the current round generates
+        rnd = len(pool) * max(self.batch_size, self.coalesce_rows) if pool is not None else 0
+        if (pool is not None and not output_logits and not isinstance(images, torch.Tensor) and isinstance(images, (list, tuple))
+                and len(images) > rnd):
+            from concurrent.futures import ThreadPoolExecutor
+            groups = [images[i:i + rnd] for i in range(0, len(images), rnd)]
+            outs = []
+            with ThreadPoolExecutor(max_workers=1) as ex:
+                nxt = ex.submit(self.preprocess, groups[0])
+                for g in range(len(groups)):
+                    px = nxt.result()
+                    if g + 1 < len(groups):
+                        nxt = ex.submit(self.preprocess, groups[g + 1])
+                    chunks = [px[i:i + self.batch_size].to(self._device) for i in range(0, px.shape[0], self.batch_size)]
+                    outs += self.pool.generate_many(chunks, threads=True, coalesce_rows=self.coalesce_rows, num_beams=self.num_beams,
+                                                    max_length=self.max_length)
         else:
-            outs = [self.engine.generate(c, num_beams=self.num_beams, max_length=self.max_length, output_logits=output_logits)
-                    for c in chunks]
+            px = self.preprocess(images)
+            chunks = [px[i:i + self.batch_size].to(self._device) for i in range(0, px.shape[0], self.batch_size)]
+            if pool is not None and len(chunks) > 1 and not output_logits:
+                outs = self.pool.generate_many(chunks, threads=True, coalesce_rows=self.coalesce_rows, num_beams=self.num_beams,
+                                               max_length=self.max_length)
+            else:
+                outs = [self.engine.generate(c, num_beams=self.num_beams, max_length=self.max_length, output_logits=output_logits)
+                        for c in chunks]
         for out in outs:
             seqs.append(out["sequences"]); lens.append(out["lengths"])
             if "sequences_scores" in out:

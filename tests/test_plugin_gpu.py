@@ -142,3 +142,21 @@ def test_generate_logits_tail_is_zero_after_early_exit():
     n = eng.last_decode_steps
     assert n < 19 and float(out["logits"][n:].abs().max()) == 0.0 and float(out["logits"][0].abs().max()) > 0.0
     eng.close()
+
+
+def test_generate_batch_long_pil_list_is_preprocessed_in_rounds_same_captions():
+    """A PIL list longer than one round of passes (engines x pass size) goes through `generate_batch` in rounds - the next round's crops are
+    preprocessed by a helper thread while the current round generates; captions are those of the one-engine wrapper."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from embodied_captioning_amd.captioner.utils.utils import Configuration
+    from embodied_captioning_amd.captioner.utils.utils_captioner import select_captioner
+    rng = np.random.default_rng(21)
+    ims = [Image.fromarray(rng.integers(0, 256, size=(30 + i % 17, 40 + i % 11, 3), dtype=np.uint8), "RGB") for i in range(83)]
+    kw = dict(arch_name="blip", model_name="procedural-blip-tiny:3:2.0", height=224, width=224, dtype="f32s", batch_size=4)
+    one = select_captioner(Configuration(**kw).captioner).eval()
+    many = select_captioner(Configuration(streams=2, **kw).captioner).eval()
+    assert many.pool is not None and len(ims) > len(many.pool) * max(many.batch_size, many.coalesce_rows)       # 83 > 2 x 16: three rounds
+    a, b = one.generate_batch(ims), many.generate_batch(ims)
+    assert torch.equal(a["sequences"], b["sequences"]) and torch.equal(a["lengths"], b["lengths"]) and a["texts"] == b["texts"]

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from embodied_captioning_amd.captioner.utils.utils import Configuration  # noqa: E402
 from embodied_captioning_amd.captioner.utils.utils_captioner import select_captioner  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 rng = np.random.default_rng(0)
 ims = [Image.fromarray(rng.integers(0, 256, size=(int(rng.integers(40, 400)), int(rng.integers(40, 400)), 3), dtype=np.uint8), "RGB") for _ in range(n)]
 for dr in (True, False):
