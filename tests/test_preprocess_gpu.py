@@ -125,3 +125,32 @@ def test_wrappers_preprocess_pil_lists_on_the_device_bit_exact(arch_name, model_
     one = dev.preprocess(ims[0])
     assert torch.equal(one.cpu(), b[:1])
     assert dev(ims[1])["text"] == host(ims[1])["text"]
+
+
+@pytest.mark.parametrize("center_crop", [False, True])
+def test_boxes_of_several_frames_in_one_call_bit_exact(center_crop):
+    """`crop_resize_u8_frames`: boxes of several frames of different sizes (only the in-frame pixels travel, packed), BGR frames,
+    boxes that leave their frame partly or wholly - every crop equal to Pillow's crop + bicubic resize (or shorter side + centre crop)."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from embodied_captioning_amd.preprocess import crop_resize_u8_frames, shorter_side_geometry
+    rng = np.random.default_rng(4)
+    S = 48
+    frames = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in ((120, 160), (64, 64), (300, 200), (37, 91))]
+    rects = [[(10, 20, 90, 100), (-15, 30, 60, 140), (100, -8, 175, 50)], [(0, 0, 64, 64)], [], [(5, 3, 30, 36), (200, 200, 230, 260), (-40, -40, 20, 20)]]
+    out = crop_resize_u8_frames(frames, rects, S, bgr=True, center_crop=center_crop).cpu().numpy()
+    k = 0
+    for fr, rs in zip(frames, rects):
+        pil = Image.fromarray(np.ascontiguousarray(fr[:, :, ::-1]))
+        for r in rs:
+            c = pil.crop(r)
+            if center_crop:
+                nw, nh, left, top = shorter_side_geometry(c.size[0], c.size[1], S)
+                want = np.asarray(c.resize((nw, nh), resample=Image.BICUBIC).crop((left, top, left + S, top + S)))
+            else:
+                want = np.asarray(c.resize((S, S), resample=Image.BICUBIC))
+            assert np.array_equal(out[k], want), (k, r)
+            k += 1
+    assert k == out.shape[0] == 7
+    assert crop_resize_u8_frames(frames[:1], [[]], S).shape == (0, S, S, 3)
