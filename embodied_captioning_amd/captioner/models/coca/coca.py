@@ -193,13 +193,28 @@ class CoCa(CaptioningPredictor):
 
     @torch.no_grad()
     def generate_batch(self, images) -> dict:
-        px = self.preprocess(images)
-        chunks = [px[i:i + self.batch_size].to(self._device) for i in range(0, px.shape[0], self.batch_size)]
         kw = dict(num_beams=self.num_beams, max_length=self.arch.seq_len, num_beam_groups=self.num_beam_groups)
-        if self.pool is not None and len(chunks) > 1:
-            outs = self.pool.generate_many(chunks, threads=True, coalesce_rows=self.coalesce_rows, **kw)
+        rnd = len(self.pool) * max(self.batch_size, self.coalesce_rows) if self.pool is not None else 0
+        if self.pool is not None and isinstance(images, (list, tuple)) and len(images) > rnd:
+            # a long list of PIL crops: in rounds of one pass per engine, the next round preprocessed by a helper thread meanwhile
+            from concurrent.futures import ThreadPoolExecutor
+            groups = [images[i:i + rnd] for i in range(0, len(images), rnd)]
+            outs = []
+            with ThreadPoolExecutor(max_workers=1) as ex:
+                nxt = ex.submit(self.preprocess, groups[0])
+                for g in range(len(groups)):
+                    px = nxt.result()
+                    if g + 1 < len(groups):
+                        nxt = ex.submit(self.preprocess, groups[g + 1])
+                    chunks = [px[i:i + self.batch_size].to(self._device) for i in range(0, px.shape[0], self.batch_size)]
+                    outs += self.pool.generate_many(chunks, threads=True, coalesce_rows=self.coalesce_rows, **kw)
         else:
-            outs = [self.engine.generate(c, **kw) for c in chunks]
+            px = self.preprocess(images)
+            chunks = [px[i:i + self.batch_size].to(self._device) for i in range(0, px.shape[0], self.batch_size)]
+            if self.pool is not None and len(chunks) > 1:
+                outs = self.pool.generate_many(chunks, threads=True, coalesce_rows=self.coalesce_rows, **kw)
+            else:
+                outs = [self.engine.generate(c, **kw) for c in chunks]
         seq, ln = torch.cat([o["sequences"] for o in outs]).cpu(), torch.cat([o["lengths"] for o in outs]).cpu()
         self._range_tick()
         res = {"texts": [self.decode(r[:n]) for r, n in zip(seq.tolist(), ln.tolist())], "sequences": seq, "lengths": ln}

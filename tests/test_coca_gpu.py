@@ -332,7 +332,7 @@ def test_coca_wrapper_streams_and_dynamic_batching_same_captions():
     from embodied_captioning_amd.captioner.utils.utils import Configuration
     from embodied_captioning_amd.captioner.utils.utils_captioner import select_captioner
     rng = np.random.default_rng(5)
-    ims = [Image.fromarray(rng.integers(0, 256, size=(40 + i, 52, 3), dtype=np.uint8), "RGB") for i in range(14)]
+    ims = [Image.fromarray(rng.integers(0, 256, size=(40 + i % 19, 52, 3), dtype=np.uint8), "RGB") for i in range(14)]
     kw = dict(arch_name="coca", model_name="procedural-coca-tiny:2:3.0", height=224, width=224, dtype="f32s", num_beams=3, batch_size=4)
     one = select_captioner(Configuration(**kw).captioner).eval()
     many = select_captioner(Configuration(streams=3, **kw).captioner).eval()
@@ -341,3 +341,7 @@ def test_coca_wrapper_streams_and_dynamic_batching_same_captions():
     assert isinstance(many.pool.last_coalesce, list) and any(len(g) > 1 for g in many.pool.last_coalesce)
     assert torch.equal(a["sequences"], b["sequences"]) and torch.equal(a["lengths"], b["lengths"]) and a["texts"] == b["texts"]
     assert torch.equal(a["scores"], b["scores"])
+    # a list longer than one round of passes (3 engines x 16 images): preprocessed round by round by a helper thread
+    long = [ims[i % 14] for i in range(61)]
+    a, b = one.generate_batch(long), many.generate_batch(long)
+    assert torch.equal(a["sequences"], b["sequences"]) and torch.equal(a["scores"], b["scores"]) and a["texts"] == b["texts"]
