@@ -33,6 +33,15 @@ The K timed steps rotate over --streams engines (default 3), each with its own a
 independent, a single generate leaves most of the GPU idle (launch-bound decode chain), and kernels of different streams
 overlap here - every step is still one whole batch and all K finish inside the timed region; --streams 1 times them one
 after the other.  The roofline / per-kernel pass, the encoder-only, fp32 and CPU legs run one engine on one stream.
+
+Context keys of a full run, measured live and labelled as such: `roofline.vendor_fp16_gemm_tflops_same_shapes` (torch.mm / hipBLASLt
+on the encoder GEMM's four shapes with plain fp16 operands - nothing in the product calls a vendor GEMM) beside the kernel's
+`executed_tflops`; `cpu_baseline.runs.hf_transformers_8_frames` (HF's own BlipForConditionalGeneration.generate, what the
+reference's wrappers call) beside the CPU port - `cpu_baseline.value` is the CPU's best figure, `kind` says whose.
+
+Other lines: --beams 3 --batch 64 (config 3), --model coca --image-size 336 --beams 5 --batch 128 (config 5 on one GPU),
+--model blip2 [--load-in-8bit] [--batch 1] (the reference's production captioner), --model minilm; --gpus 2 --share-gpu
+rehearses the N > 1 path with real engines on a one-GPU box (all ranks on cuda:0 over gloo; not a scaling figure).
 """
 import argparse
 import json
