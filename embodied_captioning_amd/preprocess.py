@@ -169,6 +169,28 @@ def crop_resize_u8_frames(frames: Sequence[np.ndarray], rects_per_frame: Sequenc
     n = len(patches)
     if n == 0:
         return torch.empty((0, size, size, 3), dtype=torch.uint8, device=dev)
+    return torch.cat([_resize_patches(patches[i:j], rects[i:j], hw[i:j], size, bgr, dev, center_crop, lib) for i, j in _byte_groups(hw)]) \
+        if _byte_groups(hw)[0][1] < n else _resize_patches(patches, rects, hw, size, bgr, dev, center_crop, lib)
+
+
+_STAGE_BYTES = 256 << 20     # pinned staging per launch: a very long list goes through in groups of at most this many bytes
+
+
+def _byte_groups(hw):
+    """[(i, j)] consecutive patch ranges whose packed bytes stay within _STAGE_BYTES (a single larger patch is a group of its own)."""
+    groups, i, acc = [], 0, 0
+    for k, (h, w) in enumerate(hw):
+        b = int(h) * int(w) * 3
+        if k > i and acc + b > _STAGE_BYTES:
+            groups.append((i, k))
+            i, acc = k, 0
+        acc += b
+    groups.append((i, len(hw)))
+    return groups
+
+
+def _resize_patches(patches, rects, hw, size, bgr, dev, center_crop, lib) -> torch.Tensor:
+    n = len(patches)
     hw = np.asarray(hw, dtype=np.int64)
     rects = np.asarray(rects, dtype=np.int64)
     nbytes = hw[:, 0] * hw[:, 1] * 3

@@ -154,3 +154,17 @@ def test_boxes_of_several_frames_in_one_call_bit_exact(center_crop):
             k += 1
     assert k == out.shape[0] == 7
     assert crop_resize_u8_frames(frames[:1], [[]], S).shape == (0, S, S, 3)
+
+
+def test_long_lists_go_through_in_byte_bounded_groups(monkeypatch):
+    """The pinned staging buffer of `resize_u8_list` / `crop_resize_u8_frames` is bounded: a list beyond the bound is resized group by
+    group - same bytes as in one go."""
+    import numpy as np
+    import torch
+    from embodied_captioning_amd import preprocess as P
+    rng = np.random.default_rng(8)
+    ims = [rng.integers(0, 256, size=(20 + i % 13, 31 + i % 7, 3), dtype=np.uint8) for i in range(40)]
+    whole = P.resize_u8_list(ims, 32)
+    monkeypatch.setattr(P, "_STAGE_BYTES", 9000)                 # a few images per group
+    assert len(P._byte_groups([a.shape[:2] for a in ims])) > 5
+    assert torch.equal(P.resize_u8_list(ims, 32), whole)
