@@ -169,8 +169,9 @@ def crop_resize_u8_frames(frames: Sequence[np.ndarray], rects_per_frame: Sequenc
     n = len(patches)
     if n == 0:
         return torch.empty((0, size, size, 3), dtype=torch.uint8, device=dev)
-    return torch.cat([_resize_patches(patches[i:j], rects[i:j], hw[i:j], size, bgr, dev, center_crop, lib) for i, j in _byte_groups(hw)]) \
-        if _byte_groups(hw)[0][1] < n else _resize_patches(patches, rects, hw, size, bgr, dev, center_crop, lib)
+    groups = _byte_groups(hw)
+    outs = [_resize_patches(patches[i:j], rects[i:j], hw[i:j], size, bgr, dev, center_crop, lib) for i, j in groups]
+    return outs[0] if len(outs) == 1 else torch.cat(outs)
 
 
 _STAGE_BYTES = 256 << 20     # pinned staging per launch: a very long list goes through in groups of at most this many bytes
